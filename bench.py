@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py — GB/s of sequence scanned by the Levenshtein n-gram hot path on MI355X.
+
+Metric (BASELINE.json): GB/s of sequence scanned (and matches/s) at |p| = 20, max_l_dist = 2.
+Workload at N = 1: BASELINE configs[1] — 1 GiB of iid random DNA bytes with 1 024 planted variants
+of a 20-byte pattern (tests/workloads.py::cfg2), resident in HBM before the timed
+region.  One "step" = one fz_lev_ngrams() call through the C-ABI over the resident sequence:
+filter kernel + verify kernel + D2H of the raw match stream + host ordering.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling — every rank owns one
+1 GiB shard of an N GiB global sequence, holds (m + k)-byte halos of its neighbours' bytes, scans
+its shard with no data-path collective and the ranks' match lists are all-gathered over RCCL
+(SURVEY.md §8(e)); value = N GiB / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mib", type=int, default=1024, help="MiB of sequence per GPU (default: 1 GiB = configs[1])")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-mib", type=int, default=1024)
+    return ap.parse_args()
+
+
+def cpu_baseline(seq, pattern, k, sample_mib):
+    """Time the reference's own native path (oracle/_ref) — or the C port — on a bounded sample."""
+    import oracle
+    n = min(len(seq), sample_mib << 20)
+    sample = seq[:n].tobytes()
+    p = pattern.tobytes()
+    kind = "port"
+    try:
+        from oracle import ref_glue, ref_loader
+        if ref_loader.have_ref_natives():
+            fn = lambda: ref_glue.lev_ngrams_raw(p, sample, k)     # noqa: E731
+            fn_small = lambda: ref_glue.lev_ngrams_raw(p, sample[:1 << 20], k)   # noqa: E731
+            fn_small()
+            kind = "reference"
+    except Exception as exc:                                        # pragma: no cover
+        print("cpu_baseline: reference natives unusable (%r); timing the C port instead" % (exc,), file=sys.stderr)
+        kind = "port"
+    if kind == "port":
+        fn = lambda: oracle.lev_ngrams_raw(p, sample, k)           # noqa: E731
+    t0 = time.perf_counter()
+    res = fn()
+    dt = time.perf_counter() - t0
+    return {"value": n / dt / 1e9, "unit": "GB/s", "cores": 1, "kind": kind,
+            "sample": "first %d MiB of the same DNA workload, |p|=20 k=2, 1 pass, single thread "
+                      "(the reference has no parallelism); %d raw matches in %.2f s" % (n >> 20, len(res), dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    torch = None
+    if world > 1:
+        # import torch BEFORE libfzhip so both share one HIP runtime (same libamdhip64 SONAME)
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from fuzzysearch_amd import _native
+    from tests import workloads
+
+    k = 2
+    shard_bytes = args.mib << 20
+    pattern = workloads.dna(20, 1)
+    m = len(pattern)
+    halo = m + k
+    p = pattern.tobytes()
+    global_n = shard_bytes * world
+
+    # ---- synthetic data: shard r of the global sequence ---------------------------------------
+    if world == 1:
+        seq, _, _ = workloads.cfg2(shard_bytes, 1024)
+    else:
+        seq = workloads.dna(shard_bytes, 20250925 + rank)
+        workloads.plant_variants(seq, pattern, 1024, 7 + rank)
+        # variants straddling the boundary with the next shard: first half lives in our tail
+        seq[-10:] = pattern[:10]
+        if rank > 0:
+            seq[:10] = pattern[10:]
+
+    engine = _native.Engine([local_rank])
+    if world == 1:
+        handle = engine.upload(seq)
+    else:
+        # halo exchange: every rank contributes its first/last `halo` bytes (RCCL all_gather)
+        edges = torch.from_numpy(np.concatenate([seq[:halo], seq[-halo:]])).cuda()
+        all_edges = [torch.empty_like(edges) for _ in range(world)]
+        dist.all_gather(all_edges, edges)
+        left = all_edges[rank - 1][halo:].cpu().numpy() if rank > 0 else np.empty(0, np.uint8)
+        right = all_edges[rank + 1][:halo].cpu().numpy() if rank + 1 < world else np.empty(0, np.uint8)
+        buf = np.concatenate([left, seq, right])
+        own_lo = rank * shard_bytes
+        handle = engine.upload_shard(buf, own_lo - len(left), own_lo, own_lo + shard_bytes, global_n)
+        del buf
+
+    def sync():
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def step():
+        # synchronous: on return the ordered raw match stream is on the host (numpy view of the
+        # C-ABI's fz_match array; no per-record Python objects inside the timed region)
+        raw = engine.lev_ngrams(handle, p, k, as_array=True)
+        if world > 1:
+            raw = raw.tolist()
+            # all-gather of Match lists over RCCL: counts, then records padded to the max count
+            cnt = torch.tensor([len(raw)], dtype=torch.int64, device="cuda")
+            counts = [torch.empty_like(cnt) for _ in range(world)]
+            dist.all_gather(counts, cnt)
+            mx = max(int(c.item()) for c in counts)
+            rec = torch.zeros((max(mx, 1), 4), dtype=torch.int64)
+            if raw:
+                rec[:len(raw)] = torch.tensor(raw, dtype=torch.int64)
+            rec = rec.cuda()
+            recs = [torch.empty_like(rec) for _ in range(world)]
+            dist.all_gather(recs, rec)
+            merged = []
+            for c, r in zip(counts, recs):
+                merged.extend(map(tuple, r[:int(c.item())].cpu().tolist()))
+            merged.sort(key=lambda x: x[3])              # block-major; rank order keeps idx ascending
+            return merged
+        return raw
+
+    for _ in range(args.warmup):
+        matches = step()
+    filter_ms, verify_ms, device_ms = [], [], []
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        matches = step()
+        st = engine.stats()
+        filter_ms.append(st["filter_ms"])
+        verify_ms.append(st["verify_ms"])
+        device_ms.append(st["device_ms"])
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    st = engine.stats()
+    if rank == 0:
+        import fuzzysearch_amd as fa
+        matches = matches.tolist() if hasattr(matches, "tolist") else matches
+        consolidated = fa.common._native.consolidate(matches)
+        ms_per_step = elapsed / args.steps * 1e3
+        value = global_n * args.steps / elapsed / 1e9
+        f_ms = float(np.mean(filter_ms))
+        achieved = shard_bytes / (f_ms * 1e-3) / 1e9           # algorithmic bytes: N read once
+        out = {
+            "metric": "GB/s of sequence scanned at |p|=20 max_l_dist=2 (levenshtein_ngram path)",
+            "value": round(value, 2),
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "%d MiB iid random DNA bytes per GPU, |pattern|=20, max_l_dist=2, "
+                                   "1024 planted variants per GiB (BASELINE configs[1]); resident in HBM" % args.mib,
+                       "bytes_per_gpu": shard_bytes, "pattern_len": m, "max_l_dist": k,
+                       "sharding": "none" if world == 1 else "contiguous shards, (m+k)-byte halo, RCCL all_gather of matches"},
+            "matches_per_s": round(len(matches) * args.steps / elapsed, 1),
+            "raw_matches": len(matches),
+            "consolidated_matches": len(consolidated),
+            "ngram_hits": st["ngram_hits"],
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "fz_filter_kernel", "avg_kernel_ms": round(f_ms, 4),
+                         "algorithmic_bytes_per_launch": shard_bytes},
+            "kernel_ms": {"filter": round(f_ms, 4), "verify": round(float(np.mean(verify_ms)), 4),
+                          "device_total": round(float(np.mean(device_ms)), 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(seq, pattern, k, args.cpu_sample_mib)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

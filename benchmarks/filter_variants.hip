@@ -1,0 +1,407 @@
+// filter_variants.hip — micro-benchmark of candidate inner loops for the n-gram filter kernel.
+// Standalone: hipcc --offload-arch=gfx950 -O3 -std=c++17 filter_variants.hip -o filter_variants
+// Each variant streams the same N bytes of pseudo-random DNA and counts fast hits of G=3 6-byte
+// n-grams (exactness is not the point here — relative cost of the compare/reduce strategy is).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+
+#define THREADS 256
+#define ROWB (THREADS * 16)
+
+__global__ void gen_dna(uint8_t *buf, uint64_t n, uint64_t seed) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n / 8; i += stride) {
+        uint64_t z = (i + seed) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        uint64_t out = 0;
+        for (int b = 0; b < 8; ++b) out |= (uint64_t)("ACGT"[(z >> (2 * b + 7)) & 3]) << (8 * b);
+        reinterpret_cast<uint64_t *>(buf)[i] = out;
+    }
+}
+
+struct Args {
+    uint32_t A[4], B[4], H[4];
+    uint32_t K;       // hash multiplier (24 bit)
+    uint32_t d2;      // second window offset (exact variants)
+    uint32_t dh;      // hash window offset
+};
+
+__device__ __forceinline__ uint32_t win(uint32_t lo, uint32_t hi, int b) {
+    return b == 0 ? lo : __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)b);
+}
+#define WIN(w, o) win((w)[(o) >> 2], (w)[((o) >> 2) + 1], (o) & 3)
+
+// ---- V4: streaming only -------------------------------------------------------------------
+template <int ROWS>
+__global__ __launch_bounds__(THREADS) void k_stream(const uint8_t *__restrict__ buf, Args a, uint64_t ntiles, unsigned long long *cnt) {
+    uint32_t acc = 0;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint8_t *src = buf + tile * (uint64_t)(ROWB * ROWS) + threadIdx.x * 16u;
+        uint4 v[ROWS]; uint2 h[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) { v[r] = *(const uint4 *)(src + r * ROWB); h[r] = *(const uint2 *)(src + r * ROWB + 16); }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) acc += v[r].x ^ v[r].y ^ v[r].z ^ v[r].w ^ h[r].x ^ h[r].y;
+    }
+    if (acc == 0x12345678u) atomicAdd(cnt, 1ull);
+}
+
+// shared rare path: count the lanes (stand-in for queue push + drain)
+__device__ __forceinline__ void rare(unsigned long long mask, uint32_t &qn) { qn += (uint32_t)__popcll(mask); }
+
+// ---- V0: exact two-window compare, s_and + s_or, branch per offset -------------------------
+template <int ROWS, int D2>
+__global__ __launch_bounds__(THREADS) void k_v0(const uint8_t *__restrict__ buf, Args a, uint64_t ntiles, unsigned long long *cnt) {
+    uint32_t A[3] = {a.A[0], a.A[1], a.A[2]}, B[3] = {a.B[0], a.B[1], a.B[2]};
+    uint32_t qn = 0;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint8_t *src = buf + tile * (uint64_t)(ROWB * ROWS) + threadIdx.x * 16u;
+        uint4 v[ROWS]; uint2 h[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) { v[r] = *(const uint4 *)(src + r * ROWB); h[r] = *(const uint2 *)(src + r * ROWB + 16); }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const uint32_t w[6] = {v[r].x, v[r].y, v[r].z, v[r].w, h[r].x, h[r].y};
+#pragma unroll
+            for (int o = 0; o < 16; ++o) {
+                const uint32_t x = WIN(w, o), y = WIN(w, o + D2);
+                unsigned long long mk[3], any = 0;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) { mk[g] = __ballot(x == A[g]) & __ballot(y == B[g]); any |= mk[g]; }
+                if (any) {
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) if (mk[g]) rare(mk[g], qn);
+                }
+            }
+        }
+    }
+    if ((threadIdx.x & 63) == 0 && qn) atomicAdd(cnt, (unsigned long long)qn);
+}
+
+// ---- V1: mad_u24 hash, cmp + s_or, branch per offset --------------------------------------
+template <int ROWS, int DH>
+__global__ __launch_bounds__(THREADS) void k_v1(const uint8_t *__restrict__ buf, Args a, uint64_t ntiles, unsigned long long *cnt) {
+    uint32_t H[3] = {a.H[0], a.H[1], a.H[2]};
+    const uint32_t K = a.K;
+    uint32_t qn = 0;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint8_t *src = buf + tile * (uint64_t)(ROWB * ROWS) + threadIdx.x * 16u;
+        uint4 v[ROWS]; uint2 h[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) { v[r] = *(const uint4 *)(src + r * ROWB); h[r] = *(const uint2 *)(src + r * ROWB + 16); }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const uint32_t w[6] = {v[r].x, v[r].y, v[r].z, v[r].w, h[r].x, h[r].y};
+#pragma unroll
+            for (int o = 0; o < 16; ++o) {
+                const uint32_t x = WIN(w, o), y = WIN(w, o + DH);
+                const uint32_t hv = __umul24(y, K) + x;   // v_mad_u32_u24
+                unsigned long long mk[3], any = 0;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) { mk[g] = __ballot(hv == H[g]); any |= mk[g]; }
+                if (any) {
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) if (mk[g]) rare(mk[g], qn);
+                }
+            }
+        }
+    }
+    if ((threadIdx.x & 63) == 0 && qn) atomicAdd(cnt, (unsigned long long)qn);
+}
+
+// ---- V2: hash, cmp + s_or, branch per 4 offsets --------------------------------------------
+template <int ROWS, int DH>
+__global__ __launch_bounds__(THREADS) void k_v2(const uint8_t *__restrict__ buf, Args a, uint64_t ntiles, unsigned long long *cnt) {
+    uint32_t H[3] = {a.H[0], a.H[1], a.H[2]};
+    const uint32_t K = a.K;
+    uint32_t qn = 0;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint8_t *src = buf + tile * (uint64_t)(ROWB * ROWS) + threadIdx.x * 16u;
+        uint4 v[ROWS]; uint2 h[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) { v[r] = *(const uint4 *)(src + r * ROWB); h[r] = *(const uint2 *)(src + r * ROWB + 16); }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const uint32_t w[6] = {v[r].x, v[r].y, v[r].z, v[r].w, h[r].x, h[r].y};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned long long mk[4][3], any = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int o = 4 * j + i;
+                    const uint32_t x = WIN(w, o), y = WIN(w, o + DH);
+                    const uint32_t hv = __umul24(y, K) + x;
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) { mk[i][g] = __ballot(hv == H[g]); any |= mk[i][g]; }
+                }
+                if (any) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) if (mk[i][g]) rare(mk[i][g], qn);
+                }
+            }
+        }
+    }
+    if ((threadIdx.x & 63) == 0 && qn) atomicAdd(cnt, (unsigned long long)qn);
+}
+
+// ---- V3: hash, xor + min3 accumulate (no SALU), one ballot per 4 offsets --------------------
+__device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) { return min(a, min(b, c)); }
+template <int ROWS, int DH, int GROUP>
+__global__ __launch_bounds__(THREADS) void k_v3(const uint8_t *__restrict__ buf, Args a, uint64_t ntiles, unsigned long long *cnt) {
+    uint32_t H[3] = {a.H[0], a.H[1], a.H[2]};
+    const uint32_t K = a.K;
+    uint32_t qn = 0;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint8_t *src = buf + tile * (uint64_t)(ROWB * ROWS) + threadIdx.x * 16u;
+        uint4 v[ROWS]; uint2 h[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) { v[r] = *(const uint4 *)(src + r * ROWB); h[r] = *(const uint2 *)(src + r * ROWB + 16); }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const uint32_t w[6] = {v[r].x, v[r].y, v[r].z, v[r].w, h[r].x, h[r].y};
+#pragma unroll
+            for (int j = 0; j < 16 / GROUP; ++j) {
+                uint32_t acc = 0xffffffffu;
+                uint32_t hv[GROUP];
+#pragma unroll
+                for (int i = 0; i < GROUP; ++i) {
+                    const int o = GROUP * j + i;
+                    const uint32_t x = WIN(w, o), y = WIN(w, o + DH);
+                    hv[i] = __umul24(y, K) + x;
+                    acc = min3u(acc, hv[i] ^ H[0], hv[i] ^ H[1]);
+                    acc = min(acc, hv[i] ^ H[2]);
+                }
+                const unsigned long long any = __ballot(acc == 0);
+                if (any) {
+#pragma unroll
+                    for (int i = 0; i < GROUP; ++i)
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) { const unsigned long long mm = __ballot(hv[i] == H[g]); if (mm) rare(mm, qn); }
+                }
+            }
+        }
+    }
+    if ((threadIdx.x & 63) == 0 && qn) atomicAdd(cnt, (unsigned long long)qn);
+}
+
+// ---- V5: hash, v_cmp + v_addc-style per-lane counter (no SALU), ballot per GROUP offsets ------
+template <int ROWS, int DH, int GROUP>
+__global__ __launch_bounds__(THREADS) void k_v5(const uint8_t *__restrict__ buf, Args a, uint64_t ntiles, unsigned long long *cnt) {
+    uint32_t H[3] = {a.H[0], a.H[1], a.H[2]};
+    const uint32_t K = a.K;
+    uint32_t qn = 0;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint8_t *src = buf + tile * (uint64_t)(ROWB * ROWS) + threadIdx.x * 16u;
+        uint4 v[ROWS]; uint2 h[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) { v[r] = *(const uint4 *)(src + r * ROWB); h[r] = *(const uint2 *)(src + r * ROWB + 16); }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const uint32_t w[6] = {v[r].x, v[r].y, v[r].z, v[r].w, h[r].x, h[r].y};
+#pragma unroll
+            for (int j = 0; j < 16 / GROUP; ++j) {
+                uint32_t acc = 0;
+                uint32_t hv[GROUP];
+#pragma unroll
+                for (int i = 0; i < GROUP; ++i) {
+                    const int o = GROUP * j + i;
+                    const uint32_t x = WIN(w, o), y = WIN(w, o + DH);
+                    hv[i] = __umul24(y, K) + x;
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) acc += (hv[i] == H[g]) ? 1u : 0u;
+                }
+                const unsigned long long any = __ballot(acc != 0);
+                if (any) {
+#pragma unroll
+                    for (int i = 0; i < GROUP; ++i)
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) { const unsigned long long mm = __ballot(hv[i] == H[g]); if (mm) rare(mm, qn); }
+                }
+            }
+        }
+    }
+    if ((threadIdx.x & 63) == 0 && qn) atomicAdd(cnt, (unsigned long long)qn);
+}
+
+
+// ---- V6: v_qsad_pk_u16_u8 / v_mqsad_pk_u16_u8: 4 byte offsets per instruction, exact 8-byte compare ----
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pkmin(uint32_t a, uint32_t b) {
+    us2 x = __builtin_bit_cast(us2, a), y = __builtin_bit_cast(us2, b);
+    us2 r = __builtin_elementwise_min(x, y);
+    return __builtin_bit_cast(uint32_t, r);
+}
+template <int ROWS>
+__global__ __launch_bounds__(THREADS) void k_v6(const uint8_t *__restrict__ buf, Args a, uint64_t ntiles, unsigned long long *cnt) {
+    uint32_t A[3] = {a.A[0], a.A[1], a.A[2]}, B[3] = {a.B[0], a.B[1], a.B[2]};   // B = bytes 4..7 (masked)
+    uint32_t qn = 0;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint8_t *src = buf + tile * (uint64_t)(ROWB * ROWS) + threadIdx.x * 16u;
+        uint4 v[ROWS]; uint2 h[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) { v[r] = *(const uint4 *)(src + r * ROWB); h[r] = *(const uint2 *)(src + r * ROWB + 16); }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const uint32_t w[6] = {v[r].x, v[r].y, v[r].z, v[r].w, h[r].x, h[r].y};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint64_t p0 = ((uint64_t)w[j + 1] << 32) | w[j];
+                const uint64_t p1 = ((uint64_t)w[j + 2] << 32) | w[j + 1];
+                uint64_t R[3];
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    R[g] = __builtin_amdgcn_qsad_pk_u16_u8(p0, A[g], 0ull);
+                    R[g] = __builtin_amdgcn_mqsad_pk_u16_u8(p1, B[g], R[g]);
+                }
+                uint32_t lo = pkmin(pkmin((uint32_t)R[0], (uint32_t)R[1]), (uint32_t)R[2]);
+                uint32_t hi = pkmin(pkmin((uint32_t)(R[0] >> 32), (uint32_t)(R[1] >> 32)), (uint32_t)(R[2] >> 32));
+                uint32_t mm = pkmin(lo, hi);
+                mm = min(mm & 0xffffu, mm >> 16);
+                const unsigned long long any = __ballot(mm == 0);
+                if (any) {
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const unsigned long long mk = __ballot(((R[g] >> (16 * i)) & 0xffffu) == 0);
+                            if (mk) rare(mk, qn);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if ((threadIdx.x & 63) == 0 && qn) atomicAdd(cnt, (unsigned long long)qn);
+}
+
+// semantic probe of the (m)qsad instructions
+__global__ void k_probe(const uint64_t *s0, const uint32_t *s1, const uint64_t *s2, uint64_t *out_q, uint64_t *out_m) {
+    const int i = threadIdx.x;
+    out_q[i] = __builtin_amdgcn_qsad_pk_u16_u8(s0[i], s1[i], s2[i]);
+    out_m[i] = __builtin_amdgcn_mqsad_pk_u16_u8(s0[i], s1[i], s2[i]);
+}
+
+static uint32_t le32(const uint8_t *p) { return p[0] | p[1] << 8 | p[2] << 16 | (uint32_t)p[3] << 24; }
+
+template <class F>
+void run(const char *name, F launch, unsigned long long *d_cnt, uint64_t n, int rows) {
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    std::vector<float> ms;
+    unsigned long long h_cnt = 0;
+    for (int it = 0; it < 7; ++it) {
+        CHECK(hipMemset(d_cnt, 0, 8));
+        CHECK(hipEventRecord(e0));
+        launch();
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        CHECK(hipGetLastError());
+        float t; CHECK(hipEventElapsedTime(&t, e0, e1));
+        ms.push_back(t);
+        CHECK(hipMemcpy(&h_cnt, d_cnt, 8, hipMemcpyDeviceToHost));
+    }
+    std::sort(ms.begin(), ms.end());
+    printf("%-28s rows=%d  min %.4f ms  med %.4f ms  -> %.0f GB/s (min)  hits=%llu\n", name, rows, ms[0], ms[ms.size() / 2],
+           n / (ms[0] * 1e-3) / 1e9, h_cnt);
+}
+
+int main(int argc, char **argv) {
+    const uint64_t n = (argc > 1 ? strtoull(argv[1], 0, 10) : 1024ull) << 20;
+    uint8_t *buf;
+    CHECK(hipMalloc((void **)&buf, n + (1 << 20)));
+    CHECK(hipMemset(buf, 0, n + (1 << 20)));
+    hipLaunchKernelGGL(gen_dna, dim3(4096), dim3(256), 0, 0, buf, n, 12345ull);
+    CHECK(hipDeviceSynchronize());
+    unsigned long long *d_cnt;
+    CHECK(hipMalloc((void **)&d_cnt, 8));
+    const uint8_t pat[21] = "GATTACAGATTACACCGTTA";
+    Args a{};
+    a.K = 0x9E3779u; a.d2 = 2; a.dh = 3;
+    for (int g = 0; g < 3; ++g) {
+        a.A[g] = le32(pat + 6 * g);
+        a.B[g] = le32(pat + 6 * g + 2);
+        a.H[g] = (le32(pat + 6 * g + 3) & 0xffffffu) * a.K + a.A[g];
+    }
+    int cus = 256;
+    hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0)); cus = prop.multiProcessorCount;
+    printf("device %s, %d CUs, n = %llu MiB\n", prop.gcnArchName, cus, (unsigned long long)(n >> 20));
+#define RUN(NAME, KERN, ROWS, GRIDMUL) { const uint64_t nt = n / (ROWB * ROWS); dim3 grid((unsigned)std::min<uint64_t>(nt, (uint64_t)cus * GRIDMUL)); \
+    run(NAME, [&]() { hipLaunchKernelGGL(KERN, grid, dim3(THREADS), 0, 0, buf, a, nt, d_cnt); }, d_cnt, n, ROWS); }
+    RUN("stream r4 g8", (k_stream<4>), 4, 8);
+    RUN("stream r8 g8", (k_stream<8>), 8, 8);
+    RUN("stream r2 g8", (k_stream<2>), 2, 8);
+    RUN("stream r4 g16", (k_stream<4>), 4, 16);
+    RUN("v0 exact s_and/s_or", (k_v0<4, 2>), 4, 8);
+    RUN("v1 hash cmp s_or br/1", (k_v1<4, 3>), 4, 8);
+    RUN("v2 hash cmp s_or br/4", (k_v2<4, 3>), 4, 8);
+    RUN("v3 hash xor min3 grp4", (k_v3<4, 3, 4>), 4, 8);
+    RUN("v3 hash xor min3 grp8", (k_v3<4, 3, 8>), 4, 8);
+    RUN("v3 hash xor min3 grp16", (k_v3<4, 3, 16>), 4, 8);
+    RUN("v5 hash cmp addc grp4", (k_v5<4, 3, 4>), 4, 8);
+    RUN("v5 hash cmp addc grp8", (k_v5<4, 3, 8>), 4, 8);
+    {   // B for V6: n-gram bytes 4..5, zero (masked) beyond L = 6
+        Args a6 = a;
+        for (int g = 0; g < 3; ++g) a6.B[g] = pat[6 * g + 4] | pat[6 * g + 5] << 8;
+        Args keep = a; a = a6;
+        RUN("v6 qsad+mqsad", (k_v6<4>), 4, 8);
+        RUN("v6 qsad+mqsad r8", (k_v6<8>), 8, 8);
+        a = keep;
+    }
+    {   // probe semantics
+        const int N = 64;
+        uint64_t hs0[N], hs2[N], hq[N], hm[N]; uint32_t hs1[N];
+        uint64_t z = 88172645463325252ull;
+        for (int i = 0; i < N; ++i) {
+            z ^= z << 13; z ^= z >> 7; z ^= z << 17; hs0[i] = z;
+            z ^= z << 13; z ^= z >> 7; z ^= z << 17; hs1[i] = (uint32_t)z;
+            z ^= z << 13; z ^= z >> 7; z ^= z << 17; hs2[i] = z & 0x0fff0fff0fff0fffull;
+            if (i % 4 == 1) hs1[i] &= 0xffff00ffu;          // zero byte in reference
+            if (i % 4 == 2) hs0[i] &= 0xffffffff00ffff00ull; // zero bytes in data
+            if (i % 8 == 3) hs1[i] &= 0x0000ffffu;
+        }
+        uint64_t *d0, *d2, *dq, *dm; uint32_t *d1;
+        CHECK(hipMalloc((void **)&d0, N * 8)); CHECK(hipMalloc((void **)&d2, N * 8)); CHECK(hipMalloc((void **)&dq, N * 8));
+        CHECK(hipMalloc((void **)&dm, N * 8)); CHECK(hipMalloc((void **)&d1, N * 4));
+        CHECK(hipMemcpy(d0, hs0, N * 8, hipMemcpyHostToDevice)); CHECK(hipMemcpy(d1, hs1, N * 4, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(d2, hs2, N * 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_probe, dim3(1), dim3(N), 0, 0, d0, d1, d2, dq, dm);
+        CHECK(hipMemcpy(hq, dq, N * 8, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(hm, dm, N * 8, hipMemcpyDeviceToHost));
+        int bad_q = 0, bad_m_ref = 0, bad_m_data = 0;
+        for (int i = 0; i < N; ++i) {
+            uint64_t eq = 0, em_ref = 0, em_data = 0;
+            for (int f = 0; f < 4; ++f) {
+                uint32_t sq = 0, smr = 0, smd = 0;
+                for (int b = 0; b < 4; ++b) {
+                    const int db = (hs0[i] >> (8 * (f + b))) & 0xff, rb = (hs1[i] >> (8 * b)) & 0xff;
+                    const int ad = db > rb ? db - rb : rb - db;
+                    sq += ad; if (rb != 0) smr += ad; if (db != 0) smd += ad;
+                }
+                const uint32_t acc = (hs2[i] >> (16 * f)) & 0xffff;
+                eq |= (uint64_t)((sq + acc) & 0xffff) << (16 * f);
+                em_ref |= (uint64_t)((smr + acc) & 0xffff) << (16 * f);
+                em_data |= (uint64_t)((smd + acc) & 0xffff) << (16 * f);
+            }
+            bad_q += eq != hq[i]; bad_m_ref += em_ref != hm[i]; bad_m_data += em_data != hm[i];
+        }
+        printf("probe: qsad mismatches %d/64; mqsad vs mask-on-REFERENCE-zero %d/64; vs mask-on-DATA-zero %d/64\n", bad_q, bad_m_ref, bad_m_data);
+        for (int i = 0; i < 4; ++i) printf("  s0=%016llx s1=%08x s2=%016llx q=%016llx m=%016llx\n", (unsigned long long)hs0[i], hs1[i], (unsigned long long)hs2[i], (unsigned long long)hq[i], (unsigned long long)hm[i]);
+    }
+    RUN("v1 r2", (k_v1<2, 3>), 2, 8);
+    RUN("v1 r8", (k_v1<8, 3>), 8, 8);
+    RUN("v3 grp4 r2", (k_v3<2, 3, 4>), 2, 8);
+    RUN("v3 grp4 r8", (k_v3<8, 3, 4>), 8, 8);
+    RUN("v1 r4 g16", (k_v1<4, 3>), 4, 16);
+    RUN("v3 grp4 r4 g16", (k_v3<4, 3, 4>), 4, 16);
+    return 0;
+}

@@ -1,0 +1,321 @@
+"""ctypes binding of libfzhip.so (include/fzhip.h).  No PyTorch, no CPU fallback.
+
+The library is built in-tree by ``fuzzysearch_amd/build.py`` (hipcc, gfx950).  If it is missing or
+there is no MI355X, every search raises — this package never computes matches on the CPU.
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfzhip.so")
+
+FZ_OK, FZ_EINVAL, FZ_ENOMEM, FZ_EDEVICE, FZ_EUNSUPPORTED, FZ_EHALO = 0, -1, -2, -3, -4, -5
+UINT64_MAX = (1 << 64) - 1
+
+# every symbol include/fzhip.h declares (tests check the library exports exactly these)
+EXPORTED_SYMBOLS = (
+    "fz_abi_version", "fz_last_error", "fz_device_count", "fz_create", "fz_destroy",
+    "fz_seq_upload", "fz_seq_upload_shard", "fz_seq_len", "fz_seq_release",
+    "fz_search_exact", "fz_lev_ngrams", "fz_subs_ngrams", "fz_generic_ngrams",
+    "fz_consolidate", "fz_group_best", "fz_stats", "fz_free",
+)
+
+
+class FzMatch(ctypes.Structure):
+    _fields_ = [("start", ctypes.c_int64), ("end", ctypes.c_int64),
+                ("dist", ctypes.c_int32), ("block", ctypes.c_int32)]
+
+
+class FzStats(ctypes.Structure):
+    _fields_ = [("bytes_scanned", ctypes.c_uint64), ("ngram_hits", ctypes.c_uint64),
+                ("raw_matches", ctypes.c_uint64), ("filter_ms", ctypes.c_double),
+                ("verify_ms", ctypes.c_double), ("device_ms", ctypes.c_double),
+                ("filter_launches", ctypes.c_uint32), ("n_devices", ctypes.c_uint32)]
+
+
+class HipEngineError(RuntimeError):
+    """libfzhip.so missing / no usable gfx950 device / HIP runtime failure."""
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library():
+    """Load libfzhip.so and declare the C-ABI.  Raises HipEngineError if it is not built."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise HipEngineError(
+                "fuzzysearch_amd: %s is missing. Build it with `python -m fuzzysearch_amd.build` "
+                "(hipcc, --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        vp, u8p = ctypes.c_void_p, ctypes.c_void_p
+        u32, u64, ci = ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int
+        mpp = ctypes.POINTER(ctypes.POINTER(FzMatch))
+        u64p = ctypes.POINTER(u64)
+        L.fz_abi_version.restype = ci
+        L.fz_abi_version.argtypes = []
+        L.fz_last_error.restype = ctypes.c_char_p
+        L.fz_last_error.argtypes = []
+        L.fz_device_count.restype = ci
+        L.fz_device_count.argtypes = [ctypes.POINTER(ci)]
+        L.fz_create.restype = ci
+        L.fz_create.argtypes = [ctypes.POINTER(ci), ci, ctypes.POINTER(vp)]
+        L.fz_destroy.restype = None
+        L.fz_destroy.argtypes = [vp]
+        L.fz_seq_upload.restype = ci
+        L.fz_seq_upload.argtypes = [vp, u8p, u64, ctypes.POINTER(vp)]
+        L.fz_seq_upload_shard.restype = ci
+        L.fz_seq_upload_shard.argtypes = [vp, u8p, u64, u64, u64, u64, u64, ctypes.POINTER(vp)]
+        L.fz_seq_len.restype = u64
+        L.fz_seq_len.argtypes = [vp]
+        L.fz_seq_release.restype = None
+        L.fz_seq_release.argtypes = [vp]
+        L.fz_search_exact.restype = ci
+        L.fz_search_exact.argtypes = [vp, vp, u8p, u32, u64, u64, ctypes.POINTER(u64p), u64p]
+        L.fz_lev_ngrams.restype = ci
+        L.fz_lev_ngrams.argtypes = [vp, vp, u8p, u32, u32, mpp, u64p]
+        L.fz_subs_ngrams.restype = ci
+        L.fz_subs_ngrams.argtypes = [vp, vp, u8p, u32, u32, mpp, u64p]
+        L.fz_generic_ngrams.restype = ci
+        L.fz_generic_ngrams.argtypes = [vp, vp, u8p, u32, u32, u32, u32, u32, mpp, u64p]
+        L.fz_consolidate.restype = ci
+        L.fz_consolidate.argtypes = [ctypes.POINTER(FzMatch), u64, mpp, u64p]
+        L.fz_group_best.restype = ci
+        L.fz_group_best.argtypes = [ctypes.POINTER(FzMatch), u64, mpp, u64p]
+        L.fz_stats.restype = ci
+        L.fz_stats.argtypes = [vp, ctypes.POINTER(FzStats)]
+        L.fz_free.restype = None
+        L.fz_free.argtypes = [vp]
+        if L.fz_abi_version() != 1:
+            raise HipEngineError("libfzhip.so ABI version mismatch")
+        _lib = L
+        return L
+
+
+def _raise(rc):
+    msg = (load_library().fz_last_error() or b"").decode("utf-8", "replace")
+    if rc == FZ_EINVAL:
+        raise ValueError(msg)
+    if rc == FZ_ENOMEM:
+        raise MemoryError(msg)
+    if rc == FZ_EUNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise HipEngineError("libfzhip error %d: %s" % (rc, msg))
+
+
+def _check(rc):
+    if rc != FZ_OK:
+        _raise(rc)
+
+
+def _buffer_address(data):
+    """-> (address, nbytes, keepalive) of a C-contiguous 1-byte-item buffer, zero-copy where the
+    buffer protocol allows (bytes, bytearray, memoryview, numpy uint8 ...).  Same acceptance rule
+    as the reference's is_simple_buffer (_c_ext_base.h:27-34)."""
+    mv = memoryview(data)
+    if mv.itemsize != 1 or mv.ndim != 1 or not mv.c_contiguous:
+        raise TypeError("only contiguous sequences of single-byte values are supported")
+    n = mv.nbytes
+    if n == 0:
+        return None, 0, mv
+    if mv.readonly:
+        # ctypes cannot wrap a read-only buffer without a copy unless it is a bytes object
+        obj = mv.obj
+        if isinstance(obj, bytes):
+            return ctypes.cast(ctypes.c_char_p(obj), ctypes.c_void_p).value + _mv_offset(mv, obj), n, (mv, obj)
+        import numpy as np
+        arr = np.frombuffer(mv, dtype=np.uint8)
+        return arr.ctypes.data, n, (mv, arr)
+    c = (ctypes.c_char * n).from_buffer(mv)
+    return ctypes.addressof(c), n, (mv, c)
+
+
+def _mv_offset(mv, obj):
+    # offset of a memoryview slice into its bytes object (memoryview(b)[a:b])
+    if len(mv) == len(obj):
+        return 0
+    import numpy as np
+    base = np.frombuffer(obj, dtype=np.uint8).ctypes.data
+    return np.frombuffer(mv, dtype=np.uint8).ctypes.data - base
+
+
+def matches_to_array(raw):
+    n = len(raw)
+    arr = (FzMatch * max(1, n))()
+    for i, r in enumerate(raw):
+        arr[i].start, arr[i].end, arr[i].dist = r[0], r[1], r[2]
+        arr[i].block = r[3] if len(r) > 3 else -1
+    return arr, n
+
+
+_MATCH_DTYPE = None
+
+
+def _match_dtype():
+    global _MATCH_DTYPE
+    if _MATCH_DTYPE is None:
+        import numpy as np
+        _MATCH_DTYPE = np.dtype([("start", "<i8"), ("end", "<i8"), ("dist", "<i4"), ("block", "<i4")])
+    return _MATCH_DTYPE
+
+
+def _take_matches_array(L, ptr, n):
+    """-> numpy structured array (start, end, dist, block); one memcpy, then the C buffer is freed."""
+    import numpy as np
+    if n == 0:
+        L.fz_free(ptr)
+        return np.empty(0, dtype=_match_dtype())
+    buf = (ctypes.c_char * (n * ctypes.sizeof(FzMatch))).from_address(ctypes.addressof(ptr.contents))
+    arr = np.frombuffer(buf, dtype=_match_dtype()).copy()
+    L.fz_free(ptr)
+    return arr
+
+
+def _take_matches(L, ptr, n):
+    return _take_matches_array(L, ptr, n).tolist()
+
+
+def consolidate(raw):
+    """consolidate_overlapping_matches (common.py:185-189) on (start, end, dist[, block]) tuples."""
+    L = load_library()
+    arr, n = matches_to_array(raw)
+    ptr = ctypes.POINTER(FzMatch)()
+    cnt = ctypes.c_uint64(0)
+    _check(L.fz_consolidate(arr, n, ctypes.byref(ptr), ctypes.byref(cnt)))
+    return _take_matches(L, ptr, cnt.value)
+
+
+def group_best(raw):
+    """[get_best_match_in_group(g) for g in group_matches(ms)] in group-list order
+    (substitutions_only.py:279-282)."""
+    L = load_library()
+    arr, n = matches_to_array(raw)
+    ptr = ctypes.POINTER(FzMatch)()
+    cnt = ctypes.c_uint64(0)
+    _check(L.fz_group_best(arr, n, ctypes.byref(ptr), ctypes.byref(cnt)))
+    return _take_matches(L, ptr, cnt.value)
+
+
+class ResidentSequence(object):
+    """A sequence resident in HBM (fz_seq).  Keeps the engine alive; release() or GC frees it."""
+
+    def __init__(self, engine, handle, nbytes):
+        self.engine = engine
+        self._h = handle
+        self.nbytes = nbytes
+
+    def __len__(self):
+        return self.nbytes
+
+    def release(self):
+        if self._h is not None and self.engine._h is not None:
+            self.engine._lib.fz_seq_release(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class Engine(object):
+    """One fz_ctx: HIP streams, hit/record buffers and the resident sequences of one host thread."""
+
+    def __init__(self, devices=None):
+        self._lib = load_library()
+        self._h = None
+        h = ctypes.c_void_p()
+        if devices:
+            ids = (ctypes.c_int * len(devices))(*devices)
+            rc = self._lib.fz_create(ids, len(devices), ctypes.byref(h))
+        else:
+            rc = self._lib.fz_create(None, 0, ctypes.byref(h))
+        _check(rc)
+        self._h = h
+        self.devices = list(devices) if devices else [0]
+
+    def close(self):
+        if self._h is not None:
+            self._lib.fz_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- residency ---------------------------------------------------------------------------
+    def upload(self, data):
+        addr, n, keep = _buffer_address(data)
+        h = ctypes.c_void_p()
+        _check(self._lib.fz_seq_upload(self._h, addr, n, ctypes.byref(h)))
+        del keep
+        return ResidentSequence(self, h, n)
+
+    def upload_shard(self, data, buf_global_off, own_lo, own_hi, global_n):
+        addr, n, keep = _buffer_address(data)
+        h = ctypes.c_void_p()
+        _check(self._lib.fz_seq_upload_shard(self._h, addr, n, buf_global_off, own_lo, own_hi,
+                                              global_n, ctypes.byref(h)))
+        del keep
+        return ResidentSequence(self, h, global_n)
+
+    # -- searches (raw streams, tuples (start, end, dist, block)) ------------------------------
+    def search_exact(self, seq, pattern, lo=0, hi=None):
+        paddr, m, keep = _buffer_address(pattern)
+        ptr = ctypes.POINTER(ctypes.c_uint64)()
+        cnt = ctypes.c_uint64(0)
+        _check(self._lib.fz_search_exact(self._h, seq._h, paddr, m, max(0, lo),
+                                         UINT64_MAX if hi is None else max(0, hi),
+                                         ctypes.byref(ptr), ctypes.byref(cnt)))
+        out = list(ptr[:cnt.value])
+        self._lib.fz_free(ptr)
+        return out
+
+    def _match_call(self, fn, seq, pattern, *ints, **kw):
+        paddr, m, keep = _buffer_address(pattern)
+        ptr = ctypes.POINTER(FzMatch)()
+        cnt = ctypes.c_uint64(0)
+        _check(fn(self._h, seq._h, paddr, m, *ints, ctypes.byref(ptr), ctypes.byref(cnt)))
+        if kw.get("as_array"):
+            return _take_matches_array(self._lib, ptr, cnt.value)
+        return _take_matches(self._lib, ptr, cnt.value)
+
+    def lev_ngrams(self, seq, pattern, k, as_array=False):
+        """Raw stream of find_near_matches_levenshtein_ngrams: list of (start, end, dist, block)
+        tuples, or a numpy structured array with those fields (as_array=True, no per-record
+        Python objects)."""
+        return self._match_call(self._lib.fz_lev_ngrams, seq, pattern, k, as_array=as_array)
+
+    def subs_ngrams(self, seq, pattern, k, as_array=False):
+        return self._match_call(self._lib.fz_subs_ngrams, seq, pattern, k, as_array=as_array)
+
+    def generic_ngrams(self, seq, pattern, max_subs, max_ins, max_dels, max_l):
+        return self._match_call(self._lib.fz_generic_ngrams, seq, pattern, max_subs, max_ins, max_dels, max_l)
+
+    def stats(self):
+        st = FzStats()
+        _check(self._lib.fz_stats(self._h, ctypes.byref(st)))
+        return {f: getattr(st, f) for f, _ in FzStats._fields_}
+
+
+_default_engine = None
+_default_lock = threading.Lock()
+
+
+def default_engine():
+    """Process-wide engine.  FUZZYSEARCH_HIP_DEVICES="0,1,..." selects the devices."""
+    global _default_engine
+    with _default_lock:
+        if _default_engine is None:
+            env = os.environ.get("FUZZYSEARCH_HIP_DEVICES", "").strip()
+            devices = [int(x) for x in env.split(",") if x.strip()] if env else None
+            _default_engine = Engine(devices)
+        return _default_engine

@@ -1,0 +1,48 @@
+"""Build libfzhip.so (the gfx950 HIP engine) in-tree with hipcc.
+
+    python -m fuzzysearch_amd.build [--force] [--report]
+
+hipcc cross-compiles for gfx950 without a GPU, so this runs in the CPU-only build container; the
+resulting fuzzysearch_amd/libfzhip.so travels to the GPU box with the repo snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libfzhip.so")
+SOURCES = ["fzhip.hip"]
+DEPS = ["fzhip.hip", "fz_kernels.h", "fz_device.h", os.path.join("..", "..", "include", "fzhip.h")]
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm >= 7.0)")
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+
+
+def build(force=False, report=False):
+    if not force and not needs_build():
+        return LIB
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
+    if report:
+        cmd.append("-Rpass-analysis=kernel-resource-usage")
+    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+    subprocess.check_call(cmd, cwd=CSRC)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, report="--report" in sys.argv))

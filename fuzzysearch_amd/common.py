@@ -1,0 +1,168 @@
+"""Result record, search parameters and the strategy-class contract of the drop-in API.
+
+Mirrors (behaviour, not code) src/fuzzysearch/common.py of the reference:
+  Match                     common.py:15-32   attrs class, frozen + slots, eq/hash/order on
+                                              (start, end, dist); ``matched`` excluded; validated
+  LevenshteinSearchParams   common.py:35-116  validation (TypeError / ValueError) + normalisation
+  FuzzySearchBase           common.py:192-209 search / consolidate_matches /
+                                              extra_items_for_chunked_search
+  consolidate_overlapping_matches, group_matches, get_best_match_in_group   common.py:145-189
+
+Consolidation runs in libfzhip's host code (fz_consolidate / fz_group_best): sort + sweep instead
+of the reference's O(M * groups) Python loop, with a deterministic tie-break (smallest start)
+where the reference's answer depends on PYTHONHASHSEED (SURVEY.md trap 3).
+"""
+import attr
+
+from . import _native
+
+__all__ = [
+    'Match', 'LevenshteinSearchParams', 'FuzzySearchBase',
+    'group_matches', 'get_best_match_in_group', 'consolidate_overlapping_matches',
+    'count_differences_with_maximum',
+]
+
+_UNLIMITED = 1 << 29
+
+
+@attr.s(frozen=True, slots=True)
+class Match(object):
+    start = attr.ib(type=int, eq=True, hash=True)
+    end = attr.ib(type=int, eq=True, hash=True)
+    dist = attr.ib(type=int, eq=True, hash=True)
+    matched = attr.ib(eq=False, hash=False)
+
+    if __debug__:
+        def __attrs_post_init__(self):
+            if not (isinstance(self.start, int) and self.start >= 0):
+                raise ValueError('start must be a non-negative integer')
+            if not (isinstance(self.end, int) and self.end >= self.start):
+                raise ValueError('end must be an integer no smaller than start')
+            if not (isinstance(self.dist, int) and self.dist >= 0):
+                raise ValueError('dist must be a non-negative integer')
+            if self.matched is None:
+                raise ValueError('matched must be supplied')
+
+
+def _is_limit(x):
+    return x is None or (isinstance(x, int) and x >= 0)
+
+
+@attr.s(frozen=True, slots=True, init=False)
+class LevenshteinSearchParams(object):
+    """(max_substitutions, max_insertions, max_deletions, max_l_dist), validated and normalised."""
+    max_substitutions = attr.ib(default=None)
+    max_insertions = attr.ib(default=None)
+    max_deletions = attr.ib(default=None)
+    max_l_dist = attr.ib(default=None)
+
+    def __init__(self, max_substitutions=None, max_insertions=None, max_deletions=None, max_l_dist=None):
+        limits = (max_substitutions, max_insertions, max_deletions)
+        if not all(_is_limit(x) for x in limits + (max_l_dist,)):
+            raise TypeError("All limits must be positive integers or None.")
+        if max_l_dist is None:
+            given = [x is not None for x in limits]
+            if not any(given):
+                raise ValueError('No limitations given!')
+            for ok, what in zip(given, ('substitutions', 'insertions', 'deletions')):
+                if not ok:
+                    raise ValueError('# %s must be limited!' % what)
+        total = sum(_UNLIMITED if x is None else x for x in limits)
+        if max_l_dist is None:
+            norm = limits + (total,)
+        else:
+            norm = tuple(max_l_dist if x is None else min(x, max_l_dist) for x in limits) \
+                + (min(max_l_dist, total),)
+        for name, value in zip(('max_substitutions', 'max_insertions', 'max_deletions', 'max_l_dist'), norm):
+            object.__setattr__(self, name, value)
+
+    @property
+    def unpacked(self):
+        return (self.max_substitutions, self.max_insertions, self.max_deletions, self.max_l_dist)
+
+
+def count_differences_with_maximum(sequence1, sequence2, max_differences):
+    """common.py:119-142 — tiny helper kept for API completeness (host side, not a hot path)."""
+    n_different = 0
+    for a, b in zip(sequence1, sequence2):
+        if a != b:
+            n_different += 1
+            if n_different == max_differences:
+                break
+    return n_different
+
+
+def _as_tuples(matches):
+    return [(m.start, m.end, m.dist) for m in matches]
+
+
+def group_matches(matches):
+    """-> list of sets of overlapping matches, in the reference's group-list order."""
+    matches = list(matches)
+    groups = []   # [start, end, set]
+    for match in matches:
+        hit = [g for g in groups if not (match.end <= g[0] or match.start >= g[1])]
+        if not hit:
+            groups.append([match.start, match.end, {match}])
+        elif len(hit) == 1:
+            g = hit[0]
+            g[0], g[1] = min(g[0], match.start), max(g[1], match.end)
+            g[2].add(match)
+        else:
+            merged = [match.start, match.end, {match}]
+            for g in hit:
+                merged[0], merged[1] = min(merged[0], g[0]), max(merged[1], g[1])
+                merged[2] |= g[2]
+            groups = [g for g in groups if not any(g is h for h in hit)]
+            groups.append(merged)
+    return [g[2] for g in groups]
+
+
+def get_best_match_in_group(group):
+    """Longest of the smallest-distance matches; ties -> smallest start (deterministic)."""
+    return min(group, key=lambda m: (m.dist, -(m.end - m.start), m.start))
+
+
+def consolidate_overlapping_matches(matches):
+    """One best match per group of overlapping matches, sorted (common.py:185-189)."""
+    matches = list(matches)
+    if not matches:
+        return []
+    by_key = {}
+    for m in matches:
+        by_key.setdefault((m.start, m.end, m.dist), m)
+    best = _native.consolidate(_as_tuples(matches))
+    return [by_key[(s, e, d)] for (s, e, d, _b) in best]
+
+
+def best_of_groups_in_discovery_order(matches):
+    """[get_best_match_in_group(g) for g in group_matches(matches)] (substitutions_only.py:279-282)."""
+    matches = list(matches)
+    if not matches:
+        return []
+    by_key = {}
+    for m in matches:
+        by_key.setdefault((m.start, m.end, m.dist), m)
+    best = _native.group_best(_as_tuples(matches))
+    return [by_key[(s, e, d)] for (s, e, d, _b) in best]
+
+
+class FuzzySearchBase(object):
+    """Strategy-class contract (common.py:192-209)."""
+
+    @classmethod
+    def search(cls, subsequence, sequence, search_params):
+        raise NotImplementedError
+
+    @classmethod
+    def consolidate_matches(cls, matches):
+        try:
+            len(matches)
+        except TypeError:
+            return list(matches)
+        else:
+            return matches
+
+    @classmethod
+    def extra_items_for_chunked_search(cls, subsequence, search_params):
+        raise NotImplementedError

@@ -1,0 +1,200 @@
+// fz_device.h — per-candidate verification logic shared by the HIP kernels (fz_kernels.h).
+//
+// Everything here is FZ_HD (__host__ __device__) so that tests/ can also compile the very same
+// functions with g++ and run them lane-by-lane against the oracle in the CPU-only container
+// (tests/host_emul.cpp).  The product only ever runs them on the GPU.
+//
+// Reference semantics (file:line into /root/reference/src/fuzzysearch/), see SURVEY.md App. A:
+//   fz_expand           <- c_expand_short / c_expand_long       _levenshtein_ngrams.pyx:9-154
+//   fz_verify_lev       <- body of the hit loop                 levenshtein_ngram.py:177-198
+//   fz_verify_subs      <- mismatch counting around a hit       _substitutions_only_ngrams_template.h:103-121
+//                          + count_differences_with_maximum     common.py:119-142 / substitutions_only.py:266-278
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define FZ_HD __host__ __device__ __forceinline__
+#else
+#define FZ_HD inline
+#endif
+
+#define FZ_MAX_BLOCKS_PER_LAUNCH 8     // n-gram blocks tested by one filter launch
+#define FZ_MAX_M 1024                  // pattern bytes carried in the kernel argument block
+#define FZ_MAX_K 255                   // largest edit budget the verify kernels support
+#define FZ_HASH_K 0x9E3779u            // 24-bit multiplier of the window hash (v_mad_u32_u24)
+
+enum FzMode : uint32_t { FZ_MODE_EXACT = 0, FZ_MODE_LEV = 1, FZ_MODE_SUBS = 2, FZ_MODE_GENERIC = 3 };
+
+// Geometry of the resident (shard of the) sequence.  All match arithmetic is in GLOBAL
+// coordinates; `buf` holds global bytes [buf_off, buf_off + buf_len).
+struct FzGeom {
+    uint64_t n;         // global sequence length (every clamp of App. A uses this)
+    uint64_t buf_off;   // global index of buf[0]
+    uint64_t buf_len;   // valid bytes in buf (the allocation is zero-padded on both sides)
+    uint64_t own_lo;    // this shard owns n-gram hits with own_lo <= idx < own_hi
+    uint64_t own_hi;
+};
+
+// One scan launch: up to 8 n-gram blocks of length L.  A hit of block b at global index idx is
+// accepted iff lo[b] <= idx && idx + L <= hi[b] && own_lo <= idx < own_hi.
+struct FzScanArgs {
+    FzGeom   geom;
+    uint32_t mode;                              // FzMode: what happens to confirmed hits
+    uint32_t m, k;                              // pattern length, edit / substitution budget
+    uint32_t L;                                 // n-gram length
+    uint32_t nblk;                              // real blocks in this launch (<= template TG)
+    uint32_t g0;                                // global block index of block 0 of this launch
+    uint32_t d2;                                // byte offset of the 2nd exact-compare window
+    uint32_t mask1;                             // mask of the 1st window ((1 << 8L) - 1 when L < 4)
+    uint32_t mask2;                             // mask of the 2nd window (n-gram bytes d2 .. d2+3)
+    uint32_t fused;                             // 1: verify inside the scan kernel, 0: emit hits
+    uint32_t band_w;                            // rolling score slots per lane (2k + 2)
+    uint32_t win_dwords;                        // window dwords staged per lane ((m + 2k + 6) / 4 + 1)
+    uint32_t H[FZ_MAX_BLOCKS_PER_LAUNCH];       // fast-path hash of each block's n-gram
+    uint32_t A[FZ_MAX_BLOCKS_PER_LAUNCH];       // 1st window value per block (little endian)
+    uint32_t B[FZ_MAX_BLOCKS_PER_LAUNCH];       // 2nd window value per block
+    uint64_t lo[FZ_MAX_BLOCKS_PER_LAUNCH];
+    uint64_t hi[FZ_MAX_BLOCKS_PER_LAUNCH];
+    uint32_t s[FZ_MAX_BLOCKS_PER_LAUNCH];       // ngram_start of each block inside the pattern
+    uint64_t hit_cap;                           // capacity of the hit list
+    uint64_t rec_cap;                           // capacity of the record list
+    uint8_t  pat[FZ_MAX_M];                     // whole pattern
+};
+
+// A hit: (block g << 56) | global idx.   A record: what verification produced for one hit.
+struct FzRec {
+    uint64_t key;        // (g << 56) | idx  -> sorting by key restores the reference's order
+    uint32_t l;          // bytes consumed to the left of idx   (start = idx - l)
+    uint32_t r;          // bytes consumed right of the n-gram  (end   = idx + L + r)
+    uint32_t dist;
+    uint32_t aux;
+};
+
+FZ_HD uint64_t fz_hit_pack(uint32_t g, uint64_t idx) { return ((uint64_t)g << 56) | idx; }
+FZ_HD uint32_t fz_hit_block(uint64_t h) { return (uint32_t)(h >> 56); }
+FZ_HD uint64_t fz_hit_index(uint64_t h) { return h & 0x00ffffffffffffffull; }
+
+// Hash of the first min(L, 8) bytes of an n-gram window as the filter's fast path computes it:
+//   x  = bytes [0, 4)                  (little-endian dword)
+//   yh = low 24 bits of the dword at byte min(L, 8) - 3, i.e. bytes [min(L,8)-3, min(L,8))
+//   h  = yh * FZ_HASH_K + x            (one v_mad_u32_u24)
+// For L <= 4 the masked dword itself is used.  Collisions only cost a visit to the exact re-check.
+FZ_HD uint32_t fz_hash_windows(uint32_t x, uint32_t yh) { return (yh & 0xffffffu) * FZ_HASH_K + x; }
+
+// ---------------------------------------------------------------------------------------------
+// Bounded edit-distance expansion == c_expand_short == c_expand_long (SURVEY.md trap 2):
+//   D[i][0] = i, D[0][j] = j, D[i][j] = min(D[i-1][j-1] + (sub[i-1] != win[j-1]), D[i][j-1]+1, D[i-1][j]+1)
+//   best = len(sub), arg = 0;  for j = 1..len(win): if D[len(sub)][j] <= best: best, arg = D[..][j], j
+//   -> (best, arg) if best <= budget else none.
+// Evaluated column by column like the reference, but only on the diagonal band |i - j| <= budget:
+// a cell outside the band is > budget, and cells > budget can never produce a cell <= budget, so
+// the banded result is exact for every outcome that passes `best <= budget` (App. A.1: 0/100000).
+// The band of one column is kept in a ring of W = 2*budget + 2 slots per lane (row i lives in slot
+// i mod W; LDS on the GPU): Sc.get(slot) / Sc.set(slot, v).
+// `sub(i)` / `win(j)` return element i / j of the (possibly reversed) piece and window.
+template <class Sc, class SubF, class WinF>
+FZ_HD bool fz_expand(Sc &sc, SubF sub, uint32_t sublen, WinF win, uint32_t winlen, uint32_t budget,
+                     uint32_t &dist, uint32_t &consumed) {
+    if (sublen == 0) { dist = 0; consumed = 0; return true; }       // pyx:28-30
+    const uint32_t big = budget + 1;                                // "more than the budget"
+    const uint32_t W = 2 * budget + 2;
+    uint32_t best = sublen, arg = 0;
+    // column 0: D[i][0] = i.  Only rows 1..budget can matter (D[i][0] > budget otherwise).
+    {
+        uint32_t rows = budget < sublen ? budget : sublen;
+        for (uint32_t i = 1; i <= rows; ++i) sc.set(i, i);          // i < W, slot = i
+    }
+    // columns beyond sublen + budget cannot hold a bottom-row value <= budget
+    uint32_t jmax = winlen;
+    if (jmax > sublen + budget) jmax = sublen + budget;
+    uint32_t i0 = 1, slot0 = 1;                                     // first band row and its slot
+    for (uint32_t j = 1; j <= jmax; ++j) {
+        const uint8_t ch = win(j - 1);
+        // rows in band for this column: i in [max(1, j - budget), min(sublen, j + budget)]
+        if (j > budget + 1) { ++i0; slot0 = (slot0 + 1 == W) ? 0 : slot0 + 1; }
+        uint32_t i1 = j + budget; if (i1 > sublen) i1 = sublen;
+        if (i0 > i1) break;                                         // band left the table (j - budget > sublen)
+        uint32_t a, c;
+        if (i0 == 1) { a = j - 1; c = j; }                          // D[0][j-1], D[0][j]  (pyx:49-50)
+        else { a = sc.get(slot0 == 0 ? W - 1 : slot0 - 1); c = big; }  // D[i0-1][j-1] in band; D[i0-1][j] out
+        uint32_t slot = slot0;
+        uint32_t cmin = c;                                          // min over this column's band (+ D[0][j])
+        for (uint32_t i = i0; i <= i1; ++i) {
+            // left neighbour D[i][j-1]: out of band when i - (j-1) > budget -> treat as > budget
+            uint32_t b = (i + 1 > j + budget) ? big : sc.get(slot);
+            uint32_t v = a + (ch != sub(i - 1) ? 1u : 0u);          // pyx:54-58
+            if (b + 1 < v) v = b + 1;
+            if (c + 1 < v) v = c + 1;
+            sc.set(slot, v);
+            c = v;
+            a = b;
+            if (v < cmin) cmin = v;
+            slot = (slot + 1 == W) ? 0 : slot + 1;
+        }
+        if (i1 == sublen && c <= best) { best = c; arg = j; }       // '<=' -> LAST arg-min (pyx:67-69)
+        // column minima never decrease: once every cell is over budget no later column can pass
+        // (the reference bails the same way, pyx:61-65)
+        if (cmin > budget) break;
+    }
+    if (best <= budget) { dist = best; consumed = arg; return true; }
+    return false;
+}
+
+// levenshtein_ngram.py:177-198 for one hit (block starting at s in the pattern, hit at idx).
+// `t.at(g)` returns the sequence byte at GLOBAL index g; only indices inside
+// [max(0, idx-s-k), min(n, idx-s+m+k)) are ever requested.
+template <class Sc, class Seq>
+FZ_HD bool fz_verify_lev(Sc &sc, const Seq &t, uint64_t n, const uint8_t *p, uint32_t m,
+                         uint32_t k, uint32_t L, uint32_t s, uint64_t idx, FzRec &rec) {
+    // right: p[s+L:] vs t[idx+L : min(n, idx-s+m+k)]      (idx >= s-k guarantees idx-s+m+k >= 0)
+    const uint32_t rlen = m - s - L;
+    uint64_t rbeg = idx + L;
+    uint64_t rend = idx + m + k - s; if (rend > n) rend = n;
+    if (rbeg > n) rbeg = n;
+    if (rend < rbeg) rend = rbeg;
+    uint32_t dR = 0, r = 0;
+    {
+        const uint8_t *ps = p + s + L;
+        auto sub = [&](uint32_t i) -> uint8_t { return ps[i]; };
+        auto win = [&](uint32_t j) -> uint8_t { return t.at(rbeg + j); };
+        if (!fz_expand(sc, sub, rlen, win, (uint32_t)(rend - rbeg), k, dR, r)) return false;
+    }
+    // left: reversed p[:s] vs reversed t[max(0, idx-s-(k-dR)) : idx], budget k - dR
+    const uint32_t bl = k - dR;
+    uint64_t want = (uint64_t)s + bl;
+    uint64_t lbeg = (idx > want) ? (idx - want) : 0;
+    uint32_t dL = 0, l = 0;
+    {
+        auto sub = [&](uint32_t i) -> uint8_t { return p[s - 1 - i]; };
+        auto win = [&](uint32_t j) -> uint8_t { return t.at(idx - 1 - j); };
+        if (!fz_expand(sc, sub, s, win, (uint32_t)(idx - lbeg), bl, dL, l)) return false;
+    }
+    rec.l = l; rec.r = r; rec.dist = dL + dR; rec.aux = 0;
+    return true;
+}
+
+// _substitutions_only_ngrams_template.h:103-121 for one hit h of the block starting at s:
+// window start i = h - s; accept iff Hamming(p, t[i:i+m]) <= k.  The caller guarantees
+// s <= h and h - s + m <= n (the block's hit range).  dist = min(Hamming, k+1) (common.py:119-142
+// as called from substitutions_only.py:270-274) which, for an accepted window, is the Hamming
+// distance itself.
+template <class Seq>
+FZ_HD bool fz_verify_subs(const Seq &t, const uint8_t *p, uint32_t m, uint32_t k, uint32_t L,
+                          uint32_t s, uint64_t h, FzRec &rec) {
+    const uint64_t i0 = h - s;
+    uint32_t nd = 0;
+    for (uint32_t q = 0; q < m; ++q) {
+        if (q == s) { q += L - 1; continue; }                       // the n-gram itself matched
+        nd += (p[q] != t.at(i0 + q)) ? 1u : 0u;
+        if (nd > k) return false;
+    }
+    rec.l = s; rec.r = m - s - L; rec.dist = nd; rec.aux = 0;
+    return true;
+}
+
+// Plain byte accessor over a resident buffer in GLOBAL coordinates (host emulation / tests).
+struct FzSeqView {
+    const uint8_t *buf;
+    uint64_t buf_off;
+    FZ_HD uint8_t at(uint64_t gidx) const { return buf[gidx - buf_off]; }
+};

@@ -1,0 +1,373 @@
+// fz_kernels.h — hand-written HIP kernels for gfx950 (MI355X, CDNA4).  Included by fzhip.hip.
+//
+//   fz_scan_kernel    ONE streaming pass over the resident sequence:
+//     K1 filter   every byte offset is tested against all G n-gram blocks at once (replaces G x
+//                 search_exact_byteslike passes, _common.c:75-102 / memmem.c:92-160): a one-op
+//                 hash of the first min(L,8) window bytes is compared with SGPR constants,
+//                 pure VALU (v_alignbyte / v_mad_u32_u24 / v_xor / v_min3), one ballot per 4
+//                 offsets; survivors go through a per-wave LDS queue to an exact re-check;
+//     K2 verify   confirmed hits wait in a per-wave LDS staging area and are verified 64 at a
+//                 time, one lane per hit, inside the same kernel: the <= m+2k window bytes are
+//                 fetched once into LDS, then the bounded edit-distance expansion right and left
+//                 (c_expand_*, _levenshtein_ngrams.pyx:9-154) or the Hamming count
+//                 (_substitutions_only_ngrams_template.h:103-121) runs on a ring of 2k+2 LDS score
+//                 slots per lane.  Only match records leave the chip.
+//   fz_verify_kernel  the same wave-level verification over a hit list in HBM, for parameter
+//                 ranges whose LDS footprint does not fit beside the filter (large m or k).
+//
+// HBM-bound integer/byte work: no MFMA.  What matters (MI355X guide): 16-byte coalesced loads,
+// >= 2048 workgroups' worth of loads in flight, no per-byte branching, SGPR-resident n-gram
+// constants, wave-uniform rare paths, ONE global atomic per bulk append (a single counter word
+// sustains only ~90 atomics/us chip-wide).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fz_device.h"
+
+#define FZ_FILTER_THREADS 256
+#define FZ_WAVES_PER_BLOCK (FZ_FILTER_THREADS / 64)
+#define FZ_FILTER_ROWS 4                                   // 16-byte rows per thread per tile
+#define FZ_ROW_BYTES (FZ_FILTER_THREADS * 16)              // 4 KiB
+#define FZ_TILE_BYTES (FZ_ROW_BYTES * FZ_FILTER_ROWS)      // 16 KiB
+#define FZ_PAD_FRONT 256                                   // zero bytes before buf[0]
+#define FZ_PAD_BACK 64                                     // zero bytes the kernels may over-read
+#define FZ_QCAP 256                                        // fast-hit queue entries per wave
+
+// 32-bit little-endian window starting `b` bytes into the 64-bit value hi:lo (v_alignbyte_b32).
+__device__ __forceinline__ uint32_t fz_win(uint32_t lo, uint32_t hi, int b) {
+    return b == 0 ? lo : __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)b);
+}
+#define FZ_WIN(w, o) fz_win((w)[(o) >> 2], (w)[((o) >> 2) + 1], (o) & 3)
+
+__device__ __forceinline__ uint32_t fz_lane() { return threadIdx.x & 63u; }
+
+__device__ __forceinline__ uint32_t fz_rank(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// Make this wave's earlier LDS writes visible to its own later LDS reads (wave-synchronous code:
+// no other wave shares these LDS regions, so no s_barrier is needed).
+__device__ __forceinline__ void fz_wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// 32-bit window at an arbitrary (unaligned) local byte position: two aligned dword loads.
+__device__ __forceinline__ uint32_t fz_load_win(const uint8_t *__restrict__ buf, int64_t local) {
+    const int64_t base = local & ~(int64_t)3;
+    const uint32_t lo = *reinterpret_cast<const uint32_t *>(buf + base);
+    const uint32_t hi = *reinterpret_cast<const uint32_t *>(buf + base + 4);
+    return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(local & 3));
+}
+
+// Per-wave LDS areas, carved from dynamic LDS by fz_wave_lds().
+struct FzWaveLds {
+    uint32_t *queue;      // [FZ_QCAP]  fast hits: tile-local offset | block << 14 | tile iteration << 17
+    uint32_t *win;        // [win_dwords * 64]  sequence window of each lane's hit (dword d of lane l at d*64+l)
+    uint16_t *scores;     // [band_w * 64]      ring of DP score slots (slot s of lane l at s*64+l)
+};
+
+__host__ __device__ inline uint32_t fz_wave_lds_bytes(uint32_t win_dwords, uint32_t band_w, bool with_queue) {
+    uint32_t b = 0;
+    if (with_queue) b += FZ_QCAP * 4;
+    b += win_dwords * 64 * 4;
+    b += ((band_w * 64 * 2) + 15u) & ~15u;
+    return b;
+}
+
+__device__ __forceinline__ FzWaveLds fz_wave_lds(uint8_t *base, uint32_t wave, uint32_t win_dwords, uint32_t band_w,
+                                                 bool with_queue) {
+    uint8_t *p = base + (size_t)wave * fz_wave_lds_bytes(win_dwords, band_w, with_queue);
+    FzWaveLds w;
+    w.queue = nullptr;
+    if (with_queue) { w.queue = reinterpret_cast<uint32_t *>(p); p += FZ_QCAP * 4; }
+    w.win = reinterpret_cast<uint32_t *>(p); p += win_dwords * 64 * 4;
+    w.scores = reinterpret_cast<uint16_t *>(p);
+    return w;
+}
+
+// LDS-resident accessors used by fz_verify_* on the GPU.
+struct FzLdsScores {
+    uint16_t *base;                                        // already offset by the lane
+    __device__ __forceinline__ uint32_t get(uint32_t slot) const { return base[slot * 64u]; }
+    __device__ __forceinline__ void set(uint32_t slot, uint32_t v) { base[slot * 64u] = (uint16_t)v; }
+};
+struct FzLdsWindow {
+    const uint8_t *base;                                   // lane's dword 0, as bytes
+    uint64_t wbase;                                        // global index of byte 0 of the window
+    __device__ __forceinline__ uint8_t at(uint64_t gidx) const {
+        const uint32_t off = (uint32_t)(gidx - wbase);
+        return base[(off >> 2) * 256u + (off & 3u)];       // dword (off/4) of this lane is 64 dwords further on
+    }
+};
+
+__device__ __forceinline__ unsigned long long fz_bcast64(unsigned long long v) {
+    return ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) |
+           __builtin_amdgcn_readfirstlane((uint32_t)v);
+}
+
+// Index-range tests of a candidate (block's accepted hit range, shard ownership).
+__device__ __forceinline__ bool fz_in_range(const FzScanArgs &a, uint32_t blk, uint64_t idx) {
+    if (blk >= a.nblk) return false;
+    if (idx < a.lo[blk] || idx + a.L > a.hi[blk]) return false;
+    return idx >= a.geom.own_lo && idx < a.geom.own_hi;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wave-level verification of up to 64 candidates: each lane owns one (hit = block | idx).
+//  1. every lane fetches the <= m + 2k window bytes around its candidate into LDS with independent
+//     aligned dword loads (one HBM/L2 round trip instead of one per byte),
+//  2. confirms the n-gram exactly (the filter only compared a hash), then runs the reference's
+//     per-hit logic (fz_verify_lev / fz_verify_subs) out of LDS,
+//  3. the wave appends its records with ONE global atomic.
+// Returns the number of exactly-confirmed n-gram hits (wave-uniform, statistics).
+__device__ __forceinline__ uint32_t fz_wave_verify(const uint8_t *__restrict__ buf, const FzScanArgs &a,
+                                                   const uint8_t *pat_lds, const FzWaveLds &w,
+                                                   uint64_t hit, bool valid,
+                                                   FzRec *__restrict__ recs, unsigned long long *__restrict__ counters) {
+    const uint32_t lane = fz_lane();
+    const uint32_t g = fz_hit_block(hit);
+    const uint64_t idx = fz_hit_index(hit);
+    const uint32_t s = g * a.L;
+    // window [wlo, whi) in global coordinates; every byte the verification touches lies inside it
+    uint64_t wlo = 0, whi = 0, wbase = 0;
+    if (valid) {
+        const uint64_t reach = (uint64_t)s + a.k;
+        wlo = idx > reach ? idx - reach : 0;
+        if (wlo < a.geom.buf_off) wlo = a.geom.buf_off;
+        whi = idx - s + a.m + a.k;
+        const uint64_t lim = a.geom.buf_off + a.geom.buf_len;
+        if (whi > lim) whi = lim;
+        if (whi > a.geom.n) whi = a.geom.n;
+        wbase = a.geom.buf_off + ((wlo - a.geom.buf_off) & ~(uint64_t)3);   // dword-aligned in the buffer
+    }
+    const uint32_t nd = valid ? (uint32_t)((whi - wbase + 3) >> 2) : 0u;
+    const int64_t lbase = (int64_t)(wbase - a.geom.buf_off);
+    for (uint32_t d = 0; d < a.win_dwords; ++d)
+        if (d < nd) w.win[d * 64u + lane] = *reinterpret_cast<const uint32_t *>(buf + lbase + (int64_t)d * 4);
+    fz_wave_lds_sync();
+    FzRec rec;
+    bool ok = false;
+    FzLdsWindow t{reinterpret_cast<const uint8_t *>(w.win + lane), wbase};
+    if (valid) {
+        const uint8_t *ng = pat_lds + s;
+        for (uint32_t b = 0; b < a.L; ++b)
+            if (ng[b] != t.at(idx + b)) { valid = false; break; }
+    }
+    const uint32_t confirmed = (uint32_t)__popcll(__ballot(valid));
+    if (valid) {
+        if (a.mode == FZ_MODE_LEV) {
+            FzLdsScores sc{w.scores + lane};
+            ok = fz_verify_lev(sc, t, a.geom.n, pat_lds, a.m, a.k, a.L, s, idx, rec);
+        } else {
+            ok = fz_verify_subs(t, pat_lds, a.m, a.k, a.L, s, idx, rec);
+        }
+    }
+    const unsigned long long mask = __ballot(ok);
+    if (mask) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&counters[1], (unsigned long long)__popcll(mask));
+        base = fz_bcast64(base);
+        if (ok) {
+            rec.key = hit;
+            const unsigned long long slot = base + fz_rank(mask);
+            if (slot < a.rec_cap) recs[slot] = rec;
+        }
+    }
+    fz_wave_lds_sync();
+    return confirmed;
+}
+
+// Exact test of one (local position, block) candidate against the buffer in HBM (emit mode).
+__device__ __forceinline__ bool fz_confirm(const uint8_t *__restrict__ buf, const FzScanArgs &a, uint32_t blk,
+                                           uint64_t local) {
+    if ((fz_load_win(buf, (int64_t)local) & a.mask1) != a.A[blk]) return false;
+    if (a.L > 4 && (fz_load_win(buf, (int64_t)local + a.d2) & a.mask2) != a.B[blk]) return false;
+    for (uint32_t b = 8; b < a.L; ++b)
+        if (buf[local + b] != a.pat[a.s[blk] + b]) return false;
+    return true;
+}
+
+// Candidate code of the queue: tile-local byte offset (14 bits) | block (3 bits) | tile iteration.
+__device__ __forceinline__ uint32_t fz_code(uint32_t off, uint32_t blk, uint32_t titer) {
+    return off | (blk << 14) | (titer << 17);
+}
+
+// Process queue entries [0, qn): range-check, then verify in place (FUSED) or confirm against HBM
+// and bulk-append to the global hit list.  Returns the number of confirmed n-gram hits.
+template <bool FUSED>
+__device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ buf, const FzScanArgs &a,
+                                                   const uint8_t *pat_lds, const FzWaveLds &w, uint32_t qn,
+                                                   uint64_t *__restrict__ hits, FzRec *__restrict__ recs,
+                                                   unsigned long long *__restrict__ counters) {
+    const uint32_t lane = fz_lane();
+    uint32_t confirmed = 0;
+    fz_wave_lds_sync();
+    for (uint32_t e0 = 0; e0 < qn; e0 += 64u) {
+        const uint32_t e = e0 + lane;
+        bool valid = e < qn;
+        uint64_t hit = 0;
+        uint64_t local = 0;
+        uint32_t blk = 0;
+        if (valid) {
+            const uint32_t code = w.queue[e];
+            blk = (code >> 14) & 7u;
+            const uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)(code >> 17) * gridDim.x;
+            local = tile * (uint64_t)FZ_TILE_BYTES + (code & 0x3fffu);
+            const uint64_t idx = a.geom.buf_off + local;
+            valid = fz_in_range(a, blk, idx);
+            hit = fz_hit_pack(a.g0 + blk, idx);
+        }
+        if (FUSED) {
+            confirmed += fz_wave_verify(buf, a, pat_lds, w, hit, valid, recs, counters);
+        } else {
+            if (valid) valid = fz_confirm(buf, a, blk, local);
+            const unsigned long long mask = __ballot(valid);
+            if (mask) {
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(&counters[0], (unsigned long long)__popcll(mask));
+                base = fz_bcast64(base);
+                const unsigned long long slot = base + fz_rank(mask);
+                if (valid && slot < a.hit_cap) hits[slot] = hit;
+            }
+        }
+    }
+    fz_wave_lds_sync();
+    return confirmed;
+}
+
+// TG    : number of n-gram blocks compiled in (hash constants live in SGPRs); nblk <= TG are real.
+// NWIN  : 1 -> the (masked) dword at the offset is its own hash (L <= 4);
+//         2 -> hash = low24(dword at offset + DH) * K + dword at offset, DH = min(L, 8) - 3.
+// FUSED : verify candidates inside this kernel (records out) or emit exact hits (hit list out).
+// Each thread owns 16 consecutive byte offsets per row and reads 24 bytes (16 + 8 halo).
+// Fast hits are queued per wave ACROSS tiles and processed 64 at a time (full lanes, one latency
+// chain per ~100 candidates instead of one per tile).  A tile denser than the queue is re-scanned
+// by enumeration ("slow tile": correctness path for pathological inputs).
+template <int TG, int NWIN, int DH, bool FUSED>
+__global__ __launch_bounds__(FZ_FILTER_THREADS) void fz_scan_kernel(
+    const uint8_t *__restrict__ buf, const FzScanArgs a, uint64_t ntiles,
+    uint64_t *__restrict__ hits, FzRec *__restrict__ recs, unsigned long long *__restrict__ counters) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t mpad = (a.m + 15u) & ~15u;
+    uint8_t *pat_lds = smem;
+    for (uint32_t i = threadIdx.x; i < a.m; i += FZ_FILTER_THREADS) pat_lds[i] = a.pat[i];
+    __syncthreads();
+    const FzWaveLds w = fz_wave_lds(smem + mpad, threadIdx.x >> 6, FUSED ? a.win_dwords : 0u,
+                                    FUSED ? a.band_w : 0u, true);
+    uint32_t H[TG];
+#pragma unroll
+    for (int g = 0; g < TG; ++g) H[g] = a.H[g];
+    const uint32_t mask1 = a.mask1;
+    const uint32_t lane = fz_lane();
+    const uint32_t lane_off = threadIdx.x * 16u;
+    uint32_t qn = 0;                                  // wave-uniform queue fill
+    uint32_t confirmed = 0;                           // wave-uniform statistics
+    uint32_t titer = 0;                               // tile iteration of this workgroup
+    uint64_t tile = blockIdx.x;
+    bool slow = false;                                // a tile is being re-scanned by enumeration
+    uint32_t slow_pos = 0;
+
+    for (;;) {
+        if (slow) {
+            // enumerate (row, offset, block) candidates of tile `tile`, 64 lanes at a time
+            const uint32_t steps = FZ_FILTER_ROWS * 16u * a.nblk;
+            while (slow_pos < steps && qn + 64u <= FZ_QCAP) {
+                const uint32_t blk = slow_pos % a.nblk;
+                const uint32_t ro = slow_pos / a.nblk;
+                w.queue[qn + lane] = fz_code((ro >> 4) * FZ_ROW_BYTES + lane_off + (ro & 15u), blk, titer);
+                qn += 64u;
+                ++slow_pos;
+            }
+            if (slow_pos >= steps) { slow = false; tile += gridDim.x; ++titer; }
+        } else {
+            while (tile < ntiles && qn <= FZ_QCAP / 2) {
+                const uint64_t tile_base = tile * (uint64_t)FZ_TILE_BYTES;
+                uint4 v[FZ_FILTER_ROWS];
+                uint2 h[FZ_FILTER_ROWS];
+#pragma unroll
+                for (int r = 0; r < FZ_FILTER_ROWS; ++r) {
+                    const uint8_t *src = buf + tile_base + lane_off + (uint64_t)r * FZ_ROW_BYTES;
+                    v[r] = *reinterpret_cast<const uint4 *>(src);
+                    h[r] = *reinterpret_cast<const uint2 *>(src + 16);
+                }
+                const uint32_t q_tile = qn;
+#pragma unroll
+                for (int r = 0; r < FZ_FILTER_ROWS; ++r) {
+                    const uint32_t w6[6] = {v[r].x, v[r].y, v[r].z, v[r].w, h[r].x, h[r].y};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {     // 4 byte offsets per ballot
+                        uint32_t hv[4], am[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int o = 4 * j + i;
+                            const uint32_t x = FZ_WIN(w6, o);
+                            if (NWIN == 1) hv[i] = x & mask1;
+                            else hv[i] = __umul24(FZ_WIN(w6, o + DH), FZ_HASH_K) + x;   // v_mad_u32_u24
+                            am[i] = 0xffffffffu;
+#pragma unroll
+                            for (int g = 0; g < TG; ++g) am[i] = min(am[i], hv[i] ^ H[g]);  // v_xor + v_min3
+                        }
+                        const uint32_t acc = min(min(am[0], am[1]), min(am[2], am[3]));
+                        if (__ballot(acc == 0)) {     // wave-uniform, rare: some lane, some offset, some block
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                if (__ballot(am[i] == 0)) {           // which offset (scalar branch)
+#pragma unroll
+                                    for (int g = 0; g < TG; ++g) {
+                                        const unsigned long long mk = __ballot(hv[i] == H[g]);
+                                        if (mk) {     // which block (scalar branch)
+                                            const uint32_t slot = qn + fz_rank(mk);
+                                            // the empty asm keeps LICM from hoisting 64 * TG
+                                            // loop-invariant queue codes into VGPRs
+                                            uint32_t code = lane_off;
+                                            asm volatile("" : "+v"(code));
+                                            code = fz_code(code + (uint32_t)(r * FZ_ROW_BYTES + 4 * j + i), (uint32_t)g, titer);
+                                            if (hv[i] == H[g] && slot < FZ_QCAP) w.queue[slot] = code;
+                                            qn += (uint32_t)__popcll(mk);
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+                if (qn > FZ_QCAP) {                   // this tile overflowed the queue: drop its
+                    qn = q_tile;                      // partial entries and re-scan it by enumeration
+                    slow = true;
+                    slow_pos = 0;
+                    break;
+                }
+                tile += gridDim.x;
+                ++titer;
+            }
+        }
+        if (qn) confirmed += fz_queue_flush<FUSED>(buf, a, pat_lds, w, qn, hits, recs, counters);
+        qn = 0;
+        if (!slow && tile >= ntiles) break;
+    }
+    if (FUSED && lane == 0 && confirmed) atomicAdd(&counters[8 + (blockIdx.x & 63u)], (unsigned long long)confirmed);
+}
+
+// Verification of a hit list in HBM (parameter ranges whose LDS footprint does not fit beside the
+// filter).  One wave verifies 64 hits at a time.  Dynamic LDS: pattern + per-wave window/score areas.
+__global__ void fz_verify_kernel(const uint8_t *__restrict__ buf, const FzScanArgs a,
+                                 const uint64_t *__restrict__ hits, FzRec *__restrict__ recs,
+                                 unsigned long long *__restrict__ counters) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t mpad = (a.m + 15u) & ~15u;
+    uint8_t *pat_lds = smem;
+    for (uint32_t i = threadIdx.x; i < a.m; i += blockDim.x) pat_lds[i] = a.pat[i];
+    __syncthreads();
+    const FzWaveLds w = fz_wave_lds(smem + mpad, threadIdx.x >> 6, a.win_dwords, a.band_w, false);
+    unsigned long long nh = counters[0];
+    if (nh > a.hit_cap) nh = a.hit_cap;
+    const uint64_t waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    for (uint64_t q0 = wave * 64u; q0 < nh; q0 += waves * 64u) {
+        const uint64_t q = q0 + fz_lane();
+        const bool valid = q < nh;
+        const uint64_t hit = valid ? hits[q] : 0;
+        fz_wave_verify(buf, a, pat_lds, w, hit, valid, recs, counters);
+    }
+}

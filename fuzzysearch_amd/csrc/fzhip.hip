@@ -1,0 +1,736 @@
+// fzhip.hip — host side of libfzhip.so: the C-ABI of include/fzhip.h over the gfx950 kernels.
+//
+// Data layout in HBM (per device shard):
+//   [FZ_PAD_FRONT zero bytes][buf_len sequence bytes][zero bytes up to a whole tile + FZ_PAD_BACK]
+// so the filter can read whole 16 KiB tiles and 8-byte halos without bounds checks; zero padding
+// can never create an accepted hit because every hit is range-checked against the global length.
+//   hits   : uint64 (block << 56 | global idx), appended through one device counter
+//   recs   : FzRec (24 B), appended through a second counter; header + records share one
+//            allocation so the usual result comes back in ONE D2H copy
+// The raw stream is put in the reference's emission order on the host by sorting records on
+// (block, idx) — the number of records is tiny next to the bytes scanned.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/fzhip.h"
+#include "fz_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char tmp[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(tmp, sizeof tmp, fmt, ap);
+    va_end(ap);
+    g_err = tmp;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? FZ_ENOMEM : FZ_EDEVICE, "%s failed: %s", #expr, \
+                        hipGetErrorString(e_));                                                    \
+    } while (0)
+
+constexpr uint64_t kHeaderBytes = 1024;          // counters[0] = emitted hits, [1] = records, [8..71] = confirmed-hit tallies
+constexpr uint64_t kFirstCopyRecs = 2048;        // records fetched together with the header
+
+struct DevState {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t *d_hits = nullptr;
+    uint64_t hit_cap = 0;
+    uint8_t *d_out = nullptr;                    // [header 64 B][recs]
+    uint64_t rec_cap = 0;
+    uint8_t *h_stage = nullptr;                  // pinned, kHeaderBytes + kFirstCopyRecs * sizeof(FzRec)
+    int n_cus = 256;
+};
+
+struct Shard {
+    int dev = 0;                                 // index into ctx->devs
+    uint8_t *d_alloc = nullptr;                  // allocation base
+    uint8_t *d_buf = nullptr;                    // = d_alloc + FZ_PAD_FRONT
+    uint64_t alloc_bytes = 0;
+    FzGeom geom{};
+};
+
+}  // namespace
+
+struct fz_ctx {
+    std::vector<DevState> devs;
+    fz_stats_t stats{};
+    bool last_fused = false;
+};
+
+struct fz_seq {
+    fz_ctx *ctx = nullptr;
+    uint64_t n = 0;                              // global length
+    std::vector<Shard> shards;
+};
+
+namespace {
+
+int ensure_hits(DevState &d, uint64_t cap) {
+    if (d.hit_cap >= cap) return FZ_OK;
+    HIP_TRY(hipSetDevice(d.device));
+    if (d.d_hits) { HIP_TRY(hipFree(d.d_hits)); d.d_hits = nullptr; d.hit_cap = 0; }
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d.d_hits), cap * sizeof(uint64_t)));
+    d.hit_cap = cap;
+    return FZ_OK;
+}
+
+int ensure_recs(DevState &d, uint64_t cap) {
+    if (d.rec_cap >= cap) return FZ_OK;
+    HIP_TRY(hipSetDevice(d.device));
+    if (d.d_out) { HIP_TRY(hipFree(d.d_out)); d.d_out = nullptr; d.rec_cap = 0; }
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d.d_out), kHeaderBytes + cap * sizeof(FzRec)));
+    d.rec_cap = cap;
+    return FZ_OK;
+}
+
+uint32_t load_le32(const uint8_t *p, uint32_t avail) {
+    uint32_t v = 0;
+    for (uint32_t i = 0; i < 4 && i < avail; ++i) v |= (uint32_t)p[i] << (8 * i);
+    return v;
+}
+
+// Describes one whole search as a list of n-gram blocks.
+struct BlockPlan {
+    uint32_t L = 0;
+    std::vector<uint32_t> s;       // ngram_start per block
+    std::vector<uint64_t> lo, hi;  // accepted hit range per block: lo <= idx, idx + L <= hi
+};
+
+using ScanKernel = void (*)(const uint8_t *, const FzScanArgs, uint64_t, uint64_t *, FzRec *, unsigned long long *);
+
+template <int TG, bool FUSED>
+ScanKernel scan_kernel_tg(int nwin, int dh) {
+    if (nwin == 1) return fz_scan_kernel<TG, 1, 0, FUSED>;
+    switch (dh) {
+        case 2: return fz_scan_kernel<TG, 2, 2, FUSED>;
+        case 3: return fz_scan_kernel<TG, 2, 3, FUSED>;
+        case 4: return fz_scan_kernel<TG, 2, 4, FUSED>;
+        default: return fz_scan_kernel<TG, 2, 5, FUSED>;
+    }
+}
+
+template <bool FUSED>
+ScanKernel scan_kernel_f(int tg, int nwin, int dh) {
+    switch (tg) {
+        case 1: return scan_kernel_tg<1, FUSED>(nwin, dh);
+        case 2: return scan_kernel_tg<2, FUSED>(nwin, dh);
+        case 3: return scan_kernel_tg<3, FUSED>(nwin, dh);
+        case 4: return scan_kernel_tg<4, FUSED>(nwin, dh);
+        case 6: return scan_kernel_tg<6, FUSED>(nwin, dh);
+        default: return scan_kernel_tg<8, FUSED>(nwin, dh);
+    }
+}
+
+ScanKernel scan_kernel(int tg, int nwin, int dh, bool fused) {
+    return fused ? scan_kernel_f<true>(tg, nwin, dh) : scan_kernel_f<false>(tg, nwin, dh);
+}
+
+int pick_tg(uint32_t nblk) {
+    if (nblk <= 4) return (int)nblk;
+    return nblk <= 6 ? 6 : 8;
+}
+
+struct Search {
+    uint32_t mode = 0, m = 0, k = 0;
+    const uint8_t *p = nullptr;
+    BlockPlan plan;
+};
+
+constexpr uint32_t kFusedLdsBudget = 64 * 1024;   // dynamic LDS per scan workgroup when verification is fused
+
+// Enqueue scan (+ separate verify when it cannot be fused) for one shard on its device stream.
+// No host synchronisation.
+int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verify) {
+    DevState &d = ctx->devs[sh.dev];
+    HIP_TRY(hipSetDevice(d.device));
+    unsigned long long *counters = reinterpret_cast<unsigned long long *>(d.d_out);
+    FzRec *recs = reinterpret_cast<FzRec *>(d.d_out + kHeaderBytes);
+    HIP_TRY(hipMemsetAsync(d.d_out, 0, kHeaderBytes, d.stream));
+    HIP_TRY(hipEventRecord(d.ev[0], d.stream));
+
+    const uint32_t L = q.plan.L;
+    const uint32_t G = (uint32_t)q.plan.s.size();
+    const uint64_t ntiles = (sh.geom.buf_len + FZ_TILE_BYTES - 1) / FZ_TILE_BYTES;
+    const uint64_t max_grid = (uint64_t)d.n_cus * 8;
+    // the queue codes carry a 15-bit per-workgroup tile iteration
+    const uint64_t min_grid = (ntiles + 32766) / 32767;
+    dim3 grid((unsigned)std::max<uint64_t>(std::max<uint64_t>(1, min_grid), std::min<uint64_t>(ntiles, max_grid)));
+
+    FzScanArgs fa;
+    memset(&fa, 0, sizeof fa);
+    fa.geom = sh.geom;
+    fa.mode = q.mode;
+    fa.m = q.m;
+    fa.k = q.k;
+    fa.L = L;
+    const int nwin = L <= 4 ? 1 : 2;
+    const int dh = nwin == 2 ? (int)std::min<uint32_t>(L, 8) - 3 : 0;
+    fa.d2 = nwin == 2 ? std::min<uint32_t>(L, 8) - 4 : 0;
+    fa.mask1 = L >= 4 ? 0xffffffffu : ((1u << (8 * L)) - 1u);
+    fa.mask2 = 0xffffffffu;
+    fa.band_w = q.mode == FZ_MODE_LEV ? 2 * q.k + 2 : 0;
+    fa.win_dwords = (q.m + 2 * q.k + 6) / 4 + 1;
+    fa.hit_cap = d.hit_cap;
+    fa.rec_cap = d.rec_cap;
+    memcpy(fa.pat, q.p, q.m);
+    const uint32_t mpad = (q.m + 15u) & ~15u;
+    const uint32_t fused_lds = mpad + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, true);
+    fa.fused = (with_verify && fused_lds <= kFusedLdsBudget) ? 1u : 0u;
+    const uint32_t scan_lds = fa.fused ? fused_lds : mpad + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(0, 0, true);
+
+    uint32_t launches = 0;
+    for (uint32_t g0 = 0; g0 < G && ntiles > 0; g0 += FZ_MAX_BLOCKS_PER_LAUNCH) {
+        const uint32_t nblk = std::min<uint32_t>(FZ_MAX_BLOCKS_PER_LAUNCH, G - g0);
+        fa.nblk = nblk;
+        fa.g0 = g0;
+        const int tg = pick_tg(nblk);
+        for (int b = 0; b < tg; ++b) {
+            const uint32_t src = (uint32_t)b < nblk ? g0 + b : g0;   // pad with a copy of block 0
+            const uint8_t *ng = q.p + q.plan.s[src];
+            fa.A[b] = load_le32(ng, L) & fa.mask1;
+            fa.B[b] = nwin == 2 ? load_le32(ng + fa.d2, 4) : 0;
+            fa.H[b] = nwin == 2 ? fz_hash_windows(fa.A[b], load_le32(ng + dh, 3)) : fa.A[b];
+            fa.lo[b] = q.plan.lo[src];
+            fa.hi[b] = q.plan.hi[src];
+            fa.s[b] = q.plan.s[src];
+        }
+        ScanKernel kern = scan_kernel(tg, nwin, dh, fa.fused != 0);
+        hipLaunchKernelGGL(kern, grid, dim3(FZ_FILTER_THREADS), scan_lds, d.stream, sh.d_buf, fa, ntiles, d.d_hits, recs,
+                           counters);
+        HIP_TRY(hipGetLastError());
+        ++launches;
+    }
+    HIP_TRY(hipEventRecord(d.ev[1], d.stream));
+    if (with_verify && !fa.fused) {
+        // LDS: pattern + per-wave window and score ring; shrink the block until it fits.
+        unsigned waves = 4;
+        while (waves > 1 && mpad + waves * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, false) > 64 * 1024) waves >>= 1;
+        const size_t lds = mpad + (size_t)waves * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, false);
+        if (lds > 160 * 1024) return fail(FZ_EUNSUPPORTED, "pattern/budget too large for the verify kernel (m=%u, k=%u)", q.m, q.k);
+        if (lds > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fz_verify_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        fa.nblk = 0;
+        hipLaunchKernelGGL(fz_verify_kernel, dim3(2048), dim3(64 * waves), lds, d.stream, sh.d_buf, fa, d.d_hits, recs,
+                           counters);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(d.ev[2], d.stream));
+    HIP_TRY(hipMemcpyAsync(d.h_stage, d.d_out, kHeaderBytes + kFirstCopyRecs * sizeof(FzRec), hipMemcpyDeviceToHost,
+                           d.stream));
+    HIP_TRY(hipEventRecord(d.ev[3], d.stream));
+    ctx->stats.filter_launches += launches;
+    ctx->last_fused = fa.fused != 0;
+    return FZ_OK;
+}
+
+// Wait for a shard, handle overflow (returns 1 = capacities grown, caller must re-run), collect.
+int collect_shard(fz_ctx *ctx, const Shard &sh, bool with_verify, std::vector<FzRec> &recs_out,
+                  std::vector<uint64_t> &hits_out, bool &rerun) {
+    DevState &d = ctx->devs[sh.dev];
+    HIP_TRY(hipSetDevice(d.device));
+    HIP_TRY(hipStreamSynchronize(d.stream));
+    const unsigned long long *cnt = reinterpret_cast<const unsigned long long *>(d.h_stage);
+    uint64_t nh = cnt[0];
+    const uint64_t nr = cnt[1];
+    const bool fused = with_verify && ctx->last_fused;
+    if (fused) { nh = 0; for (int i = 0; i < 64; ++i) nh += cnt[8 + i]; }
+    rerun = false;
+    if (nh > d.hit_cap && !fused) {
+        int rc = ensure_hits(d, nh + nh / 8 + 1024);
+        if (rc) return rc;
+        rerun = true;
+    }
+    if (nr > d.rec_cap) {
+        int rc = ensure_recs(d, nr + nr / 8 + 1024);
+        if (rc) return rc;
+        rerun = true;
+    }
+    if (rerun) return FZ_OK;
+    float f = 0, v = 0, t = 0;
+    HIP_TRY(hipEventElapsedTime(&f, d.ev[0], d.ev[1]));
+    HIP_TRY(hipEventElapsedTime(&v, d.ev[1], d.ev[2]));
+    HIP_TRY(hipEventElapsedTime(&t, d.ev[0], d.ev[3]));
+    ctx->stats.filter_ms = std::max<double>(ctx->stats.filter_ms, f);
+    ctx->stats.verify_ms = std::max<double>(ctx->stats.verify_ms, v);
+    ctx->stats.device_ms = std::max<double>(ctx->stats.device_ms, t);
+    ctx->stats.bytes_scanned += sh.geom.buf_len;
+    ctx->stats.ngram_hits += nh;
+    if (with_verify) {
+        ctx->stats.raw_matches += nr;
+        const size_t base = recs_out.size();
+        recs_out.resize(base + nr);
+        const uint64_t first = std::min<uint64_t>(nr, kFirstCopyRecs);
+        if (first) memcpy(recs_out.data() + base, d.h_stage + kHeaderBytes, first * sizeof(FzRec));
+        if (nr > first)
+            HIP_TRY(hipMemcpy(recs_out.data() + base + first, d.d_out + kHeaderBytes + first * sizeof(FzRec),
+                              (nr - first) * sizeof(FzRec), hipMemcpyDeviceToHost));
+    } else {
+        const size_t base = hits_out.size();
+        hits_out.resize(base + nh);
+        if (nh) HIP_TRY(hipMemcpy(hits_out.data() + base, d.d_hits, nh * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    }
+    return FZ_OK;
+}
+
+int check_halo(const fz_seq *seq, uint64_t need) {
+    for (const Shard &sh : seq->shards) {
+        const FzGeom &g = sh.geom;
+        const uint64_t want_lo = g.own_lo > need ? g.own_lo - need : 0;
+        const uint64_t want_hi = std::min<uint64_t>(g.n, g.own_hi + need);
+        if (g.own_hi > g.own_lo && (g.buf_off > want_lo || g.buf_off + g.buf_len < want_hi))
+            return fail(FZ_EHALO, "shard halo too small: need %llu bytes around [%llu, %llu)",
+                        (unsigned long long)need, (unsigned long long)g.own_lo, (unsigned long long)g.own_hi);
+    }
+    return FZ_OK;
+}
+
+int run_search(fz_ctx *ctx, fz_seq *seq, const Search &q, bool with_verify, std::vector<FzRec> &recs,
+               std::vector<uint64_t> &hits) {
+    memset(&ctx->stats, 0, sizeof ctx->stats);
+    ctx->stats.n_devices = (uint32_t)ctx->devs.size();
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        recs.clear();
+        hits.clear();
+        ctx->stats.filter_launches = 0;
+        ctx->stats.bytes_scanned = ctx->stats.ngram_hits = ctx->stats.raw_matches = 0;
+        ctx->stats.filter_ms = ctx->stats.verify_ms = ctx->stats.device_ms = 0;
+        for (const Shard &sh : seq->shards) {
+            int rc = enqueue_shard(ctx, sh, q, with_verify);
+            if (rc) return rc;
+        }
+        bool any_rerun = false;
+        for (const Shard &sh : seq->shards) {
+            bool rr = false;
+            int rc = collect_shard(ctx, sh, with_verify, recs, hits, rr);
+            if (rc) return rc;
+            any_rerun |= rr;
+        }
+        if (!any_rerun) return FZ_OK;
+    }
+    return fail(FZ_EDEVICE, "result buffers kept overflowing");
+}
+
+int alloc_out(uint64_t n, size_t elem, void **out) {
+    *out = malloc(std::max<size_t>(1, n * elem));
+    if (!*out) return fail(FZ_ENOMEM, "out of host memory for %llu results", (unsigned long long)n);
+    return FZ_OK;
+}
+
+int validate(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m) {
+    if (!ctx || !seq || seq->ctx != ctx) return fail(FZ_EINVAL, "bad ctx/seq handle");
+    if (!p || m == 0) return fail(FZ_EINVAL, "subsequence must not be empty");
+    if (m > FZ_MAX_M) return fail(FZ_EUNSUPPORTED, "subsequence longer than %d bytes", FZ_MAX_M);
+    return FZ_OK;
+}
+
+void sort_recs(std::vector<FzRec> &recs) {
+    std::sort(recs.begin(), recs.end(), [](const FzRec &a, const FzRec &b) { return a.key < b.key; });
+}
+
+int emit_matches(const std::vector<FzRec> &recs, uint32_t L, fz_match **out, uint64_t *n) {
+    void *mem = nullptr;
+    int rc = alloc_out(recs.size(), sizeof(fz_match), &mem);
+    if (rc) return rc;
+    fz_match *mo = static_cast<fz_match *>(mem);
+    for (size_t i = 0; i < recs.size(); ++i) {
+        const uint64_t idx = fz_hit_index(recs[i].key);
+        mo[i].start = (int64_t)(idx - recs[i].l);
+        mo[i].end = (int64_t)(idx + L + recs[i].r);
+        mo[i].dist = (int32_t)recs[i].dist;
+        mo[i].block = (int32_t)fz_hit_block(recs[i].key);
+    }
+    *out = mo;
+    *n = recs.size();
+    return FZ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fz_abi_version(void) { return FZ_ABI_VERSION; }
+
+const char *fz_last_error(void) { return g_err.c_str(); }
+
+int fz_device_count(int *n) {
+    if (!n) return fail(FZ_EINVAL, "null argument");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *n = 0; return fail(FZ_EDEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *n = c;
+    return FZ_OK;
+}
+
+int fz_create(const int *device_ids, int n_devices, fz_ctx **out) {
+    if (!out) return fail(FZ_EINVAL, "null argument");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(FZ_EDEVICE, "no HIP device available (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    std::vector<int> ids;
+    if (!device_ids || n_devices <= 0) ids.push_back(0);
+    else ids.assign(device_ids, device_ids + n_devices);
+    fz_ctx *ctx = new (std::nothrow) fz_ctx();
+    if (!ctx) return fail(FZ_ENOMEM, "out of memory");
+    for (int id : ids) {
+        if (id < 0 || id >= count) { fz_destroy(ctx); return fail(FZ_EINVAL, "device id %d out of range (have %d)", id, count); }
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, id) != hipSuccess) { fz_destroy(ctx); return fail(FZ_EDEVICE, "hipGetDeviceProperties failed"); }
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            fz_destroy(ctx);
+            return fail(FZ_EDEVICE, "device %d is %s; libfzhip is built for gfx950 (MI355X) only", id, prop.gcnArchName);
+        }
+        ctx->devs.emplace_back();
+        DevState &d = ctx->devs.back();
+        d.device = id;
+        d.n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        int rc = FZ_OK;
+        auto init = [&]() -> int {
+            HIP_TRY(hipSetDevice(id));
+            HIP_TRY(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+            for (auto &ev : d.ev) HIP_TRY(hipEventCreate(&ev));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&d.h_stage), kHeaderBytes + kFirstCopyRecs * sizeof(FzRec), hipHostMallocDefault));
+            return FZ_OK;
+        };
+        rc = init();
+        if (rc == FZ_OK) rc = ensure_hits(d, 1u << 20);
+        if (rc == FZ_OK) rc = ensure_recs(d, 1u << 16);
+        if (rc) { fz_destroy(ctx); return rc; }
+    }
+    *out = ctx;
+    return FZ_OK;
+}
+
+void fz_destroy(fz_ctx *ctx) {
+    if (!ctx) return;
+    for (DevState &d : ctx->devs) {
+        (void)hipSetDevice(d.device);
+        if (d.stream) (void)hipStreamSynchronize(d.stream);
+        if (d.d_hits) (void)hipFree(d.d_hits);
+        if (d.d_out) (void)hipFree(d.d_out);
+        if (d.h_stage) (void)hipHostFree(d.h_stage);
+        for (auto &ev : d.ev) if (ev) (void)hipEventDestroy(ev);
+        if (d.stream) (void)hipStreamDestroy(d.stream);
+    }
+    delete ctx;
+}
+
+static int upload_one(fz_ctx *ctx, int dev_index, const uint8_t *host_buf, const FzGeom &geom, Shard &sh) {
+    DevState &d = ctx->devs[dev_index];
+    HIP_TRY(hipSetDevice(d.device));
+    const uint64_t tiles = (geom.buf_len + FZ_TILE_BYTES - 1) / FZ_TILE_BYTES;
+    const uint64_t body = std::max<uint64_t>(1, tiles) * FZ_TILE_BYTES;
+    sh.dev = dev_index;
+    sh.alloc_bytes = FZ_PAD_FRONT + body + FZ_PAD_BACK;
+    sh.geom = geom;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sh.d_alloc), sh.alloc_bytes));
+    sh.d_buf = sh.d_alloc + FZ_PAD_FRONT;
+    HIP_TRY(hipMemsetAsync(sh.d_alloc, 0, FZ_PAD_FRONT, d.stream));
+    HIP_TRY(hipMemsetAsync(sh.d_buf + geom.buf_len, 0, sh.alloc_bytes - FZ_PAD_FRONT - geom.buf_len, d.stream));
+    if (geom.buf_len) HIP_TRY(hipMemcpyAsync(sh.d_buf, host_buf, geom.buf_len, hipMemcpyHostToDevice, d.stream));
+    // grow the hit list with the sequence: n-gram hits on 4-letter text run at ~G * n / 4^L
+    int rc = ensure_hits(d, std::max<uint64_t>(1u << 20, geom.buf_len / 64));
+    if (rc) return rc;
+    return FZ_OK;
+}
+
+int fz_seq_upload(fz_ctx *ctx, const uint8_t *host, uint64_t n, fz_seq **out) {
+    if (!ctx || !out || (!host && n)) return fail(FZ_EINVAL, "null argument");
+    if (n >= (1ull << 56)) return fail(FZ_EUNSUPPORTED, "sequence too long");
+    *out = nullptr;
+    fz_seq *seq = new (std::nothrow) fz_seq();
+    if (!seq) return fail(FZ_ENOMEM, "out of memory");
+    seq->ctx = ctx;
+    seq->n = n;
+    const uint64_t R = ctx->devs.size();
+    const uint64_t halo = 2 * FZ_MAX_M + 64;          // >= m + k for every supported query
+    for (uint64_t r = 0; r < R; ++r) {
+        FzGeom g;
+        g.n = n;
+        g.own_lo = n / R * r + std::min<uint64_t>(r, n % R);
+        g.own_hi = n / R * (r + 1) + std::min<uint64_t>(r + 1, n % R);
+        const uint64_t lo = g.own_lo > halo ? g.own_lo - halo : 0;
+        const uint64_t hi = std::min<uint64_t>(n, g.own_hi + halo);
+        g.buf_off = lo;
+        g.buf_len = hi - lo;
+        if (R > 1 && g.own_hi == g.own_lo) continue;   // nothing to own
+        seq->shards.emplace_back();
+        int rc = upload_one(ctx, (int)r, host + lo, g, seq->shards.back());
+        if (rc) { fz_seq_release(seq); return rc; }
+    }
+    for (Shard &sh : seq->shards) {
+        (void)hipSetDevice(ctx->devs[sh.dev].device);
+        hipError_t e = hipStreamSynchronize(ctx->devs[sh.dev].stream);
+        if (e != hipSuccess) { fz_seq_release(seq); return fail(FZ_EDEVICE, "upload failed: %s", hipGetErrorString(e)); }
+    }
+    *out = seq;
+    return FZ_OK;
+}
+
+int fz_seq_upload_shard(fz_ctx *ctx, const uint8_t *host_buf, uint64_t buf_len, uint64_t buf_global_off,
+                        uint64_t own_lo, uint64_t own_hi, uint64_t global_n, fz_seq **out) {
+    if (!ctx || !out || (!host_buf && buf_len)) return fail(FZ_EINVAL, "null argument");
+    if (global_n >= (1ull << 56)) return fail(FZ_EUNSUPPORTED, "sequence too long");
+    if (buf_global_off + buf_len > global_n || own_lo > own_hi || own_hi > global_n)
+        return fail(FZ_EINVAL, "shard ranges outside the global sequence");
+    if (own_hi > own_lo && (own_lo < buf_global_off || own_hi > buf_global_off + buf_len))
+        return fail(FZ_EINVAL, "owned range not inside the shard buffer");
+    *out = nullptr;
+    fz_seq *seq = new (std::nothrow) fz_seq();
+    if (!seq) return fail(FZ_ENOMEM, "out of memory");
+    seq->ctx = ctx;
+    seq->n = global_n;
+    FzGeom g;
+    g.n = global_n;
+    g.buf_off = buf_global_off;
+    g.buf_len = buf_len;
+    g.own_lo = own_lo;
+    g.own_hi = own_hi;
+    seq->shards.emplace_back();
+    int rc = upload_one(ctx, 0, host_buf, g, seq->shards.back());
+    if (rc == FZ_OK) {
+        hipError_t e = hipStreamSynchronize(ctx->devs[0].stream);
+        if (e != hipSuccess) rc = fail(FZ_EDEVICE, "upload failed: %s", hipGetErrorString(e));
+    }
+    if (rc) { fz_seq_release(seq); return rc; }
+    *out = seq;
+    return FZ_OK;
+}
+
+uint64_t fz_seq_len(const fz_seq *seq) { return seq ? seq->n : 0; }
+
+void fz_seq_release(fz_seq *seq) {
+    if (!seq) return;
+    for (Shard &sh : seq->shards) {
+        if (sh.d_alloc) {
+            (void)hipSetDevice(seq->ctx->devs[sh.dev].device);
+            (void)hipFree(sh.d_alloc);
+        }
+    }
+    delete seq;
+}
+
+int fz_search_exact(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint64_t lo, uint64_t hi,
+                    uint64_t **idx, uint64_t *n) {
+    if (!idx || !n) return fail(FZ_EINVAL, "null argument");
+    *idx = nullptr; *n = 0;
+    int rc = validate(ctx, seq, p, m);
+    if (rc) return rc;
+    rc = check_halo(seq, m);
+    if (rc) return rc;
+    const uint64_t N = seq->n;
+    lo = std::min(lo, N);                                  // search_exact.py:70-71
+    hi = std::max(lo, std::min(hi, N));
+    Search q;
+    q.mode = FZ_MODE_EXACT; q.m = m; q.k = 0; q.p = p;
+    q.plan.L = m;
+    q.plan.s = {0};
+    q.plan.lo = {lo};
+    q.plan.hi = {hi};
+    std::vector<FzRec> recs;
+    std::vector<uint64_t> hits;
+    rc = run_search(ctx, seq, q, /*with_verify=*/false, recs, hits);
+    if (rc) return rc;
+    std::sort(hits.begin(), hits.end());
+    void *mem = nullptr;
+    rc = alloc_out(hits.size(), sizeof(uint64_t), &mem);
+    if (rc) return rc;
+    uint64_t *o = static_cast<uint64_t *>(mem);
+    for (size_t i = 0; i < hits.size(); ++i) o[i] = fz_hit_index(hits[i]);
+    *idx = o; *n = hits.size();
+    ctx->stats.raw_matches = hits.size();
+    return FZ_OK;
+}
+
+int fz_lev_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, fz_match **out, uint64_t *n) {
+    if (!out || !n) return fail(FZ_EINVAL, "null argument");
+    *out = nullptr; *n = 0;
+    int rc = validate(ctx, seq, p, m);
+    if (rc) return rc;
+    const uint32_t L = m / (k + 1);
+    if (L == 0) return fail(FZ_EINVAL, "the subsequence length must be greater than max_l_dist");
+    if (k > FZ_MAX_K) return fail(FZ_EUNSUPPORTED, "max_l_dist above %d is not supported by the verify kernels", FZ_MAX_K);
+    rc = check_halo(seq, (uint64_t)m + k);
+    if (rc) return rc;
+    const int64_t N = (int64_t)seq->n;
+    Search q;
+    q.mode = FZ_MODE_LEV; q.m = m; q.k = k; q.p = p;
+    q.plan.L = L;
+    for (uint32_t s = 0; s + L <= m; s += L) {              // levenshtein_ngram.py:171-176
+        int64_t lo = (int64_t)s - (int64_t)k; if (lo < 0) lo = 0; if (lo > N) lo = N;
+        int64_t hi = N - (int64_t)m + s + L + k; if (hi > N) hi = N; if (hi < lo) hi = lo;
+        q.plan.s.push_back(s);
+        q.plan.lo.push_back((uint64_t)lo);
+        q.plan.hi.push_back((uint64_t)hi);
+    }
+    if (q.plan.s.size() > 255) return fail(FZ_EUNSUPPORTED, "more than 255 n-gram blocks");
+    std::vector<FzRec> recs;
+    std::vector<uint64_t> hits;
+    rc = run_search(ctx, seq, q, true, recs, hits);
+    if (rc) return rc;
+    sort_recs(recs);
+    return emit_matches(recs, L, out, n);
+}
+
+int fz_subs_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, fz_match **out, uint64_t *n) {
+    if (!out || !n) return fail(FZ_EINVAL, "null argument");
+    *out = nullptr; *n = 0;
+    int rc = validate(ctx, seq, p, m);
+    if (rc) return rc;
+    const uint32_t L = m / (k + 1);
+    if (L == 0) return fail(FZ_EUNSUPPORTED, "max_substitutions >= len(subsequence): every window matches; not a GPU path");
+    rc = check_halo(seq, m);
+    if (rc) return rc;
+    const uint64_t N = seq->n;
+    if (N < m) return FZ_OK;                                   // template :66-68
+    Search q;
+    q.mode = FZ_MODE_SUBS; q.m = m; q.k = k; q.p = p;
+    q.plan.L = L;
+    for (uint32_t s = 0; s + L <= m; s += L) {                  // template :92-101
+        q.plan.s.push_back(s);
+        q.plan.lo.push_back(s);
+        q.plan.hi.push_back(N - (m - s - L));
+    }
+    if (q.plan.s.size() > 255) return fail(FZ_EUNSUPPORTED, "more than 255 n-gram blocks");
+    std::vector<FzRec> recs;
+    std::vector<uint64_t> hits;
+    rc = run_search(ctx, seq, q, true, recs, hits);
+    if (rc) return rc;
+    sort_recs(recs);
+    return emit_matches(recs, L, out, n);
+}
+
+int fz_generic_ngrams(fz_ctx *, fz_seq *, const uint8_t *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t,
+                      fz_match **out, uint64_t *n) {
+    if (out) *out = nullptr;
+    if (n) *n = 0;
+    return fail(FZ_EUNSUPPORTED, "generic (mixed-limit) search is not implemented on the GPU yet");
+}
+
+// ---- host-side consolidation (common.py:145-189) -------------------------------------------
+// The partition into overlap groups is input-order independent, so for
+// fz_consolidate a sort + sweep replaces the reference's O(M * groups) loop.
+int fz_consolidate(const fz_match *in, uint64_t n, fz_match **out, uint64_t *n_out) {
+    if (!out || !n_out || (!in && n)) return fail(FZ_EINVAL, "null argument");
+    *out = nullptr; *n_out = 0;
+    std::vector<fz_match> v(in, in + n);
+    std::sort(v.begin(), v.end(), [](const fz_match &a, const fz_match &b) {
+        if (a.start != b.start) return a.start < b.start;
+        if (a.end != b.end) return a.end < b.end;
+        return a.dist < b.dist;
+    });
+    // Zero-length matches (start == end) never overlap anything under
+    // `not (end <= g.start or start >= g.end)` unless strictly inside a group, so the sweep uses the
+    // same predicate against the running hull instead of assuming sorted-interval merging.
+    std::vector<fz_match> best;
+    std::vector<std::pair<int64_t, int64_t>> hull;
+    for (const fz_match &mt : v) {
+        bool placed = false;
+        if (!hull.empty()) {
+            auto &h = hull.back();
+            if (!(mt.end <= h.first || mt.start >= h.second)) {
+                h.first = std::min(h.first, mt.start);
+                h.second = std::max(h.second, mt.end);
+                fz_match &b = best.back();
+                const int64_t lm = mt.end - mt.start, lb = b.end - b.start;
+                if (mt.dist < b.dist || (mt.dist == b.dist && (lm > lb || (lm == lb && mt.start < b.start)))) b = mt;
+                placed = true;
+            }
+        }
+        if (!placed) { hull.emplace_back(mt.start, mt.end); best.push_back(mt); }
+    }
+    std::sort(best.begin(), best.end(), [](const fz_match &a, const fz_match &b) {
+        if (a.start != b.start) return a.start < b.start;
+        if (a.end != b.end) return a.end < b.end;
+        return a.dist < b.dist;
+    });
+    void *mem = nullptr;
+    int rc = alloc_out(best.size(), sizeof(fz_match), &mem);
+    if (rc) return rc;
+    if (!best.empty()) memcpy(mem, best.data(), best.size() * sizeof(fz_match));
+    *out = static_cast<fz_match *>(mem);
+    *n_out = best.size();
+    return FZ_OK;
+}
+
+// Faithful group-list-order version (common.py:161-177), needed by the substitutions-only path.
+int fz_group_best(const fz_match *in, uint64_t n, fz_match **out, uint64_t *n_out) {
+    if (!out || !n_out || (!in && n)) return fail(FZ_EINVAL, "null argument");
+    *out = nullptr; *n_out = 0;
+    struct Grp { int64_t s, e; fz_match best; };
+    std::vector<Grp> groups;
+    auto better = [](const fz_match &a, const fz_match &b) {
+        const int64_t la = a.end - a.start, lb = b.end - b.start;
+        return a.dist < b.dist || (a.dist == b.dist && (la > lb || (la == lb && a.start < b.start)));
+    };
+    std::vector<size_t> ov;
+    for (uint64_t i = 0; i < n; ++i) {
+        const fz_match &mt = in[i];
+        ov.clear();
+        // Matches arrive mostly in ascending order: scan from the back and stop early is NOT
+        // valid in general (merges reorder groups), so test every group like the reference.
+        for (size_t g = 0; g < groups.size(); ++g)
+            if (!(mt.end <= groups[g].s || mt.start >= groups[g].e)) ov.push_back(g);
+        if (ov.empty()) {
+            groups.push_back({mt.start, mt.end, mt});
+        } else if (ov.size() == 1) {
+            Grp &g = groups[ov[0]];
+            g.s = std::min(g.s, mt.start);
+            g.e = std::max(g.e, mt.end);
+            if (better(mt, g.best)) g.best = mt;
+        } else {
+            Grp u{mt.start, mt.end, mt};
+            for (size_t gi : ov) {
+                u.s = std::min(u.s, groups[gi].s);
+                u.e = std::max(u.e, groups[gi].e);
+                if (better(groups[gi].best, u.best)) u.best = groups[gi].best;
+            }
+            size_t w = 0, qi = 0;
+            for (size_t g = 0; g < groups.size(); ++g) {
+                if (qi < ov.size() && ov[qi] == g) { ++qi; continue; }
+                groups[w++] = groups[g];
+            }
+            groups.resize(w);
+            groups.push_back(u);
+        }
+    }
+    void *mem = nullptr;
+    int rc = alloc_out(groups.size(), sizeof(fz_match), &mem);
+    if (rc) return rc;
+    fz_match *o = static_cast<fz_match *>(mem);
+    for (size_t g = 0; g < groups.size(); ++g) o[g] = groups[g].best;
+    *out = o;
+    *n_out = groups.size();
+    return FZ_OK;
+}
+
+int fz_stats(fz_ctx *ctx, fz_stats_t *out) {
+    if (!ctx || !out) return fail(FZ_EINVAL, "null argument");
+    *out = ctx->stats;
+    return FZ_OK;
+}
+
+void fz_free(void *p) { free(p); }
+
+}  // extern "C"

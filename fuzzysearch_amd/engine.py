@@ -1,0 +1,157 @@
+"""Host-side glue between Python sequences and the HIP engine.
+
+* ``encode_pair`` turns (subsequence, sequence) of any type the reference accepts into two byte
+  buffers with IDENTICAL index semantics, so that every (start, end, dist) the kernels produce is
+  valid for the original objects:
+    - bytes-like (bytes, bytearray, memoryview, numpy uint8 ...): zero-copy pass-through — the
+      reference's "byteslike" native path (_c_ext_base.h:27-34);
+    - ``str``: latin-1 encoding when every code point fits a byte (same indices), else
+    - anything else (str with wide code points, list, tuple): symbol remapping.  All algorithms on
+      this path only ever compare a subsequence item with a sequence item
+      (levenshtein_ngram.py:55, _generic_search.pyx:100, search_exact.py:46), so mapping each
+      distinct subsequence symbol to a code 1..255 and every other sequence symbol to 0 preserves
+      every comparison.
+* ``DeviceSequence`` keeps a sequence resident in HBM across queries (upload once, search often).
+"""
+import numpy as np
+
+from . import _native
+
+__all__ = ['DeviceSequence', 'resident', 'encode_pair', 'is_byteslike']
+
+
+def is_byteslike(x):
+    if isinstance(x, (bytes, bytearray)):
+        return True
+    if isinstance(x, (str, list, tuple)):
+        return False
+    try:
+        mv = memoryview(x)
+    except TypeError:
+        return False
+    return mv.itemsize == 1 and mv.ndim == 1 and mv.c_contiguous
+
+
+def _remap_str(subsequence, sequence):
+    p = np.frombuffer(subsequence.encode('utf-32-le'), dtype=np.uint32)
+    t = np.frombuffer(sequence.encode('utf-32-le'), dtype=np.uint32)
+    symbols = np.unique(p)
+    if len(symbols) > 255:
+        raise NotImplementedError('subsequences with more than 255 distinct symbols are not supported')
+
+    def code(a):
+        if len(a) == 0:
+            return b''
+        pos = np.minimum(np.searchsorted(symbols, a), len(symbols) - 1)
+        return np.where(symbols[pos] == a, pos + 1, 0).astype(np.uint8).tobytes()
+    return code(p), code(t)
+
+
+def _remap_items(subsequence, sequence):
+    table = {}
+    for item in subsequence:
+        if item not in table:
+            if len(table) == 255:
+                raise NotImplementedError('subsequences with more than 255 distinct symbols are not supported')
+            table[item] = len(table) + 1
+    get = table.get
+    return bytes(table[item] for item in subsequence), bytes(bytearray(get(item, 0) for item in sequence))
+
+
+def encode_pair(subsequence, sequence):
+    """-> (pattern_bytes_like, sequence_bytes_like, byteslike: bool)."""
+    sub_b, seq_b = is_byteslike(subsequence), is_byteslike(sequence)
+    if sub_b and seq_b:
+        return subsequence, sequence, True
+    if isinstance(subsequence, str) and isinstance(sequence, str):
+        try:
+            return subsequence.encode('latin-1'), sequence.encode('latin-1'), False
+        except UnicodeEncodeError:
+            p, t = _remap_str(subsequence, sequence)
+            return p, t, False
+    if isinstance(sequence, (list, tuple)):
+        p, t = _remap_items(subsequence, sequence)
+        return p, t, False
+    raise TypeError('unsupported combination of subsequence / sequence types: %s / %s'
+                    % (type(subsequence).__name__, type(sequence).__name__))
+
+
+class DeviceSequence(object):
+    """A sequence made resident in HBM once; pass it as ``sequence`` to find_near_matches().
+
+    Only bytes-like and latin-1 ``str`` sequences can be made resident ahead of the query (symbol
+    remapping depends on the subsequence).  ``len()``, slicing and ``matched`` come from the
+    original object, which is kept alive.
+    """
+
+    def __init__(self, sequence, engine=None):
+        self.original = sequence
+        self.engine = engine or _native.default_engine()
+        if is_byteslike(sequence):
+            data = sequence
+            self.byteslike = True
+        elif isinstance(sequence, str):
+            data = sequence.encode('latin-1')      # UnicodeEncodeError -> not residency-capable
+            self.byteslike = False
+        else:
+            raise TypeError('only bytes-like or latin-1 str sequences can be made resident')
+        self.handle = self.engine.upload(data)
+
+    def __len__(self):
+        return len(self.original)
+
+    def __getitem__(self, item):
+        return self.original[item]
+
+    def release(self):
+        self.handle.release()
+
+
+def resident(sequence, engine=None):
+    """Upload ``sequence`` to HBM and return a handle usable wherever a sequence is expected."""
+    return DeviceSequence(sequence, engine)
+
+
+class _Prepared(object):
+    """(engine, resident handle, pattern bytes, original sequence, byteslike flag) for one query."""
+    __slots__ = ('engine', 'handle', 'pattern', 'original', 'byteslike', 'owned')
+
+    def release(self):
+        if self.owned:
+            self.handle.release()
+
+
+def prepare(subsequence, sequence):
+    pr = _Prepared()
+    if isinstance(sequence, DeviceSequence):
+        pr.engine = sequence.engine
+        pr.handle = sequence.handle
+        pr.original = sequence.original
+        pr.byteslike = sequence.byteslike
+        pr.owned = False
+        if sequence.byteslike:
+            if not is_byteslike(subsequence):
+                raise TypeError('a bytes-like subsequence is required for a bytes-like sequence')
+            pr.pattern = subsequence
+        else:
+            if not isinstance(subsequence, str):
+                raise TypeError('a str subsequence is required for a str sequence')
+            try:
+                pr.pattern = subsequence.encode('latin-1')
+            except UnicodeEncodeError:
+                # a symbol the resident latin-1 text cannot contain: it can never match anything.
+                # 0xFF..0x00 trick is unsafe, so fall back to a per-query upload with remapping.
+                p, t, _ = encode_pair(subsequence, sequence.original)
+                pr.engine = sequence.engine
+                pr.handle = pr.engine.upload(t)
+                pr.pattern = p
+                pr.owned = True
+        return pr
+    p, t, byteslike = encode_pair(subsequence, sequence)
+    pr.engine = _native.default_engine()
+    pr.handle = pr.engine.upload(t)
+    pr.pattern = p
+    pr.original = sequence
+    pr.byteslike = byteslike
+    pr.owned = True
+    return pr

@@ -1,0 +1,51 @@
+"""Generic (separate substitution / insertion / deletion limits) search.
+
+Mirrors src/fuzzysearch/generic_search.py:25-54, :198-237, :256-273.
+"""
+from .common import FuzzySearchBase, Match, consolidate_overlapping_matches
+from .engine import prepare
+from .search_exact import search_exact
+
+__all__ = ['find_near_matches_generic', 'find_near_matches_generic_ngrams', 'GenericSearch']
+
+
+def find_near_matches_generic_ngrams(subsequence, sequence, search_params):
+    if not len(subsequence):
+        raise ValueError('Given subsequence is empty!')
+    max_subs, max_ins, max_dels, max_l = search_params.unpacked
+    if len(subsequence) // (max_l + 1) == 0:
+        raise ValueError('the subsequence length must be greater than max_l_dist')
+    pr = prepare(subsequence, sequence)
+    try:
+        raw = pr.engine.generic_ngrams(pr.handle, pr.pattern, max_subs, max_ins, max_dels, max_l)
+    finally:
+        pr.release()
+    seq = pr.original
+    return [Match(s, e, d, matched=seq[s:e]) for (s, e, d, _g) in raw]
+
+
+def find_near_matches_generic(subsequence, sequence, search_params):
+    if not len(subsequence):
+        raise ValueError('Given subsequence is empty!')
+    m = len(subsequence)
+    if search_params.max_l_dist == 0:
+        return [Match(i, i + m, 0, matched=sequence[i:i + m]) for i in search_exact(subsequence, sequence)]
+    if m // (search_params.max_l_dist + 1) >= 3:
+        return find_near_matches_generic_ngrams(subsequence, sequence, search_params)
+    raise NotImplementedError(
+        'subsequence too short for the n-gram search (len // (max_l_dist + 1) < 3); '
+        'the linear-programming fallback is not implemented on the GPU')
+
+
+class GenericSearch(FuzzySearchBase):
+    @classmethod
+    def search(cls, subsequence, sequence, search_params):
+        return find_near_matches_generic(subsequence, sequence, search_params)
+
+    @classmethod
+    def consolidate_matches(cls, matches):
+        return consolidate_overlapping_matches(matches)
+
+    @classmethod
+    def extra_items_for_chunked_search(cls, subsequence, search_params):
+        return max(x for x in (search_params.max_l_dist, search_params.max_insertions) if x is not None)

@@ -1,0 +1,37 @@
+"""Levenshtein search dispatcher (mirrors src/fuzzysearch/levenshtein.py:9-38, :151-164)."""
+from .common import FuzzySearchBase, Match, consolidate_overlapping_matches
+from .levenshtein_ngram import find_near_matches_levenshtein_ngrams
+from .search_exact import search_exact
+
+__all__ = ['find_near_matches_levenshtein', 'LevenshteinSearch']
+
+
+def find_near_matches_levenshtein(subsequence, sequence, max_l_dist):
+    if not len(subsequence):
+        raise ValueError('Given subsequence is empty!')
+    if max_l_dist < 0:
+        raise ValueError('Maximum Levenshtein distance must be >= 0!')
+    m = len(subsequence)
+    if max_l_dist == 0:
+        return [Match(i, i + m, 0, sequence[i:i + m]) for i in search_exact(subsequence, sequence)]
+    if m // (max_l_dist + 1) >= 3:
+        return find_near_matches_levenshtein_ngrams(subsequence, sequence, max_l_dist)
+    # levenshtein.py:52-148 (pure-Python candidate automaton, len(p) // (k+1) < 3) is outside the
+    # GPU hot path; there is deliberately no CPU fallback in this package.
+    raise NotImplementedError(
+        'subsequence too short for the n-gram search (len // (max_l_dist + 1) < 3); '
+        'the linear-programming fallback is not implemented on the GPU')
+
+
+class LevenshteinSearch(FuzzySearchBase):
+    @classmethod
+    def search(cls, subsequence, sequence, search_params):
+        return find_near_matches_levenshtein(subsequence, sequence, search_params.max_l_dist)
+
+    @classmethod
+    def consolidate_matches(cls, matches):
+        return consolidate_overlapping_matches(matches)
+
+    @classmethod
+    def extra_items_for_chunked_search(cls, subsequence, search_params):
+        return search_params.max_l_dist

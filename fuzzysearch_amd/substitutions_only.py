@@ -1,0 +1,65 @@
+"""Substitutions-only search (mirrors src/fuzzysearch/substitutions_only.py:37-63, :236-301).
+
+SURVEY.md trap 5: for bytes-like input the reference returns the best match of every overlap
+group in group-creation order (C path + group_matches, :258-282); for ``str`` it returns every
+Hamming <= k window sorted by start (pure-Python path, :160-167).  Both are reproduced from the
+same GPU raw stream (fz_subs_ngrams).
+"""
+from .common import FuzzySearchBase, Match, best_of_groups_in_discovery_order
+from .engine import prepare
+from .search_exact import search_exact
+
+__all__ = ['find_near_matches_substitutions', 'find_near_matches_substitutions_ngrams',
+           'SubstitutionsOnlySearch']
+
+
+def _check_arguments(subsequence, sequence, max_substitutions):
+    if not len(subsequence):
+        raise ValueError('Given subsequence is empty!')
+    if max_substitutions is None or max_substitutions < 0:
+        raise ValueError('Maximum number of substitutions must be >= 0!')
+
+
+def find_near_matches_substitutions_ngrams(subsequence, sequence, max_substitutions):
+    _check_arguments(subsequence, sequence, max_substitutions)
+    m = len(subsequence)
+    if m // (max_substitutions + 1) == 0:
+        raise ValueError("The subsequence's length must be greater than max_substitutions!")
+    pr = prepare(subsequence, sequence)
+    try:
+        raw = pr.engine.subs_ngrams(pr.handle, pr.pattern, max_substitutions)
+    finally:
+        pr.release()
+    seq = pr.original
+    if pr.byteslike:
+        matches = [Match(s, e, d, matched=seq[s:e]) for (s, e, d, _g) in raw]
+        return best_of_groups_in_discovery_order(matches)
+    seen, out = set(), []
+    for (s, e, d, _g) in raw:
+        if s not in seen:
+            seen.add(s)
+            out.append(Match(s, e, d, matched=seq[s:e]))
+    return sorted(out, key=lambda match: match.start)
+
+
+def find_near_matches_substitutions(subsequence, sequence, max_substitutions):
+    _check_arguments(subsequence, sequence, max_substitutions)
+    m = len(subsequence)
+    if max_substitutions == 0:
+        return [Match(i, i + m, 0, sequence[i:i + m]) for i in search_exact(subsequence, sequence)]
+    if m // (max_substitutions + 1) >= 3:
+        return find_near_matches_substitutions_ngrams(subsequence, sequence, max_substitutions)
+    raise NotImplementedError(
+        'subsequence too short for the n-gram search (len // (max_substitutions + 1) < 3); '
+        'the linear-programming fallback is not implemented on the GPU')
+
+
+class SubstitutionsOnlySearch(FuzzySearchBase):
+    @classmethod
+    def search(cls, subsequence, sequence, search_params):
+        k = min(x for x in (search_params.max_l_dist, search_params.max_substitutions) if x is not None)
+        return find_near_matches_substitutions(subsequence, sequence, k)
+
+    @classmethod
+    def extra_items_for_chunked_search(cls, subsequence, search_params):
+        return 0

@@ -1,0 +1,139 @@
+/* fzhip.h — C-ABI of libfzhip.so, the MI355X (gfx950) fuzzy substring search engine.
+ *
+ * This is the drop-in boundary for the hot path of taleinat/fuzzysearch 0.8.1.
+ * The reference's native hooks are per-candidate CPython functions (GIL held, `y*` buffers):
+ *
+ *   search_exact_byteslike(sub, seq, start, end) -> list[int]        src/fuzzysearch/_common.c:5-112
+ *   count_differences_with_maximum_byteslike(a, b, max) -> int       src/fuzzysearch/_common.c:115-173
+ *   substitutions_only_find_near_matches_ngrams_byteslike(sub, seq, k) -> list[int]
+ *                                   src/fuzzysearch/_substitutions_only_ngrams_template.h:10-138
+ *   c_expand_short / c_expand_long(sub, seq, k) -> (dist, n) | (None, None)
+ *                                   src/fuzzysearch/_levenshtein_ngrams.pyx:9-75, :78-154
+ *   c_find_near_matches_generic_linear_programming(sub, seq, params) -> list[Match]
+ *                                   src/fuzzysearch/_generic_search.pyx:25-233
+ *
+ * That granularity (one call per n-gram hit) cannot feed a GPU, so the replacement boundary sits
+ * one level up, at the whole-search functions that *drive* those hooks:
+ *
+ *   fz_search_exact    <->  search_exact()                          search_exact.py:59-77
+ *   fz_lev_ngrams      <->  find_near_matches_levenshtein_ngrams()  levenshtein_ngram.py:159-198
+ *   fz_subs_ngrams     <->  substitutions_only_find_near_matches_ngrams_byteslike + the Match
+ *                           construction of substitutions_only.py:258-278
+ *   fz_generic_ngrams  <->  find_near_matches_generic_ngrams()      generic_search.py:198-237
+ *   fz_consolidate     <->  consolidate_overlapping_matches()       common.py:185-189
+ *   fz_group_best      <->  [get_best_match_in_group(g) for g in group_matches(ms)]
+ *                                                                   substitutions_only.py:279-282
+ *
+ * Conventions: plain pointers and sizes only (no torch / Python types).  Every function returns
+ * FZ_OK (0) or a negative FZ_E* code; fz_last_error() gives the text for the calling thread.
+ * Inputs are borrowed for the duration of the call.  Outputs (`fz_match**`, `uint64_t**`) are
+ * allocated by the library and released with fz_free().  A fz_ctx is not internally locked: use one
+ * per host thread.  All device work happens on the ctx's own HIP streams; calls return after the
+ * results are on the host.
+ *
+ * Error behaviour mirrors the reference: empty subsequence / n-gram length 0 -> FZ_EINVAL (the
+ * reference raises ValueError: levenshtein_ngram.py:164-165, _common.c:50-53).
+ */
+#ifndef FZHIP_H
+#define FZHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FZ_ABI_VERSION 1
+
+#define FZ_OK          0
+#define FZ_EINVAL     -1   /* invalid argument (maps to ValueError in the Python layer)     */
+#define FZ_ENOMEM     -2   /* host or device allocation failed (MemoryError)               */
+#define FZ_EDEVICE    -3   /* HIP runtime error / no usable gfx950 device (RuntimeError)   */
+#define FZ_EUNSUPPORTED -4 /* parameters outside what the kernels support (m, k limits)    */
+#define FZ_EHALO      -5   /* shard halo too small for this pattern (m + k bytes needed)   */
+
+typedef struct fz_ctx fz_ctx;
+typedef struct fz_seq fz_seq;
+
+/* Raw-stream record.  `block` = n-gram block index g = ngram_start / ngram_len (the outer loop
+ * variable of levenshtein_ngram.py:171); -1 where it does not apply.  Field order start, end,
+ * dist matches fuzzysearch.Match (common.py:15-20). */
+typedef struct {
+    int64_t start, end;
+    int32_t dist;
+    int32_t block;
+} fz_match;
+
+typedef struct {
+    uint64_t bytes_scanned;    /* sequence bytes streamed by the filter kernel(s), last call  */
+    uint64_t ngram_hits;       /* exact n-gram hits handed to verification, last call        */
+    uint64_t raw_matches;      /* raw-stream records produced, last call                     */
+    double   filter_ms;        /* hipEvent span of the filter kernel(s), last call           */
+    double   verify_ms;        /* hipEvent span of the verify kernel(s), last call           */
+    double   device_ms;        /* hipEvent span first launch -> results on host, last call   */
+    uint32_t filter_launches;  /* number of filter kernel launches in the last call          */
+    uint32_t n_devices;
+} fz_stats_t;
+
+int         fz_abi_version(void);
+const char *fz_last_error(void);
+int         fz_device_count(int *n);
+
+/* device_ids == NULL / n_devices == 0 -> device 0 only.  Requires gfx950. */
+int  fz_create(const int *device_ids, int n_devices, fz_ctx **out);
+void fz_destroy(fz_ctx *ctx);
+
+/* Make a sequence resident in HBM.  With several devices in the ctx it is split into contiguous
+ * shards, each with a halo, and every later search runs on all devices concurrently
+ * (SURVEY.md §8(e)). */
+int  fz_seq_upload(fz_ctx *ctx, const uint8_t *host, uint64_t n, fz_seq **out);
+
+/* One-process-per-GPU form (torchrun / RCCL jobs): this process holds bytes
+ * [buf_global_off, buf_global_off + buf_len) of a global sequence of global_n bytes and OWNS the
+ * n-gram hits whose index lies in [own_lo, own_hi).  The buffer must extend (m + k) bytes past
+ * the owned range on both sides (clamped to the global sequence) for every later query, else the
+ * query returns FZ_EHALO.  Results are in GLOBAL coordinates. */
+int  fz_seq_upload_shard(fz_ctx *ctx, const uint8_t *host_buf, uint64_t buf_len,
+                         uint64_t buf_global_off, uint64_t own_lo, uint64_t own_hi,
+                         uint64_t global_n, fz_seq **out);
+uint64_t fz_seq_len(const fz_seq *seq);       /* global length */
+void fz_seq_release(fz_seq *seq);
+
+/* All (overlapping) occurrences of p in seq[lo:hi], ascending.  lo/hi are clamped like
+ * search_exact.py:70-71; pass hi = UINT64_MAX for "to the end". */
+int fz_search_exact(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m,
+                    uint64_t lo, uint64_t hi, uint64_t **idx, uint64_t *n);
+
+/* Raw, un-consolidated match stream of find_near_matches_levenshtein_ngrams, in the reference's
+ * emission order (block ascending, then hit index ascending).  Requires m / (k+1) >= 1. */
+int fz_lev_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k,
+                  fz_match **out, uint64_t *n);
+
+/* Raw stream of the substitutions-only n-gram search: (i, i+m, min(Hamming, k+1), block) in the
+ * reference's discovery order, cross-block duplicates preserved. */
+int fz_subs_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k,
+                   fz_match **out, uint64_t *n);
+
+/* Raw stream of find_near_matches_generic_ngrams (the greedy candidate-set automaton run on the
+ * window around every n-gram hit), reference emission order. */
+int fz_generic_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m,
+                      uint32_t max_subs, uint32_t max_ins, uint32_t max_dels, uint32_t max_l,
+                      fz_match **out, uint64_t *n);
+
+/* consolidate_overlapping_matches: overlap groups -> best (dist, -len) per group -> sorted by
+ * (start, end, dist).  Ties inside a group (the reference breaks them by set iteration order, i.e.
+ * by PYTHONHASHSEED) are broken deterministically: smallest start. */
+int fz_consolidate(const fz_match *in, uint64_t n, fz_match **out, uint64_t *n_out);
+
+/* Best match of every overlap group in the reference's group-LIST order (group_matches appends new
+ * groups and re-appends merged ones at the end, common.py:161-177) — the order that
+ * substitutions_only.py:279-282 exposes.  Input order matters. */
+int fz_group_best(const fz_match *in, uint64_t n, fz_match **out, uint64_t *n_out);
+
+int  fz_stats(fz_ctx *ctx, fz_stats_t *out);
+void fz_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FZHIP_H */

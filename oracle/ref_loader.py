@@ -54,7 +54,7 @@ def load_reference_natives():
         raise RuntimeError("oracle/_ref is not built: run `make -C oracle ref` in the build container")
     out = {}
     for name in ("_common", "_substitutions_only", "_levenshtein_ngrams"):
-        out[name] = _load_ext("fzref" + name, _so(name))
+        out[name] = _load_ext("fzref." + name, _so(name))   # PyInit_<last dotted part>
     return out
 
 

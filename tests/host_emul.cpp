@@ -1,0 +1,78 @@
+// host_emul.cpp — TEST HARNESS: compiles the FZ_HD verification functions of
+// fuzzysearch_amd/csrc/fz_device.h with g++ and drives them one "lane" at a time, so the banded
+// expansion / clamping logic that the GPU kernels run can be checked against the oracle in the
+// CPU-only build container.  The n-gram hit enumeration here is a plain memcmp loop standing in
+// for the filter kernel (which only exists as HIP and is tested with -m gpu).
+// Never part of the product: built and loaded by tests/test_device_logic_host.py only.
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../fuzzysearch_amd/csrc/fz_device.h"
+
+struct HostScores {
+    std::vector<uint16_t> v;
+    uint32_t get(uint32_t i) const { return v[i]; }
+    void set(uint32_t i, uint32_t x) { v[i] = (uint16_t)x; }
+};
+
+struct OutRec { int64_t start, end; int32_t dist, block; };
+
+extern "C" {
+
+// mode 1 = Levenshtein n-grams, 2 = substitutions-only n-grams.  The sequence is presented to the
+// device functions as a shard buffer [buf_off, buf_off + buf_len) of a global sequence of n bytes
+// (t points at global byte 0) owning hits in [own_lo, own_hi).
+int64_t emul_search(int mode, const uint8_t *p, uint32_t m, const uint8_t *t, uint64_t n, uint32_t k,
+                    uint64_t buf_off, uint64_t buf_len, uint64_t own_lo, uint64_t own_hi,
+                    OutRec *out, int64_t cap) {
+    const uint32_t L = m / (k + 1);
+    if (L == 0) return -1;
+    HostScores sc;
+    sc.v.assign(2 * k + 4, 0);
+    // copy the shard so that any out-of-shard access reads poison, not neighbouring data
+    std::vector<uint8_t> shard(buf_len + 64, 0xEE);
+    memcpy(shard.data(), t + buf_off, buf_len);
+    FzSeqView view{shard.data(), buf_off};
+    int64_t cnt = 0;
+    uint32_t g = 0;
+    for (uint32_t s = 0; s + L <= m; s += L, ++g) {
+        int64_t lo, hi;
+        const int64_t N = (int64_t)n;
+        if (mode == 1) {
+            lo = (int64_t)s - (int64_t)k; if (lo < 0) lo = 0; if (lo > N) lo = N;
+            hi = N - (int64_t)m + s + L + k; if (hi > N) hi = N; if (hi < lo) hi = lo;
+        } else {
+            if (n < m) return 0;
+            lo = s; hi = N - (int64_t)(m - s - L);
+        }
+        for (int64_t idx = lo; idx + (int64_t)L <= hi; ++idx) {
+            if ((uint64_t)idx < own_lo || (uint64_t)idx >= own_hi) continue;
+            if (memcmp(t + idx, p + s, L) != 0) continue;
+            FzRec rec;
+            bool ok = mode == 1 ? fz_verify_lev(sc, view, n, p, m, k, L, s, (uint64_t)idx, rec)
+                                : fz_verify_subs(view, p, m, k, L, s, (uint64_t)idx, rec);
+            if (!ok) continue;
+            if (cnt < cap) {
+                out[cnt].start = idx - (int64_t)rec.l;
+                out[cnt].end = idx + L + rec.r;
+                out[cnt].dist = (int32_t)rec.dist;
+                out[cnt].block = (int32_t)g;
+            }
+            ++cnt;
+        }
+    }
+    return cnt;
+}
+
+int emul_expand(const uint8_t *sub, uint32_t sublen, const uint8_t *win, uint32_t winlen, uint32_t budget,
+                uint32_t *dist, uint32_t *consumed) {
+    HostScores sc;
+    sc.v.assign(2 * budget + 4, 0);
+    auto s = [&](uint32_t i) -> uint8_t { return sub[i]; };
+    auto w = [&](uint32_t j) -> uint8_t { return win[j]; };
+    return fz_expand(sc, s, sublen, w, winlen, budget, *dist, *consumed) ? 1 : 0;
+}
+
+}  // extern "C"

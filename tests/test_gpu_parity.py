@@ -1,0 +1,180 @@
+"""-m gpu: the HIP path (through the C-ABI) against the oracle, bit-exact and ordered."""
+import random
+
+import numpy as np
+import pytest
+
+import oracle
+from tests import workloads
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_case(rnd, max_n=300, max_m=24, max_k=4):
+    sigma = rnd.choice([2, 2, 3, 4, 4, 20])
+    alpha = bytes(rnd.sample(range(33, 127), sigma))
+    n = rnd.randint(0, max_n)
+    t = bytes(rnd.choice(alpha) for _ in range(n))
+    k = rnd.randint(1, max_k)
+    m = rnd.randint(k + 1, max_m)
+    if rnd.random() < 0.6 and n >= m:
+        st = rnd.randint(0, n - m)
+        p = bytearray(t[st:st + m])
+        for _ in range(rnd.randint(0, k)):
+            q = rnd.randrange(len(p))
+            op = rnd.random()
+            if op < 0.4:
+                p[q] = rnd.choice(alpha)
+            elif op < 0.7 and len(p) > k + 1:
+                del p[q]
+            else:
+                p.insert(q, rnd.choice(alpha))
+        p = bytes(p)
+    else:
+        p = bytes(rnd.choice(alpha) for _ in range(m))
+    return p, t, k
+
+
+def test_lev_ngrams_raw_random(engine):
+    rnd = random.Random(11)
+    n_cases = 0
+    for _ in range(1500):
+        p, t, k = _rand_case(rnd)
+        if len(p) // (k + 1) == 0:
+            continue
+        seq = engine.upload(t)
+        got = engine.lev_ngrams(seq, p, k)
+        seq.release()
+        assert got == oracle.lev_ngrams_raw(p, t, k), (p, t, k)
+        n_cases += 1
+    assert n_cases > 1000
+
+
+def test_subs_ngrams_raw_random(engine):
+    rnd = random.Random(12)
+    for _ in range(1000):
+        p, t, k = _rand_case(rnd)
+        if len(p) // (k + 1) == 0:
+            continue
+        seq = engine.upload(t)
+        got = engine.subs_ngrams(seq, p, k)
+        seq.release()
+        assert got == oracle.subs_ngrams_raw(p, t, k), (p, t, k)
+
+
+def test_search_exact_random(engine):
+    rnd = random.Random(13)
+    for _ in range(1000):
+        sigma = rnd.choice([1, 2, 3, 4])
+        alpha = bytes(rnd.sample(range(65, 91), sigma))
+        n = rnd.randint(0, 400)
+        t = bytes(rnd.choice(alpha) for _ in range(n))
+        m = rnd.randint(1, 14)
+        p = bytes(rnd.choice(alpha) for _ in range(m))
+        lo = rnd.randint(-3, n + 3)
+        hi = rnd.randint(-3, n + 3)
+        seq = engine.upload(t)
+        got = engine.search_exact(seq, p, max(0, lo), max(0, hi))
+        got_all = engine.search_exact(seq, p)
+        seq.release()
+        assert got == oracle.search_exact(p, t, lo, hi), (p, t, lo, hi)
+        assert got_all == oracle.search_exact(p, t), (p, t)
+
+
+@pytest.mark.parametrize("m,k", [(20, 2), (9, 2), (12, 1), (32, 3), (23, 5), (64, 5), (10, 0 + 1), (40, 12)])
+def test_lev_ngrams_medium_dna(engine, m, k):
+    """4 MiB of DNA with planted variants: every n-gram length / block count regime."""
+    n = 4 << 20
+    seq = workloads.dna(n, 99 + m)
+    pattern = workloads.dna(m, 5 + k)
+    workloads.plant_variants(seq, pattern, 256, 3)
+    t, p = seq.tobytes(), pattern.tobytes()
+    h = engine.upload(seq)
+    got = engine.lev_ngrams(h, p, k)
+    h.release()
+    exp = oracle.lev_ngrams_raw(p, t, k)
+    assert got == exp
+    assert len(exp) >= 100
+
+
+@pytest.mark.parametrize("m,k", [(32, 3), (20, 2), (12, 3), (9, 2)])
+def test_subs_ngrams_medium(engine, m, k):
+    n = 4 << 20
+    seq = workloads.dna(n, 199 + m)
+    pattern = workloads.dna(m, 15 + k)
+    workloads.plant_variants(seq, pattern, 256, 4)
+    t, p = seq.tobytes(), pattern.tobytes()
+    h = engine.upload(seq)
+    got = engine.subs_ngrams(h, p, k)
+    h.release()
+    assert got == oracle.subs_ngrams_raw(p, t, k)
+
+
+def test_dense_and_degenerate_inputs(engine):
+    """Pathological hit densities: queue overflow -> slow tile path, record/hit buffer growth."""
+    t = b'A' * 200000
+    h = engine.upload(t)
+    for p, k in [(b'A' * 9, 2), (b'AAAAAAAAAAAB', 2), (b'AAAB', 0 + 1 - 1 + 1)]:
+        if len(p) // (k + 1) == 0:
+            continue
+        got = engine.lev_ngrams(h, p, k)
+        assert got == oracle.lev_ngrams_raw(p, t, k)
+        got = engine.subs_ngrams(h, p, k)
+        assert got == oracle.subs_ngrams_raw(p, t, k)
+    assert engine.search_exact(h, b'AAA') == oracle.search_exact(b'AAA', t)
+    h.release()
+    # zero bytes in pattern and sequence (the device buffer is zero padded)
+    t = bytes(1000) + b'\x01\x00\x00\x02' + bytes(50)
+    h = engine.upload(t)
+    for p, k in [(bytes(12), 2), (b'\x00\x00\x01\x00\x00\x02\x00\x00\x00', 2)]:
+        assert engine.lev_ngrams(h, p, k) == oracle.lev_ngrams_raw(p, t, k)
+        assert engine.subs_ngrams(h, p, k) == oracle.subs_ngrams_raw(p, t, k)
+    assert engine.search_exact(h, bytes(5)) == oracle.search_exact(bytes(5), t)
+    h.release()
+    # empty and shorter-than-pattern sequences
+    for t in (b'', b'ACG', b'ACGTACGTAC'):
+        h = engine.upload(t)
+        assert engine.lev_ngrams(h, b'ACGTACGTACGT', 2) == oracle.lev_ngrams_raw(b'ACGTACGTACGT', t, 2)
+        assert engine.subs_ngrams(h, b'ACGTACGTACGT', 2) == oracle.subs_ngrams_raw(b'ACGTACGTACGT', t, 2)
+        assert engine.search_exact(h, b'ACG') == oracle.search_exact(b'ACG', t)
+        h.release()
+
+
+def test_sharded_equals_unsharded(engine):
+    """Two shards with (m + k) halos, hits owned by index == one sequence."""
+    rnd = random.Random(21)
+    n = 1 << 20
+    seq = workloads.dna(n, 77)
+    pattern = workloads.dna(20, 1)
+    workloads.plant_variants(seq, pattern, 512, 9)
+    p, k = pattern.tobytes(), 2
+    t = seq.tobytes()
+    exp = oracle.lev_ngrams_raw(p, t, k)
+    halo = len(p) + k
+    for _ in range(6):
+        cut = rnd.choice([0, 1, halo - 1, halo, n // 2, n - halo, n - 1, n, rnd.randint(0, n)])
+        a = engine.upload_shard(seq[:min(n, cut + halo)], 0, 0, cut, n)
+        lo = max(0, cut - halo)
+        b = engine.upload_shard(seq[lo:], lo, cut, n, n)
+        got = engine.lev_ngrams(a, p, k) + engine.lev_ngrams(b, p, k)
+        a.release()
+        b.release()
+        got.sort(key=lambda r: r[3])          # stable: block major, rank order keeps idx ascending
+        assert got == exp, cut
+
+
+def test_public_api_matches_oracle(engine):
+    import fuzzysearch_amd as fa
+    rnd = random.Random(31)
+    for _ in range(300):
+        p, t, k = _rand_case(rnd, max_n=200)
+        m = len(p)
+        if m // (k + 1) < 3:
+            continue
+        got = fa.find_near_matches(p, t, max_l_dist=k)
+        exp = oracle.consolidate(oracle.lev_ngrams_raw(p, t, k))
+        assert [(x.start, x.end, x.dist) for x in got] == exp, (p, t, k)
+        assert all(x.matched == t[x.start:x.end] for x in got)
+    assert fa.find_near_matches(b'PATTERN', b'---PATERN---', max_l_dist=1) == \
+        [fa.Match(3, 9, 1, b'PATERN')]
+    assert fa.find_near_matches('PATTERN', '---PATERN---', max_l_dist=1) == [fa.Match(3, 9, 1, 'PATERN')]

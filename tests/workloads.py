@@ -1,0 +1,52 @@
+"""Deterministic synthetic workloads shared by tests/ and bench.py."""
+import numpy as np
+
+DNA = np.frombuffer(b'ACGT', dtype=np.uint8)
+TEXT65 = np.frombuffer(b'ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789 .,', dtype=np.uint8)
+
+
+def dna(n, seed):
+    return DNA[np.random.default_rng(seed).integers(0, 4, n, dtype=np.uint8)]
+
+
+def text65(n, seed):
+    return TEXT65[np.random.default_rng(seed).integers(0, 65, n, dtype=np.uint8)]
+
+
+def plant_variants(seq, pattern, n_plant, seed, alphabet=DNA):
+    """Overwrite `seq` (uint8 array, in place) with n_plant variants of `pattern` at sorted random
+    positions at least 64 apart: variant i % 4 in {exact, 1 substitution, 1 deletion, 1 insertion}.
+    Returns the list of (position, kind)."""
+    rng = np.random.default_rng(seed)
+    n, m = len(seq), len(pattern)
+    if n < 4 * (m + 64):
+        return []
+    pos = np.sort(rng.choice(n - 64 - m, size=min(n_plant, (n - 64 - m) // 128), replace=False))
+    out, last = [], -10 ** 9
+    for i, p0 in enumerate(pos):
+        p0 = int(p0)
+        if p0 - last < 64 + m:
+            continue
+        last = p0
+        kind = i % 4
+        v = bytearray(pattern.tobytes())
+        q = int(rng.integers(1, m - 1))
+        if kind == 1:
+            cur = v[q]
+            idx = int(np.where(alphabet == cur)[0][0]) if cur in alphabet else 0
+            v[q] = int(alphabet[(idx + 1) % len(alphabet)])
+        elif kind == 2:
+            del v[q]
+        elif kind == 3:
+            v.insert(q, int(alphabet[0]))
+        seq[p0:p0 + len(v)] = np.frombuffer(bytes(v), dtype=np.uint8)
+        out.append((p0, kind))
+    return out
+
+
+def cfg2(n=2 ** 30, n_plant=1024):
+    """BASELINE config 2: n bytes of iid DNA, |p| = 20, k = 2, planted variants."""
+    seq = dna(n, 20250925)
+    pattern = dna(20, 1)
+    planted = plant_variants(seq, pattern, n_plant, 7)
+    return seq, pattern, planted
