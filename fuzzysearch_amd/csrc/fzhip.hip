@@ -46,7 +46,7 @@ int fail(int code, const char *fmt, ...) {
     } while (0)
 
 constexpr uint64_t kHeaderBytes = 1024;          // counters[0] = emitted hits, [1] = records, [8..71] = confirmed-hit tallies
-constexpr uint64_t kFirstCopyRecs = 2048;        // records fetched together with the header
+constexpr uint64_t kFirstCopyRecs = 4096;        // records fetched together with the header
 
 struct DevState {
     int device = 0;
@@ -170,7 +170,13 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     const uint32_t L = q.plan.L;
     const uint32_t G = (uint32_t)q.plan.s.size();
     const uint64_t ntiles = (sh.geom.buf_len + FZ_TILE_BYTES - 1) / FZ_TILE_BYTES;
-    const uint64_t max_grid = (uint64_t)d.n_cus * 8;
+    // Grid: every workgroup strides over ~16 tiles (256 KiB).  Measured on MI355X at 1 GiB: 6 / 8 /
+    // 12 / 16 / 20 / 32 / 64 workgroups per CU -> 0.302 / 0.302 / 0.276 / 0.267 / 0.265 / 0.280 /
+    // 0.333 ms: several rounds of short workgroups overlap one workgroup's end-of-life verification
+    // (latency-bound) with the others' streaming; too many pay the per-workgroup fixed cost.  At least
+    // 6 per CU (the co-resident count at this kernel's SGPR use) so small inputs still fill the chip.
+    static const int tiles_per_wg = []() { const char *e = getenv("FZ_TILES_PER_WG"); int v = e ? atoi(e) : 0; return v > 0 ? v : 16; }();
+    const uint64_t max_grid = std::max<uint64_t>((uint64_t)d.n_cus * 6, ntiles / tiles_per_wg);
     // the queue codes carry a 15-bit per-workgroup tile iteration
     const uint64_t min_grid = (ntiles + 32766) / 32767;
     dim3 grid((unsigned)std::max<uint64_t>(std::max<uint64_t>(1, min_grid), std::min<uint64_t>(ntiles, max_grid)));
@@ -343,8 +349,28 @@ int validate(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m) {
     return FZ_OK;
 }
 
+// Order records by key = (block, idx): LSD radix sort over the key bytes that actually vary
+// (O(M) — a comparison sort of the 24-byte records costs ~40 ns per record on the host).
 void sort_recs(std::vector<FzRec> &recs) {
-    std::sort(recs.begin(), recs.end(), [](const FzRec &a, const FzRec &b) { return a.key < b.key; });
+    const size_t n = recs.size();
+    if (n < 2) return;
+    if (n < 64) {
+        std::sort(recs.begin(), recs.end(), [](const FzRec &a, const FzRec &b) { return a.key < b.key; });
+        return;
+    }
+    uint64_t diff = 0;
+    for (size_t i = 1; i < n; ++i) diff |= recs[i].key ^ recs[0].key;
+    std::vector<FzRec> tmp(n);
+    FzRec *src = recs.data(), *dst = tmp.data();
+    for (int byte = 0; byte < 8; ++byte) {
+        if (((diff >> (8 * byte)) & 0xff) == 0) continue;
+        size_t count[257] = {0};
+        for (size_t i = 0; i < n; ++i) ++count[((src[i].key >> (8 * byte)) & 0xff) + 1];
+        for (int b = 0; b < 256; ++b) count[b + 1] += count[b];
+        for (size_t i = 0; i < n; ++i) dst[count[(src[i].key >> (8 * byte)) & 0xff]++] = src[i];
+        std::swap(src, dst);
+    }
+    if (src != recs.data()) memcpy(recs.data(), src, n * sizeof(FzRec));
 }
 
 int emit_matches(const std::vector<FzRec> &recs, uint32_t L, fz_match **out, uint64_t *n) {
