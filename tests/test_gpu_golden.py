@@ -1,0 +1,155 @@
+"""-m gpu: the drop-in API on the MI355X replayed against the golden vectors recorded from the
+reference's own unit tests (tests/golden/reference_calls.jsonl).  Each test mirrors one of the
+reference's behavioural base classes: same inputs, expected outputs taken from the
+reference run."""
+import pytest
+
+import fuzzysearch_amd as fa
+import oracle
+from fuzzysearch_amd import levenshtein, levenshtein_ngram, search_exact, substitutions_only
+from tests import golden_io
+
+pytestmark = pytest.mark.gpu
+
+_EXC = {"ValueError": ValueError, "TypeError": TypeError}
+
+
+def _matches(result):
+    return [(m.start, m.end, m.dist, m.matched) for m in result]
+
+
+def _expect(rec):
+    return [(m.start, m.end, m.dist, m.matched) for m in rec["result"]]
+
+
+def _route_is_ngram(m, k):
+    return k == 0 or m // (k + 1) >= 3
+
+
+def test_search_exact_golden(engine):
+    n = 0
+    for rec in golden_io.load("search_exact"):
+        if "raises" in rec:
+            if rec["raises"] in _EXC and len(rec["args"]) >= 2 and len(rec["args"][0]) == 0:
+                with pytest.raises(_EXC[rec["raises"]]):
+                    search_exact.search_exact(*rec["args"], **rec["kwargs"])
+            continue
+        assert list(search_exact.search_exact(*rec["args"], **rec["kwargs"])) == list(rec["result"]), rec["args"][2:]
+        n += 1
+    assert n >= 300
+
+
+def test_levenshtein_ngrams_raw_golden(engine):
+    n = 0
+    for rec in golden_io.load("find_near_matches_levenshtein_ngrams"):
+        if "raises" in rec:
+            with pytest.raises(_EXC[rec["raises"]]):
+                levenshtein_ngram.find_near_matches_levenshtein_ngrams(*rec["args"])
+            continue
+        got = levenshtein_ngram.find_near_matches_levenshtein_ngrams(*rec["args"])
+        assert _matches(got) == _expect(rec), rec["args"]
+        n += 1
+    assert n >= 30
+
+
+def test_find_near_matches_levenshtein_golden(engine):
+    n = 0
+    for rec in golden_io.load("find_near_matches_levenshtein"):
+        sub, seq, k = (list(rec["args"]) + [rec["kwargs"].get("max_l_dist")])[:3]
+        if "raises" in rec:
+            if len(sub) == 0:
+                with pytest.raises(ValueError):
+                    list(levenshtein.find_near_matches_levenshtein(sub, seq, k))
+            continue
+        if not _route_is_ngram(len(sub), k):
+            with pytest.raises(NotImplementedError):       # LP route: outside the GPU hot path
+                levenshtein.find_near_matches_levenshtein(sub, seq, k)
+            continue
+        got = levenshtein.find_near_matches_levenshtein(sub, seq, k)
+        assert _matches(got) == _expect(rec), (sub, seq, k)
+        n += 1
+    assert n >= 50
+
+
+def test_substitutions_golden(engine):
+    n = 0
+    for rec in golden_io.load("find_near_matches_substitutions") + golden_io.load("find_near_matches_substitutions_ngrams"):
+        sub, seq, k = (list(rec["args"]) + [rec["kwargs"].get("max_substitutions")])[:3]
+        fn = getattr(substitutions_only, rec["fn"])
+        if "raises" in rec:
+            if rec["raises"] == "ValueError":
+                with pytest.raises(ValueError):
+                    fn(sub, seq, k)
+            continue
+        ngram_fn = rec["fn"].endswith("ngrams")
+        if (ngram_fn and len(sub) // (k + 1) == 0) or (not ngram_fn and not _route_is_ngram(len(sub), k)):
+            continue
+        got, exp = _matches(fn(sub, seq, k)), _expect(rec)
+        assert len(got) == len(exp), (sub, seq, k)
+        for g, e in zip(got, exp):           # group order pinned; in-group ties are hash-seed dependent
+            assert g == e or (g[2] == e[2] and g[1] - g[0] == e[1] - e[0]), (sub, seq, k, got, exp)
+        n += 1
+    assert n >= 40
+
+
+def test_find_near_matches_public_api_golden(engine):
+    """Every find_near_matches(...) call of the reference's suite whose route is on the GPU."""
+    n = skipped = 0
+    for rec in golden_io.load("find_near_matches"):
+        args, kwargs = rec["args"], rec["kwargs"]
+        if "raises" in rec:
+            if rec["raises"] in _EXC:
+                with pytest.raises(_EXC[rec["raises"]]):
+                    fa.find_near_matches(*args, **kwargs)
+            continue
+        try:
+            got = fa.find_near_matches(*args, **kwargs)
+        except NotImplementedError:
+            skipped += 1                      # LP / generic routes
+            continue
+        got, exp = _matches(got), _expect(rec)
+        params = fa.LevenshteinSearchParams(*(list(args[2:]) + [None] * 4)[:4]) if len(args) > 2 else \
+            fa.LevenshteinSearchParams(**kwargs)
+        cls = fa.choose_search_class(params)
+        if cls is fa.SubstitutionsOnlySearch:
+            assert len(got) == len(exp)
+            for g, e in zip(got, exp):
+                assert g == e or (g[2] == e[2] and g[1] - g[0] == e[1] - e[0]), (args, kwargs)
+        elif got != exp:
+            sub, seq = args[0], args[1]
+            from fuzzysearch_amd.engine import encode_pair
+            p, t, _ = encode_pair(sub, seq)
+            raw = oracle.lev_ngrams_raw(bytes(p), bytes(t), params.max_l_dist)
+            assert golden_io.equal_modulo_ties([g[:3] for g in got], [e[:3] for e in exp], raw), (args, kwargs, got, exp)
+        n += 1
+    assert n >= 100, (n, skipped)
+
+
+def test_reference_readme_examples(engine):
+    assert fa.find_near_matches('PATTERN', '---PATERN---', max_l_dist=1) == [fa.Match(3, 9, 1, 'PATERN')]
+    seq = '''GACTAGCACTGTAGGGATAACAATTTCACACAGGTGGACAATTACATTGAAAATCACAGATTGGTCACACACACATTGGACATACATAGAAACACACACACATACATTAGATACGAACATAGAAACACACATTAGACGCGTACATAGACACAAACACATTGACAGGCAGTTCAGATGATGACGCCCGACTGATACTCGCGTAGTCGTGGGAGGCAAGGCACACAGGGGATAGG'''
+    sub = 'TGCACTGTAGGGATAACAAT'
+    assert fa.find_near_matches(sub, seq, max_l_dist=2) == [fa.Match(3, 24, 1, 'TAGCACTGTAGGGATAACAAT')]
+    assert fa.find_near_matches(sub.encode(), seq.encode(), max_l_dist=2) == [fa.Match(3, 24, 1, b'x')]
+
+
+def test_find_near_matches_in_file_on_gpu(engine, tmp_path):
+    """The reference's chunk-boundary sweep (tests/test_find_near_matches_in_file.py:73-152) on the
+    n-gram route, binary and text mode."""
+    import attr
+    needle, hay = b'PATTERNPATTERN', b'PATTERNPATERN'
+    fn = tmp_path / "hay.bin"
+    for chunk_size in (100, 1 << 10, 1 << 12):
+        for delta in sorted({-len(needle), -len(needle) + 1, -4, -2, -1, 0, 1}):
+            data = bytearray(chunk_size + 100)
+            data[chunk_size + delta:chunk_size + delta + len(hay)] = hay
+            fn.write_bytes(bytes(data))
+            exp_raw = oracle.consolidate(oracle.lev_ngrams_raw(needle, bytes(data), 2))
+            for cs in (chunk_size, chunk_size // 2):
+                with open(fn, 'rb') as f:
+                    got = fa.find_near_matches_in_file(needle, f, max_l_dist=2, _chunk_size=cs)
+                assert [(m.start, m.end, m.dist) for m in got] == exp_raw, (chunk_size, delta, cs)
+                assert all(m.matched == bytes(data[m.start:m.end]) for m in got)
+            with open(fn, 'r', encoding='latin-1') as f:
+                got = fa.find_near_matches_in_file(needle.decode(), f, max_l_dist=2, _chunk_size=chunk_size)
+            assert [(m.start, m.end, m.dist) for m in got] == exp_raw

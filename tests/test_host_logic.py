@@ -1,0 +1,182 @@
+"""Host-side logic of the drop-in layer: parameter validation / normalisation, strategy choice,
+Match semantics, input encoding, and libfzhip's host-only consolidation entry points
+(fz_consolidate / fz_group_best run on the CPU, no device needed).  CPU only."""
+import random
+
+import attr
+import pytest
+
+import fuzzysearch_amd as fa
+import oracle
+from fuzzysearch_amd import _native, common, engine
+from fuzzysearch_amd.common import LevenshteinSearchParams, Match
+from tests import golden_io
+
+
+def test_library_loads_and_exports_the_declared_abi():
+    import os
+    import re
+    lib = _native.load_library()
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "fzhip.h")).read()
+    declared = set(re.findall(r"\b(fz_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(_native.EXPORTED_SYMBOLS), declared ^ set(_native.EXPORTED_SYMBOLS)
+    for sym in declared:
+        assert getattr(lib, sym) is not None
+    assert lib.fz_abi_version() == 1
+
+
+def test_no_device_fails_loudly():
+    """Without an MI355X the product raises; it never computes matches on the CPU."""
+    import ctypes
+    lib = _native.load_library()
+    n = ctypes.c_int(-1)
+    lib.fz_device_count(ctypes.byref(n))
+    if n.value > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(_native.HipEngineError):
+        fa.find_near_matches(b"PATTERN", b"---PATERN---", max_l_dist=1)
+
+
+def test_params_validation_and_normalisation():
+    """Golden: every LevenshteinSearchParams outcome the reference's dispatcher tests rely on
+    (common.py:61-116)."""
+    P = LevenshteinSearchParams
+    with pytest.raises(ValueError):
+        P()
+    for bad in [dict(max_substitutions=1), dict(max_insertions=1, max_deletions=1),
+                dict(max_substitutions=1, max_insertions=1), dict(max_substitutions=1, max_deletions=1)]:
+        with pytest.raises(ValueError):
+            P(**bad)
+    for bad in [dict(max_l_dist=-1), dict(max_l_dist=1.5), dict(max_substitutions="1", max_l_dist=2)]:
+        with pytest.raises(TypeError):
+            P(**bad)
+    assert P(None, None, None, 2).unpacked == (2, 2, 2, 2)
+    assert P(1, 2, 3, None).unpacked == (1, 2, 3, 6)
+    assert P(5, 2, 2, 5).unpacked == (5, 2, 2, 5)
+    assert P(1, 1, 1, 10).unpacked == (1, 1, 1, 3)
+    assert P(3, 0, 0, None).unpacked == (3, 0, 0, 3)
+    assert P(None, 0, 0, 4).unpacked == (4, 0, 0, 4)
+    assert attr.evolve(P(1, 2, 3, None), max_l_dist=2).unpacked == (1, 2, 2, 2)
+
+
+def test_choose_search_class_rules():
+    """SURVEY.md A.4 / __init__.py:60-83, incl. trap 4 (max_l_dist alone never reaches Generic)."""
+    P = LevenshteinSearchParams
+    assert fa.choose_search_class(P(0, 0, 0, 0)) is fa.ExactSearch
+    assert fa.choose_search_class(P(3, 3, 3, 0)) is fa.ExactSearch
+    assert fa.choose_search_class(P(3, 0, 0, None)) is fa.SubstitutionsOnlySearch
+    assert fa.choose_search_class(P(3, 0, 0, 5)) is fa.SubstitutionsOnlySearch
+    assert fa.choose_search_class(P(None, None, None, 5)) is fa.LevenshteinSearch
+    assert fa.choose_search_class(P(5, 5, 5, 5)) is fa.LevenshteinSearch
+    assert fa.choose_search_class(P(5, 2, 2, 5)) is fa.GenericSearch
+    assert fa.choose_search_class(P(1, 1, 1, None)) is fa.GenericSearch
+    assert fa.LevenshteinSearch.extra_items_for_chunked_search(b"x", P(None, None, None, 3)) == 3
+    assert fa.GenericSearch.extra_items_for_chunked_search(b"x", P(5, 4, 2, 5)) == 5
+    assert fa.ExactSearch.extra_items_for_chunked_search(b"x", P(0, 0, 0, 0)) == 0
+    assert fa.SubstitutionsOnlySearch.extra_items_for_chunked_search(b"x", P(2, 0, 0, 2)) == 0
+
+
+def test_match_semantics():
+    a, b = Match(1, 5, 2, b"abcd"), Match(1, 5, 2, "other")
+    assert a == b and hash(a) == hash(b) and len({a, b}) == 1        # `matched` is not identity
+    assert sorted([Match(3, 4, 0, "x"), Match(1, 9, 2, "y"), Match(1, 5, 2, "z")])[0].end == 5
+    assert attr.evolve(a, start=0).start == 0
+    with pytest.raises(attr.exceptions.FrozenInstanceError):
+        a.start = 3
+    for bad in [(-1, 2, 0, "x"), (3, 2, 0, "x"), (1, 2, -1, "x"), (1, 2, 0, None)]:
+        with pytest.raises(ValueError):
+            Match(*bad)
+    assert repr(Match(3, 9, 1, "PATERN")) == "Match(start=3, end=9, dist=1, matched='PATERN')"
+
+
+def test_encode_pair_preserves_comparisons():
+    p, t, byteslike = engine.encode_pair(b"abc", bytearray(b"xxabcxx"))
+    assert byteslike and bytes(t) == b"xxabcxx"
+    p, t, byteslike = engine.encode_pair("abc", "xxabcxx")
+    assert not byteslike and (p, t) == (b"abc", b"xxabcxx")
+    p, t, _ = engine.encode_pair("a中c", "xxa中cx中é")
+    assert len(p) == 3 and len(t) == 8
+    assert [t[i] == p[j] for i in range(8) for j in range(3)] == \
+        ["xxa中cx中é"[i] == "a中c"[j] for i in range(8) for j in range(3)]
+    words_p, words_t = "over a lazy dog".split(), "the big brown fox jumped over the lazy dog".split()
+    p, t, _ = engine.encode_pair(words_p, words_t)
+    assert [t[i] == p[j] for i in range(len(t)) for j in range(len(p))] == \
+        [words_t[i] == words_p[j] for i in range(len(words_t)) for j in range(len(words_p))]
+    with pytest.raises(TypeError):
+        engine.encode_pair("abc", b"abc")
+    with pytest.raises(NotImplementedError):
+        engine.encode_pair([str(i) for i in range(300)], ["1", "2"])
+
+
+def test_fz_consolidate_and_group_best_against_oracle_and_golden():
+    rnd = random.Random(9)
+    for _ in range(3000):
+        n = rnd.randint(0, 25)
+        raw = []
+        for _ in range(n):
+            s = rnd.randint(0, 40)
+            e = s + rnd.choice([0, 0, 1, 2, 3, 5, 8])
+            raw.append((s, e, rnd.randint(0, 3), rnd.randint(0, 2)))
+        best, _hull = oracle.group_best(raw)
+        assert [b[:3] for b in _native.group_best(raw)] == [b[:3] for b in best], raw
+        assert [b[:3] for b in _native.consolidate(raw)] == oracle.consolidate(raw), raw
+    for rec in golden_io.load("consolidate_overlapping_matches"):
+        raw = golden_io.triples(list(rec["args"][0]))
+        got = [b[:3] for b in _native.consolidate(raw)]
+        assert golden_io.equal_modulo_ties(got, golden_io.triples(rec["result"]), raw)
+
+
+def test_python_level_consolidation_helpers():
+    ms = [Match(22, 34, 0, "a"), Match(2, 14, 1, "b"), Match(3, 15, 2, "c"), Match(40, 41, 0, "d")]
+    assert common.consolidate_overlapping_matches(ms) == [Match(2, 14, 1, "b"), Match(22, 34, 0, "a"), Match(40, 41, 0, "d")]
+    assert common.best_of_groups_in_discovery_order(ms) == [Match(22, 34, 0, "a"), Match(2, 14, 1, "b"), Match(40, 41, 0, "d")]
+    groups = common.group_matches(ms)
+    assert [sorted((m.start for m in g)) for g in groups] == [[22], [2, 3], [40]]
+    assert common.get_best_match_in_group(groups[1]) == Match(2, 14, 1, "b")
+    assert common.consolidate_overlapping_matches([]) == []
+    assert common.count_differences_with_maximum(b"abcd", b"abXX", 5) == 2
+    assert common.count_differences_with_maximum(b"abcd", b"XXXX", 2) == 2
+
+
+def test_file_api_chunk_geometry_with_a_recording_search_class():
+    """find_near_matches_in_file must reproduce the reference's chunking:
+    _chunk_size windows that overlap by len(p) - 1 + extra, offsets re-based, one consolidation."""
+    import io
+    seen = []
+
+    class Recorder(common.FuzzySearchBase):
+        @classmethod
+        def search(cls, subsequence, sequence, search_params):
+            seen.append(sequence.encode() if isinstance(sequence, str) else bytes(sequence))
+            return [Match(0, 1, 0, sequence[:1])] if len(sequence) else []
+
+        @classmethod
+        def extra_items_for_chunked_search(cls, subsequence, search_params):
+            return 2
+    import tempfile
+    data = bytes(range(256)) * 2
+    orig = fa.choose_search_class
+    fa.choose_search_class = lambda params: Recorder
+    keep = 4 - 1 + 2
+    try:
+        with tempfile.TemporaryFile() as f:              # 'rb+' -> binary reader (__init__.py:129-171)
+            f.write(data)
+            f.seek(0)
+            out = fa.find_near_matches_in_file(b"abcd", f, max_l_dist=2, _chunk_size=100)
+        pos, exp = 0, []
+        while pos < len(data):                           # reference geometry: keep + (100 - keep) new bytes
+            exp.append(data[pos:pos + 100])
+            if pos + 100 >= len(data):
+                break
+            pos += 100 - keep
+        assert seen == exp
+        assert [m.start for m in out][:3] == [0, 95, 190]
+        # no 'b' in mode and not RawIOBase -> the text reader (__init__.py:174-200): keep + 100 new items
+        del seen[:]
+        text = "".join(chr(65 + i % 26) for i in range(330))
+        fa.find_near_matches_in_file("abcd", io.StringIO(text), max_l_dist=2, _chunk_size=100)
+        assert seen == [text[0:100].encode(), text[95:200].encode(), text[195:300].encode(), text[295:330].encode()]
+    finally:
+        fa.choose_search_class = orig
+    with pytest.raises(ValueError):
+        fa.find_near_matches_in_file(b"", io.BytesIO(data), max_l_dist=1)

@@ -1,0 +1,162 @@
+"""The oracle against the golden vectors recorded from the reference's own unit tests
+(tests/golden/reference_calls.jsonl).  CPU only."""
+import pytest
+
+import oracle
+from fuzzysearch_amd.engine import encode_pair
+from tests import golden_io
+
+
+def _bytes_pair(sub, seq):
+    """Same index semantics as the reference's str / list inputs, as bytes for the C oracle."""
+    p, t, _ = encode_pair(sub, seq)
+    return bytes(p), bytes(t)
+
+
+def _records(fn):
+    recs = golden_io.load(fn)
+    assert recs, "no golden records for %s" % fn
+    return recs
+
+
+def test_expand_kats():
+    n = 0
+    for rec in _records("expand"):
+        sub, win, budget = rec["args"]
+        p, t = _bytes_pair(sub, win)
+        assert oracle.expand(p, t, budget) == tuple(rec["result"]), rec["args"]
+        n += 1
+    assert n >= 100
+
+
+def test_search_exact():
+    for rec in _records("search_exact"):
+        args = list(rec["args"])
+        sub, seq = args[0], args[1]
+        start = args[2] if len(args) > 2 else rec["kwargs"].get("start_index", 0)
+        end = args[3] if len(args) > 3 else rec["kwargs"].get("end_index", None)
+        if "raises" in rec:
+            if rec["raises"] == "ValueError":
+                with pytest.raises(ValueError):
+                    oracle.search_exact(*_bytes_pair(sub, seq), start, end)
+            continue
+        p, t = _bytes_pair(sub, seq)
+        assert oracle.search_exact(p, t, start, end) == list(rec["result"]), (sub, start, end)
+
+
+def test_levenshtein_ngrams_raw_stream():
+    n = 0
+    for rec in _records("find_near_matches_levenshtein_ngrams"):
+        sub, seq, k = rec["args"]
+        if "raises" in rec:
+            assert rec["raises"] == "ValueError"
+            with pytest.raises(ValueError):
+                oracle.lev_ngrams_raw(*_bytes_pair(sub, seq), k)
+            continue
+        got = [r[:3] for r in oracle.lev_ngrams_raw(*_bytes_pair(sub, seq), k)]
+        assert got == golden_io.triples(rec["result"]), (sub, seq, k)
+        n += 1
+    assert n >= 30
+
+
+def test_find_near_matches_levenshtein_dispatch():
+    """find_near_matches_levenshtein (levenshtein.py:9-38): k == 0 -> exact; n-gram route when
+    len // (k+1) >= 3; the LP route is outside the hot path (not restated)."""
+    n = 0
+    for rec in _records("find_near_matches_levenshtein"):
+        sub, seq, k = (list(rec["args"]) + [rec["kwargs"].get("max_l_dist")])[:3]
+        if "raises" in rec or len(sub) == 0:
+            continue
+        m = len(sub)
+        p, t = _bytes_pair(sub, seq)
+        if k == 0:
+            got = [(i, i + m, 0) for i in oracle.search_exact(p, t)]
+        elif m // (k + 1) >= 3:
+            got = [r[:3] for r in oracle.lev_ngrams_raw(p, t, k)]
+        else:
+            continue
+        assert got == golden_io.triples(rec["result"]), (sub, seq, k)
+        n += 1
+    assert n >= 50
+
+
+def test_substitutions_ngrams():
+    """bytes: best of every overlap group in group-list order; str: all windows sorted by start
+    (SURVEY.md trap 5)."""
+    n = 0
+    for rec in _records("find_near_matches_substitutions_ngrams") + _records("find_near_matches_substitutions"):
+        sub, seq, k = (list(rec["args"]) + [rec["kwargs"].get("max_substitutions")])[:3]
+        if "raises" in rec or len(sub) == 0:
+            continue
+        m = len(sub)
+        if rec["fn"] == "find_near_matches_substitutions" and (k == 0 or m // (k + 1) < 3):
+            continue
+        if m // (k + 1) == 0:
+            continue
+        p, t = _bytes_pair(sub, seq)
+        raw = oracle.subs_ngrams_raw(p, t, k)
+        if isinstance(seq, (bytes, bytearray)):
+            best, _ = oracle.group_best(raw)
+            got = [b[:3] for b in best]
+            exp = golden_io.triples(rec["result"])
+            assert len(got) == len(exp)
+            # group order is pinned; inside a group the reference's pick depends on the hash seed
+            for g, e in zip(got, exp):
+                assert g == e or (g[2] == e[2] and g[1] - g[0] == e[1] - e[0]), (sub, seq, k)
+        else:
+            seen, got = set(), []
+            for r in raw:
+                if r[0] not in seen:
+                    seen.add(r[0])
+                    got.append(r[:3])
+            got.sort(key=lambda r: r[0])
+            assert got == golden_io.triples(rec["result"]), (sub, seq, k)
+        n += 1
+    assert n >= 40
+
+
+def test_generic_lp_and_ngrams_raw_streams():
+    n = 0
+    for rec in _records("find_near_matches_generic_linear_programming") + _records("find_near_matches_generic_ngrams"):
+        sub, seq, params = rec["args"]
+        if "raises" in rec or len(sub) == 0:
+            continue
+        subs, ins, dels, l = [x if x is not None else (1 << 29) for x in params]
+        p, t = _bytes_pair(sub, seq)
+        if rec["fn"].endswith("linear_programming"):
+            got = oracle.generic_lp_raw(p, t, subs, ins, dels, l)
+        else:
+            if len(sub) // (l + 1) == 0:
+                continue
+            got = oracle.generic_ngrams_raw(p, t, subs, ins, dels, l)
+        assert [g[:3] for g in got] == golden_io.triples(rec["result"]), (sub, seq, params)
+        n += 1
+    assert n >= 100
+
+
+def test_group_matches_and_consolidation():
+    for rec in _records("group_matches"):
+        (matches,) = rec["args"]
+        matches = list(matches)
+        raw = golden_io.triples(matches)
+        _best, hull = oracle.group_best(raw)
+        exp_groups = rec["result"]
+        assert len(hull) == len(exp_groups)
+        for h, grp in zip(hull, exp_groups):            # same partition, same group-list order
+            assert h[0] == min(x.start for x in grp) and h[1] == max(x.end for x in grp)
+    n = 0
+    for rec in _records("consolidate_overlapping_matches"):
+        (matches,) = rec["args"]
+        raw = golden_io.triples(list(matches))
+        assert golden_io.equal_modulo_ties(oracle.consolidate(raw), golden_io.triples(rec["result"]), raw)
+        n += 1
+    assert n >= 50
+
+
+def test_count_differences_with_maximum():
+    for rec in _records("count_differences_with_maximum"):
+        a, b, mx = rec["args"]
+        if "raises" in rec or len(a) != len(b):
+            continue
+        pa, pb = _bytes_pair(a, b) if not isinstance(a, (bytes, bytearray)) else (bytes(a), bytes(b))
+        assert oracle.count_differences_with_maximum(pa, pb, mx) == rec["result"]
