@@ -130,6 +130,11 @@ print("reference tests run: %d, failures %d, errors %d, skipped %d" %
 # the one known error is the reference's dead c_find_near_matches_generic_ngrams
 assert not result.failures and len(result.errors) <= 1, (result.failures, result.errors)
 
+# tests/test_find_near_matches.py:12-51 patches the strategy classes with mocks that answer
+# [Match(42, 43, 0, 'x')]: those calls exercise the dispatcher, not a search -> not golden data
+MOCK = {"l": [{"m": [42, 43, 0, "x"]}]}
+records = [r for r in records if not (r["fn"] == "find_near_matches" and r.get("result") == MOCK)]
+
 with open(OUT, "w") as f:
     for rec in records:
         f.write(json.dumps(rec, sort_keys=True) + "\n")
