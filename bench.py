@@ -73,7 +73,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     torch = None
-    if world > 1:
+    # FZ_BENCH_FORCE_DIST=1: take the RCCL code path with a single rank too (1-GPU smoke of it)
+    use_dist = world > 1 or os.environ.get("FZ_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         # import torch BEFORE libfzhip so both share one HIP runtime (same libamdhip64 SONAME)
         import torch
         import torch.distributed as dist
@@ -81,6 +83,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from fuzzysearch_amd import _native
+    from fuzzysearch_amd import distributed as fzd
     from tests import workloads
 
     k = 2
@@ -103,22 +106,18 @@ def main():
             seq[:10] = pattern[10:]
 
     engine = _native.Engine([local_rank])
-    if world == 1:
+    if not use_dist:
         handle = engine.upload(seq)
     else:
-        # halo exchange: every rank contributes its first/last `halo` bytes (RCCL all_gather)
-        edges = torch.from_numpy(np.concatenate([seq[:halo], seq[-halo:]])).cuda()
-        all_edges = [torch.empty_like(edges) for _ in range(world)]
-        dist.all_gather(all_edges, edges)
-        left = all_edges[rank - 1][halo:].cpu().numpy() if rank > 0 else np.empty(0, np.uint8)
-        right = all_edges[rank + 1][:halo].cpu().numpy() if rank + 1 < world else np.empty(0, np.uint8)
+        # halo exchange, once at load: neighbours' (m + k) edge bytes (RCCL all_gather)
+        left, right = fzd.exchange_halos(seq, halo)
         buf = np.concatenate([left, seq, right])
         own_lo = rank * shard_bytes
         handle = engine.upload_shard(buf, own_lo - len(left), own_lo, own_lo + shard_bytes, global_n)
         del buf
 
     def sync():
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -127,24 +126,8 @@ def main():
         # synchronous: on return the ordered raw match stream is on the host (numpy view of the
         # C-ABI's fz_match array; no per-record Python objects inside the timed region)
         raw = engine.lev_ngrams(handle, p, k, as_array=True)
-        if world > 1:
-            raw = raw.tolist()
-            # all-gather of Match lists over RCCL: counts, then records padded to the max count
-            cnt = torch.tensor([len(raw)], dtype=torch.int64, device="cuda")
-            counts = [torch.empty_like(cnt) for _ in range(world)]
-            dist.all_gather(counts, cnt)
-            mx = max(int(c.item()) for c in counts)
-            rec = torch.zeros((max(mx, 1), 4), dtype=torch.int64)
-            if raw:
-                rec[:len(raw)] = torch.tensor(raw, dtype=torch.int64)
-            rec = rec.cuda()
-            recs = [torch.empty_like(rec) for _ in range(world)]
-            dist.all_gather(recs, rec)
-            merged = []
-            for c, r in zip(counts, recs):
-                merged.extend(map(tuple, r[:int(c.item())].cpu().tolist()))
-            merged.sort(key=lambda x: x[3])              # block-major; rank order keeps idx ascending
-            return merged
+        if use_dist:
+            return fzd.allgather_matches(raw)            # RCCL all_gather of counts + padded records
         return raw
 
     for _ in range(args.warmup):
@@ -160,7 +143,7 @@ def main():
         device_ms.append(st["device_ms"])
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -168,7 +151,7 @@ def main():
     st = engine.stats()
     if rank == 0:
         import fuzzysearch_amd as fa
-        matches = matches.tolist() if hasattr(matches, "tolist") else matches
+        matches = [tuple(int(x) for x in r) for r in matches.tolist()]
         consolidated = fa.common._native.consolidate(matches)
         ms_per_step = elapsed / args.steps * 1e3
         value = global_n * args.steps / elapsed / 1e9
@@ -190,14 +173,14 @@ def main():
             "config": {"workload": "%d MiB iid random DNA bytes per GPU, |pattern|=20, max_l_dist=2, "
                                    "1024 planted variants per GiB (BASELINE configs[1]); resident in HBM" % args.mib,
                        "bytes_per_gpu": shard_bytes, "pattern_len": m, "max_l_dist": k,
-                       "sharding": "none" if world == 1 else "contiguous shards, (m+k)-byte halo, RCCL all_gather of matches"},
+                       "sharding": "none" if not use_dist else "contiguous shards, (m+k)-byte halo, RCCL all_gather of matches"},
             "matches_per_s": round(len(matches) * args.steps / elapsed, 1),
             "raw_matches": len(matches),
             "consolidated_matches": len(consolidated),
             "ngram_hits": st["ngram_hits"],
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "fz_filter_kernel", "avg_kernel_ms": round(f_ms, 4),
+                         "kernel": "fz_scan_kernel", "avg_kernel_ms": round(f_ms, 4),
                          "algorithmic_bytes_per_launch": shard_bytes},
             "kernel_ms": {"filter": round(f_ms, 4), "verify": round(float(np.mean(verify_ms)), 4),
                           "device_total": round(float(np.mean(device_ms)), 4)},
@@ -207,7 +190,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

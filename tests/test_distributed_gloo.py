@@ -1,0 +1,53 @@
+"""N > 1 path on the CPU: world_size 2 and 3 over gloo (127.0.0.1 rendezvous)."""
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.fixture(scope="module")
+def emul_so():
+    out = os.path.join(tempfile.gettempdir(), "fz_hostemul_dist_%d.so" % os.getpid())
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", os.path.join(HERE, "host_emul.cpp"), "-o", out])
+    yield out
+    os.remove(out)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_search_allgather_equals_unsharded(world, emul_so):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(HERE, "dist_worker.py"), emul_so]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = res.stdout.decode()
+    assert res.returncode == 0, out[-3000:]
+    assert out.count("PASS") == world, out[-3000:]
+
+
+def test_shard_bounds_and_merge():
+    import numpy as np
+    from fuzzysearch_amd import distributed as fzd
+    for n in (0, 1, 7, 100, 1 << 20):
+        for world in (1, 2, 3, 8):
+            b = [fzd.shard_bounds(n, world, r) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
+    a = [(5, 9, 0, 0), (40, 44, 1, 1)]
+    c = [(105, 109, 0, 0), (101, 106, 2, 1), (130, 134, 1, 2)]
+    m = fzd.merge_rank_streams([a, c, []])
+    assert [tuple(r) for r in m.tolist()] == [(5, 9, 0, 0), (105, 109, 0, 0), (40, 44, 1, 1), (101, 106, 2, 1), (130, 134, 1, 2)]
+    assert fzd.merge_rank_streams([[], []]).shape == (0, 4)
