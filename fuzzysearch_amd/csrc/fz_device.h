@@ -50,6 +50,8 @@ struct FzScanArgs {
     uint32_t fused;                             // 1: verify inside the scan kernel, 0: emit hits
     uint32_t band_w;                            // rolling score slots per lane (2k + 2)
     uint32_t win_dwords;                        // window dwords staged per lane ((m + 2k + 6) / 4 + 1)
+    uint32_t max_subs, max_ins, max_dels;       // generic search limits (k = max_l_dist there)
+    uint32_t cand_cap;                          // generic search: candidate slots per list (LDS)
     uint32_t H[FZ_MAX_BLOCKS_PER_LAUNCH];       // fast-path hash of each block's n-gram
     uint32_t A[FZ_MAX_BLOCKS_PER_LAUNCH];       // 1st window value per block (little endian)
     uint32_t B[FZ_MAX_BLOCKS_PER_LAUNCH];       // 2nd window value per block
@@ -191,6 +193,80 @@ FZ_HD bool fz_verify_subs(const Seq &t, const uint8_t *p, uint32_t m, uint32_t k
     rec.l = s; rec.r = m - s - L; rec.dist = nd; rec.aux = 0;
     return true;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Generic search: the greedy candidate-set automaton of
+// _find_near_matches_generic_linear_programming (generic_search.py:57-177, _generic_search.pyx:61-233;
+// SURVEY.md trap 6 / App. A.3 — NOT a DP).  One candidate, one window character -> up to three
+// successor candidates and up to two matches, in the reference's order.  Coordinates are relative
+// to the window (<= m + 2k bytes), so 16 bits suffice.
+struct FzGCand {
+    uint16_t start, j;                 // window-relative start, next pattern index (subseq_index)
+    uint8_t l, ns, ni, nd;             // l_dist, n_subs, n_ins, n_dels
+};
+
+struct FzGOut {
+    FzGCand succ[3];
+    uint32_t nsucc;
+    uint32_t mstart[2], mend[2], mdist[2];
+    uint32_t nmatch;
+};
+
+template <class PatF>
+FZ_HD void fz_generic_step(const FzGCand &c, uint8_t ch, uint32_t index, uint32_t m, PatF pat,
+                           uint32_t max_subs, uint32_t max_ins, uint32_t max_dels, uint32_t max_l, FzGOut &o) {
+    o.nsucc = 0; o.nmatch = 0;
+    auto match = [&](uint32_t end, uint32_t dist) {
+        o.mstart[o.nmatch] = c.start; o.mend[o.nmatch] = end; o.mdist[o.nmatch] = dist; ++o.nmatch;
+    };
+    if (ch == pat(c.j)) {                                              // py:85-94
+        if (c.j + 1u == m) match(index + 1, c.l);
+        else { FzGCand x = c; x.j = (uint16_t)(c.j + 1); o.succ[o.nsucc++] = x; }
+        return;
+    }
+    if (c.l == max_l) return;                                          // py:101-102
+    if (c.ni < max_ins) {                                              // py:104-109: skip a sequence char
+        FzGCand x = c; x.ni++; x.l++; o.succ[o.nsucc++] = x;
+    }
+    if (c.j + 1u < m) {                                                // py:111-128
+        if (c.ns < max_subs) {
+            FzGCand x = c; x.ns++; x.j++; x.l++; o.succ[o.nsucc++] = x;
+        } else if (c.nd < max_dels && c.ni < max_ins) {
+            FzGCand x = c; x.ni++; x.nd++; x.j++; x.l++; o.succ[o.nsucc++] = x;
+        }
+    } else if (c.ns < max_subs || (c.nd < max_dels && c.ni < max_ins)) {   // py:129-138
+        match(index + 1, c.l + 1u);
+    }
+    uint32_t lim = max_dels - c.nd;                                    // py:141-165: skip pattern chars
+    if (max_l - c.l < lim) lim = max_l - c.l;
+    for (uint32_t sk = 1; sk <= lim; ++sk) {
+        if (c.j + sk == m) { match(index, c.l + sk); break; }
+        if (pat(c.j + sk) == ch) {
+            if (c.j + sk + 1u == m) match(index, c.l + sk);
+            else {
+                FzGCand x = c; x.nd = (uint8_t)(c.nd + sk); x.j = (uint16_t)(c.j + 1u + sk); x.l = (uint8_t)(c.l + sk);
+                o.succ[o.nsucc++] = x;
+            }
+            break;
+        }
+    }
+}
+
+// End-of-window flush of one surviving candidate (py:172-177): -> true and dist if it matches.
+FZ_HD bool fz_generic_final(const FzGCand &c, uint32_t m, uint32_t max_dels, uint32_t max_l, uint32_t &dist) {
+    const uint32_t sk = m - c.j;
+    if (c.nd + sk <= max_dels && c.l + sk <= max_l) { dist = c.l + sk; return true; }
+    return false;
+}
+
+// Record of the generic search: one emitted match of the automaton run on the window of hit `key`.
+struct FzGenRec {
+    uint64_t key;        // (block << 56) | idx of the n-gram hit
+    uint32_t seq;        // emission number within that hit's window
+    uint32_t se;         // window-relative start | end << 16
+    uint32_t dist;
+    uint32_t pad;
+};
 
 // Plain byte accessor over a resident buffer in GLOBAL coordinates (host emulation / tests).
 struct FzSeqView {

@@ -371,3 +371,127 @@ __global__ void fz_verify_kernel(const uint8_t *__restrict__ buf, const FzScanAr
         fz_wave_verify(buf, a, pat_lds, w, hit, valid, recs, counters);
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// K4  fz_generic_kernel: the generic (mixed-limit) search's per-hit verification — the greedy
+// candidate-set automaton of generic_search.py:57-177 run on the window
+// seq[max(0, idx-s-k) : idx-s+m+k] of every exact n-gram hit (generic_search.py:222-237).
+// One WAVE per hit: the candidate list lives in LDS and its 64-wide slices are advanced by the 64
+// lanes; successor candidates and matches are written through wave prefix sums, so both lists keep
+// exactly the reference's order (its emitted *list*, not just the set, is reproduced).  The
+// character loop is inherently sequential; parallelism comes from hits x candidates.
+#define FZ_GEN_MCAP 512                                    // match-buffer entries per wave
+
+__device__ __forceinline__ uint32_t fz_wave_incl_scan(uint32_t v) {
+    const uint32_t lane = fz_lane();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(v, d);
+        if (lane >= (uint32_t)d) v += o;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(64) void fz_generic_kernel(const uint8_t *__restrict__ buf, const FzScanArgs a,
+                                                        const uint64_t *__restrict__ hits,
+                                                        FzGenRec *__restrict__ recs,
+                                                        unsigned long long *__restrict__ counters) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t mpad = (a.m + 15u) & ~15u;
+    const uint32_t wmax = a.m + 2u * a.k;
+    const uint32_t wpad = (wmax + 15u) & ~15u;
+    uint8_t *pat = smem;
+    uint8_t *win = smem + mpad;
+    FzGCand *cur = reinterpret_cast<FzGCand *>(smem + mpad + wpad);
+    FzGCand *nxt = cur + a.cand_cap;
+    uint64_t *mbuf = reinterpret_cast<uint64_t *>(nxt + a.cand_cap);
+    for (uint32_t i = lane; i < a.m; i += 64u) pat[i] = a.pat[i];
+    fz_wave_lds_sync();
+    auto patf = [&](uint32_t i) -> uint8_t { return pat[i]; };
+
+    unsigned long long nh = counters[0];
+    if (nh > a.hit_cap) nh = a.hit_cap;
+    for (uint64_t q = blockIdx.x; q < nh; q += gridDim.x) {
+        const uint64_t hit = hits[q];
+        const uint32_t s = fz_hit_block(hit) * a.L;
+        const uint64_t idx = fz_hit_index(hit);
+        const uint64_t reach = (uint64_t)s + a.k;
+        const uint64_t w0 = idx > reach ? idx - reach : 0;             // generic_search.py:231
+        uint64_t w1 = idx - s + a.m + a.k;
+        if (w1 > a.geom.n) w1 = a.geom.n;
+        const uint32_t wlen = (uint32_t)(w1 - w0);
+        for (uint32_t i = lane; i < wlen; i += 64u) win[i] = buf[(w0 - a.geom.buf_off) + i];
+        fz_wave_lds_sync();
+
+        uint32_t ncur = 0, mb = 0, mseq = 0;
+        bool overflow = false;
+        auto flush_matches = [&]() {
+            if (mb == 0) return;
+            fz_wave_lds_sync();
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(&counters[1], (unsigned long long)mb);
+            base = fz_bcast64(base);
+            for (uint32_t e = lane; e < mb; e += 64u) {
+                if (base + e < a.rec_cap) {
+                    const uint64_t v = mbuf[e];
+                    FzGenRec r;
+                    r.key = hit; r.seq = mseq + e; r.se = (uint32_t)v; r.dist = (uint32_t)(v >> 32); r.pad = 0;
+                    recs[base + e] = r;
+                }
+            }
+            mseq += mb;
+            mb = 0;
+            fz_wave_lds_sync();
+        };
+        for (uint32_t index = 0; index <= wlen && !overflow; ++index) {
+            const bool last = index == wlen;                           // end-of-window flush pass
+            uint8_t ch = 0;
+            if (!last) {
+                ch = win[index];
+                if (ncur >= a.cand_cap) { overflow = true; break; }
+                if (lane == 0) { FzGCand f; f.start = (uint16_t)index; f.j = 0; f.l = f.ns = f.ni = f.nd = 0; cur[ncur] = f; }
+                ++ncur;
+                fz_wave_lds_sync();
+            }
+            uint32_t nnext = 0;
+            for (uint32_t c0 = 0; c0 < ncur; c0 += 64u) {
+                const bool valid = c0 + lane < ncur;
+                FzGOut o;
+                o.nsucc = 0; o.nmatch = 0;
+                if (valid) {
+                    const FzGCand c = cur[c0 + lane];
+                    if (!last) {
+                        fz_generic_step(c, ch, index, a.m, patf, a.max_subs, a.max_ins, a.max_dels, a.k, o);
+                    } else {
+                        uint32_t d;
+                        if (fz_generic_final(c, a.m, a.max_dels, a.k, d)) {
+                            o.mstart[0] = c.start; o.mend[0] = wlen; o.mdist[0] = d; o.nmatch = 1;
+                        }
+                    }
+                }
+                const uint32_t packed = o.nsucc | (o.nmatch << 16);
+                const uint32_t incl = fz_wave_incl_scan(packed);
+                const uint32_t tot = __builtin_amdgcn_readlane(incl, 63);
+                const uint32_t excl = incl - packed;
+                const uint32_t tot_s = tot & 0xffffu, tot_m = tot >> 16;
+                if (nnext + tot_s > a.cand_cap) { overflow = true; break; }
+                if (mb + tot_m > FZ_GEN_MCAP) flush_matches();
+                for (uint32_t i = 0; i < o.nsucc; ++i) nxt[nnext + (excl & 0xffffu) + i] = o.succ[i];
+                for (uint32_t i = 0; i < o.nmatch; ++i)
+                    mbuf[mb + (excl >> 16) + i] = (uint64_t)(o.mstart[i] | (o.mend[i] << 16)) | ((uint64_t)o.mdist[i] << 32);
+                nnext += tot_s;
+                mb += tot_m;
+            }
+            fz_wave_lds_sync();
+            FzGCand *tmp = cur; cur = nxt; nxt = tmp;
+            ncur = nnext;
+        }
+        if (overflow) {
+            if (lane == 0) atomicAdd(&counters[2], 1ull);              // host retries with bigger lists
+        } else {
+            flush_matches();
+        }
+        fz_wave_lds_sync();
+    }
+}

@@ -151,6 +151,7 @@ int pick_tg(uint32_t nblk) {
 
 struct Search {
     uint32_t mode = 0, m = 0, k = 0;
+    uint32_t max_subs = 0, max_ins = 0, max_dels = 0;      // generic search only
     const uint8_t *p = nullptr;
     BlockPlan plan;
 };
@@ -159,7 +160,7 @@ constexpr uint32_t kFusedLdsBudget = 64 * 1024;   // dynamic LDS per scan workgr
 
 // Enqueue scan (+ separate verify when it cannot be fused) for one shard on its device stream.
 // No host synchronisation.
-int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verify) {
+int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verify, bool copy_back = true) {
     DevState &d = ctx->devs[sh.dev];
     HIP_TRY(hipSetDevice(d.device));
     unsigned long long *counters = reinterpret_cast<unsigned long long *>(d.d_out);
@@ -240,10 +241,12 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
                            counters);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(d.ev[2], d.stream));
-    HIP_TRY(hipMemcpyAsync(d.h_stage, d.d_out, kHeaderBytes + kFirstCopyRecs * sizeof(FzRec), hipMemcpyDeviceToHost,
-                           d.stream));
-    HIP_TRY(hipEventRecord(d.ev[3], d.stream));
+    if (copy_back) {
+        HIP_TRY(hipEventRecord(d.ev[2], d.stream));
+        HIP_TRY(hipMemcpyAsync(d.h_stage, d.d_out, kHeaderBytes + kFirstCopyRecs * sizeof(FzRec), hipMemcpyDeviceToHost,
+                               d.stream));
+        HIP_TRY(hipEventRecord(d.ev[3], d.stream));
+    }
     ctx->stats.filter_launches += launches;
     ctx->last_fused = fa.fused != 0;
     return FZ_OK;
@@ -334,6 +337,80 @@ int run_search(fz_ctx *ctx, fz_seq *seq, const Search &q, bool with_verify, std:
         if (!any_rerun) return FZ_OK;
     }
     return fail(FZ_EDEVICE, "result buffers kept overflowing");
+}
+
+// Generic search: scan (emit exact hits) -> fz_generic_kernel (one wave per hit) -> records.
+// Re-runs with larger buffers on overflow: hit list, record list, then candidate lists.
+int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec> &recs_out) {
+    memset(&ctx->stats, 0, sizeof ctx->stats);
+    ctx->stats.n_devices = (uint32_t)ctx->devs.size();
+    static_assert(sizeof(FzGenRec) == sizeof(FzRec), "record buffers are shared");
+    uint32_t cand_cap = 1024;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        recs_out.clear();
+        bool rerun = false;
+        ctx->stats.filter_launches = 0;
+        ctx->stats.bytes_scanned = ctx->stats.ngram_hits = ctx->stats.raw_matches = 0;
+        ctx->stats.filter_ms = ctx->stats.verify_ms = ctx->stats.device_ms = 0;
+        const uint32_t mpad = (q.m + 15u) & ~15u, wpad = (q.m + 2 * q.k + 15u) & ~15u;
+        const size_t lds = mpad + wpad + 2 * (size_t)cand_cap * sizeof(FzGCand) + FZ_GEN_MCAP * 8;
+        if (lds > 160 * 1024) return fail(FZ_EUNSUPPORTED, "generic search: candidate lists do not fit LDS");
+        for (const Shard &sh : seq->shards) {
+            int rc = enqueue_shard(ctx, sh, q, /*with_verify=*/false, /*copy_back=*/false);
+            if (rc) return rc;
+            DevState &d = ctx->devs[sh.dev];
+            FzScanArgs fa;
+            memset(&fa, 0, sizeof fa);
+            fa.geom = sh.geom;
+            fa.mode = q.mode; fa.m = q.m; fa.k = q.k; fa.L = q.plan.L;
+            fa.max_subs = q.max_subs; fa.max_ins = q.max_ins; fa.max_dels = q.max_dels;
+            fa.cand_cap = cand_cap;
+            fa.hit_cap = d.hit_cap;
+            fa.rec_cap = d.rec_cap;
+            memcpy(fa.pat, q.p, q.m);
+            unsigned long long *counters = reinterpret_cast<unsigned long long *>(d.d_out);
+            FzGenRec *recs = reinterpret_cast<FzGenRec *>(d.d_out + kHeaderBytes);
+            if (lds > 64 * 1024)
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fz_generic_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(fz_generic_kernel, dim3(d.n_cus * 16), dim3(64), lds, d.stream, sh.d_buf, fa, d.d_hits,
+                               recs, counters);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(d.ev[2], d.stream));
+            HIP_TRY(hipMemcpyAsync(d.h_stage, d.d_out, kHeaderBytes + kFirstCopyRecs * sizeof(FzRec),
+                                   hipMemcpyDeviceToHost, d.stream));
+            HIP_TRY(hipEventRecord(d.ev[3], d.stream));
+        }
+        for (const Shard &sh : seq->shards) {
+            DevState &d = ctx->devs[sh.dev];
+            HIP_TRY(hipSetDevice(d.device));
+            HIP_TRY(hipStreamSynchronize(d.stream));
+            const unsigned long long *cnt = reinterpret_cast<const unsigned long long *>(d.h_stage);
+            const uint64_t nh = cnt[0], nr = cnt[1], novf = cnt[2];
+            if (nh > d.hit_cap) { int rc = ensure_hits(d, nh + nh / 8 + 1024); if (rc) return rc; rerun = true; }
+            if (nr > d.rec_cap) { int rc = ensure_recs(d, nr + nr / 8 + 1024); if (rc) return rc; rerun = true; }
+            if (novf) { cand_cap *= 4; rerun = true; }
+            if (rerun) continue;
+            float f = 0, v = 0, t = 0;
+            HIP_TRY(hipEventElapsedTime(&f, d.ev[0], d.ev[1]));
+            HIP_TRY(hipEventElapsedTime(&v, d.ev[1], d.ev[2]));
+            HIP_TRY(hipEventElapsedTime(&t, d.ev[0], d.ev[3]));
+            ctx->stats.filter_ms = std::max<double>(ctx->stats.filter_ms, f);
+            ctx->stats.verify_ms = std::max<double>(ctx->stats.verify_ms, v);
+            ctx->stats.device_ms = std::max<double>(ctx->stats.device_ms, t);
+            ctx->stats.bytes_scanned += sh.geom.buf_len;
+            ctx->stats.ngram_hits += nh;
+            const size_t base = recs_out.size();
+            recs_out.resize(base + nr);
+            const uint64_t first = std::min<uint64_t>(nr, kFirstCopyRecs);
+            if (first) memcpy(recs_out.data() + base, d.h_stage + kHeaderBytes, first * sizeof(FzGenRec));
+            if (nr > first)
+                HIP_TRY(hipMemcpy(recs_out.data() + base + first, d.d_out + kHeaderBytes + first * sizeof(FzGenRec),
+                                  (nr - first) * sizeof(FzGenRec), hipMemcpyDeviceToHost));
+        }
+        if (!rerun) return FZ_OK;
+    }
+    return fail(FZ_EUNSUPPORTED, "generic search: candidate lists / result buffers kept overflowing");
 }
 
 int alloc_out(uint64_t n, size_t elem, void **out) {
@@ -647,11 +724,56 @@ int fz_subs_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint3
     return emit_matches(recs, L, out, n);
 }
 
-int fz_generic_ngrams(fz_ctx *, fz_seq *, const uint8_t *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t,
-                      fz_match **out, uint64_t *n) {
-    if (out) *out = nullptr;
-    if (n) *n = 0;
-    return fail(FZ_EUNSUPPORTED, "generic (mixed-limit) search is not implemented on the GPU yet");
+int fz_generic_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t max_subs, uint32_t max_ins,
+                      uint32_t max_dels, uint32_t max_l, fz_match **out, uint64_t *n) {
+    if (!out || !n) return fail(FZ_EINVAL, "null argument");
+    *out = nullptr; *n = 0;
+    int rc = validate(ctx, seq, p, m);
+    if (rc) return rc;
+    const uint32_t k = max_l;
+    if (k > FZ_MAX_K) return fail(FZ_EUNSUPPORTED, "max_l_dist above %d is not supported by the verify kernels", FZ_MAX_K);
+    const uint32_t L = m / (k + 1);
+    if (L == 0) return fail(FZ_EINVAL, "the subsequence length must be greater than max_l_dist");
+    rc = check_halo(seq, (uint64_t)m + k);
+    if (rc) return rc;
+    const int64_t N = (int64_t)seq->n;
+    Search q;
+    q.mode = FZ_MODE_GENERIC; q.m = m; q.k = k; q.p = p;
+    q.max_subs = std::min(max_subs, 255u); q.max_ins = std::min(max_ins, 255u); q.max_dels = std::min(max_dels, 255u);
+    q.plan.L = L;
+    for (uint32_t s = 0; s + L <= m; s += L) {              // generic_search.py:221-228
+        int64_t lo = (int64_t)s - (int64_t)k; if (lo < 0) lo = 0; if (lo > N) lo = N;
+        int64_t hi = N - (int64_t)m + s + L + k; if (hi > N) hi = N; if (hi < lo) hi = lo;
+        q.plan.s.push_back(s);
+        q.plan.lo.push_back((uint64_t)lo);
+        q.plan.hi.push_back((uint64_t)hi);
+    }
+    if (q.plan.s.size() > 255) return fail(FZ_EUNSUPPORTED, "more than 255 n-gram blocks");
+    std::vector<FzGenRec> recs;
+    rc = run_generic(ctx, seq, q, recs);
+    if (rc) return rc;
+    // reference order: hits in (block, idx) order, each hit's matches in automaton emission order
+    std::sort(recs.begin(), recs.end(), [](const FzGenRec &a, const FzGenRec &b) {
+        return a.key != b.key ? a.key < b.key : a.seq < b.seq;
+    });
+    void *mem = nullptr;
+    rc = alloc_out(recs.size(), sizeof(fz_match), &mem);
+    if (rc) return rc;
+    fz_match *mo = static_cast<fz_match *>(mem);
+    for (size_t i = 0; i < recs.size(); ++i) {
+        const uint64_t idx = fz_hit_index(recs[i].key);
+        const uint32_t blk = fz_hit_block(recs[i].key);
+        const uint64_t reach = (uint64_t)blk * L + k;
+        const uint64_t w0 = idx > reach ? idx - reach : 0;
+        mo[i].start = (int64_t)(w0 + (recs[i].se & 0xffffu));
+        mo[i].end = (int64_t)(w0 + (recs[i].se >> 16));
+        mo[i].dist = (int32_t)recs[i].dist;
+        mo[i].block = (int32_t)blk;
+    }
+    *out = mo;
+    *n = recs.size();
+    ctx->stats.raw_matches = recs.size();
+    return FZ_OK;
 }
 
 // ---- host-side consolidation (common.py:145-189) -------------------------------------------

@@ -66,6 +66,36 @@ int64_t emul_search(int mode, const uint8_t *p, uint32_t m, const uint8_t *t, ui
     return cnt;
 }
 
+// Generic automaton over one window, driven candidate by candidate through fz_generic_step exactly
+// as the GPU kernel does (the kernel only parallelises the candidate loop and keeps the order).
+int64_t emul_generic_lp(const uint8_t *p, uint32_t m, const uint8_t *t, uint32_t n, uint32_t max_subs,
+                        uint32_t max_ins, uint32_t max_dels, uint32_t max_l, OutRec *out, int64_t cap) {
+    std::vector<FzGCand> cur, nxt;
+    int64_t cnt = 0;
+    auto pat = [&](uint32_t i) -> uint8_t { return p[i]; };
+    auto emit = [&](uint32_t s, uint32_t e, uint32_t d) {
+        if (cnt < cap) { out[cnt].start = s; out[cnt].end = e; out[cnt].dist = (int32_t)d; out[cnt].block = -1; }
+        ++cnt;
+    };
+    for (uint32_t index = 0; index < n; ++index) {
+        FzGCand fresh{(uint16_t)index, 0, 0, 0, 0, 0};
+        cur.push_back(fresh);
+        nxt.clear();
+        for (const FzGCand &c : cur) {
+            FzGOut o;
+            fz_generic_step(c, t[index], index, m, pat, max_subs, max_ins, max_dels, max_l, o);
+            for (uint32_t i = 0; i < o.nsucc; ++i) nxt.push_back(o.succ[i]);
+            for (uint32_t i = 0; i < o.nmatch; ++i) emit(o.mstart[i], o.mend[i], o.mdist[i]);
+        }
+        cur.swap(nxt);
+    }
+    for (const FzGCand &c : cur) {
+        uint32_t d;
+        if (fz_generic_final(c, m, max_dels, max_l, d)) emit(c.start, n, d);
+    }
+    return cnt;
+}
+
 int emul_expand(const uint8_t *sub, uint32_t sublen, const uint8_t *win, uint32_t winlen, uint32_t budget,
                 uint32_t *dist, uint32_t *consumed) {
     HostScores sc;

@@ -92,6 +92,29 @@ def test_substitutions_golden(engine):
     assert n >= 40
 
 
+def test_generic_golden(engine):
+    """find_near_matches_generic_ngrams / find_near_matches_generic on their n-gram route."""
+    from fuzzysearch_amd import generic_search
+    n = 0
+    for rec in golden_io.load("find_near_matches_generic_ngrams") + golden_io.load("find_near_matches_generic"):
+        sub, seq, params = rec["args"]
+        if "raises" in rec or len(sub) == 0:
+            continue
+        sp = fa.LevenshteinSearchParams(*params)
+        l = sp.max_l_dist
+        if rec["fn"].endswith("ngrams"):
+            if len(sub) // (l + 1) == 0:
+                continue
+            got = generic_search.find_near_matches_generic_ngrams(sub, seq, sp)
+        else:
+            if not _route_is_ngram(len(sub), l):
+                continue
+            got = generic_search.find_near_matches_generic(sub, seq, sp)
+        assert _matches(got) == _expect(rec), (sub, seq, params)
+        n += 1
+    assert n >= 60
+
+
 def test_find_near_matches_public_api_golden(engine):
     """Every find_near_matches(...) call of the reference's suite whose route is on the GPU."""
     n = skipped = 0
@@ -119,7 +142,10 @@ def test_find_near_matches_public_api_golden(engine):
             sub, seq = args[0], args[1]
             from fuzzysearch_amd.engine import encode_pair
             p, t, _ = encode_pair(sub, seq)
-            raw = oracle.lev_ngrams_raw(bytes(p), bytes(t), params.max_l_dist)
+            if cls is fa.GenericSearch:
+                raw = oracle.generic_ngrams_raw(bytes(p), bytes(t), *params.unpacked)
+            else:
+                raw = oracle.lev_ngrams_raw(bytes(p), bytes(t), params.max_l_dist)
             assert golden_io.equal_modulo_ties([g[:3] for g in got], [e[:3] for e in exp], raw), (args, kwargs, got, exp)
         n += 1
     assert n >= 100, (n, skipped)

@@ -178,3 +178,74 @@ def test_public_api_matches_oracle(engine):
     assert fa.find_near_matches(b'PATTERN', b'---PATERN---', max_l_dist=1) == \
         [fa.Match(3, 9, 1, b'PATERN')]
     assert fa.find_near_matches('PATTERN', '---PATERN---', max_l_dist=1) == [fa.Match(3, 9, 1, 'PATERN')]
+
+
+def test_generic_ngrams_raw_random(engine):
+    """a11: the candidate-set automaton, ordered raw stream == oracle (App. A.3)."""
+    rnd = random.Random(41)
+    n_cases = 0
+    for _ in range(1200):
+        sigma = rnd.choice([2, 3, 4, 4, 20])
+        alpha = bytes(rnd.sample(range(33, 127), sigma))
+        t = bytes(rnd.choice(alpha) for _ in range(rnd.randint(0, 200)))
+        m = rnd.randint(2, 20)
+        if rnd.random() < 0.6 and len(t) >= m:
+            st = rnd.randint(0, len(t) - m)
+            p = bytearray(t[st:st + m])
+            for _ in range(rnd.randint(0, 3)):
+                q = rnd.randrange(len(p))
+                op = rnd.random()
+                if op < 0.4:
+                    p[q] = rnd.choice(alpha)
+                elif op < 0.7 and len(p) > 2:
+                    del p[q]
+                else:
+                    p.insert(q, rnd.choice(alpha))
+            p = bytes(p)
+        else:
+            p = bytes(rnd.choice(alpha) for _ in range(m))
+        ms, mi, md = rnd.randint(0, 3), rnd.randint(0, 3), rnd.randint(0, 3)
+        ml = rnd.randint(1, max(1, ms + mi + md))
+        ms, mi, md = min(ms, ml), min(mi, ml), min(md, ml)
+        if len(p) // (ml + 1) == 0:
+            continue
+        seq = engine.upload(t)
+        got = engine.generic_ngrams(seq, p, ms, mi, md, ml)
+        seq.release()
+        assert got == oracle.generic_ngrams_raw(p, t, ms, mi, md, ml), (p, t, (ms, mi, md, ml))
+        n_cases += 1
+    assert n_cases > 800
+
+
+@pytest.mark.parametrize("m,limits", [(20, (2, 1, 1, 2)), (20, (3, 1, 2, 3)), (40, (5, 2, 2, 5)), (64, (5, 2, 2, 5)), (12, (1, 1, 0, 1))])
+def test_generic_ngrams_medium(engine, m, limits):
+    n = 2 << 20
+    seq = workloads.dna(n, 300 + m) if m < 64 else workloads.text65(n, 300 + m)
+    pattern = workloads.dna(m, 30 + m) if m < 64 else workloads.text65(m, 30 + m)
+    workloads.plant_variants(seq, pattern, 128, 13, workloads.DNA if m < 64 else workloads.TEXT65)
+    t, p = seq.tobytes(), pattern.tobytes()
+    h = engine.upload(seq)
+    got = engine.generic_ngrams(h, p, *limits)
+    h.release()
+    exp = oracle.generic_ngrams_raw(p, t, *limits)
+    assert got == exp
+    assert len(exp) > 50
+
+
+def test_generic_public_api(engine):
+    import fuzzysearch_amd as fa
+    rnd = random.Random(43)
+    n = 0
+    for _ in range(200):
+        alpha = bytes(rnd.sample(range(65, 91), rnd.choice([2, 3, 4])))
+        t = bytes(rnd.choice(alpha) for _ in range(rnd.randint(20, 150)))
+        m = rnd.randint(9, 16)
+        st = rnd.randint(0, len(t) - m)
+        p = bytearray(t[st:st + m])
+        p[rnd.randrange(m)] = rnd.choice(alpha)
+        p = bytes(p)
+        got = fa.find_near_matches(p, t, max_substitutions=2, max_insertions=1, max_deletions=1, max_l_dist=2)
+        raw = oracle.generic_ngrams_raw(p, t, 2, 1, 1, 2)
+        assert [(x.start, x.end, x.dist) for x in got] == oracle.consolidate(raw), (p, t)
+        n += 1
+    assert n == 200
