@@ -66,6 +66,22 @@ def cpu_baseline(seq, pattern, k, sample_mib):
                       "(the reference has no parallelism); %d raw matches in %.2f s" % (n >> 20, len(res), dt)}
 
 
+def measured_traffic(shard_bytes):
+    """HBM bytes per launch of the scan kernel from the committed PMC profile (FETCH_SIZE with the
+    gfx950 x2 correction + WRITE_SIZE, separate rocprofv3 --pmc passes: benchmarks/profile.sh ->
+    profiles/*_pmc_summary.json).  Only reported for the workload size the profile was taken at."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            if d.get("algorithmic_bytes_per_launch") == shard_bytes:
+                return round(d["hbm_traffic"]["traffic_bytes"] / 1e9, 4), os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -157,6 +173,7 @@ def main():
         value = global_n * args.steps / elapsed / 1e9
         f_ms = float(np.mean(filter_ms))
         achieved = shard_bytes / (f_ms * 1e-3) / 1e9           # algorithmic bytes: N read once
+        traffic_gb, traffic_src = measured_traffic(shard_bytes)
         out = {
             "metric": "GB/s of sequence scanned at |p|=20 max_l_dist=2 (levenshtein_ngram path)",
             "value": round(value, 2),
@@ -179,7 +196,8 @@ def main():
             "consolidated_matches": len(consolidated),
             "ngram_hits": st["ngram_hits"],
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic_gb,
+                         "traffic_unit": "GB per launch (rocprofv3 PMC, committed profile)", "traffic_source": traffic_src,
                          "kernel": "fz_scan_kernel", "avg_kernel_ms": round(f_ms, 4),
                          "algorithmic_bytes_per_launch": shard_bytes},
             "kernel_ms": {"filter": round(f_ms, 4), "verify": round(float(np.mean(verify_ms)), 4),

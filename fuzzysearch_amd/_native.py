@@ -18,6 +18,7 @@ EXPORTED_SYMBOLS = (
     "fz_abi_version", "fz_last_error", "fz_device_count", "fz_create", "fz_destroy",
     "fz_seq_upload", "fz_seq_upload_shard", "fz_seq_len", "fz_seq_release",
     "fz_search_exact", "fz_lev_ngrams", "fz_subs_ngrams", "fz_generic_ngrams",
+    "fz_lev_lp", "fz_subs_lp", "fz_generic_lp",
     "fz_consolidate", "fz_group_best", "fz_stats", "fz_free",
 )
 
@@ -83,6 +84,12 @@ def load_library():
         L.fz_subs_ngrams.argtypes = [vp, vp, u8p, u32, u32, mpp, u64p]
         L.fz_generic_ngrams.restype = ci
         L.fz_generic_ngrams.argtypes = [vp, vp, u8p, u32, u32, u32, u32, u32, mpp, u64p]
+        L.fz_lev_lp.restype = ci
+        L.fz_lev_lp.argtypes = [vp, vp, u8p, u32, u32, mpp, u64p]
+        L.fz_subs_lp.restype = ci
+        L.fz_subs_lp.argtypes = [vp, vp, u8p, u32, u32, mpp, u64p]
+        L.fz_generic_lp.restype = ci
+        L.fz_generic_lp.argtypes = [vp, vp, u8p, u32, u32, u32, u32, u32, mpp, u64p]
         L.fz_consolidate.restype = ci
         L.fz_consolidate.argtypes = [ctypes.POINTER(FzMatch), u64, mpp, u64p]
         L.fz_group_best.restype = ci
@@ -299,6 +306,15 @@ class Engine(object):
 
     def generic_ngrams(self, seq, pattern, max_subs, max_ins, max_dels, max_l):
         return self._match_call(self._lib.fz_generic_ngrams, seq, pattern, max_subs, max_ins, max_dels, max_l)
+
+    def lev_lp(self, seq, pattern, k):
+        return self._match_call(self._lib.fz_lev_lp, seq, pattern, k)
+
+    def subs_lp(self, seq, pattern, k):
+        return self._match_call(self._lib.fz_subs_lp, seq, pattern, k)
+
+    def generic_lp(self, seq, pattern, max_subs, max_ins, max_dels, max_l):
+        return self._match_call(self._lib.fz_generic_lp, seq, pattern, max_subs, max_ins, max_dels, max_l)
 
     def stats(self):
         st = FzStats()

@@ -23,6 +23,13 @@
 #define FZ_MAX_K 255                   // largest edit budget the verify kernels support
 #define FZ_HASH_K 0x9E3779u            // 24-bit multiplier of the window hash (v_mad_u32_u24)
 
+// What fz_lp_kernel iterates over.
+enum FzLpKind : uint32_t {
+    FZ_LP_GENERIC_HIT = 0,   // generic automaton on the window around every n-gram hit (generic_search.py:198-237)
+    FZ_LP_GENERIC_SEQ = 1,   // generic automaton over the whole sequence (generic_search.py:57-177), tiled by start
+    FZ_LP_LEV_SEQ = 2,       // Levenshtein automaton over the whole sequence (levenshtein.py:52-148), tiled by start
+};
+
 enum FzMode : uint32_t { FZ_MODE_EXACT = 0, FZ_MODE_LEV = 1, FZ_MODE_SUBS = 2, FZ_MODE_GENERIC = 3 };
 
 // Geometry of the resident (shard of the) sequence.  All match arithmetic is in GLOBAL
@@ -51,7 +58,9 @@ struct FzScanArgs {
     uint32_t band_w;                            // rolling score slots per lane (2k + 2)
     uint32_t win_dwords;                        // window dwords staged per lane ((m + 2k + 6) / 4 + 1)
     uint32_t max_subs, max_ins, max_dels;       // generic search limits (k = max_l_dist there)
-    uint32_t cand_cap;                          // generic search: candidate slots per list (LDS)
+    uint32_t cand_cap;                          // automaton kernels: candidate slots per list (LDS)
+    uint32_t lp_kind;                           // FzLpKind of fz_lp_kernel
+    uint32_t lp_starts;                         // tiled modes: start positions owned by one window
     uint32_t H[FZ_MAX_BLOCKS_PER_LAUNCH];       // fast-path hash of each block's n-gram
     uint32_t A[FZ_MAX_BLOCKS_PER_LAUNCH];       // 1st window value per block (little endian)
     uint32_t B[FZ_MAX_BLOCKS_PER_LAUNCH];       // 2nd window value per block
@@ -252,6 +261,41 @@ FZ_HD void fz_generic_step(const FzGCand &c, uint8_t ch, uint32_t index, uint32_
     }
 }
 
+// find_near_matches_levenshtein_linear_programming (levenshtein.py:52-148): one candidate, one
+// sequence character.  `more_seq` is the reference's `index + 1 < len(sequence)` (global).
+template <class PatF>
+FZ_HD void fz_levlp_step(const FzGCand &c, uint8_t ch, uint32_t index, bool more_seq, uint32_t m, PatF pat,
+                         uint32_t k, FzGOut &o) {
+    o.nsucc = 0; o.nmatch = 0;
+    auto match = [&](uint32_t end, uint32_t dist) {
+        o.mstart[o.nmatch] = c.start; o.mend[o.nmatch] = end; o.mdist[o.nmatch] = dist; ++o.nmatch;
+    };
+    if (pat(c.j) == ch) {                                              // :84-92
+        if (c.j + 1u == m) match(index + 1, c.l);
+        else { FzGCand x = c; x.j = (uint16_t)(c.j + 1); o.succ[o.nsucc++] = x; }
+        return;
+    }
+    if (c.l == k) return;                                              // :99-100
+    { FzGCand x = c; x.l++; o.succ[o.nsucc++] = x; }                   // :103 skip a sequence char
+    if (more_seq && c.j + 1u < m) {                                    // :105-111 skip both
+        FzGCand x = c; x.l++; x.j++; o.succ[o.nsucc++] = x;
+    }
+    for (uint32_t sk = 1; sk <= k - c.l; ++sk) {                       // :114-137 skip pattern chars
+        if (c.j + sk == m) { match(index + 1, c.l + sk); break; }
+        if (pat(c.j + sk) == ch) {
+            if (c.j + sk + 1u == m) match(index + 1, c.l + sk);
+            else { FzGCand x = c; x.l = (uint8_t)(c.l + sk); x.j = (uint16_t)(c.j + 1u + sk); o.succ[o.nsucc++] = x; }
+            break;
+        }
+    }
+}
+
+// levenshtein.py:144-148
+FZ_HD bool fz_levlp_final(const FzGCand &c, uint32_t m, uint32_t k, uint32_t &dist) {
+    dist = c.l + m - c.j;
+    return dist <= k;
+}
+
 // End-of-window flush of one surviving candidate (py:172-177): -> true and dist if it matches.
 FZ_HD bool fz_generic_final(const FzGCand &c, uint32_t m, uint32_t max_dels, uint32_t max_l, uint32_t &dist) {
     const uint32_t sk = m - c.j;
@@ -261,11 +305,11 @@ FZ_HD bool fz_generic_final(const FzGCand &c, uint32_t m, uint32_t max_dels, uin
 
 // Record of the generic search: one emitted match of the automaton run on the window of hit `key`.
 struct FzGenRec {
-    uint64_t key;        // (block << 56) | idx of the n-gram hit
-    uint32_t seq;        // emission number within that hit's window
+    uint64_t key;        // per-hit mode: (block << 56) | idx of the n-gram hit; tiled modes: global step index
+    uint32_t seq;        // emission number within the work item (hit window / tile)
     uint32_t se;         // window-relative start | end << 16
     uint32_t dist;
-    uint32_t pad;
+    uint32_t win;        // tiled modes: window (tile) number
 };
 
 // Plain byte accessor over a resident buffer in GLOBAL coordinates (host emulation / tests).

@@ -392,14 +392,14 @@ __device__ __forceinline__ uint32_t fz_wave_incl_scan(uint32_t v) {
     return v;
 }
 
-__global__ __launch_bounds__(64) void fz_generic_kernel(const uint8_t *__restrict__ buf, const FzScanArgs a,
-                                                        const uint64_t *__restrict__ hits,
-                                                        FzGenRec *__restrict__ recs,
-                                                        unsigned long long *__restrict__ counters) {
+__global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ buf, const FzScanArgs a,
+                                                   const uint64_t *__restrict__ hits, uint64_t n_items,
+                                                   FzGenRec *__restrict__ recs,
+                                                   unsigned long long *__restrict__ counters) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t lane = threadIdx.x;
     const uint32_t mpad = (a.m + 15u) & ~15u;
-    const uint32_t wmax = a.m + 2u * a.k;
+    const uint32_t wmax = a.m + 2u * a.k + a.lp_starts;
     const uint32_t wpad = (wmax + 15u) & ~15u;
     uint8_t *pat = smem;
     uint8_t *win = smem + mpad;
@@ -409,23 +409,42 @@ __global__ __launch_bounds__(64) void fz_generic_kernel(const uint8_t *__restric
     for (uint32_t i = lane; i < a.m; i += 64u) pat[i] = a.pat[i];
     fz_wave_lds_sync();
     auto patf = [&](uint32_t i) -> uint8_t { return pat[i]; };
+    const bool per_hit = a.lp_kind == FZ_LP_GENERIC_HIT;
+    const bool lev = a.lp_kind == FZ_LP_LEV_SEQ;
 
-    unsigned long long nh = counters[0];
-    if (nh > a.hit_cap) nh = a.hit_cap;
-    for (uint64_t q = blockIdx.x; q < nh; q += gridDim.x) {
-        const uint64_t hit = hits[q];
-        const uint32_t s = fz_hit_block(hit) * a.L;
-        const uint64_t idx = fz_hit_index(hit);
-        const uint64_t reach = (uint64_t)s + a.k;
-        const uint64_t w0 = idx > reach ? idx - reach : 0;             // generic_search.py:231
-        uint64_t w1 = idx - s + a.m + a.k;
-        if (w1 > a.geom.n) w1 = a.geom.n;
+    unsigned long long nitems = n_items;
+    if (per_hit) { nitems = counters[0]; if (nitems > a.hit_cap) nitems = a.hit_cap; }
+    for (uint64_t q = blockIdx.x; q < nitems; q += gridDim.x) {
+        uint64_t key_base, w0, w1;
+        uint32_t spawn_len;
+        bool flush_end;
+        if (per_hit) {
+            const uint64_t hit = hits[q];
+            const uint32_t s = fz_hit_block(hit) * a.L;
+            const uint64_t idx = fz_hit_index(hit);
+            const uint64_t reach = (uint64_t)s + a.k;
+            w0 = idx > reach ? idx - reach : 0;                        // generic_search.py:231
+            w1 = idx - s + a.m + a.k;
+            if (w1 > a.geom.n) w1 = a.geom.n;
+            spawn_len = (uint32_t)(w1 - w0);
+            flush_end = true;                                          // the window IS the sequence there
+            key_base = hit;
+        } else {
+            w0 = a.geom.own_lo + q * a.lp_starts;
+            const uint64_t own_end = a.geom.own_hi < a.geom.n ? a.geom.own_hi : a.geom.n;
+            spawn_len = (uint32_t)((own_end - w0) < a.lp_starts ? (own_end - w0) : a.lp_starts);
+            w1 = w0 + spawn_len + a.m + a.k;
+            if (w1 > a.geom.n) w1 = a.geom.n;
+            flush_end = w1 == a.geom.n;     // candidates alive at the true sequence end are flushed;
+            key_base = w0;                  // elsewhere every candidate of this tile has died by w1
+        }
         const uint32_t wlen = (uint32_t)(w1 - w0);
         for (uint32_t i = lane; i < wlen; i += 64u) win[i] = buf[(w0 - a.geom.buf_off) + i];
         fz_wave_lds_sync();
 
         uint32_t ncur = 0, mb = 0, mseq = 0;
         bool overflow = false;
+        // match buffer entry: se (32) | dist (16) | step-in-window (16)
         auto flush_matches = [&]() {
             if (mb == 0) return;
             fz_wave_lds_sync();
@@ -436,7 +455,8 @@ __global__ __launch_bounds__(64) void fz_generic_kernel(const uint8_t *__restric
                 if (base + e < a.rec_cap) {
                     const uint64_t v = mbuf[e];
                     FzGenRec r;
-                    r.key = hit; r.seq = mseq + e; r.se = (uint32_t)v; r.dist = (uint32_t)(v >> 32); r.pad = 0;
+                    r.key = per_hit ? key_base : key_base + (v >> 48);
+                    r.seq = mseq + e; r.se = (uint32_t)v; r.dist = (uint32_t)(v >> 32) & 0xffffu; r.win = (uint32_t)q;
                     recs[base + e] = r;
                 }
             }
@@ -446,15 +466,35 @@ __global__ __launch_bounds__(64) void fz_generic_kernel(const uint8_t *__restric
         };
         for (uint32_t index = 0; index <= wlen && !overflow; ++index) {
             const bool last = index == wlen;                           // end-of-window flush pass
+            if (last && !flush_end) break;
             uint8_t ch = 0;
+            uint32_t nnext = 0;
             if (!last) {
                 ch = win[index];
-                if (ncur >= a.cand_cap) { overflow = true; break; }
-                if (lane == 0) { FzGCand f; f.start = (uint16_t)index; f.j = 0; f.l = f.ns = f.ni = f.nd = 0; cur[ncur] = f; }
-                ++ncur;
-                fz_wave_lds_sync();
+                if (index < spawn_len) {
+                    if (!lev) {                                        // generic: fresh candidate appended (py:80)
+                        if (ncur >= a.cand_cap) { overflow = true; break; }
+                        if (lane == 0) { FzGCand f; f.start = (uint16_t)index; f.j = 0; f.l = f.ns = f.ni = f.nd = 0; cur[ncur] = f; }
+                        ++ncur;
+                        fz_wave_lds_sync();
+                    } else {                                           // Levenshtein: levenshtein.py:75-80
+                        uint32_t f = 0xffffffffu;
+                        const uint32_t lim = a.k + 1 < a.m ? a.k + 1 : a.m;
+                        for (uint32_t i = 0; i < lim; ++i) if (pat[i] == ch) { f = i; break; }
+                        if (f != 0xffffffffu) {
+                            if (f + 1 == a.m) {                        // immediate match, emitted first
+                                if (mb + 1 > FZ_GEN_MCAP) flush_matches();
+                                if (lane == 0) mbuf[mb] = (uint64_t)(index | ((index + 1) << 16)) | ((uint64_t)f << 32) | ((uint64_t)index << 48);
+                                ++mb;
+                            } else {                                   // new candidate goes FIRST
+                                if (lane == 0) { FzGCand c; c.start = (uint16_t)index; c.j = (uint16_t)(f + 1); c.l = (uint8_t)f; c.ns = c.ni = c.nd = 0; nxt[0] = c; }
+                                nnext = 1;
+                            }
+                        }
+                    }
+                }
             }
-            uint32_t nnext = 0;
+            const bool more_seq = w0 + index + 1 < a.geom.n;
             for (uint32_t c0 = 0; c0 < ncur; c0 += 64u) {
                 const bool valid = c0 + lane < ncur;
                 FzGOut o;
@@ -462,12 +502,12 @@ __global__ __launch_bounds__(64) void fz_generic_kernel(const uint8_t *__restric
                 if (valid) {
                     const FzGCand c = cur[c0 + lane];
                     if (!last) {
-                        fz_generic_step(c, ch, index, a.m, patf, a.max_subs, a.max_ins, a.max_dels, a.k, o);
+                        if (lev) fz_levlp_step(c, ch, index, more_seq, a.m, patf, a.k, o);
+                        else fz_generic_step(c, ch, index, a.m, patf, a.max_subs, a.max_ins, a.max_dels, a.k, o);
                     } else {
                         uint32_t d;
-                        if (fz_generic_final(c, a.m, a.max_dels, a.k, d)) {
-                            o.mstart[0] = c.start; o.mend[0] = wlen; o.mdist[0] = d; o.nmatch = 1;
-                        }
+                        const bool hit_end = lev ? fz_levlp_final(c, a.m, a.k, d) : fz_generic_final(c, a.m, a.max_dels, a.k, d);
+                        if (hit_end) { o.mstart[0] = c.start; o.mend[0] = wlen; o.mdist[0] = d; o.nmatch = 1; }
                     }
                 }
                 const uint32_t packed = o.nsucc | (o.nmatch << 16);
@@ -479,7 +519,8 @@ __global__ __launch_bounds__(64) void fz_generic_kernel(const uint8_t *__restric
                 if (mb + tot_m > FZ_GEN_MCAP) flush_matches();
                 for (uint32_t i = 0; i < o.nsucc; ++i) nxt[nnext + (excl & 0xffffu) + i] = o.succ[i];
                 for (uint32_t i = 0; i < o.nmatch; ++i)
-                    mbuf[mb + (excl >> 16) + i] = (uint64_t)(o.mstart[i] | (o.mend[i] << 16)) | ((uint64_t)o.mdist[i] << 32);
+                    mbuf[mb + (excl >> 16) + i] = (uint64_t)(o.mstart[i] | (o.mend[i] << 16)) | ((uint64_t)o.mdist[i] << 32) |
+                                                  ((uint64_t)index << 48);
                 nnext += tot_s;
                 mb += tot_m;
             }
@@ -493,5 +534,41 @@ __global__ __launch_bounds__(64) void fz_generic_kernel(const uint8_t *__restric
             flush_matches();
         }
         fz_wave_lds_sync();
+    }
+}
+
+// (f)3  Substitutions-only without the n-gram filter (_find_near_matches_substitutions_lp,
+// substitutions_only.py:82-136): every window with Hamming distance <= k.  One lane per start.
+__global__ __launch_bounds__(256) void fz_hamming_kernel(const uint8_t *__restrict__ buf, const FzScanArgs a,
+                                                         FzRec *__restrict__ recs,
+                                                         unsigned long long *__restrict__ counters) {
+    __shared__ uint8_t pat[FZ_MAX_M];
+    for (uint32_t i = threadIdx.x; i < a.m; i += blockDim.x) pat[i] = a.pat[i];
+    __syncthreads();
+    const uint64_t lo = a.geom.own_lo;
+    uint64_t hi = a.geom.own_hi;                                       // starts i with i + m <= n
+    if (a.geom.n < a.m) hi = lo;
+    else if (hi > a.geom.n - a.m + 1) hi = a.geom.n - a.m + 1;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t span = hi > lo ? hi - lo : 0;
+    for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < span; base += stride) {
+        const uint64_t i = lo + base + threadIdx.x;
+        bool ok = base + threadIdx.x < span;
+        uint32_t d = 0;
+        if (ok) {
+            const uint8_t *t = buf + (i - a.geom.buf_off);
+            for (uint32_t q = 0; q < a.m && d <= a.k; ++q) d += (pat[q] != t[q]) ? 1u : 0u;
+            ok = d <= a.k;
+        }
+        const unsigned long long mask = __ballot(ok);
+        if (mask) {
+            unsigned long long slot0 = 0;
+            if (fz_lane() == 0) slot0 = atomicAdd(&counters[1], (unsigned long long)__popcll(mask));
+            slot0 = fz_bcast64(slot0);
+            if (ok) {
+                const unsigned long long slot = slot0 + fz_rank(mask);
+                if (slot < a.rec_cap) { FzRec r; r.key = i; r.l = 0; r.r = 0; r.dist = d; r.aux = 0; recs[slot] = r; }
+            }
+        }
     }
 }

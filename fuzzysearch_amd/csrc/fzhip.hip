@@ -365,16 +365,18 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             fa.mode = q.mode; fa.m = q.m; fa.k = q.k; fa.L = q.plan.L;
             fa.max_subs = q.max_subs; fa.max_ins = q.max_ins; fa.max_dels = q.max_dels;
             fa.cand_cap = cand_cap;
+            fa.lp_kind = FZ_LP_GENERIC_HIT;
+            fa.lp_starts = 0;
             fa.hit_cap = d.hit_cap;
             fa.rec_cap = d.rec_cap;
             memcpy(fa.pat, q.p, q.m);
             unsigned long long *counters = reinterpret_cast<unsigned long long *>(d.d_out);
             FzGenRec *recs = reinterpret_cast<FzGenRec *>(d.d_out + kHeaderBytes);
             if (lds > 64 * 1024)
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fz_generic_kernel),
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fz_lp_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(fz_generic_kernel, dim3(d.n_cus * 16), dim3(64), lds, d.stream, sh.d_buf, fa, d.d_hits,
-                               recs, counters);
+            hipLaunchKernelGGL(fz_lp_kernel, dim3(d.n_cus * 16), dim3(64), lds, d.stream, sh.d_buf, fa, d.d_hits,
+                               (uint64_t)0, recs, counters);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(d.ev[2], d.stream));
             HIP_TRY(hipMemcpyAsync(d.h_stage, d.d_out, kHeaderBytes + kFirstCopyRecs * sizeof(FzRec),
@@ -775,6 +777,230 @@ int fz_generic_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, ui
     ctx->stats.raw_matches = recs.size();
     return FZ_OK;
 }
+
+}  // extern "C"
+
+// ---- (f)3: the reference's linear-programming fallbacks for short patterns, on the GPU ---------
+namespace {
+
+struct LpRec { int64_t start, end; int32_t dist; uint64_t step; uint64_t w0; uint32_t seq; };
+
+constexpr uint32_t kLpStarts = 256;      // start positions owned by one window (one wave)
+
+// Whole-sequence automaton (generic or Levenshtein), tiled by start position: tile w spawns the
+// candidates of starts [w0, w0 + 256) and runs them over [w0, w0 + 256 + m + k) — a candidate lives
+// at most m - 1 + k characters, so tiles are independent; only the tile reaching the sequence end
+// performs the reference's end-of-sequence flush.
+int run_lp(fz_ctx *ctx, fz_seq *seq, const Search &q, uint32_t lp_kind, std::vector<LpRec> &out) {
+    memset(&ctx->stats, 0, sizeof ctx->stats);
+    ctx->stats.n_devices = (uint32_t)ctx->devs.size();
+    uint32_t cand_cap = 1024;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        out.clear();
+        bool rerun = false;
+        const uint32_t mpad = (q.m + 15u) & ~15u, wpad = (q.m + 2 * q.k + kLpStarts + 15u) & ~15u;
+        const size_t lds = mpad + wpad + 2 * (size_t)cand_cap * sizeof(FzGCand) + FZ_GEN_MCAP * 8;
+        if (lds > 160 * 1024) return fail(FZ_EUNSUPPORTED, "automaton candidate lists do not fit LDS");
+        for (const Shard &sh : seq->shards) {
+            DevState &d = ctx->devs[sh.dev];
+            HIP_TRY(hipSetDevice(d.device));
+            unsigned long long *counters = reinterpret_cast<unsigned long long *>(d.d_out);
+            FzGenRec *recs = reinterpret_cast<FzGenRec *>(d.d_out + kHeaderBytes);
+            HIP_TRY(hipMemsetAsync(d.d_out, 0, kHeaderBytes, d.stream));
+            HIP_TRY(hipEventRecord(d.ev[0], d.stream));
+            FzScanArgs fa;
+            memset(&fa, 0, sizeof fa);
+            fa.geom = sh.geom;
+            fa.mode = q.mode; fa.m = q.m; fa.k = q.k; fa.L = 0;
+            fa.max_subs = q.max_subs; fa.max_ins = q.max_ins; fa.max_dels = q.max_dels;
+            fa.cand_cap = cand_cap;
+            fa.lp_kind = lp_kind;
+            fa.lp_starts = kLpStarts;
+            fa.rec_cap = d.rec_cap;
+            memcpy(fa.pat, q.p, q.m);
+            const uint64_t own = sh.geom.own_hi - sh.geom.own_lo;
+            const uint64_t nwin = (own + kLpStarts - 1) / kLpStarts;
+            if (lds > 64 * 1024)
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fz_lp_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (nwin) {
+                const unsigned grid = (unsigned)std::min<uint64_t>(nwin, (uint64_t)d.n_cus * 64);
+                hipLaunchKernelGGL(fz_lp_kernel, dim3(grid), dim3(64), lds, d.stream, sh.d_buf, fa, d.d_hits, nwin, recs,
+                                   counters);
+                HIP_TRY(hipGetLastError());
+            }
+            HIP_TRY(hipEventRecord(d.ev[1], d.stream));
+            HIP_TRY(hipMemcpyAsync(d.h_stage, d.d_out, kHeaderBytes + kFirstCopyRecs * sizeof(FzRec),
+                                   hipMemcpyDeviceToHost, d.stream));
+            HIP_TRY(hipEventRecord(d.ev[3], d.stream));
+        }
+        for (const Shard &sh : seq->shards) {
+            DevState &d = ctx->devs[sh.dev];
+            HIP_TRY(hipSetDevice(d.device));
+            HIP_TRY(hipStreamSynchronize(d.stream));
+            const unsigned long long *cnt = reinterpret_cast<const unsigned long long *>(d.h_stage);
+            const uint64_t nr = cnt[1], novf = cnt[2];
+            if (nr > d.rec_cap) { int rc = ensure_recs(d, nr + nr / 8 + 1024); if (rc) return rc; rerun = true; }
+            if (novf) { cand_cap *= 4; rerun = true; }
+            if (rerun) continue;
+            float f = 0, t = 0;
+            HIP_TRY(hipEventElapsedTime(&f, d.ev[0], d.ev[1]));
+            HIP_TRY(hipEventElapsedTime(&t, d.ev[0], d.ev[3]));
+            ctx->stats.verify_ms = std::max<double>(ctx->stats.verify_ms, f);
+            ctx->stats.device_ms = std::max<double>(ctx->stats.device_ms, t);
+            ctx->stats.bytes_scanned += sh.geom.buf_len;
+            std::vector<FzGenRec> tmp(nr);
+            const uint64_t first = std::min<uint64_t>(nr, kFirstCopyRecs);
+            if (first) memcpy(tmp.data(), d.h_stage + kHeaderBytes, first * sizeof(FzGenRec));
+            if (nr > first)
+                HIP_TRY(hipMemcpy(tmp.data() + first, d.d_out + kHeaderBytes + first * sizeof(FzGenRec),
+                                  (nr - first) * sizeof(FzGenRec), hipMemcpyDeviceToHost));
+            for (const FzGenRec &r : tmp) {
+                LpRec o;
+                o.w0 = sh.geom.own_lo + (uint64_t)r.win * kLpStarts;
+                o.start = (int64_t)(o.w0 + (r.se & 0xffffu));
+                o.end = (int64_t)(o.w0 + (r.se >> 16));
+                o.dist = (int32_t)r.dist;
+                o.step = r.key;
+                o.seq = r.seq;
+                out.push_back(o);
+            }
+        }
+        if (!rerun) { ctx->stats.raw_matches = out.size(); return FZ_OK; }
+    }
+    return fail(FZ_EUNSUPPORTED, "automaton candidate lists / result buffers kept overflowing");
+}
+
+int emit_lp(std::vector<LpRec> &recs, bool newest_first, fz_match **out, uint64_t *n) {
+    // reference emission order: by sequence step; within a step by candidate-list order, i.e. by
+    // start ascending (generic: fresh candidates are appended) or descending (Levenshtein: the fresh
+    // candidate goes first); within one tile the kernel already kept list order (seq).
+    std::sort(recs.begin(), recs.end(), [newest_first](const LpRec &a, const LpRec &b) {
+        if (a.step != b.step) return a.step < b.step;
+        if (a.w0 != b.w0) return newest_first ? a.w0 > b.w0 : a.w0 < b.w0;
+        return a.seq < b.seq;
+    });
+    void *mem = nullptr;
+    int rc = alloc_out(recs.size(), sizeof(fz_match), &mem);
+    if (rc) return rc;
+    fz_match *mo = static_cast<fz_match *>(mem);
+    for (size_t i = 0; i < recs.size(); ++i) {
+        mo[i].start = recs[i].start; mo[i].end = recs[i].end; mo[i].dist = recs[i].dist; mo[i].block = -1;
+    }
+    *out = mo;
+    *n = recs.size();
+    return FZ_OK;
+}
+
+}  // namespace
+
+extern "C" int fz_lev_lp(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, fz_match **out, uint64_t *n) {
+    if (!out || !n) return fail(FZ_EINVAL, "null argument");
+    *out = nullptr; *n = 0;
+    int rc = validate(ctx, seq, p, m);
+    if (rc) return rc;
+    if (k >= m) {                                              // levenshtein.py:62-65: data independent
+        const uint64_t cnt = seq->n + 1;
+        void *mem = nullptr;
+        rc = alloc_out(cnt, sizeof(fz_match), &mem);
+        if (rc) return rc;
+        fz_match *mo = static_cast<fz_match *>(mem);
+        for (uint64_t i = 0; i < cnt; ++i) { mo[i].start = mo[i].end = (int64_t)i; mo[i].dist = (int32_t)m; mo[i].block = -1; }
+        *out = mo; *n = cnt;
+        return FZ_OK;
+    }
+    if (k > FZ_MAX_K) return fail(FZ_EUNSUPPORTED, "max_l_dist above %d is not supported", FZ_MAX_K);
+    rc = check_halo(seq, (uint64_t)m + k);
+    if (rc) return rc;
+    Search q;
+    q.mode = FZ_MODE_LEV; q.m = m; q.k = k; q.p = p;
+    std::vector<LpRec> recs;
+    rc = run_lp(ctx, seq, q, FZ_LP_LEV_SEQ, recs);
+    if (rc) return rc;
+    return emit_lp(recs, /*newest_first=*/true, out, n);
+}
+
+extern "C" int fz_generic_lp(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t max_subs, uint32_t max_ins,
+                             uint32_t max_dels, uint32_t max_l, fz_match **out, uint64_t *n) {
+    if (!out || !n) return fail(FZ_EINVAL, "null argument");
+    *out = nullptr; *n = 0;
+    int rc = validate(ctx, seq, p, m);
+    if (rc) return rc;
+    if (max_l > FZ_MAX_K) return fail(FZ_EUNSUPPORTED, "max_l_dist above %d is not supported", FZ_MAX_K);
+    rc = check_halo(seq, (uint64_t)m + max_l);
+    if (rc) return rc;
+    Search q;
+    q.mode = FZ_MODE_GENERIC; q.m = m; q.k = max_l; q.p = p;
+    q.max_subs = std::min(max_subs, 255u); q.max_ins = std::min(max_ins, 255u); q.max_dels = std::min(max_dels, 255u);
+    std::vector<LpRec> recs;
+    rc = run_lp(ctx, seq, q, FZ_LP_GENERIC_SEQ, recs);
+    if (rc) return rc;
+    return emit_lp(recs, /*newest_first=*/false, out, n);
+}
+
+extern "C" int fz_subs_lp(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, fz_match **out, uint64_t *n) {
+    if (!out || !n) return fail(FZ_EINVAL, "null argument");
+    *out = nullptr; *n = 0;
+    int rc = validate(ctx, seq, p, m);
+    if (rc) return rc;
+    rc = check_halo(seq, m);
+    if (rc) return rc;
+    memset(&ctx->stats, 0, sizeof ctx->stats);
+    ctx->stats.n_devices = (uint32_t)ctx->devs.size();
+    std::vector<FzRec> recs;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        recs.clear();
+        bool rerun = false;
+        for (const Shard &sh : seq->shards) {
+            DevState &d = ctx->devs[sh.dev];
+            HIP_TRY(hipSetDevice(d.device));
+            unsigned long long *counters = reinterpret_cast<unsigned long long *>(d.d_out);
+            FzRec *drecs = reinterpret_cast<FzRec *>(d.d_out + kHeaderBytes);
+            HIP_TRY(hipMemsetAsync(d.d_out, 0, kHeaderBytes, d.stream));
+            FzScanArgs fa;
+            memset(&fa, 0, sizeof fa);
+            fa.geom = sh.geom; fa.mode = FZ_MODE_SUBS; fa.m = m; fa.k = k; fa.rec_cap = d.rec_cap;
+            memcpy(fa.pat, p, m);
+            const uint64_t own = sh.geom.own_hi - sh.geom.own_lo;
+            const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((own + 255) / 256, (uint64_t)d.n_cus * 16));
+            hipLaunchKernelGGL(fz_hamming_kernel, dim3(grid), dim3(256), 0, d.stream, sh.d_buf, fa, drecs, counters);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(d.h_stage, d.d_out, kHeaderBytes + kFirstCopyRecs * sizeof(FzRec),
+                                   hipMemcpyDeviceToHost, d.stream));
+        }
+        for (const Shard &sh : seq->shards) {
+            DevState &d = ctx->devs[sh.dev];
+            HIP_TRY(hipSetDevice(d.device));
+            HIP_TRY(hipStreamSynchronize(d.stream));
+            const unsigned long long *cnt = reinterpret_cast<const unsigned long long *>(d.h_stage);
+            const uint64_t nr = cnt[1];
+            if (nr > d.rec_cap) { rc = ensure_recs(d, nr + nr / 8 + 1024); if (rc) return rc; rerun = true; continue; }
+            const size_t base = recs.size();
+            recs.resize(base + nr);
+            const uint64_t first = std::min<uint64_t>(nr, kFirstCopyRecs);
+            if (first) memcpy(recs.data() + base, d.h_stage + kHeaderBytes, first * sizeof(FzRec));
+            if (nr > first)
+                HIP_TRY(hipMemcpy(recs.data() + base + first, d.d_out + kHeaderBytes + first * sizeof(FzRec),
+                                  (nr - first) * sizeof(FzRec), hipMemcpyDeviceToHost));
+            ctx->stats.bytes_scanned += sh.geom.buf_len;
+        }
+        if (!rerun) break;
+        if (attempt == 3) return fail(FZ_EDEVICE, "result buffers kept overflowing");
+    }
+    sort_recs(recs);
+    void *mem = nullptr;
+    rc = alloc_out(recs.size(), sizeof(fz_match), &mem);
+    if (rc) return rc;
+    fz_match *mo = static_cast<fz_match *>(mem);
+    for (size_t i = 0; i < recs.size(); ++i) {
+        mo[i].start = (int64_t)recs[i].key; mo[i].end = (int64_t)recs[i].key + m; mo[i].dist = (int32_t)recs[i].dist; mo[i].block = -1;
+    }
+    *out = mo; *n = recs.size();
+    ctx->stats.raw_matches = recs.size();
+    return FZ_OK;
+}
+
+extern "C" {
 
 // ---- host-side consolidation (common.py:145-189) -------------------------------------------
 // The partition into overlap groups is input-order independent, so for

@@ -6,7 +6,8 @@ from .common import FuzzySearchBase, Match, consolidate_overlapping_matches
 from .engine import prepare
 from .search_exact import search_exact
 
-__all__ = ['find_near_matches_generic', 'find_near_matches_generic_ngrams', 'GenericSearch']
+__all__ = ['find_near_matches_generic', 'find_near_matches_generic_ngrams',
+           'find_near_matches_generic_linear_programming', 'GenericSearch']
 
 
 def find_near_matches_generic_ngrams(subsequence, sequence, search_params):
@@ -32,9 +33,22 @@ def find_near_matches_generic(subsequence, sequence, search_params):
         return [Match(i, i + m, 0, matched=sequence[i:i + m]) for i in search_exact(subsequence, sequence)]
     if m // (search_params.max_l_dist + 1) >= 3:
         return find_near_matches_generic_ngrams(subsequence, sequence, search_params)
-    raise NotImplementedError(
-        'subsequence too short for the n-gram search (len // (max_l_dist + 1) < 3); '
-        'the linear-programming fallback is not implemented on the GPU')
+    return find_near_matches_generic_linear_programming(subsequence, sequence, search_params)
+
+
+def find_near_matches_generic_linear_programming(subsequence, sequence, search_params):
+    """generic_search.py:57-177 over the whole sequence, on the GPU tiled by start position."""
+    if not len(subsequence):
+        raise ValueError('Given subsequence is empty!')
+    unlimited = 1 << 29
+    max_subs, max_ins, max_dels, max_l = (unlimited if x is None else x for x in search_params.unpacked)
+    pr = prepare(subsequence, sequence)
+    try:
+        raw = pr.engine.generic_lp(pr.handle, pr.pattern, max_subs, max_ins, max_dels, min(max_l, 255))
+    finally:
+        pr.release()
+    seq = pr.original
+    return [Match(s, e, d, matched=seq[s:e]) for (s, e, d, _g) in raw]
 
 
 class GenericSearch(FuzzySearchBase):

@@ -1,9 +1,11 @@
 """Levenshtein search dispatcher (mirrors src/fuzzysearch/levenshtein.py:9-38, :151-164)."""
 from .common import FuzzySearchBase, Match, consolidate_overlapping_matches
+from .engine import prepare
 from .levenshtein_ngram import find_near_matches_levenshtein_ngrams
 from .search_exact import search_exact
 
-__all__ = ['find_near_matches_levenshtein', 'LevenshteinSearch']
+__all__ = ['find_near_matches_levenshtein', 'find_near_matches_levenshtein_linear_programming',
+           'LevenshteinSearch']
 
 
 def find_near_matches_levenshtein(subsequence, sequence, max_l_dist):
@@ -16,11 +18,21 @@ def find_near_matches_levenshtein(subsequence, sequence, max_l_dist):
         return [Match(i, i + m, 0, sequence[i:i + m]) for i in search_exact(subsequence, sequence)]
     if m // (max_l_dist + 1) >= 3:
         return find_near_matches_levenshtein_ngrams(subsequence, sequence, max_l_dist)
-    # levenshtein.py:52-148 (pure-Python candidate automaton, len(p) // (k+1) < 3) is outside the
-    # GPU hot path; there is deliberately no CPU fallback in this package.
-    raise NotImplementedError(
-        'subsequence too short for the n-gram search (len // (max_l_dist + 1) < 3); '
-        'the linear-programming fallback is not implemented on the GPU')
+    return find_near_matches_levenshtein_linear_programming(subsequence, sequence, max_l_dist)
+
+
+def find_near_matches_levenshtein_linear_programming(subsequence, sequence, max_l_dist):
+    """levenshtein.py:52-148 — the candidate automaton for short patterns, run on the GPU tiled by
+    start position (fz_lev_lp); same ordered list of matches as the reference yields."""
+    if not len(subsequence):
+        raise ValueError('Given subsequence is empty!')
+    pr = prepare(subsequence, sequence)
+    try:
+        raw = pr.engine.lev_lp(pr.handle, pr.pattern, max_l_dist)
+    finally:
+        pr.release()
+    seq = pr.original
+    return [Match(s, e, d, matched=seq[s:e]) for (s, e, d, _g) in raw]
 
 
 class LevenshteinSearch(FuzzySearchBase):

@@ -10,6 +10,7 @@ from .engine import prepare
 from .search_exact import search_exact
 
 __all__ = ['find_near_matches_substitutions', 'find_near_matches_substitutions_ngrams',
+           'find_near_matches_substitutions_lp',
            'SubstitutionsOnlySearch']
 
 
@@ -49,9 +50,20 @@ def find_near_matches_substitutions(subsequence, sequence, max_substitutions):
         return [Match(i, i + m, 0, sequence[i:i + m]) for i in search_exact(subsequence, sequence)]
     if m // (max_substitutions + 1) >= 3:
         return find_near_matches_substitutions_ngrams(subsequence, sequence, max_substitutions)
-    raise NotImplementedError(
-        'subsequence too short for the n-gram search (len // (max_substitutions + 1) < 3); '
-        'the linear-programming fallback is not implemented on the GPU')
+    return find_near_matches_substitutions_lp(subsequence, sequence, max_substitutions)
+
+
+def find_near_matches_substitutions_lp(subsequence, sequence, max_substitutions):
+    """substitutions_only.py:65-136: every window with at most max_substitutions mismatches,
+    ascending start (fz_subs_lp: a Hamming kernel without the n-gram filter)."""
+    _check_arguments(subsequence, sequence, max_substitutions)
+    pr = prepare(subsequence, sequence)
+    try:
+        raw = pr.engine.subs_lp(pr.handle, pr.pattern, max_substitutions)
+    finally:
+        pr.release()
+    seq = pr.original
+    return [Match(s, e, d, matched=seq[s:e]) for (s, e, d, _g) in raw]
 
 
 class SubstitutionsOnlySearch(FuzzySearchBase):

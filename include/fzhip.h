@@ -120,6 +120,18 @@ int fz_generic_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m,
                       uint32_t max_subs, uint32_t max_ins, uint32_t max_dels, uint32_t max_l,
                       fz_match **out, uint64_t *n);
 
+/* The reference's linear-programming fallbacks, used by its dispatchers when
+ * len(subsequence) // (k + 1) < 3 (short patterns).  Whole-sequence candidate automata, tiled by
+ * start position on the GPU; ordered emission lists exactly as the reference yields them.
+ *   fz_lev_lp     <->  find_near_matches_levenshtein_linear_programming   levenshtein.py:52-148
+ *   fz_subs_lp    <->  _find_near_matches_substitutions_lp                substitutions_only.py:82-136
+ *   fz_generic_lp <->  _find_near_matches_generic_linear_programming      generic_search.py:57-177 */
+int fz_lev_lp(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, fz_match **out, uint64_t *n);
+int fz_subs_lp(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, fz_match **out, uint64_t *n);
+int fz_generic_lp(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m,
+                  uint32_t max_subs, uint32_t max_ins, uint32_t max_dels, uint32_t max_l,
+                  fz_match **out, uint64_t *n);
+
 /* consolidate_overlapping_matches: overlap groups -> best (dist, -len) per group -> sorted by
  * (start, end, dist).  Ties inside a group (the reference breaks them by set iteration order, i.e.
  * by PYTHONHASHSEED) are broken deterministically: smallest start. */

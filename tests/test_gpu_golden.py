@@ -61,11 +61,7 @@ def test_find_near_matches_levenshtein_golden(engine):
                 with pytest.raises(ValueError):
                     list(levenshtein.find_near_matches_levenshtein(sub, seq, k))
             continue
-        if not _route_is_ngram(len(sub), k):
-            with pytest.raises(NotImplementedError):       # LP route: outside the GPU hot path
-                levenshtein.find_near_matches_levenshtein(sub, seq, k)
-            continue
-        got = levenshtein.find_near_matches_levenshtein(sub, seq, k)
+        got = levenshtein.find_near_matches_levenshtein(sub, seq, k)    # n-gram or LP route
         assert _matches(got) == _expect(rec), (sub, seq, k)
         n += 1
     assert n >= 50
@@ -82,7 +78,7 @@ def test_substitutions_golden(engine):
                     fn(sub, seq, k)
             continue
         ngram_fn = rec["fn"].endswith("ngrams")
-        if (ngram_fn and len(sub) // (k + 1) == 0) or (not ngram_fn and not _route_is_ngram(len(sub), k)):
+        if ngram_fn and len(sub) // (k + 1) == 0:
             continue
         got, exp = _matches(fn(sub, seq, k)), _expect(rec)
         assert len(got) == len(exp), (sub, seq, k)
@@ -96,6 +92,12 @@ def test_generic_golden(engine):
     """find_near_matches_generic_ngrams / find_near_matches_generic on their n-gram route."""
     from fuzzysearch_amd import generic_search
     n = 0
+    for rec in golden_io.load("find_near_matches_generic_linear_programming"):
+        sub, seq, params = rec["args"]
+        if "raises" in rec or len(sub) == 0:
+            continue
+        got = generic_search.find_near_matches_generic_linear_programming(sub, seq, fa.LevenshteinSearchParams(*params))
+        assert _matches(got) == _expect(rec), (sub, seq, params)
     for rec in golden_io.load("find_near_matches_generic_ngrams") + golden_io.load("find_near_matches_generic"):
         sub, seq, params = rec["args"]
         if "raises" in rec or len(sub) == 0:
@@ -107,8 +109,6 @@ def test_generic_golden(engine):
                 continue
             got = generic_search.find_near_matches_generic_ngrams(sub, seq, sp)
         else:
-            if not _route_is_ngram(len(sub), l):
-                continue
             got = generic_search.find_near_matches_generic(sub, seq, sp)
         assert _matches(got) == _expect(rec), (sub, seq, params)
         n += 1
@@ -142,10 +142,12 @@ def test_find_near_matches_public_api_golden(engine):
             sub, seq = args[0], args[1]
             from fuzzysearch_amd.engine import encode_pair
             p, t, _ = encode_pair(sub, seq)
+            k = params.max_l_dist
+            ngram = len(sub) // (k + 1) >= 3
             if cls is fa.GenericSearch:
-                raw = oracle.generic_ngrams_raw(bytes(p), bytes(t), *params.unpacked)
+                raw = (oracle.generic_ngrams_raw if ngram else oracle.generic_lp_raw)(bytes(p), bytes(t), *params.unpacked)
             else:
-                raw = oracle.lev_ngrams_raw(bytes(p), bytes(t), params.max_l_dist)
+                raw = (oracle.lev_ngrams_raw if ngram else oracle.lev_lp_raw)(bytes(p), bytes(t), k)
             assert golden_io.equal_modulo_ties([g[:3] for g in got], [e[:3] for e in exp], raw), (args, kwargs, got, exp)
         n += 1
     assert n >= 100, (n, skipped)

@@ -249,3 +249,69 @@ def test_generic_public_api(engine):
         assert [(x.start, x.end, x.dist) for x in got] == oracle.consolidate(raw), (p, t)
         n += 1
     assert n == 200
+
+
+def test_multi_device_context_on_one_gpu():
+    """fz_create([0, 0, 0]): three device states on the same GPU exercise the single-process
+    multi-device path (shard + halo + concurrent launches + host merge) end to end."""
+    from fuzzysearch_amd import _native
+    eng = _native.Engine([0, 0, 0])
+    rnd = random.Random(51)
+    for n in (0, 5, 100, 5000, 1 << 20):
+        seq = workloads.dna(n, 500 + n % 97)
+        pattern = workloads.dna(20, 1)
+        if n >= 4096:
+            workloads.plant_variants(seq, pattern, 64, 3)
+            for cut in (n // 3, 2 * n // 3, n // 3 + 1):      # variants straddling the shard cuts
+                seq[cut - 9:cut + 11] = pattern
+        t, p = seq.tobytes(), pattern.tobytes()
+        h = eng.upload(seq)
+        assert eng.lev_ngrams(h, p, 2) == oracle.lev_ngrams_raw(p, t, 2), n
+        assert eng.subs_ngrams(h, p, 2) == oracle.subs_ngrams_raw(p, t, 2), n
+        assert eng.search_exact(h, p[:7]) == oracle.search_exact(p[:7], t), n
+        assert eng.generic_ngrams(h, p, 2, 1, 1, 2) == oracle.generic_ngrams_raw(p, t, 2, 1, 1, 2), n
+        h.release()
+    assert eng.stats()["n_devices"] == 3
+    eng.close()
+
+
+def test_lp_fallbacks_raw_random(engine):
+    """(f)3: the reference's linear-programming fallbacks (short patterns), ordered lists == oracle."""
+    rnd = random.Random(61)
+    for _ in range(1500):
+        sigma = rnd.choice([2, 3, 4, 4, 20])
+        alpha = bytes(rnd.sample(range(33, 127), sigma))
+        t = bytes(rnd.choice(alpha) for _ in range(rnd.choice([0, 1, 5, 40, 300, 700])))
+        p = bytes(rnd.choice(alpha) for _ in range(rnd.randint(1, 10)))
+        k = rnd.randint(0, 4)
+        seq = engine.upload(t)
+        try:
+            assert engine.lev_lp(seq, p, k) == oracle.lev_lp_raw(p, t, k), (p, t, k)
+            assert engine.subs_lp(seq, p, k) == oracle.subs_lp_raw(p, t, k), (p, t, k)
+            ms, mi, md = rnd.randint(0, 3), rnd.randint(0, 3), rnd.randint(0, 3)
+            ml = rnd.randint(0, ms + mi + md)
+            ms, mi, md = min(ms, ml), min(mi, ml), min(md, ml)
+            assert engine.generic_lp(seq, p, ms, mi, md, ml) == oracle.generic_lp_raw(p, t, ms, mi, md, ml), (p, t, (ms, mi, md, ml))
+        finally:
+            seq.release()
+
+
+def test_lp_fallbacks_medium_and_api(engine):
+    import fuzzysearch_amd as fa
+    n = 1 << 18
+    seq = workloads.dna(n, 71)
+    t = seq.tobytes()
+    h = engine.upload(seq)
+    for p, k in [(b'ACGTA', 1), (b'GATTACA', 2), (b'ACG', 1)]:
+        assert engine.lev_lp(h, p, k) == oracle.lev_lp_raw(p, t, k)
+        assert engine.subs_lp(h, p, k) == oracle.subs_lp_raw(p, t, k)
+    assert engine.generic_lp(h, b'GATTACA', 2, 1, 1, 2) == oracle.generic_lp_raw(b'GATTACA', t, 2, 1, 1, 2)
+    h.release()
+    small = t[:5000]
+    got = fa.find_near_matches(b'GATTACA', small, max_l_dist=2)              # 7 // 3 < 3 -> LP route
+    assert [(x.start, x.end, x.dist) for x in got] == oracle.consolidate(oracle.lev_lp_raw(b'GATTACA', small, 2))
+    got = fa.find_near_matches(b'GATTA', small, max_substitutions=1, max_insertions=0, max_deletions=0)
+    assert [(x.start, x.end, x.dist) for x in got] == [r[:3] for r in oracle.subs_lp_raw(b'GATTA', small, 1)]
+    got = fa.find_near_matches(b'GATTACA', small, max_substitutions=2, max_insertions=1, max_deletions=1, max_l_dist=2)
+    assert [(x.start, x.end, x.dist) for x in got] == oracle.consolidate(oracle.generic_lp_raw(b'GATTACA', small, 2, 1, 1, 2))
+    assert len(fa.find_near_matches(b'ab', b'xxxx', max_l_dist=2)) == 5     # k >= m: levenshtein.py:62-65
