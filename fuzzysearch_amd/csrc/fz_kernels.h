@@ -27,7 +27,9 @@
 #define FZ_WAVES_PER_BLOCK (FZ_FILTER_THREADS / 64)
 #define FZ_FILTER_ROWS 4                                   // 16-byte rows per thread per tile
 #define FZ_ROW_BYTES (FZ_FILTER_THREADS * 16)              // 4 KiB
-#define FZ_TILE_BYTES (FZ_ROW_BYTES * FZ_FILTER_ROWS)      // 16 KiB
+#define FZ_TILE_BYTES (FZ_ROW_BYTES * FZ_FILTER_ROWS)      // 16 KiB (4 rows) / 32 KiB (8 rows)
+#define FZ_TILE_BITS (FZ_FILTER_ROWS == 8 ? 15 : 14)       // log2(FZ_TILE_BYTES)
+#define FZ_TITER_MAX ((1u << (32 - FZ_TILE_BITS - 3)) - 1) // tile iterations a queue code can carry
 #define FZ_PAD_FRONT 256                                   // zero bytes before buf[0]
 #define FZ_PAD_BACK 64                                     // zero bytes the kernels may over-read
 #define FZ_QCAP 256                                        // fast-hit queue entries per wave
@@ -190,7 +192,7 @@ __device__ __forceinline__ bool fz_confirm(const uint8_t *__restrict__ buf, cons
 
 // Candidate code of the queue: tile-local byte offset (14 bits) | block (3 bits) | tile iteration.
 __device__ __forceinline__ uint32_t fz_code(uint32_t off, uint32_t blk, uint32_t titer) {
-    return off | (blk << 14) | (titer << 17);
+    return off | (blk << FZ_TILE_BITS) | (titer << (FZ_TILE_BITS + 3));
 }
 
 // Process queue entries [0, qn): range-check, then verify in place (FUSED) or confirm against HBM
@@ -211,9 +213,9 @@ __device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ b
         uint32_t blk = 0;
         if (valid) {
             const uint32_t code = w.queue[e];
-            blk = (code >> 14) & 7u;
-            const uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)(code >> 17) * gridDim.x;
-            local = tile * (uint64_t)FZ_TILE_BYTES + (code & 0x3fffu);
+            blk = (code >> FZ_TILE_BITS) & 7u;
+            const uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)(code >> (FZ_TILE_BITS + 3)) * gridDim.x;
+            local = tile * (uint64_t)FZ_TILE_BYTES + (code & (FZ_TILE_BYTES - 1u));
             const uint64_t idx = a.geom.buf_off + local;
             valid = fz_in_range(a, blk, idx);
             hit = fz_hit_pack(a.g0 + blk, idx);

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -24,6 +25,21 @@
 #include "fz_kernels.h"
 
 namespace {
+
+// FZ_TRACE=1: per-phase host timings of a search call on stderr (tuning aid)
+struct Trace {
+    bool on;
+    std::chrono::steady_clock::time_point t0, last;
+    Trace() : on(getenv("FZ_TRACE") != nullptr) { t0 = last = std::chrono::steady_clock::now(); }
+    void mark(const char *what) {
+        if (!on) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[fz] %-18s %8.1f us (total %8.1f)\n", what,
+                std::chrono::duration<double, std::micro>(now - last).count(),
+                std::chrono::duration<double, std::micro>(now - t0).count());
+        last = now;
+    }
+};
 
 thread_local std::string g_err;
 
@@ -57,6 +73,8 @@ struct DevState {
     uint8_t *d_out = nullptr;                    // [header 64 B][recs]
     uint64_t rec_cap = 0;
     uint8_t *h_stage = nullptr;                  // pinned, kHeaderBytes + kFirstCopyRecs * sizeof(FzRec)
+    uint64_t first_copy = 512;                   // records fetched with the header (tracks the last count)
+    bool header_zeroed = false;                  // the counters were already zeroed after the last D2H copy
     int n_cus = 256;
 };
 
@@ -99,6 +117,7 @@ int ensure_recs(DevState &d, uint64_t cap) {
     if (d.d_out) { HIP_TRY(hipFree(d.d_out)); d.d_out = nullptr; d.rec_cap = 0; }
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d.d_out), kHeaderBytes + cap * sizeof(FzRec)));
     d.rec_cap = cap;
+    d.header_zeroed = false;
     return FZ_OK;
 }
 
@@ -165,7 +184,8 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     HIP_TRY(hipSetDevice(d.device));
     unsigned long long *counters = reinterpret_cast<unsigned long long *>(d.d_out);
     FzRec *recs = reinterpret_cast<FzRec *>(d.d_out + kHeaderBytes);
-    HIP_TRY(hipMemsetAsync(d.d_out, 0, kHeaderBytes, d.stream));
+    if (!d.header_zeroed) HIP_TRY(hipMemsetAsync(d.d_out, 0, kHeaderBytes, d.stream));
+    d.header_zeroed = false;
     HIP_TRY(hipEventRecord(d.ev[0], d.stream));
 
     const uint32_t L = q.plan.L;
@@ -178,8 +198,8 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     // 6 per CU (the co-resident count at this kernel's SGPR use) so small inputs still fill the chip.
     static const int tiles_per_wg = []() { const char *e = getenv("FZ_TILES_PER_WG"); int v = e ? atoi(e) : 0; return v > 0 ? v : 16; }();
     const uint64_t max_grid = std::max<uint64_t>((uint64_t)d.n_cus * 6, ntiles / tiles_per_wg);
-    // the queue codes carry a 15-bit per-workgroup tile iteration
-    const uint64_t min_grid = (ntiles + 32766) / 32767;
+    // the queue codes carry a bounded per-workgroup tile iteration
+    const uint64_t min_grid = (ntiles + FZ_TITER_MAX - 1) / FZ_TITER_MAX;
     dim3 grid((unsigned)std::max<uint64_t>(std::max<uint64_t>(1, min_grid), std::min<uint64_t>(ntiles, max_grid)));
 
     FzScanArgs fa;
@@ -243,9 +263,13 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     }
     if (copy_back) {
         HIP_TRY(hipEventRecord(d.ev[2], d.stream));
-        HIP_TRY(hipMemcpyAsync(d.h_stage, d.d_out, kHeaderBytes + kFirstCopyRecs * sizeof(FzRec), hipMemcpyDeviceToHost,
+        d.first_copy = std::min<uint64_t>(std::min<uint64_t>(d.first_copy, kFirstCopyRecs), d.rec_cap);
+        HIP_TRY(hipMemcpyAsync(d.h_stage, d.d_out, kHeaderBytes + d.first_copy * sizeof(FzRec), hipMemcpyDeviceToHost,
                                d.stream));
         HIP_TRY(hipEventRecord(d.ev[3], d.stream));
+        // zero the counters for the NEXT search now, off the critical path of that call
+        HIP_TRY(hipMemsetAsync(d.d_out, 0, kHeaderBytes, d.stream));
+        d.header_zeroed = true;
     }
     ctx->stats.filter_launches += launches;
     ctx->last_fused = fa.fused != 0;
@@ -257,7 +281,9 @@ int collect_shard(fz_ctx *ctx, const Shard &sh, bool with_verify, std::vector<Fz
                   std::vector<uint64_t> &hits_out, bool &rerun) {
     DevState &d = ctx->devs[sh.dev];
     HIP_TRY(hipSetDevice(d.device));
+    Trace tr;
     HIP_TRY(hipStreamSynchronize(d.stream));
+    tr.mark("  sync");
     const unsigned long long *cnt = reinterpret_cast<const unsigned long long *>(d.h_stage);
     uint64_t nh = cnt[0];
     const uint64_t nr = cnt[1];
@@ -288,11 +314,12 @@ int collect_shard(fz_ctx *ctx, const Shard &sh, bool with_verify, std::vector<Fz
         ctx->stats.raw_matches += nr;
         const size_t base = recs_out.size();
         recs_out.resize(base + nr);
-        const uint64_t first = std::min<uint64_t>(nr, kFirstCopyRecs);
+        const uint64_t first = std::min<uint64_t>(nr, d.first_copy);
         if (first) memcpy(recs_out.data() + base, d.h_stage + kHeaderBytes, first * sizeof(FzRec));
         if (nr > first)
             HIP_TRY(hipMemcpy(recs_out.data() + base + first, d.d_out + kHeaderBytes + first * sizeof(FzRec),
                               (nr - first) * sizeof(FzRec), hipMemcpyDeviceToHost));
+        d.first_copy = std::max<uint64_t>(512, nr + nr / 4 + 64);      // next call: fetch about this many
     } else {
         const size_t base = hits_out.size();
         hits_out.resize(base + nh);
@@ -323,10 +350,12 @@ int run_search(fz_ctx *ctx, fz_seq *seq, const Search &q, bool with_verify, std:
         ctx->stats.filter_launches = 0;
         ctx->stats.bytes_scanned = ctx->stats.ngram_hits = ctx->stats.raw_matches = 0;
         ctx->stats.filter_ms = ctx->stats.verify_ms = ctx->stats.device_ms = 0;
+        Trace tr;
         for (const Shard &sh : seq->shards) {
             int rc = enqueue_shard(ctx, sh, q, with_verify);
             if (rc) return rc;
         }
+        tr.mark(" enqueue");
         bool any_rerun = false;
         for (const Shard &sh : seq->shards) {
             bool rr = false;
@@ -334,6 +363,7 @@ int run_search(fz_ctx *ctx, fz_seq *seq, const Search &q, bool with_verify, std:
             if (rc) return rc;
             any_rerun |= rr;
         }
+        tr.mark(" collect");
         if (!any_rerun) return FZ_OK;
     }
     return fail(FZ_EDEVICE, "result buffers kept overflowing");
@@ -692,10 +722,15 @@ int fz_lev_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32
     if (q.plan.s.size() > 255) return fail(FZ_EUNSUPPORTED, "more than 255 n-gram blocks");
     std::vector<FzRec> recs;
     std::vector<uint64_t> hits;
+    Trace tr;
     rc = run_search(ctx, seq, q, true, recs, hits);
     if (rc) return rc;
+    tr.mark("run_search");
     sort_recs(recs);
-    return emit_matches(recs, L, out, n);
+    tr.mark("sort");
+    rc = emit_matches(recs, L, out, n);
+    tr.mark("emit");
+    return rc;
 }
 
 int fz_subs_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, fz_match **out, uint64_t *n) {
@@ -807,6 +842,7 @@ int run_lp(fz_ctx *ctx, fz_seq *seq, const Search &q, uint32_t lp_kind, std::vec
             unsigned long long *counters = reinterpret_cast<unsigned long long *>(d.d_out);
             FzGenRec *recs = reinterpret_cast<FzGenRec *>(d.d_out + kHeaderBytes);
             HIP_TRY(hipMemsetAsync(d.d_out, 0, kHeaderBytes, d.stream));
+            d.header_zeroed = false;
             HIP_TRY(hipEventRecord(d.ev[0], d.stream));
             FzScanArgs fa;
             memset(&fa, 0, sizeof fa);
@@ -957,6 +993,7 @@ extern "C" int fz_subs_lp(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m
             unsigned long long *counters = reinterpret_cast<unsigned long long *>(d.d_out);
             FzRec *drecs = reinterpret_cast<FzRec *>(d.d_out + kHeaderBytes);
             HIP_TRY(hipMemsetAsync(d.d_out, 0, kHeaderBytes, d.stream));
+            d.header_zeroed = false;
             FzScanArgs fa;
             memset(&fa, 0, sizeof fa);
             fa.geom = sh.geom; fa.mode = FZ_MODE_SUBS; fa.m = m; fa.k = k; fa.rec_cap = d.rec_cap;
