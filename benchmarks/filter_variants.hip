@@ -285,6 +285,55 @@ __global__ __launch_bounds__(THREADS) void k_v6(const uint8_t *__restrict__ buf,
     if ((threadIdx.x & 63) == 0 && qn) atomicAdd(cnt, (unsigned long long)qn);
 }
 
+// ---- V7/V8: per-workgroup LDS byte table indexed by the top TB bits of the hash; FRAC_LDS of the
+// 4-offset groups of a row use the table (VALU: alignbyte + mad + shift + or), the rest xor/min3.
+template <int ROWS, int DH, int TB, int LDS_GROUPS>
+__global__ __launch_bounds__(THREADS) void k_v7(const uint8_t *__restrict__ buf, Args a, uint64_t ntiles, unsigned long long *cnt) {
+    __shared__ uint8_t table[1 << TB];
+    for (int i = threadIdx.x * 16; i < (1 << TB); i += THREADS * 16) *(uint4 *)(table + i) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    if (threadIdx.x < 3) table[a.H[threadIdx.x] >> (32 - TB)] = 1;
+    __syncthreads();
+    uint32_t H[3] = {a.H[0], a.H[1], a.H[2]};
+    const uint32_t K = a.K;
+    uint32_t qn = 0;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint8_t *src = buf + tile * (uint64_t)(ROWB * ROWS) + threadIdx.x * 16u;
+        uint4 v[ROWS]; uint2 h[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) { v[r] = *(const uint4 *)(src + r * ROWB); h[r] = *(const uint2 *)(src + r * ROWB + 16); }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const uint32_t w[6] = {v[r].x, v[r].y, v[r].z, v[r].w, h[r].x, h[r].y};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t hv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const int o = 4 * j + i; hv[i] = __umul24(WIN(w, o + DH), K) + WIN(w, o); }
+                unsigned long long any;
+                if (j < LDS_GROUPS) {
+                    uint32_t acc = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc |= table[hv[i] >> (32 - TB)];
+                    any = __ballot(acc != 0);
+                } else {
+                    uint32_t acc = 0xffffffffu;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { acc = min3u(acc, hv[i] ^ H[0], hv[i] ^ H[1]); acc = min(acc, hv[i] ^ H[2]); }
+                    any = __ballot(acc == 0);
+                }
+                if (any) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) { const unsigned long long mm = __ballot(hv[i] == H[g]); if (mm) rare(mm, qn); }
+                }
+            }
+        }
+    }
+    if ((threadIdx.x & 63) == 0 && qn) atomicAdd(cnt, (unsigned long long)qn);
+}
+
 // semantic probe of the (m)qsad instructions
 __global__ void k_probe(const uint64_t *s0, const uint32_t *s1, const uint64_t *s2, uint64_t *out_q, uint64_t *out_m) {
     const int i = threadIdx.x;
@@ -397,6 +446,14 @@ int main(int argc, char **argv) {
         printf("probe: qsad mismatches %d/64; mqsad vs mask-on-REFERENCE-zero %d/64; vs mask-on-DATA-zero %d/64\n", bad_q, bad_m_ref, bad_m_data);
         for (int i = 0; i < 4; ++i) printf("  s0=%016llx s1=%08x s2=%016llx q=%016llx m=%016llx\n", (unsigned long long)hs0[i], hs1[i], (unsigned long long)hs2[i], (unsigned long long)hq[i], (unsigned long long)hm[i]);
     }
+    RUN("v7 lds15 4/4 groups", (k_v7<4, 3, 15, 4>), 4, 8);
+    RUN("v7 lds15 3/4 groups", (k_v7<4, 3, 15, 3>), 4, 8);
+    RUN("v7 lds15 2/4 groups", (k_v7<4, 3, 15, 2>), 4, 8);
+    RUN("v7 lds15 1/4 groups", (k_v7<4, 3, 15, 1>), 4, 8);
+    RUN("v7 lds14 3/4 groups", (k_v7<4, 3, 14, 3>), 4, 8);
+    RUN("v7 lds14 2/4 groups", (k_v7<4, 3, 14, 2>), 4, 8);
+    RUN("v7 lds13 2/4 groups", (k_v7<4, 3, 13, 2>), 4, 8);
+    RUN("v7 lds15 2/4 g16", (k_v7<4, 3, 15, 2>), 4, 16);
     RUN("v1 r2", (k_v1<2, 3>), 2, 8);
     RUN("v1 r8", (k_v1<8, 3>), 8, 8);
     RUN("v3 grp4 r2", (k_v3<2, 3, 4>), 2, 8);

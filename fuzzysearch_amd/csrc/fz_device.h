@@ -57,6 +57,7 @@ struct FzScanArgs {
     uint32_t fused;                             // 1: verify inside the scan kernel, 0: emit hits
     uint32_t band_w;                            // rolling score slots per lane (2k + 2)
     uint32_t win_dwords;                        // window dwords staged per lane ((m + 2k + 6) / 4 + 1)
+    uint32_t vlanes;                            // lanes of a wave that verify at once (64, 32 or 16): LDS vs lane use
     uint32_t max_subs, max_ins, max_dels;       // generic search limits (k = max_l_dist there)
     uint32_t cand_cap;                          // automaton kernels: candidate slots per list (LDS)
     uint32_t lp_kind;                           // FzLpKind of fz_lp_kernel

@@ -69,21 +69,22 @@ struct FzWaveLds {
     uint16_t *scores;     // [band_w * 64]      ring of DP score slots (slot s of lane l at s*64+l)
 };
 
-__host__ __device__ inline uint32_t fz_wave_lds_bytes(uint32_t win_dwords, uint32_t band_w, bool with_queue) {
+__host__ __device__ inline uint32_t fz_wave_lds_bytes(uint32_t win_dwords, uint32_t band_w, uint32_t vlanes,
+                                                      bool with_queue) {
     uint32_t b = 0;
     if (with_queue) b += FZ_QCAP * 4;
-    b += win_dwords * 64 * 4;
-    b += ((band_w * 64 * 2) + 15u) & ~15u;
+    b += win_dwords * vlanes * 4;
+    b += ((band_w * vlanes * 2) + 15u) & ~15u;
     return b;
 }
 
 __device__ __forceinline__ FzWaveLds fz_wave_lds(uint8_t *base, uint32_t wave, uint32_t win_dwords, uint32_t band_w,
-                                                 bool with_queue) {
-    uint8_t *p = base + (size_t)wave * fz_wave_lds_bytes(win_dwords, band_w, with_queue);
+                                                 uint32_t vlanes, bool with_queue) {
+    uint8_t *p = base + (size_t)wave * fz_wave_lds_bytes(win_dwords, band_w, vlanes, with_queue);
     FzWaveLds w;
     w.queue = nullptr;
     if (with_queue) { w.queue = reinterpret_cast<uint32_t *>(p); p += FZ_QCAP * 4; }
-    w.win = reinterpret_cast<uint32_t *>(p); p += win_dwords * 64 * 4;
+    w.win = reinterpret_cast<uint32_t *>(p); p += win_dwords * vlanes * 4;
     w.scores = reinterpret_cast<uint16_t *>(p);
     return w;
 }
@@ -91,15 +92,17 @@ __device__ __forceinline__ FzWaveLds fz_wave_lds(uint8_t *base, uint32_t wave, u
 // LDS-resident accessors used by fz_verify_* on the GPU.
 struct FzLdsScores {
     uint16_t *base;                                        // already offset by the lane
-    __device__ __forceinline__ uint32_t get(uint32_t slot) const { return base[slot * 64u]; }
-    __device__ __forceinline__ void set(uint32_t slot, uint32_t v) { base[slot * 64u] = (uint16_t)v; }
+    uint32_t stride;                                       // = vlanes
+    __device__ __forceinline__ uint32_t get(uint32_t slot) const { return base[slot * stride]; }
+    __device__ __forceinline__ void set(uint32_t slot, uint32_t v) { base[slot * stride] = (uint16_t)v; }
 };
 struct FzLdsWindow {
     const uint8_t *base;                                   // lane's dword 0, as bytes
     uint64_t wbase;                                        // global index of byte 0 of the window
+    uint32_t stride4;                                      // = vlanes * 4: bytes between a lane's consecutive dwords
     __device__ __forceinline__ uint8_t at(uint64_t gidx) const {
         const uint32_t off = (uint32_t)(gidx - wbase);
-        return base[(off >> 2) * 256u + (off & 3u)];       // dword (off/4) of this lane is 64 dwords further on
+        return base[(off >> 2) * stride4 + (off & 3u)];
     }
 };
 
@@ -146,11 +149,11 @@ __device__ __forceinline__ uint32_t fz_wave_verify(const uint8_t *__restrict__ b
     const uint32_t nd = valid ? (uint32_t)((whi - wbase + 3) >> 2) : 0u;
     const int64_t lbase = (int64_t)(wbase - a.geom.buf_off);
     for (uint32_t d = 0; d < a.win_dwords; ++d)
-        if (d < nd) w.win[d * 64u + lane] = *reinterpret_cast<const uint32_t *>(buf + lbase + (int64_t)d * 4);
+        if (d < nd) w.win[d * a.vlanes + lane] = *reinterpret_cast<const uint32_t *>(buf + lbase + (int64_t)d * 4);
     fz_wave_lds_sync();
     FzRec rec;
     bool ok = false;
-    FzLdsWindow t{reinterpret_cast<const uint8_t *>(w.win + lane), wbase};
+    FzLdsWindow t{reinterpret_cast<const uint8_t *>(w.win + lane), wbase, a.vlanes * 4u};
     if (valid) {
         const uint8_t *ng = pat_lds + s;
         for (uint32_t b = 0; b < a.L; ++b)
@@ -159,7 +162,7 @@ __device__ __forceinline__ uint32_t fz_wave_verify(const uint8_t *__restrict__ b
     const uint32_t confirmed = (uint32_t)__popcll(__ballot(valid));
     if (valid) {
         if (a.mode == FZ_MODE_LEV) {
-            FzLdsScores sc{w.scores + lane};
+            FzLdsScores sc{w.scores + lane, a.vlanes};
             ok = fz_verify_lev(sc, t, a.geom.n, pat_lds, a.m, a.k, a.L, s, idx, rec);
         } else {
             ok = fz_verify_subs(t, pat_lds, a.m, a.k, a.L, s, idx, rec);
@@ -205,9 +208,10 @@ __device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ b
     const uint32_t lane = fz_lane();
     uint32_t confirmed = 0;
     fz_wave_lds_sync();
-    for (uint32_t e0 = 0; e0 < qn; e0 += 64u) {
+    const uint32_t width = FUSED ? a.vlanes : 64u;          // candidates handled per pass
+    for (uint32_t e0 = 0; e0 < qn; e0 += width) {
         const uint32_t e = e0 + lane;
-        bool valid = e < qn;
+        bool valid = lane < width && e < qn;
         uint64_t hit = 0;
         uint64_t local = 0;
         uint32_t blk = 0;
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) void fz_scan_kernel(
     for (uint32_t i = threadIdx.x; i < a.m; i += FZ_FILTER_THREADS) pat_lds[i] = a.pat[i];
     __syncthreads();
     const FzWaveLds w = fz_wave_lds(smem + mpad, threadIdx.x >> 6, FUSED ? a.win_dwords : 0u,
-                                    FUSED ? a.band_w : 0u, true);
+                                    FUSED ? a.band_w : 0u, a.vlanes, true);
     uint32_t H[TG];
 #pragma unroll
     for (int g = 0; g < TG; ++g) H[g] = a.H[g];
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) void fz_scan_kernel(
                             for (int g = 0; g < TG; ++g) am[i] = min(am[i], hv[i] ^ H[g]);  // v_xor + v_min3
                         }
                         const uint32_t acc = min(min(am[0], am[1]), min(am[2], am[3]));
-                        if (__ballot(acc == 0)) {     // wave-uniform, rare: some lane, some offset, some block
+                        if (__builtin_expect(__ballot(acc == 0) != 0, 0)) {   // wave-uniform, rare: some lane, some offset, some block
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
                                 if (__ballot(am[i] == 0)) {           // which offset (scalar branch)
@@ -361,14 +365,14 @@ __global__ void fz_verify_kernel(const uint8_t *__restrict__ buf, const FzScanAr
     uint8_t *pat_lds = smem;
     for (uint32_t i = threadIdx.x; i < a.m; i += blockDim.x) pat_lds[i] = a.pat[i];
     __syncthreads();
-    const FzWaveLds w = fz_wave_lds(smem + mpad, threadIdx.x >> 6, a.win_dwords, a.band_w, false);
+    const FzWaveLds w = fz_wave_lds(smem + mpad, threadIdx.x >> 6, a.win_dwords, a.band_w, a.vlanes, false);
     unsigned long long nh = counters[0];
     if (nh > a.hit_cap) nh = a.hit_cap;
     const uint64_t waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    for (uint64_t q0 = wave * 64u; q0 < nh; q0 += waves * 64u) {
+    for (uint64_t q0 = wave * a.vlanes; q0 < nh; q0 += waves * a.vlanes) {
         const uint64_t q = q0 + fz_lane();
-        const bool valid = q < nh;
+        const bool valid = fz_lane() < a.vlanes && q < nh;
         const uint64_t hit = valid ? hits[q] : 0;
         fz_wave_verify(buf, a, pat_lds, w, hit, valid, recs, counters);
     }

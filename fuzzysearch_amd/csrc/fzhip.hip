@@ -175,7 +175,7 @@ struct Search {
     BlockPlan plan;
 };
 
-constexpr uint32_t kFusedLdsBudget = 64 * 1024;   // dynamic LDS per scan workgroup when verification is fused
+static const uint32_t kFusedLdsBudget = []() { const char *e = getenv("FZ_FUSED_LDS_KB"); int v = e ? atoi(e) : 0; return (uint32_t)(v > 0 ? v : 64) * 1024u; }();   // dynamic LDS per scan workgroup when verification is fused
 
 // Enqueue scan (+ separate verify when it cannot be fused) for one shard on its device stream.
 // No host synchronisation.
@@ -220,9 +220,16 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     fa.rec_cap = d.rec_cap;
     memcpy(fa.pat, q.p, q.m);
     const uint32_t mpad = (q.m + 15u) & ~15u;
-    const uint32_t fused_lds = mpad + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, true);
+    // Lanes that verify at once: all 64 while the staged windows stay small; fewer for long patterns
+    // so that the scan keeps ~8 workgroups per CU resident (measured at m = 64, k = 5 on 1 GiB of text:
+    // 64 lanes -> 31.6 KB LDS, 5 workgroups/CU, scan 0.540 ms; candidates are rare there anyway).
+    static const uint32_t target = []() { const char *e = getenv("FZ_FUSED_TARGET_KB"); int v = e ? atoi(e) : 0; return (uint32_t)(v > 0 ? v : 18) * 1024u; }();
+    fa.vlanes = 64;
+    while (fa.vlanes > 16 && mpad + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, fa.vlanes, true) > target)
+        fa.vlanes >>= 1;
+    const uint32_t fused_lds = mpad + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, fa.vlanes, true);
     fa.fused = (with_verify && fused_lds <= kFusedLdsBudget) ? 1u : 0u;
-    const uint32_t scan_lds = fa.fused ? fused_lds : mpad + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(0, 0, true);
+    const uint32_t scan_lds = fa.fused ? fused_lds : mpad + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(0, 0, 64, true);
 
     uint32_t launches = 0;
     for (uint32_t g0 = 0; g0 < G && ntiles > 0; g0 += FZ_MAX_BLOCKS_PER_LAUNCH) {
@@ -241,7 +248,8 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
             fa.s[b] = q.plan.s[src];
         }
         ScanKernel kern = scan_kernel(tg, nwin, dh, fa.fused != 0);
-        hipLaunchKernelGGL(kern, grid, dim3(FZ_FILTER_THREADS), scan_lds, d.stream, sh.d_buf, fa, ntiles, d.d_hits, recs,
+        static const uint32_t extra_lds = []() { const char *e = getenv("FZ_EXTRA_LDS_KB"); return e ? (uint32_t)atoi(e) * 1024u : 0u; }();
+        hipLaunchKernelGGL(kern, grid, dim3(FZ_FILTER_THREADS), scan_lds + extra_lds, d.stream, sh.d_buf, fa, ntiles, d.d_hits, recs,
                            counters);
         HIP_TRY(hipGetLastError());
         ++launches;
@@ -250,8 +258,9 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     if (with_verify && !fa.fused) {
         // LDS: pattern + per-wave window and score ring; shrink the block until it fits.
         unsigned waves = 4;
-        while (waves > 1 && mpad + waves * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, false) > 64 * 1024) waves >>= 1;
-        const size_t lds = mpad + (size_t)waves * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, false);
+        fa.vlanes = 64;
+        while (waves > 1 && mpad + waves * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, 64, false) > 64 * 1024) waves >>= 1;
+        const size_t lds = mpad + (size_t)waves * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, 64, false);
         if (lds > 160 * 1024) return fail(FZ_EUNSUPPORTED, "pattern/budget too large for the verify kernel (m=%u, k=%u)", q.m, q.k);
         if (lds > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fz_verify_kernel),
