@@ -152,10 +152,86 @@ FZ_HD bool fz_expand(Sc &sc, SubF sub, uint32_t sublen, WinF win, uint32_t winle
     return false;
 }
 
+// Register-resident variant of fz_expand for small budgets (K = the search's max_l_dist, <= FZ_REG_BAND_MAX):
+// the same DP table, evaluated row by row on the band |j - i| <= K with the 2K+1 cells of a row and
+// the 2K+1 window characters they are compared with held in statically indexed registers (the
+// loops over the band offset d are fully unrolled) — no LDS round trip per cell, which made the
+// ring version latency-bound (~300 cycles per cell).  Same result: the table does not depend on
+// the evaluation order, the band K >= budget contains every cell <= budget, the bottom row is
+// scanned in ascending j with '<=' (last arg-min) from the column-0 baseline, and a row whose
+// minimum exceeds the budget ends the search (row minima never decrease).
+#define FZ_REG_BAND_MAX 8
+template <int K, class SubF, class WinF>
+FZ_HD bool fz_expand_band(SubF sub, uint32_t sublen, WinF win, uint32_t winlen, uint32_t budget,
+                          uint32_t &dist, uint32_t &consumed) {
+    if (sublen == 0) { dist = 0; consumed = 0; return true; }
+    constexpr uint32_t INF = 0x3fffffffu;
+    constexpr int W = 2 * K + 1;
+    uint32_t cell[W];            // row i: cell[d + K] = D[i][i + d]
+    uint32_t chr[W];             // row i: chr[d + K] = win[i + d - 1], the character of column j = i + d
+#pragma unroll
+    for (int x = 0; x < W; ++x) {
+        const int d = x - K;
+        cell[x] = (d >= 0 && (uint32_t)d <= winlen) ? (uint32_t)d : INF;      // row 0: D[0][j] = j
+        chr[x] = (d >= 0 && (uint32_t)d < winlen) ? (uint32_t)win((uint32_t)d) : 0x100u;   // row 1 compares win[d]
+    }
+    for (uint32_t i = 1; i <= sublen; ++i) {
+        const uint32_t pc = sub(i - 1);
+        uint32_t left = INF, rowmin = INF;
+#pragma unroll
+        for (int x = 0; x < W; ++x) {
+            const int d = x - K;
+            const int64_t j = (int64_t)i + d;
+            const uint32_t diag = cell[x];
+            const uint32_t up = (x + 1 < W) ? cell[x + 1] : INF;
+            uint32_t v = diag + (chr[x] != pc ? 1u : 0u);
+            if (up + 1 < v) v = up + 1;
+            if (left + 1 < v) v = left + 1;
+            if (j == 0) v = i;                                               // column 0: D[i][0] = i
+            if (j < 0 || j > (int64_t)winlen) v = INF;
+            cell[x] = v;
+            left = v;
+            if (v < rowmin) rowmin = v;
+        }
+        if (rowmin > budget) return false;
+#pragma unroll
+        for (int x = 0; x + 1 < W; ++x) chr[x] = chr[x + 1];
+        const uint32_t nj = i + K;                                           // next row's rightmost column - 1
+        chr[W - 1] = nj < winlen ? (uint32_t)win(nj) : 0x100u;
+    }
+    uint32_t best = sublen, arg = 0;                                         // column-0 baseline (pyx:33-34)
+#pragma unroll
+    for (int x = 0; x < W; ++x) {
+        const int64_t j = (int64_t)sublen + (x - K);
+        if (j >= 1 && j <= (int64_t)winlen && cell[x] <= best) { best = cell[x]; arg = (uint32_t)j; }
+    }
+    if (best <= budget) { dist = best; consumed = arg; return true; }
+    return false;
+}
+
+// Budget-dispatched expansion: register band for k <= MAXK (<= FZ_REG_BAND_MAX), LDS ring otherwise.
+// MAXK is a compile-time cap so that a kernel only pays (in VGPRs) for the band widths it may run:
+// the fused scan kernel uses 4 (keeps it at <= 64 VGPRs), the stand-alone verify kernel 8.
+template <int MAXK, class Sc, class SubF, class WinF>
+FZ_HD bool fz_expand_any(Sc &sc, uint32_t k, SubF sub, uint32_t sublen, WinF win, uint32_t winlen, uint32_t budget,
+                         uint32_t &dist, uint32_t &consumed) {
+    if (k == 1) return fz_expand_band<1>(sub, sublen, win, winlen, budget, dist, consumed);
+    if (k == 2) return fz_expand_band<2>(sub, sublen, win, winlen, budget, dist, consumed);
+    if (k == 3) return fz_expand_band<3>(sub, sublen, win, winlen, budget, dist, consumed);
+    if (k == 4) return fz_expand_band<4>(sub, sublen, win, winlen, budget, dist, consumed);
+    if constexpr (MAXK >= 8) {
+        if (k == 5) return fz_expand_band<5>(sub, sublen, win, winlen, budget, dist, consumed);
+        if (k == 6) return fz_expand_band<6>(sub, sublen, win, winlen, budget, dist, consumed);
+        if (k == 7) return fz_expand_band<7>(sub, sublen, win, winlen, budget, dist, consumed);
+        if (k == 8) return fz_expand_band<8>(sub, sublen, win, winlen, budget, dist, consumed);
+    }
+    return fz_expand(sc, sub, sublen, win, winlen, budget, dist, consumed);
+}
+
 // levenshtein_ngram.py:177-198 for one hit (block starting at s in the pattern, hit at idx).
 // `t.at(g)` returns the sequence byte at GLOBAL index g; only indices inside
 // [max(0, idx-s-k), min(n, idx-s+m+k)) are ever requested.
-template <class Sc, class Seq>
+template <int MAXK, class Sc, class Seq>
 FZ_HD bool fz_verify_lev(Sc &sc, const Seq &t, uint64_t n, const uint8_t *p, uint32_t m,
                          uint32_t k, uint32_t L, uint32_t s, uint64_t idx, FzRec &rec) {
     // right: p[s+L:] vs t[idx+L : min(n, idx-s+m+k)]      (idx >= s-k guarantees idx-s+m+k >= 0)
@@ -169,7 +245,7 @@ FZ_HD bool fz_verify_lev(Sc &sc, const Seq &t, uint64_t n, const uint8_t *p, uin
         const uint8_t *ps = p + s + L;
         auto sub = [&](uint32_t i) -> uint8_t { return ps[i]; };
         auto win = [&](uint32_t j) -> uint8_t { return t.at(rbeg + j); };
-        if (!fz_expand(sc, sub, rlen, win, (uint32_t)(rend - rbeg), k, dR, r)) return false;
+        if (!fz_expand_any<MAXK>(sc, k, sub, rlen, win, (uint32_t)(rend - rbeg), k, dR, r)) return false;
     }
     // left: reversed p[:s] vs reversed t[max(0, idx-s-(k-dR)) : idx], budget k - dR
     const uint32_t bl = k - dR;
@@ -179,7 +255,7 @@ FZ_HD bool fz_verify_lev(Sc &sc, const Seq &t, uint64_t n, const uint8_t *p, uin
     {
         auto sub = [&](uint32_t i) -> uint8_t { return p[s - 1 - i]; };
         auto win = [&](uint32_t j) -> uint8_t { return t.at(idx - 1 - j); };
-        if (!fz_expand(sc, sub, s, win, (uint32_t)(idx - lbeg), bl, dL, l)) return false;
+        if (!fz_expand_any<MAXK>(sc, k, sub, s, win, (uint32_t)(idx - lbeg), bl, dL, l)) return false;
     }
     rec.l = l; rec.r = r; rec.dist = dL + dR; rec.aux = 0;
     return true;

@@ -126,6 +126,7 @@ __device__ __forceinline__ bool fz_in_range(const FzScanArgs &a, uint32_t blk, u
 //     per-hit logic (fz_verify_lev / fz_verify_subs) out of LDS,
 //  3. the wave appends its records with ONE global atomic.
 // Returns the number of exactly-confirmed n-gram hits (wave-uniform, statistics).
+template <int MAXK>
 __device__ __forceinline__ uint32_t fz_wave_verify(const uint8_t *__restrict__ buf, const FzScanArgs &a,
                                                    const uint8_t *pat_lds, const FzWaveLds &w,
                                                    uint64_t hit, bool valid,
@@ -163,7 +164,7 @@ __device__ __forceinline__ uint32_t fz_wave_verify(const uint8_t *__restrict__ b
     if (valid) {
         if (a.mode == FZ_MODE_LEV) {
             FzLdsScores sc{w.scores + lane, a.vlanes};
-            ok = fz_verify_lev(sc, t, a.geom.n, pat_lds, a.m, a.k, a.L, s, idx, rec);
+            ok = fz_verify_lev<MAXK>(sc, t, a.geom.n, pat_lds, a.m, a.k, a.L, s, idx, rec);
         } else {
             ok = fz_verify_subs(t, pat_lds, a.m, a.k, a.L, s, idx, rec);
         }
@@ -225,7 +226,7 @@ __device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ b
             hit = fz_hit_pack(a.g0 + blk, idx);
         }
         if (FUSED) {
-            confirmed += fz_wave_verify(buf, a, pat_lds, w, hit, valid, recs, counters);
+            confirmed += fz_wave_verify<4>(buf, a, pat_lds, w, hit, valid, recs, counters);
         } else {
             if (valid) valid = fz_confirm(buf, a, blk, local);
             const unsigned long long mask = __ballot(valid);
@@ -374,7 +375,7 @@ __global__ void fz_verify_kernel(const uint8_t *__restrict__ buf, const FzScanAr
         const uint64_t q = q0 + fz_lane();
         const bool valid = fz_lane() < a.vlanes && q < nh;
         const uint64_t hit = valid ? hits[q] : 0;
-        fz_wave_verify(buf, a, pat_lds, w, hit, valid, recs, counters);
+        fz_wave_verify<FZ_REG_BAND_MAX>(buf, a, pat_lds, w, hit, valid, recs, counters);
     }
 }
 

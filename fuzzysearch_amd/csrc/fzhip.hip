@@ -228,7 +228,8 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     while (fa.vlanes > 16 && mpad + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, fa.vlanes, true) > target)
         fa.vlanes >>= 1;
     const uint32_t fused_lds = mpad + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, fa.vlanes, true);
-    fa.fused = (with_verify && fused_lds <= kFusedLdsBudget) ? 1u : 0u;
+    // k > 4 (register band too wide for the scan kernel's VGPR budget) -> verify in fz_verify_kernel
+    fa.fused = (with_verify && fused_lds <= kFusedLdsBudget && (q.mode != FZ_MODE_LEV || q.k <= 4)) ? 1u : 0u;
     const uint32_t scan_lds = fa.fused ? fused_lds : mpad + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(0, 0, 64, true);
 
     uint32_t launches = 0;
@@ -266,7 +267,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fz_verify_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         fa.nblk = 0;
-        hipLaunchKernelGGL(fz_verify_kernel, dim3(2048), dim3(64 * waves), lds, d.stream, sh.d_buf, fa, d.d_hits, recs,
+        hipLaunchKernelGGL(fz_verify_kernel, dim3(d.n_cus * 4), dim3(64 * waves), lds, d.stream, sh.d_buf, fa, d.d_hits, recs,
                            counters);
         HIP_TRY(hipGetLastError());
     }

@@ -51,7 +51,7 @@ int64_t emul_search(int mode, const uint8_t *p, uint32_t m, const uint8_t *t, ui
             if ((uint64_t)idx < own_lo || (uint64_t)idx >= own_hi) continue;
             if (memcmp(t + idx, p + s, L) != 0) continue;
             FzRec rec;
-            bool ok = mode == 1 ? fz_verify_lev(sc, view, n, p, m, k, L, s, (uint64_t)idx, rec)
+            bool ok = mode == 1 ? fz_verify_lev<FZ_REG_BAND_MAX>(sc, view, n, p, m, k, L, s, (uint64_t)idx, rec)
                                 : fz_verify_subs(view, p, m, k, L, s, (uint64_t)idx, rec);
             if (!ok) continue;
             if (cnt < cap) {
@@ -103,6 +103,16 @@ int emul_expand(const uint8_t *sub, uint32_t sublen, const uint8_t *win, uint32_
     auto s = [&](uint32_t i) -> uint8_t { return sub[i]; };
     auto w = [&](uint32_t j) -> uint8_t { return win[j]; };
     return fz_expand(sc, s, sublen, w, winlen, budget, *dist, *consumed) ? 1 : 0;
+}
+
+// register-band variant: band K (the search's k) may exceed the budget of this call
+int emul_expand_band(int K, const uint8_t *sub, uint32_t sublen, const uint8_t *win, uint32_t winlen, uint32_t budget,
+                     uint32_t *dist, uint32_t *consumed) {
+    HostScores sc;
+    sc.v.assign(2 * (K > (int)budget ? K : budget) + 4, 0);
+    auto s = [&](uint32_t i) -> uint8_t { return sub[i]; };
+    auto w = [&](uint32_t j) -> uint8_t { return win[j]; };
+    return fz_expand_any<FZ_REG_BAND_MAX>(sc, (uint32_t)K, s, sublen, w, winlen, budget, *dist, *consumed) ? 1 : 0;
 }
 
 }  // extern "C"
