@@ -73,6 +73,10 @@ struct DevState {
     uint8_t *d_out = nullptr;                    // [header 64 B][recs]
     uint64_t rec_cap = 0;
     uint8_t *h_stage = nullptr;                  // pinned, kHeaderBytes + kFirstCopyRecs * sizeof(FzRec)
+    // one recycled sequence allocation (chunked file reads upload / release 1 MiB buffers in a loop;
+    // hipMalloc + hipFree per chunk would dominate)
+    uint8_t *spare_alloc = nullptr;
+    uint64_t spare_bytes = 0;
     uint64_t first_copy = 512;                   // records fetched with the header (tracks the last count)
     bool header_zeroed = false;                  // the counters were already zeroed after the last D2H copy
     int n_cus = 256;
@@ -533,6 +537,10 @@ int fz_create(const int *device_ids, int n_devices, fz_ctx **out) {
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)
         return fail(FZ_EDEVICE, "no HIP device available (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    // a search call is ~0.3 ms: spin instead of sleeping on the completion interrupt (ignored if the
+    // runtime was already initialised with other flags, e.g. by torch in a distributed job)
+    if (!getenv("FZ_NO_SPIN")) (void)hipSetDeviceFlags(hipDeviceScheduleSpin);
+    (void)hipGetLastError();
     std::vector<int> ids;
     if (!device_ids || n_devices <= 0) ids.push_back(0);
     else ids.assign(device_ids, device_ids + n_devices);
@@ -574,6 +582,7 @@ void fz_destroy(fz_ctx *ctx) {
         if (d.stream) (void)hipStreamSynchronize(d.stream);
         if (d.d_hits) (void)hipFree(d.d_hits);
         if (d.d_out) (void)hipFree(d.d_out);
+        if (d.spare_alloc) (void)hipFree(d.spare_alloc);
         if (d.h_stage) (void)hipHostFree(d.h_stage);
         for (auto &ev : d.ev) if (ev) (void)hipEventDestroy(ev);
         if (d.stream) (void)hipStreamDestroy(d.stream);
@@ -589,7 +598,14 @@ static int upload_one(fz_ctx *ctx, int dev_index, const uint8_t *host_buf, const
     sh.dev = dev_index;
     sh.alloc_bytes = FZ_PAD_FRONT + body + FZ_PAD_BACK;
     sh.geom = geom;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sh.d_alloc), sh.alloc_bytes));
+    if (d.spare_alloc && d.spare_bytes >= sh.alloc_bytes && d.spare_bytes <= 4 * sh.alloc_bytes + (1u << 20)) {
+        sh.d_alloc = d.spare_alloc;               // recycle (the stream orders the reuse)
+        sh.alloc_bytes = d.spare_bytes;
+        d.spare_alloc = nullptr;
+        d.spare_bytes = 0;
+    } else {
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sh.d_alloc), sh.alloc_bytes));
+    }
     sh.d_buf = sh.d_alloc + FZ_PAD_FRONT;
     HIP_TRY(hipMemsetAsync(sh.d_alloc, 0, FZ_PAD_FRONT, d.stream));
     HIP_TRY(hipMemsetAsync(sh.d_buf + geom.buf_len, 0, sh.alloc_bytes - FZ_PAD_FRONT - geom.buf_len, d.stream));
@@ -669,8 +685,15 @@ void fz_seq_release(fz_seq *seq) {
     if (!seq) return;
     for (Shard &sh : seq->shards) {
         if (sh.d_alloc) {
-            (void)hipSetDevice(seq->ctx->devs[sh.dev].device);
-            (void)hipFree(sh.d_alloc);
+            DevState &d = seq->ctx->devs[sh.dev];
+            (void)hipSetDevice(d.device);
+            if (sh.alloc_bytes <= (64u << 20) && (!d.spare_alloc || d.spare_bytes < sh.alloc_bytes)) {
+                if (d.spare_alloc) (void)hipFree(d.spare_alloc);
+                d.spare_alloc = sh.d_alloc;       // keep small buffers for the next upload
+                d.spare_bytes = sh.alloc_bytes;
+            } else {
+                (void)hipFree(sh.d_alloc);
+            }
         }
     }
     delete seq;
