@@ -147,7 +147,7 @@ def main():
         # C-ABI's fz_match array; no per-record Python objects inside the timed region)
         raw = engine.lev_ngrams(handle, p, k, as_array=True)
         if use_dist:
-            return fzd.allgather_matches(raw)            # RCCL all_gather of counts + padded records
+            return fzd.allgather_matches(raw, as_array=True)   # ONE RCCL all_gather: counts + padded records
         return raw
 
     # setup self-check + clock settle (untimed): repeated searches must return the identical stream

@@ -87,42 +87,116 @@ def exchange_halos(shard, halo, group=None):
     return left, right
 
 
-_gather_cap = {}          # group -> agreed row capacity of the single-collective fast path
+MATCH_DTYPE = np.dtype([("start", "<i8"), ("end", "<i8"), ("dist", "<i4"), ("block", "<i4")])   # = fz_match
+
+_gather_state = {}        # group -> dict(cap, host staging tensors, device tensors)
 
 
-def allgather_matches(raw, group=None):
-    """raw: this rank's stream, rows (start, end, dist, block) in global coordinates (list of tuples
-    or structured/2-D numpy array).  -> (M_total, 4) int64 array in the reference's global order, on
-    every rank.
+def _as_match_array(raw):
+    if isinstance(raw, np.ndarray) and raw.dtype == MATCH_DTYPE:
+        return np.ascontiguousarray(raw)
+    rows = np.asarray(raw, dtype=np.int64).reshape(-1, 4)
+    out = np.empty(len(rows), dtype=MATCH_DTYPE)
+    out["start"], out["end"], out["dist"], out["block"] = rows[:, 0], rows[:, 1], rows[:, 2], rows[:, 3]
+    return out
+
+
+def merge_rank_arrays(parts, block_counts=None):
+    """parts[r] = rank r's fz_match array in reference order (block-major, index ascending within a
+    block), ranks owning ascending index ranges -> one array in the global reference order: for every
+    block, the ranks' segments of that block back to back (no sort: O(total) copies on int64 views).
+    block_counts[r][g] (optional) = number of rank r's records of block g."""
+    world = len(parts)
+    if block_counts is None:
+        nb = max([int(p["block"][-1]) + 1 for p in parts if len(p)] or [0])
+        block_counts = np.zeros((world, nb), dtype=np.int64)
+        for r, p in enumerate(parts):
+            if len(p):
+                block_counts[r, :] = np.bincount(p["block"], minlength=nb)[:nb]
+    block_counts = np.asarray(block_counts, dtype=np.int64)
+    total = int(block_counts.sum())
+    out = np.empty((total, 3), dtype=np.int64)
+    if total:
+        src_off = np.zeros_like(block_counts)
+        src_off[:, 1:] = np.cumsum(block_counts, axis=1)[:, :-1]        # segment start inside rank r's array
+        dst_off = np.cumsum(block_counts.T.reshape(-1)) - block_counts.T.reshape(-1)   # (g, r) order
+        views = [np.ascontiguousarray(p).view(np.int64).reshape(-1, 3) if len(p) else None for p in parts]
+        nb = block_counts.shape[1]
+        for g in range(nb):
+            for r in range(world):
+                c = int(block_counts[r, g])
+                if c:
+                    d0, s0 = int(dst_off[g * world + r]), int(src_off[r, g])
+                    out[d0:d0 + c] = views[r][s0:s0 + c]
+    return out.reshape(-1).view(MATCH_DTYPE)
+
+
+_HDR_ROWS = 1 + 86        # row 0: [count, nblocks, 0]; rows 1..86: per-block counts, three per row (<= 255 blocks)
+
+
+def allgather_matches(raw, group=None, as_array=False):
+    """raw: this rank's stream in global coordinates — the fz_match structured array of
+    Engine.lev_ngrams(..., as_array=True) or a list of (start, end, dist, block) tuples.
+    -> the merged stream in the reference's global order on every rank, as an (M, 4) int64 array
+    (or the fz_match structured array with as_array=True).
 
     ONE collective per call in the common case: every rank contributes a fixed-capacity block
-    [count, rows...]; the counts ride along, so no separate count exchange and a single device->host
-    copy.  If some rank's count exceeds the agreed capacity every rank sees it in the gathered
-    counts, the capacity is raised identically everywhere and the gather is repeated."""
+    [header: count, per-block counts | 24-byte fz_match records] (the counts ride along, so there is no
+    separate count exchange and the merge needs no sort), staged through persistent pinned host
+    buffers with a single stream synchronisation.  If some rank's count exceeds the agreed capacity
+    every rank sees it in the gathered headers, the capacity is raised identically everywhere and the
+    gather is repeated."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     dev = _device_for(group)
-    if isinstance(raw, np.ndarray) and raw.dtype.names:
-        rows = np.stack([raw[f].astype(np.int64) for f in ('start', 'end', 'dist', 'block')], axis=1) \
-            if len(raw) else np.empty((0, 4), np.int64)
-    else:
-        rows = np.asarray(raw, dtype=np.int64).reshape(-1, 4)
+    mine = _as_match_array(raw)
+    nb_mine = int(mine["block"][-1]) + 1 if len(mine) else 0
+    if nb_mine > 255:
+        raise ValueError("more than 255 n-gram blocks")
     key = id(group) if group is not None else 0
     while True:
-        cap = _gather_cap.get(key, 4096)
-        block = np.zeros((cap + 1, 4), dtype=np.int64)
-        block[0, 0] = len(rows)
-        fit = min(len(rows), cap)
-        block[1:1 + fit] = rows[:fit]
-        mine = torch.from_numpy(block).to(dev)
-        gathered = torch.empty((world,) + tuple(mine.shape), dtype=torch.int64, device=dev)
-        dist.all_gather(list(gathered.unbind(0)), mine, group=group)     # works on nccl and gloo
-        host = gathered.cpu().numpy()
+        st = _gather_state.get(key)
+        if st is None or st["world"] != world:
+            cap = st["cap"] if st else 4096
+            pin = dev.type == "cuda"
+            rows = _HDR_ROWS + cap
+            st = {"cap": cap, "world": world,
+                  "h_send": torch.zeros((rows, 3), dtype=torch.int64, pin_memory=pin),
+                  "h_recv": torch.zeros((world, rows, 3), dtype=torch.int64, pin_memory=pin)}
+            if pin:
+                st["d_send"] = torch.zeros((rows, 3), dtype=torch.int64, device=dev)
+                st["d_recv"] = torch.zeros((world, rows, 3), dtype=torch.int64, device=dev)
+            _gather_state[key] = st
+        cap = st["cap"]
+        send = st["h_send"].numpy()
+        send[0, 0], send[0, 1] = len(mine), nb_mine
+        hdr = send[1:_HDR_ROWS].reshape(-1)
+        hdr[:] = 0
+        if nb_mine:
+            hdr[:nb_mine] = np.bincount(mine["block"], minlength=nb_mine)
+        fit = min(len(mine), cap)
+        send[_HDR_ROWS:_HDR_ROWS + fit] = mine[:fit].view(np.int64).reshape(-1, 3)   # 24-byte records as 3 x int64
+        if dev.type == "cuda":
+            st["d_send"].copy_(st["h_send"], non_blocking=True)
+            dist.all_gather_into_tensor(st["d_recv"], st["d_send"], group=group)
+            st["h_recv"].copy_(st["d_recv"], non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        else:
+            dist.all_gather(list(st["h_recv"].unbind(0)), st["h_send"], group=group)
+        host = st["h_recv"].numpy()
         counts = host[:, 0, 0]
         if int(counts.max()) <= cap:
-            return merge_rank_streams([host[r, 1:1 + int(counts[r])] for r in range(world)])
+            nb = int(host[:, 0, 1].max())
+            block_counts = host[:, 1:_HDR_ROWS].reshape(world, -1)[:, :nb]
+            parts = [host[r, _HDR_ROWS:_HDR_ROWS + int(counts[r])].reshape(-1).view(MATCH_DTYPE) for r in range(world)]
+            merged = merge_rank_arrays(parts, block_counts)
+            if as_array:
+                return merged
+            out = np.empty((len(merged), 4), dtype=np.int64)
+            out[:, 0], out[:, 1], out[:, 2], out[:, 3] = merged["start"], merged["end"], merged["dist"], merged["block"]
+            return out
         new_cap = cap
         while new_cap < int(counts.max()):
             new_cap *= 2
-        _gather_cap[key] = new_cap
+        _gather_state[key] = {"cap": new_cap, "world": -1}               # rebuild buffers at the new capacity

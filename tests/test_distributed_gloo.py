@@ -51,3 +51,21 @@ def test_shard_bounds_and_merge():
     m = fzd.merge_rank_streams([a, c, []])
     assert [tuple(r) for r in m.tolist()] == [(5, 9, 0, 0), (105, 109, 0, 0), (40, 44, 1, 1), (101, 106, 2, 1), (130, 134, 1, 2)]
     assert fzd.merge_rank_streams([[], []]).shape == (0, 4)
+    # the sort-free merge of fz_match arrays gives the same order
+    import random
+    rnd = random.Random(3)
+    for _ in range(200):
+        world, nblocks = rnd.randint(1, 5), rnd.randint(1, 4)
+        parts, base = [], 0
+        for r in range(world):
+            rows = []
+            for g in range(nblocks):
+                for _i in range(rnd.randint(0, 4)):
+                    st = base + rnd.randint(0, 50)
+                    rows.append((st, st + rnd.randint(0, 9), rnd.randint(0, 3), g))
+            rows.sort(key=lambda x: x[3])
+            parts.append(rows)
+            base += 1000
+        exp = fzd.merge_rank_streams(parts)
+        got = fzd.merge_rank_arrays([fzd._as_match_array(p) for p in parts])
+        assert [tuple(x) for x in got.tolist()] == [tuple(x) for x in exp.tolist()]
