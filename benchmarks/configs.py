@@ -30,7 +30,7 @@ def utf8_text(n, seed):
     return base
 
 
-def timeit(fn, reps=30, warm=10):
+def timeit(fn, reps=100, warm=60):
     for _ in range(warm):
         fn()
     t0 = time.perf_counter()
@@ -48,7 +48,7 @@ cases = [
     ("cfg3a UTF-8 m=64 k=5 (levenshtein_ngram, wide band)", None,
      lambda h, p: eng.lev_ngrams(h, p, 5, as_array=True), lambda p, t: oracle.lev_ngrams_raw(p, t, 5)),
     ("cfg3b UTF-8 m=64 (5,2,2,5) (generic_search)", None,
-     lambda h, p: np.array(eng.generic_ngrams(h, p, 5, 2, 2, 5)), lambda p, t: oracle.generic_ngrams_raw(p, t, 5, 2, 2, 5)),
+     lambda h, p: eng.generic_ngrams(h, p, 5, 2, 2, 5, as_array=True), lambda p, t: oracle.generic_ngrams_raw(p, t, 5, 2, 2, 5)),
 ]
 for name, gen, run, orc in cases:
     if gen is not None:

@@ -304,8 +304,9 @@ class Engine(object):
     def subs_ngrams(self, seq, pattern, k, as_array=False):
         return self._match_call(self._lib.fz_subs_ngrams, seq, pattern, k, as_array=as_array)
 
-    def generic_ngrams(self, seq, pattern, max_subs, max_ins, max_dels, max_l):
-        return self._match_call(self._lib.fz_generic_ngrams, seq, pattern, max_subs, max_ins, max_dels, max_l)
+    def generic_ngrams(self, seq, pattern, max_subs, max_ins, max_dels, max_l, as_array=False):
+        return self._match_call(self._lib.fz_generic_ngrams, seq, pattern, max_subs, max_ins, max_dels, max_l,
+                                as_array=as_array)
 
     def lev_lp(self, seq, pattern, k):
         return self._match_call(self._lib.fz_lev_lp, seq, pattern, k)

@@ -496,6 +496,40 @@ void sort_recs(std::vector<FzRec> &recs) {
     if (src != recs.data()) memcpy(recs.data(), src, n * sizeof(FzRec));
 }
 
+// (key, seq) order of generic-search records: LSD radix, seq bytes first, then the varying key bytes.
+void sort_gen_recs(std::vector<FzGenRec> &recs) {
+    const size_t n = recs.size();
+    if (n < 2) return;
+    if (n < 64) {
+        std::sort(recs.begin(), recs.end(), [](const FzGenRec &a, const FzGenRec &b) {
+            return a.key != b.key ? a.key < b.key : a.seq < b.seq;
+        });
+        return;
+    }
+    uint64_t kdiff = 0;
+    uint32_t sdiff = 0;
+    for (size_t i = 1; i < n; ++i) { kdiff |= recs[i].key ^ recs[0].key; sdiff |= recs[i].seq ^ recs[0].seq; }
+    std::vector<FzGenRec> tmp(n);
+    FzGenRec *src = recs.data(), *dst = tmp.data();
+    for (int pass = 0; pass < 12; ++pass) {
+        const bool on_seq = pass < 4;
+        const int byte = on_seq ? pass : pass - 4;
+        if (on_seq ? ((sdiff >> (8 * byte)) & 0xff) == 0 : ((kdiff >> (8 * byte)) & 0xff) == 0) continue;
+        size_t count[257] = {0};
+        for (size_t i = 0; i < n; ++i) {
+            const unsigned b = on_seq ? (src[i].seq >> (8 * byte)) & 0xff : (unsigned)((src[i].key >> (8 * byte)) & 0xff);
+            ++count[b + 1];
+        }
+        for (int b = 0; b < 256; ++b) count[b + 1] += count[b];
+        for (size_t i = 0; i < n; ++i) {
+            const unsigned b = on_seq ? (src[i].seq >> (8 * byte)) & 0xff : (unsigned)((src[i].key >> (8 * byte)) & 0xff);
+            dst[count[b]++] = src[i];
+        }
+        std::swap(src, dst);
+    }
+    if (src != recs.data()) memcpy(recs.data(), src, n * sizeof(FzGenRec));
+}
+
 int emit_matches(const std::vector<FzRec> &recs, uint32_t L, fz_match **out, uint64_t *n) {
     void *mem = nullptr;
     int rc = alloc_out(recs.size(), sizeof(fz_match), &mem);
@@ -823,9 +857,7 @@ int fz_generic_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, ui
     rc = run_generic(ctx, seq, q, recs);
     if (rc) return rc;
     // reference order: hits in (block, idx) order, each hit's matches in automaton emission order
-    std::sort(recs.begin(), recs.end(), [](const FzGenRec &a, const FzGenRec &b) {
-        return a.key != b.key ? a.key < b.key : a.seq < b.seq;
-    });
+    sort_gen_recs(recs);
     void *mem = nullptr;
     rc = alloc_out(recs.size(), sizeof(fz_match), &mem);
     if (rc) return rc;
