@@ -287,7 +287,10 @@ class Engine(object):
         return out
 
     def _match_call(self, fn, seq, pattern, *ints, **kw):
-        paddr, m, keep = _buffer_address(pattern)
+        if type(pattern) is bytes:                 # ctypes passes a bytes object as a pointer to its buffer
+            paddr, m, keep = pattern, len(pattern), None
+        else:
+            paddr, m, keep = _buffer_address(pattern)
         ptr = ctypes.POINTER(FzMatch)()
         cnt = ctypes.c_uint64(0)
         _check(fn(self._h, seq._h, paddr, m, *ints, ctypes.byref(ptr), ctypes.byref(cnt)))

@@ -13,7 +13,11 @@
 //                 (_substitutions_only_ngrams_template.h:103-121) runs on a ring of 2k+2 LDS score
 //                 slots per lane.  Only match records leave the chip.
 //   fz_verify_kernel  the same wave-level verification over a hit list in HBM, for parameter
-//                 ranges whose LDS footprint does not fit beside the filter (large m or k).
+//                 ranges that do not fit beside the filter (k > 4, or large m + 2k).
+//   fz_lp_kernel      one wave per work item: the reference's greedy candidate-set automata
+//                 (generic search per n-gram hit; generic / Levenshtein linear-programming fallbacks
+//                 tiled over the whole sequence), candidate lists in LDS, order preserved.
+//   fz_hamming_kernel every window's Hamming distance (substitutions-only LP fallback).
 //
 // HBM-bound integer/byte work: no MFMA.  What matters (MI355X guide): 16-byte coalesced loads,
 // >= 2048 workgroups' worth of loads in flight, no per-byte branching, SGPR-resident n-gram

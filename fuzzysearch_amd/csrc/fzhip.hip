@@ -2,13 +2,20 @@
 //
 // Data layout in HBM (per device shard):
 //   [FZ_PAD_FRONT zero bytes][buf_len sequence bytes][zero bytes up to a whole tile + FZ_PAD_BACK]
-// so the filter can read whole 16 KiB tiles and 8-byte halos without bounds checks; zero padding
-// can never create an accepted hit because every hit is range-checked against the global length.
-//   hits   : uint64 (block << 56 | global idx), appended through one device counter
-//   recs   : FzRec (24 B), appended through a second counter; header + records share one
-//            allocation so the usual result comes back in ONE D2H copy
-// The raw stream is put in the reference's emission order on the host by sorting records on
-// (block, idx) — the number of records is tiny next to the bytes scanned.
+// so the scan can read whole 16 KiB tiles and 8-byte halos without bounds checks; zero padding can
+// never create an accepted hit because every candidate is range-checked against the global length.
+//   d_out  : [1 KiB header: counters][records, 24 B each] in one allocation, so the usual result
+//            comes back in ONE D2H copy (header + about as many records as the previous call had)
+//              counters[0]      hits emitted to d_hits (non-fused paths)
+//              counters[1]      records written
+//              counters[2]      automaton work items whose candidate lists overflowed
+//              counters[8..71]  confirmed n-gram hits of the fused scan (64 words: one word only
+//                               sustains ~90 atomics/us)
+//   d_hits : uint64 (block << 56 | global idx) hit list — only the non-fused paths use it
+// The GPU produces records unordered; the host puts them in the reference's emission order by a radix
+// sort on (block, idx) — the number of records is tiny next to the bytes scanned.
+// Every search is synchronous: when a fz_* call returns its results are on the host and nothing is
+// in flight on the sequence.  Buffers that turn out too small are grown and the search re-runs.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -70,7 +77,7 @@ struct DevState {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     uint64_t *d_hits = nullptr;
     uint64_t hit_cap = 0;
-    uint8_t *d_out = nullptr;                    // [header 64 B][recs]
+    uint8_t *d_out = nullptr;                    // [header kHeaderBytes][recs]
     uint64_t rec_cap = 0;
     uint8_t *h_stage = nullptr;                  // pinned, kHeaderBytes + kFirstCopyRecs * sizeof(FzRec)
     // one recycled sequence allocation (chunked file reads upload / release 1 MiB buffers in a loop;
