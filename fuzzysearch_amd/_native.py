@@ -221,7 +221,8 @@ class ResidentSequence(object):
 
     def release(self):
         if self._h is not None and self.engine._h is not None:
-            self.engine._lib.fz_seq_release(self._h)
+            with self.engine._lock:
+                self.engine._lib.fz_seq_release(self._h)
         self._h = None
 
     def __del__(self):
@@ -246,6 +247,8 @@ class Engine(object):
         _check(rc)
         self._h = h
         self.devices = list(devices) if devices else [0]
+        # a fz_ctx is not internally locked and ctypes drops the GIL during calls: serialise per engine
+        self._lock = threading.Lock()
 
     def close(self):
         if self._h is not None:
@@ -262,15 +265,17 @@ class Engine(object):
     def upload(self, data):
         addr, n, keep = _buffer_address(data)
         h = ctypes.c_void_p()
-        _check(self._lib.fz_seq_upload(self._h, addr, n, ctypes.byref(h)))
+        with self._lock:
+            _check(self._lib.fz_seq_upload(self._h, addr, n, ctypes.byref(h)))
         del keep
         return ResidentSequence(self, h, n)
 
     def upload_shard(self, data, buf_global_off, own_lo, own_hi, global_n):
         addr, n, keep = _buffer_address(data)
         h = ctypes.c_void_p()
-        _check(self._lib.fz_seq_upload_shard(self._h, addr, n, buf_global_off, own_lo, own_hi,
-                                              global_n, ctypes.byref(h)))
+        with self._lock:
+            _check(self._lib.fz_seq_upload_shard(self._h, addr, n, buf_global_off, own_lo, own_hi,
+                                                  global_n, ctypes.byref(h)))
         del keep
         return ResidentSequence(self, h, global_n)
 
@@ -279,9 +284,10 @@ class Engine(object):
         paddr, m, keep = _buffer_address(pattern)
         ptr = ctypes.POINTER(ctypes.c_uint64)()
         cnt = ctypes.c_uint64(0)
-        _check(self._lib.fz_search_exact(self._h, seq._h, paddr, m, max(0, lo),
-                                         UINT64_MAX if hi is None else max(0, hi),
-                                         ctypes.byref(ptr), ctypes.byref(cnt)))
+        with self._lock:
+            _check(self._lib.fz_search_exact(self._h, seq._h, paddr, m, max(0, lo),
+                                             UINT64_MAX if hi is None else max(0, hi),
+                                             ctypes.byref(ptr), ctypes.byref(cnt)))
         out = list(ptr[:cnt.value])
         self._lib.fz_free(ptr)
         return out
@@ -293,7 +299,8 @@ class Engine(object):
             paddr, m, keep = _buffer_address(pattern)
         ptr = ctypes.POINTER(FzMatch)()
         cnt = ctypes.c_uint64(0)
-        _check(fn(self._h, seq._h, paddr, m, *ints, ctypes.byref(ptr), ctypes.byref(cnt)))
+        with self._lock:
+            _check(fn(self._h, seq._h, paddr, m, *ints, ctypes.byref(ptr), ctypes.byref(cnt)))
         if kw.get("as_array"):
             return _take_matches_array(self._lib, ptr, cnt.value)
         return _take_matches(self._lib, ptr, cnt.value)

@@ -341,3 +341,28 @@ def test_beyond_4gib_indices(engine):
     assert len(planted) >= 200 and len(got_tail) >= len(planted)
     keys = [(g, s) for (s, e, d, g) in got]
     assert keys == sorted(keys)                          # block-major, ascending: reference order
+
+
+def test_threads_share_the_default_engine(engine):
+    """ctypes drops the GIL during fz_* calls; the per-engine lock must keep a shared fz_ctx sane."""
+    import threading
+    import fuzzysearch_amd as fa
+    seq = workloads.dna(1 << 18, 77)
+    pats = [workloads.dna(20, 100 + i) for i in range(8)]
+    for p in pats:
+        workloads.plant_variants(seq, p, 16, int(p[0]) + 1)
+    t = seq.tobytes()
+    exp = [oracle.consolidate(oracle.lev_ngrams_raw(p.tobytes(), t, 2)) for p in pats]
+    res, errs = [None] * len(pats), []
+
+    def work(i):
+        try:
+            for _ in range(5):
+                res[i] = [(m.start, m.end, m.dist) for m in fa.find_near_matches(pats[i].tobytes(), t, max_l_dist=2)]
+        except Exception as e:          # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(pats))]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errs, errs
+    assert res == exp
