@@ -29,7 +29,7 @@ __global__ void gen_dna(uint8_t *buf, uint64_t n, uint64_t seed) {
 }
 
 struct Args {
-    uint32_t A[4], B[4], H[4];
+    uint32_t A[4], B[4], H[4], HP[4];
     uint32_t K;       // hash multiplier (24 bit)
     uint32_t d2;      // second window offset (exact variants)
     uint32_t dh;      // hash window offset
@@ -157,13 +157,18 @@ __global__ __launch_bounds__(THREADS) void k_v2(const uint8_t *__restrict__ buf,
 
 // ---- V3: hash, xor + min3 accumulate (no SALU), one ballot per 4 offsets --------------------
 __device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) { return min(a, min(b, c)); }
-template <int ROWS, int DH, int GROUP>
+template <int ROWS, int DH, int GROUP, int WRAPBITS = 63, bool HV = false, int NB = 3>
 __global__ __launch_bounds__(THREADS) void k_v3(const uint8_t *__restrict__ buf, Args a, uint64_t ntiles, unsigned long long *cnt) {
     uint32_t H[3] = {a.H[0], a.H[1], a.H[2]};
+    if (HV) {   // block hashes in VGPRs: v_xor with an SGPR operand issues at ~4.5 cycles, VGPR-only at ~2.6
+#pragma unroll
+        for (int g = 0; g < 3; ++g) asm volatile("v_mov_b32 %0, %1" : "=v"(H[g]) : "s"(a.H[g]));
+    }
     const uint32_t K = a.K;
     uint32_t qn = 0;
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint8_t *src = buf + tile * (uint64_t)(ROWB * ROWS) + threadIdx.x * 16u;
+        // WRAPBITS < 63: all tiles alias a small L2-resident region -> compute-only time
+        const uint8_t *src = buf + (tile & ((1ull << WRAPBITS) - 1)) * (uint64_t)(ROWB * ROWS) + threadIdx.x * 16u;
         uint4 v[ROWS]; uint2 h[ROWS];
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) { v[r] = *(const uint4 *)(src + r * ROWB); h[r] = *(const uint2 *)(src + r * ROWB + 16); }
@@ -179,15 +184,16 @@ __global__ __launch_bounds__(THREADS) void k_v3(const uint8_t *__restrict__ buf,
                     const int o = GROUP * j + i;
                     const uint32_t x = WIN(w, o), y = WIN(w, o + DH);
                     hv[i] = __umul24(y, K) + x;
-                    acc = min3u(acc, hv[i] ^ H[0], hv[i] ^ H[1]);
-                    acc = min(acc, hv[i] ^ H[2]);
+                    if (NB == 3) { acc = min3u(acc, hv[i] ^ H[0], hv[i] ^ H[1]); acc = min(acc, hv[i] ^ H[2]); }
+                    else if (NB == 2) acc = min3u(acc, hv[i] ^ H[0], hv[i] ^ H[1]);
+                    else acc = min(acc, hv[i] ^ H[0]);
                 }
                 const unsigned long long any = __ballot(acc == 0);
                 if (any) {
 #pragma unroll
                     for (int i = 0; i < GROUP; ++i)
 #pragma unroll
-                        for (int g = 0; g < 3; ++g) { const unsigned long long mm = __ballot(hv[i] == H[g]); if (mm) rare(mm, qn); }
+                        for (int g = 0; g < NB; ++g) { const unsigned long long mm = __ballot(hv[i] == H[g]); if (mm) rare(mm, qn); }
                 }
             }
         }
@@ -334,6 +340,159 @@ __global__ __launch_bounds__(THREADS) void k_v7(const uint8_t *__restrict__ buf,
     if ((threadIdx.x & 63) == 0 && qn) atomicAdd(cnt, (unsigned long long)qn);
 }
 
+// ---- V8: four byte-shifted (unaligned) dwordx4 loads per row instead of v_alignbyte: every 32-bit
+// window of the row is a loaded register (VOP3 ops such as v_alignbyte cost 2x a VOP2 op) ----------
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+struct __attribute__((packed, aligned(1))) U4 { uint32_t x, y, z, w; };
+template <int ROWS, int DH>
+__global__ __launch_bounds__(THREADS) void k_v8(const uint8_t *__restrict__ buf, Args a, uint64_t ntiles, unsigned long long *cnt) {
+    uint32_t H[3] = {a.H[0], a.H[1], a.H[2]};
+    const uint32_t K = a.K;
+    uint32_t qn = 0;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint8_t *src = buf + tile * (uint64_t)(ROWB * ROWS) + threadIdx.x * 16u;
+        U4 p[ROWS][4]; uint32_t e[ROWS][4];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                p[r][b] = *(const U4 *)(src + r * ROWB + b);
+                e[r][b] = *(const u32_unaligned *)(src + r * ROWB + 16 + b);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            // win(o) for o in 0..19
+            uint32_t wv[20];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { wv[b] = p[r][b].x; wv[4 + b] = p[r][b].y; wv[8 + b] = p[r][b].z; wv[12 + b] = p[r][b].w; wv[16 + b] = e[r][b]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t acc = 0xffffffffu;
+                uint32_t hv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int o = 4 * j + i;
+                    hv[i] = __umul24(wv[o + DH], K) + wv[o];
+                    acc = min3u(acc, hv[i] ^ H[0], hv[i] ^ H[1]);
+                    acc = min(acc, hv[i] ^ H[2]);
+                }
+                const unsigned long long any = __ballot(acc == 0);
+                if (any) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) { const unsigned long long mm = __ballot(hv[i] == H[g]); if (mm) rare(mm, qn); }
+                }
+            }
+        }
+    }
+    if ((threadIdx.x & 63) == 0 && qn) atomicAdd(cnt, (unsigned long long)qn);
+}
+
+// ---- V9: v3 + software pipelining: the next tile's rows are requested before this tile is processed ----
+template <int ROWS, int DH>
+__global__ __launch_bounds__(THREADS) void k_v9(const uint8_t *__restrict__ buf, Args a, uint64_t ntiles, unsigned long long *cnt) {
+    uint32_t H[3] = {a.H[0], a.H[1], a.H[2]};
+    const uint32_t K = a.K;
+    uint32_t qn = 0;
+    uint4 nv[ROWS]; uint2 nh[ROWS];
+    uint64_t tile = blockIdx.x;
+    if (tile < ntiles) {
+        const uint8_t *src = buf + tile * (uint64_t)(ROWB * ROWS) + threadIdx.x * 16u;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) { nv[r] = *(const uint4 *)(src + r * ROWB); nh[r] = *(const uint2 *)(src + r * ROWB + 16); }
+    }
+    for (; tile < ntiles; tile += gridDim.x) {
+        uint4 v[ROWS]; uint2 h[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) { v[r] = nv[r]; h[r] = nh[r]; }
+        const uint64_t nt = tile + gridDim.x;
+        if (nt < ntiles) {
+            const uint8_t *src = buf + nt * (uint64_t)(ROWB * ROWS) + threadIdx.x * 16u;
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) { nv[r] = *(const uint4 *)(src + r * ROWB); nh[r] = *(const uint2 *)(src + r * ROWB + 16); }
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const uint32_t w[6] = {v[r].x, v[r].y, v[r].z, v[r].w, h[r].x, h[r].y};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t acc = 0xffffffffu;
+                uint32_t hv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int o = 4 * j + i;
+                    hv[i] = __umul24(WIN(w, o + DH), K) + WIN(w, o);
+                    acc = min3u(acc, hv[i] ^ H[0], hv[i] ^ H[1]);
+                    acc = min(acc, hv[i] ^ H[2]);
+                }
+                const unsigned long long any = __ballot(acc == 0);
+                if (any) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) { const unsigned long long mm = __ballot(hv[i] == H[g]); if (mm) rare(mm, qn); }
+                }
+            }
+        }
+    }
+    if ((threadIdx.x & 63) == 0 && qn) atomicAdd(cnt, (unsigned long long)qn);
+}
+
+// ---- V10: 16-bit hashes of two adjacent offsets packed in one dword (v_perm / v_pk_mad_u16 /
+//      v_xor / v_pk_min_u16), block hashes in VGPRs, one ballot per GROUP offsets ----------------
+__device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) { uint32_t d; asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c)); return d; }
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t min_u16(uint32_t a, uint32_t b) { uint32_t d; asm("v_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+template <int ROWS, int GROUP, int WRAPBITS = 63>
+__global__ __launch_bounds__(THREADS) void k_v10(const uint8_t *__restrict__ buf, Args a, uint64_t ntiles, unsigned long long *cnt) {
+    uint32_t HP[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) asm volatile("v_mov_b32 %0, %1" : "=v"(HP[g]) : "s"(a.HP[g]));
+    const uint32_t K2 = (a.K & 0xffffu) * 0x10001u;
+    uint32_t qn = 0;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint8_t *src = buf + (tile & ((1ull << WRAPBITS) - 1)) * (uint64_t)(ROWB * ROWS) + threadIdx.x * 16u;
+        uint4 v[ROWS]; uint2 h[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) { v[r] = *(const uint4 *)(src + r * ROWB); h[r] = *(const uint2 *)(src + r * ROWB + 16); }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const uint32_t w[6] = {v[r].x, v[r].y, v[r].z, v[r].w, h[r].x, h[r].y};
+            uint32_t P[10];     // P[j] = 16-bit windows at byte offsets 2j and 2j+1
+#pragma unroll
+            for (int j = 0; j < 10; ++j)
+                P[j] = (j & 1) ? __builtin_amdgcn_perm(w[j / 2 + 1], w[j / 2], 0x04030302u)
+                               : __builtin_amdgcn_perm(w[j / 2], w[j / 2], 0x02010100u);
+            uint32_t hp[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hp[j] = pk_mad(P[j + 1], K2, P[j]) ^ P[j + 2];
+#pragma unroll
+            for (int q = 0; q < 16 / GROUP; ++q) {
+                uint32_t acc = 0xffffffffu;
+#pragma unroll
+                for (int j = q * GROUP / 2; j < (q + 1) * GROUP / 2; ++j)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) acc = pk_min(acc, hp[j] ^ HP[g]);
+                const uint32_t t = min_u16(acc >> 16, acc);
+                if (__ballot((t & 0xffffu) == 0)) {
+#pragma unroll
+                    for (int j = q * GROUP / 2; j < (q + 1) * GROUP / 2; ++j)
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) {
+                            const uint32_t x = hp[j] ^ HP[g];
+                            const unsigned long long m0 = __ballot((x & 0xffffu) == 0), m1 = __ballot((x >> 16) == 0);
+                            if (m0) rare(m0, qn);
+                            if (m1) rare(m1, qn);
+                        }
+                }
+            }
+        }
+    }
+    if ((threadIdx.x & 63) == 0 && qn) atomicAdd(cnt, (unsigned long long)qn);
+}
+
 // semantic probe of the (m)qsad instructions
 __global__ void k_probe(const uint64_t *s0, const uint32_t *s1, const uint64_t *s2, uint64_t *out_q, uint64_t *out_m) {
     const int i = threadIdx.x;
@@ -381,6 +540,8 @@ int main(int argc, char **argv) {
         a.A[g] = le32(pat + 6 * g);
         a.B[g] = le32(pat + 6 * g + 2);
         a.H[g] = (le32(pat + 6 * g + 3) & 0xffffffu) * a.K + a.A[g];
+        { const uint32_t p0 = le32(pat + 6 * g) & 0xffffu, p1 = le32(pat + 6 * g + 2) & 0xffffu, p2 = le32(pat + 6 * g + 4) & 0xffffu;
+          const uint32_t h16 = ((p0 + (a.K & 0xffffu) * p1) & 0xffffu) ^ p2; a.HP[g] = h16 * 0x10001u; }
     }
     int cus = 256;
     hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0)); cus = prop.multiProcessorCount;
@@ -446,6 +607,33 @@ int main(int argc, char **argv) {
         printf("probe: qsad mismatches %d/64; mqsad vs mask-on-REFERENCE-zero %d/64; vs mask-on-DATA-zero %d/64\n", bad_q, bad_m_ref, bad_m_data);
         for (int i = 0; i < 4; ++i) printf("  s0=%016llx s1=%08x s2=%016llx q=%016llx m=%016llx\n", (unsigned long long)hs0[i], hs1[i], (unsigned long long)hs2[i], (unsigned long long)hq[i], (unsigned long long)hm[i]);
     }
+    RUN("v9 prefetch r4 g8", (k_v9<4, 3>), 4, 8);
+    RUN("v9 prefetch r4 g6", (k_v9<4, 3>), 4, 6);
+    RUN("v9 prefetch r4 g4", (k_v9<4, 3>), 4, 4);
+    RUN("v9 prefetch r2 g8", (k_v9<2, 3>), 2, 8);
+    RUN("v9 prefetch r2 g16", (k_v9<2, 3>), 2, 16);
+    RUN("v9 prefetch r8 g4", (k_v9<8, 3>), 8, 4);
+    RUN("v3 r4 g8 H-in-VGPR", (k_v3<4, 3, 4, 63, true>), 4, 8);
+    RUN("v3 r4 g8 HV 2 blocks", (k_v3<4, 3, 4, 63, true, 2>), 4, 8);
+    RUN("v3 r4 g8 HV 1 block", (k_v3<4, 3, 4, 63, true, 1>), 4, 8);
+    RUN("v3 r4 g8 HV 1 block L2res", (k_v3<4, 3, 4, 6, true, 1>), 4, 8);
+    RUN("v3 r8 g8 HV 1 block", (k_v3<8, 3, 4, 63, true, 1>), 8, 8);
+    RUN("v3 r4 g8 H-in-VGPR L2-res", (k_v3<4, 3, 4, 6, true>), 4, 8);
+    RUN("v3 r8 g8 H-in-VGPR", (k_v3<8, 3, 4, 63, true>), 8, 8);
+    RUN("v10 packed16 r4 grp4", (k_v10<4, 4>), 4, 8);
+    RUN("v10 packed16 r4 grp8", (k_v10<4, 8>), 4, 8);
+    RUN("v10 packed16 r4 grp4 L2-res", (k_v10<4, 4, 6>), 4, 8);
+    RUN("v10 packed16 r8 grp4", (k_v10<8, 4>), 8, 8);
+    RUN("v10 packed16 r4 grp4 g6", (k_v10<4, 4>), 4, 6);
+    RUN("v3 r4 g8 L2-resident (1MB)", (k_v3<4, 3, 4, 6>), 4, 8);
+    RUN("v3 r4 g8 L2-resident (256K)", (k_v3<4, 3, 4, 4>), 4, 8);
+    RUN("v3 r4 g8 MALL-resident (64MB)", (k_v3<4, 3, 4, 12>), 4, 8);
+    RUN("stream r4 g8 again", (k_stream<4>), 4, 8);
+    RUN("v3 r4 g6", (k_v3<4, 3, 4>), 4, 6);
+    RUN("v3 r4 g4", (k_v3<4, 3, 4>), 4, 4);
+    RUN("v8 shifted loads r2", (k_v8<2, 3>), 2, 8);
+    RUN("v8 shifted loads r1", (k_v8<1, 3>), 1, 8);
+    RUN("v8 shifted loads r2 g16", (k_v8<2, 3>), 2, 16);
     RUN("v7 lds15 4/4 groups", (k_v7<4, 3, 15, 4>), 4, 8);
     RUN("v7 lds15 3/4 groups", (k_v7<4, 3, 15, 3>), 4, 8);
     RUN("v7 lds15 2/4 groups", (k_v7<4, 3, 15, 2>), 4, 8);

@@ -266,9 +266,11 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) void fz_scan_kernel(
     __syncthreads();
     const FzWaveLds w = fz_wave_lds(smem + mpad, threadIdx.x >> 6, FUSED ? a.win_dwords : 0u,
                                     FUSED ? a.band_w : 0u, a.vlanes, true);
+    // Block hashes live in VGPRs on purpose: on gfx950 a v_xor_b32 with an SGPR operand issues at
+    // ~4.5 cycles per wave, a VGPR-only one at ~2.6 (benchmarks/valu_rates.hip).
     uint32_t H[TG];
 #pragma unroll
-    for (int g = 0; g < TG; ++g) H[g] = a.H[g];
+    for (int g = 0; g < TG; ++g) asm volatile("v_mov_b32 %0, %1" : "=v"(H[g]) : "s"(a.H[g]));
     const uint32_t mask1 = a.mask1;
     const uint32_t lane = fz_lane();
     const uint32_t lane_off = threadIdx.x * 16u;
