@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <string>
+#include <cstring>
 #include <cstdlib>
 #include <vector>
 
@@ -43,6 +45,7 @@ __device__ __forceinline__ uint32_t win(uint32_t lo, uint32_t hi, int b) {
 // ---- V4: streaming only -------------------------------------------------------------------
 template <int ROWS>
 __global__ __launch_bounds__(THREADS) void k_stream(const uint8_t *__restrict__ buf, Args a, uint64_t ntiles, unsigned long long *cnt) {
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
     uint32_t acc = 0;
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint8_t *src = buf + tile * (uint64_t)(ROWB * ROWS) + threadIdx.x * 16u;
@@ -53,6 +56,7 @@ __global__ __launch_bounds__(THREADS) void k_stream(const uint8_t *__restrict__ 
         for (int r = 0; r < ROWS; ++r) acc += v[r].x ^ v[r].y ^ v[r].z ^ v[r].w ^ h[r].x ^ h[r].y;
     }
     if (acc == 0x12345678u) atomicAdd(cnt, 1ull);
+    if (threadIdx.x == 0) { if (blockIdx.x == 0) { cnt[1] = clock64() - c0; cnt[2] = wall_clock64() - w0; } if (blockIdx.x < 8192) { cnt[8 + 2 * blockIdx.x] = w0; cnt[9 + 2 * blockIdx.x] = wall_clock64(); } }
 }
 
 // shared rare path: count the lanes (stand-in for queue push + drain)
@@ -157,8 +161,9 @@ __global__ __launch_bounds__(THREADS) void k_v2(const uint8_t *__restrict__ buf,
 
 // ---- V3: hash, xor + min3 accumulate (no SALU), one ballot per 4 offsets --------------------
 __device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) { return min(a, min(b, c)); }
-template <int ROWS, int DH, int GROUP, int WRAPBITS = 63, bool HV = false, int NB = 3>
+template <int ROWS, int DH, int GROUP, int WRAPBITS = 63, bool HV = false, int NB = 3, int ASSIGN = 0>
 __global__ __launch_bounds__(THREADS) void k_v3(const uint8_t *__restrict__ buf, Args a, uint64_t ntiles, unsigned long long *cnt) {
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
     uint32_t H[3] = {a.H[0], a.H[1], a.H[2]};
     if (HV) {   // block hashes in VGPRs: v_xor with an SGPR operand issues at ~4.5 cycles, VGPR-only at ~2.6
 #pragma unroll
@@ -166,12 +171,19 @@ __global__ __launch_bounds__(THREADS) void k_v3(const uint8_t *__restrict__ buf,
     }
     const uint32_t K = a.K;
     uint32_t qn = 0;
-    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const uint64_t per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const uint64_t t_begin = ASSIGN == 1 ? blockIdx.x * per : blockIdx.x;
+    const uint64_t t_end = ASSIGN == 1 ? (t_begin + per < ntiles ? t_begin + per : ntiles) : ntiles;
+    const uint64_t t_step = ASSIGN == 1 ? 1 : gridDim.x;
+    // ASSIGN 2: each wave reads ROWS consecutive 1 KiB segments (4 KiB contiguous per wave)
+    const uint32_t lane_off = ASSIGN == 2 ? (threadIdx.x >> 6) * (ROWS * 1024u) + (threadIdx.x & 63u) * 16u : threadIdx.x * 16u;
+    constexpr uint32_t ROWSTEP = ASSIGN == 2 ? 1024u : ROWB;
+    for (uint64_t tile = t_begin; tile < t_end; tile += t_step) {
         // WRAPBITS < 63: all tiles alias a small L2-resident region -> compute-only time
-        const uint8_t *src = buf + (tile & ((1ull << WRAPBITS) - 1)) * (uint64_t)(ROWB * ROWS) + threadIdx.x * 16u;
+        const uint8_t *src = buf + (tile & ((1ull << WRAPBITS) - 1)) * (uint64_t)(ROWB * ROWS) + lane_off;
         uint4 v[ROWS]; uint2 h[ROWS];
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) { v[r] = *(const uint4 *)(src + r * ROWB); h[r] = *(const uint2 *)(src + r * ROWB + 16); }
+        for (int r = 0; r < ROWS; ++r) { v[r] = *(const uint4 *)(src + r * ROWSTEP); h[r] = *(const uint2 *)(src + r * ROWSTEP + 16); }
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             const uint32_t w[6] = {v[r].x, v[r].y, v[r].z, v[r].w, h[r].x, h[r].y};
@@ -199,6 +211,7 @@ __global__ __launch_bounds__(THREADS) void k_v3(const uint8_t *__restrict__ buf,
         }
     }
     if ((threadIdx.x & 63) == 0 && qn) atomicAdd(cnt, (unsigned long long)qn);
+    if (threadIdx.x == 0) { if (blockIdx.x == 0) { cnt[1] = clock64() - c0; cnt[2] = wall_clock64() - w0; } if (blockIdx.x < 8192) { cnt[8 + 2 * blockIdx.x] = w0; cnt[9 + 2 * blockIdx.x] = wall_clock64(); } }
 }
 
 // ---- V5: hash, v_cmp + v_addc-style per-lane counter (no SALU), ballot per GROUP offsets ------
@@ -493,6 +506,63 @@ __global__ __launch_bounds__(THREADS) void k_v10(const uint8_t *__restrict__ buf
     if ((threadIdx.x & 63) == 0 && qn) atomicAdd(cnt, (unsigned long long)qn);
 }
 
+// ---- V11: v3 (block hashes in VGPRs) with DYNAMIC work distribution: every wave grabs chunks of
+//      C consecutive 4 KiB wave-tiles from one of P atomic counters (next grab prefetched) ----------
+template <int NB, int WRAPBITS = 63>
+__global__ __launch_bounds__(THREADS) void k_v11(const uint8_t *__restrict__ buf, Args a, uint64_t ntiles, unsigned long long *cnt) {
+    const unsigned long long w0 = wall_clock64();
+    uint32_t H[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) asm volatile("v_mov_b32 %0, %1" : "=v"(H[g]) : "s"(a.H[g]));
+    const uint32_t K = a.K;
+    const uint32_t C = a.d2, P = a.dh;                 // chunk size in wave-tiles, number of counters (reused fields)
+    const uint64_t nwt = ntiles * 4;                   // 4 KiB wave-tiles
+    const uint64_t nchunks = (nwt + C - 1) / C;
+    unsigned int *sched = reinterpret_cast<unsigned int *>(cnt + 8 + 2 * 8192);
+    const uint32_t part = blockIdx.x % P;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t qn = 0;
+    uint32_t nextv = 0;
+    if (lane == 0) nextv = atomicAdd(&sched[part * 16], 1u);
+    for (;;) {
+        const uint32_t c = __builtin_amdgcn_readfirstlane(nextv);
+        const uint64_t gc = (uint64_t)c * P + part;
+        if (gc >= nchunks) break;
+        if (lane == 0) nextv = atomicAdd(&sched[part * 16], 1u);
+        const uint64_t t0 = gc * C, t1 = t0 + C < nwt ? t0 + C : nwt;
+        for (uint64_t wt = t0; wt < t1; ++wt) {
+            const uint8_t *src = buf + (wt & ((1ull << WRAPBITS) - 1)) * 4096ull + lane * 16u;
+            uint4 v[4]; uint2 h[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = *(const uint4 *)(src + r * 1024); h[r] = *(const uint2 *)(src + r * 1024 + 16); }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t w[6] = {v[r].x, v[r].y, v[r].z, v[r].w, h[r].x, h[r].y};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint32_t acc = 0xffffffffu;
+                    uint32_t hv[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int o = 4 * j + i;
+                        hv[i] = __umul24(WIN(w, o + 3), K) + WIN(w, o);
+                        if (NB == 3) { acc = min3u(acc, hv[i] ^ H[0], hv[i] ^ H[1]); acc = min(acc, hv[i] ^ H[2]); }
+                        else acc = min(acc, hv[i] ^ H[0]);
+                    }
+                    if (__ballot(acc == 0)) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int g = 0; g < NB; ++g) { const unsigned long long mm = __ballot(hv[i] == H[g]); if (mm) rare(mm, qn); }
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0 && qn) atomicAdd(cnt, (unsigned long long)qn);
+    if (threadIdx.x == 0 && blockIdx.x < 8192) { cnt[8 + 2 * blockIdx.x] = w0; cnt[9 + 2 * blockIdx.x] = wall_clock64(); if (blockIdx.x == 0) { cnt[1] = 1; cnt[2] = 1; } }
+}
+
 // semantic probe of the (m)qsad instructions
 __global__ void k_probe(const uint64_t *s0, const uint32_t *s1, const uint64_t *s2, uint64_t *out_q, uint64_t *out_m) {
     const int i = threadIdx.x;
@@ -504,12 +574,19 @@ static uint32_t le32(const uint8_t *p) { return p[0] | p[1] << 8 | p[2] << 16 | 
 
 template <class F>
 void run(const char *name, F launch, unsigned long long *d_cnt, uint64_t n, int rows) {
+    if (const char *only = getenv("FV_ONLY")) {          // ';'-separated substrings
+        bool hit = false; std::string o(only); size_t p0 = 0;
+        while (p0 <= o.size()) { size_t p1 = o.find(';', p0); if (p1 == std::string::npos) p1 = o.size();
+            if (p1 > p0 && strstr(name, o.substr(p0, p1 - p0).c_str())) hit = true; p0 = p1 + 1; }
+        if (!hit) return;
+    }
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     std::vector<float> ms;
-    unsigned long long h_cnt = 0;
+    unsigned long long h_cnt = 0, h_clk[3] = {0, 0, 0};
+    static std::vector<unsigned long long> h_t(8 + 2 * 8192);
     for (int it = 0; it < 7; ++it) {
-        CHECK(hipMemset(d_cnt, 0, 8));
+        CHECK(hipMemset(d_cnt, 0, 64 + 8192 * 16 + 64 * 64));
         CHECK(hipEventRecord(e0));
         launch();
         CHECK(hipEventRecord(e1));
@@ -517,11 +594,26 @@ void run(const char *name, F launch, unsigned long long *d_cnt, uint64_t n, int 
         CHECK(hipGetLastError());
         float t; CHECK(hipEventElapsedTime(&t, e0, e1));
         ms.push_back(t);
-        CHECK(hipMemcpy(&h_cnt, d_cnt, 8, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(h_clk, d_cnt, 24, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(h_t.data(), d_cnt, (8 + 2 * 8192) * 8, hipMemcpyDeviceToHost));
+        h_cnt = h_clk[0];
     }
     std::sort(ms.begin(), ms.end());
     printf("%-28s rows=%d  min %.4f ms  med %.4f ms  -> %.0f GB/s (min)  hits=%llu\n", name, rows, ms[0], ms[ms.size() / 2],
            n / (ms[0] * 1e-3) / 1e9, h_cnt);
+    if (h_clk[2]) {
+        unsigned long long t0 = ~0ull, t1 = 0; int nwg = 0;
+        for (int b = 0; b < 8192; ++b) if (h_t[9 + 2 * b]) { ++nwg; t0 = std::min(t0, h_t[8 + 2 * b]); t1 = std::max(t1, h_t[9 + 2 * b]); }
+        std::vector<unsigned long long> dur, st;
+        for (int b = 0; b < 8192; ++b) if (h_t[9 + 2 * b]) { dur.push_back(h_t[9 + 2 * b] - h_t[8 + 2 * b]); st.push_back(h_t[8 + 2 * b] - t0); }
+        std::sort(dur.begin(), dur.end()); std::sort(st.begin(), st.end());
+        printf("    %d WGs, span %.1f us; WG duration min/med/max %.1f/%.1f/%.1f us; start time med/p90/max %.1f/%.1f/%.1f us; active WGs at 10%%..90%% of span:", nwg, (t1 - t0) / 100.0,
+               dur[0] / 100.0, dur[dur.size() / 2] / 100.0, dur.back() / 100.0, st[st.size() / 2] / 100.0, st[st.size() * 9 / 10] / 100.0, st.back() / 100.0);
+        for (int q = 1; q < 10; q += 2) { const unsigned long long t = t0 + (t1 - t0) * q / 10; int act = 0;
+            for (int b = 0; b < 8192; ++b) if (h_t[9 + 2 * b] && h_t[8 + 2 * b] <= t && h_t[9 + 2 * b] > t) ++act; printf(" %d", act); }
+        printf("\n");
+    }
+    if (h_clk[2]) printf("    WG0: %llu core cycles / %llu ticks@100MHz -> %.0f MHz\n", h_clk[1], h_clk[2], (double)h_clk[1] / h_clk[2] * 100.0);
 }
 
 int main(int argc, char **argv) {
@@ -532,7 +624,7 @@ int main(int argc, char **argv) {
     hipLaunchKernelGGL(gen_dna, dim3(4096), dim3(256), 0, 0, buf, n, 12345ull);
     CHECK(hipDeviceSynchronize());
     unsigned long long *d_cnt;
-    CHECK(hipMalloc((void **)&d_cnt, 8));
+    CHECK(hipMalloc((void **)&d_cnt, 64 + 8192 * 16 + 64 * 64));
     const uint8_t pat[21] = "GATTACAGATTACACCGTTA";
     Args a{};
     a.K = 0x9E3779u; a.d2 = 2; a.dh = 3;
@@ -613,7 +705,26 @@ int main(int argc, char **argv) {
     RUN("v9 prefetch r2 g8", (k_v9<2, 3>), 2, 8);
     RUN("v9 prefetch r2 g16", (k_v9<2, 3>), 2, 16);
     RUN("v9 prefetch r8 g4", (k_v9<8, 3>), 8, 4);
+#define RUNL(NAME, KERN, ROWS, GRIDMUL, LDS) { const uint64_t nt = n / (ROWB * ROWS); dim3 grid((unsigned)std::min<uint64_t>(nt, (uint64_t)cus * GRIDMUL)); \
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&KERN), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    run(NAME, [&]() { hipLaunchKernelGGL(KERN, grid, dim3(THREADS), LDS, 0, buf, a, nt, d_cnt); }, d_cnt, n, ROWS); }
+    RUNL("stream r4, 4 WG/CU (40K LDS)", (k_stream<4>), 4, 4, 40 * 1024);
+    RUNL("stream r4, 2 WG/CU (80K LDS)", (k_stream<4>), 4, 2, 80 * 1024);
+    RUNL("stream r4, 1 WG/CU (159K LDS)", (k_stream<4>), 4, 1, 159 * 1024);
+    RUNL("stream r8, 2 WG/CU (80K LDS)", (k_stream<8>), 8, 2, 80 * 1024);
+    RUNL("stream r8, 1 WG/CU (159K LDS)", (k_stream<8>), 8, 1, 159 * 1024);
+    RUNL("stream r4, 6 WG/CU (26K LDS)", (k_stream<4>), 4, 6, 26 * 1024);
+    { Args keep = a;
+      for (int C : {1, 2, 4, 8, 16}) for (int P : {64, 8}) { a.d2 = C; a.dh = P; char nm[64]; snprintf(nm, sizeof nm, "v11 dynamic 3blk C=%d P=%d g8", C, P); RUN(nm, (k_v11<3>), 4, 8); }
+      a.d2 = 4; a.dh = 64; RUN("v11 dynamic 3blk C=4 P=64 g6", (k_v11<3>), 4, 6);
+      a.d2 = 4; a.dh = 64; RUN("v11 dynamic 1blk C=4 P=64 g8", (k_v11<1>), 4, 8);
+      a.d2 = 4; a.dh = 64; RUN("v11 dynamic 3blk C=4 P=64 g8 L2res", (k_v11<3, 8>), 4, 8);
+      a = keep; }
     RUN("v3 r4 g8 H-in-VGPR", (k_v3<4, 3, 4, 63, true>), 4, 8);
+    RUN("v3 r4 g8 HV 1 block contiguous-per-WG", (k_v3<4, 3, 4, 63, true, 1, 1>), 4, 8);
+    RUN("v3 r4 g8 HV 1 block wave-contig rows", (k_v3<4, 3, 4, 63, true, 1, 2>), 4, 8);
+    RUN("v3 r4 g8 HV 3 block contiguous-per-WG", (k_v3<4, 3, 4, 63, true, 3, 1>), 4, 8);
+    RUN("v3 r4 g8 HV 3 block wave-contig rows", (k_v3<4, 3, 4, 63, true, 3, 2>), 4, 8);
     RUN("v3 r4 g8 HV 2 blocks", (k_v3<4, 3, 4, 63, true, 2>), 4, 8);
     RUN("v3 r4 g8 HV 1 block", (k_v3<4, 3, 4, 63, true, 1>), 4, 8);
     RUN("v3 r4 g8 HV 1 block L2res", (k_v3<4, 3, 4, 6, true, 1>), 4, 8);

@@ -70,6 +70,8 @@ struct FzScanArgs {
     uint32_t s[FZ_MAX_BLOCKS_PER_LAUNCH];       // ngram_start of each block inside the pattern
     uint64_t hit_cap;                           // capacity of the hit list
     uint64_t rec_cap;                           // capacity of the record list
+    uint64_t host_hdr;                          // device-visible address of the host copy of the counters
+                                                // (0: none); the last workgroup of the launch fills it
     uint8_t  pat[FZ_MAX_M];                     // whole pattern
 };
 

@@ -198,6 +198,33 @@ __device__ __forceinline__ bool fz_confirm(const uint8_t *__restrict__ buf, cons
     return true;
 }
 
+
+#define FZ_HDR_WORDS 128                                   // 64-bit counters in the result header
+#define FZ_HDR_TICKET 3                                    // counters[3]: workgroups that finished (final launch)
+
+// End of the final kernel of a search: the LAST workgroup to get here copies the counters into
+// host-visible memory (a.host_hdr), so the host needs no D2H copy command after the kernel (the
+// records themselves are then written straight to pinned host memory as well).  Every thread of
+// the workgroup must call it.
+// No agent-scope fence on purpose: on this multi-XCD part __threadfence() writes back the XCD's L2,
+// and one per workgroup made the scan 1.7x slower.  It is not needed either: everything the last
+// workgroup reads was produced by agent-scope atomics (performed memory-side), __syncthreads() makes
+// each wave wait for its own outstanding atomics (s_waitcnt vmcnt(0)) before the ticket is taken,
+// and the counters are read back with agent-scope atomic loads.
+__device__ __forceinline__ void fz_publish_header(const FzScanArgs &a, unsigned long long *__restrict__ counters) {
+    if (!a.host_hdr) return;
+    __shared__ uint32_t is_last;
+    __syncthreads();                                       // all waves' counter atomics are complete
+    if (threadIdx.x == 0)
+        is_last = atomicAdd(&counters[FZ_HDR_TICKET], 1ull) == (unsigned long long)gridDim.x - 1ull;
+    __syncthreads();
+    if (is_last) {
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.host_hdr);
+        for (uint32_t i = threadIdx.x; i < FZ_HDR_WORDS; i += blockDim.x)
+            dst[i] = __hip_atomic_load(&counters[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // Candidate code of the queue: tile-local byte offset (14 bits) | block (3 bits) | tile iteration.
 __device__ __forceinline__ uint32_t fz_code(uint32_t off, uint32_t blk, uint32_t titer) {
     return off | (blk << FZ_TILE_BITS) | (titer << (FZ_TILE_BITS + 3));
@@ -360,6 +387,7 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) void fz_scan_kernel(
         if (!slow && tile >= ntiles) break;
     }
     if (FUSED && lane == 0 && confirmed) atomicAdd(&counters[8 + (blockIdx.x & 63u)], (unsigned long long)confirmed);
+    fz_publish_header(a, counters);
 }
 
 // Verification of a hit list in HBM (parameter ranges whose LDS footprint does not fit beside the
@@ -383,6 +411,7 @@ __global__ void fz_verify_kernel(const uint8_t *__restrict__ buf, const FzScanAr
         const uint64_t hit = valid ? hits[q] : 0;
         fz_wave_verify<FZ_REG_BAND_MAX>(buf, a, pat_lds, w, hit, valid, recs, counters);
     }
+    fz_publish_header(a, counters);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -70,6 +70,8 @@ int fail(int code, const char *fmt, ...) {
 
 constexpr uint64_t kHeaderBytes = 1024;          // counters[0] = emitted hits, [1] = records, [8..71] = confirmed-hit tallies
 constexpr uint64_t kFirstCopyRecs = 4096;        // records fetched together with the header
+constexpr uint64_t kHostRecs = 16384;            // records the pinned staging buffer holds (direct mode)
+static_assert(kHeaderBytes == FZ_HDR_WORDS * 8, "header layout");
 
 struct DevState {
     int device = 0;
@@ -79,13 +81,20 @@ struct DevState {
     uint64_t hit_cap = 0;
     uint8_t *d_out = nullptr;                    // [header kHeaderBytes][recs]
     uint64_t rec_cap = 0;
-    uint8_t *h_stage = nullptr;                  // pinned, kHeaderBytes + kFirstCopyRecs * sizeof(FzRec)
+    uint8_t *h_stage = nullptr;                  // pinned, kHeaderBytes + kHostRecs * sizeof(FzRec)
+    uint8_t *h_stage_dev = nullptr;              // the same memory as the device addresses it
+    // Direct mode: the kernels write records and (last workgroup) the counters straight into h_stage,
+    // no D2H copy command.  Left when a search produces more than kHostRecs records, re-entered when
+    // the counts are small again.
+    bool direct = true;
+    bool last_direct = false;                    // mode of the search being collected
     // one recycled sequence allocation (chunked file reads upload / release 1 MiB buffers in a loop;
     // hipMalloc + hipFree per chunk would dominate)
     uint8_t *spare_alloc = nullptr;
     uint64_t spare_bytes = 0;
     uint64_t first_copy = 512;                   // records fetched with the header (tracks the last count)
     bool header_zeroed = false;                  // the counters were already zeroed after the last D2H copy
+    bool verify_launched = false;                // the last enqueue ran fz_verify_kernel (ev[2] recorded)
     int n_cus = 256;
 };
 
@@ -195,6 +204,11 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     HIP_TRY(hipSetDevice(d.device));
     unsigned long long *counters = reinterpret_cast<unsigned long long *>(d.d_out);
     FzRec *recs = reinterpret_cast<FzRec *>(d.d_out + kHeaderBytes);
+    static const bool no_direct = getenv("FZ_NO_DIRECT") != nullptr;
+    // direct mode needs a kernel to publish the counters: an empty buffer launches none
+    const bool direct = copy_back && d.direct && !no_direct && sh.geom.buf_len > 0 && !q.plan.s.empty();
+    if (direct && with_verify) recs = reinterpret_cast<FzRec *>(d.h_stage_dev + kHeaderBytes);
+    d.last_direct = direct;
     if (!d.header_zeroed) HIP_TRY(hipMemsetAsync(d.d_out, 0, kHeaderBytes, d.stream));
     d.header_zeroed = false;
     HIP_TRY(hipEventRecord(d.ev[0], d.stream));
@@ -228,7 +242,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     fa.band_w = q.mode == FZ_MODE_LEV ? 2 * q.k + 2 : 0;
     fa.win_dwords = (q.m + 2 * q.k + 6) / 4 + 1;
     fa.hit_cap = d.hit_cap;
-    fa.rec_cap = d.rec_cap;
+    fa.rec_cap = direct ? kHostRecs : d.rec_cap;
     memcpy(fa.pat, q.p, q.m);
     const uint32_t mpad = (q.m + 15u) & ~15u;
     // Lanes that verify at once: all 64 while the staged windows stay small; fewer for long patterns
@@ -259,6 +273,9 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
             fa.hi[b] = q.plan.hi[src];
             fa.s[b] = q.plan.s[src];
         }
+        // the final kernel of the search publishes the counters to the host (direct mode)
+        const bool verify_follows = with_verify && !fa.fused;
+        fa.host_hdr = (direct && !verify_follows && g0 + FZ_MAX_BLOCKS_PER_LAUNCH >= G) ? reinterpret_cast<uint64_t>(d.h_stage_dev) : 0;
         ScanKernel kern = scan_kernel(tg, nwin, dh, fa.fused != 0);
         static const uint32_t extra_lds = []() { const char *e = getenv("FZ_EXTRA_LDS_KB"); return e ? (uint32_t)atoi(e) * 1024u : 0u; }();
         hipLaunchKernelGGL(kern, grid, dim3(FZ_FILTER_THREADS), scan_lds + extra_lds, d.stream, sh.d_buf, fa, ntiles, d.d_hits, recs,
@@ -267,7 +284,9 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
         ++launches;
     }
     HIP_TRY(hipEventRecord(d.ev[1], d.stream));
+    d.verify_launched = false;
     if (with_verify && !fa.fused) {
+        d.verify_launched = true;
         // LDS: pattern + per-wave window and score ring; shrink the block until it fits.
         unsigned waves = 4;
         fa.vlanes = 64;
@@ -278,15 +297,18 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fz_verify_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         fa.nblk = 0;
+        fa.host_hdr = direct ? reinterpret_cast<uint64_t>(d.h_stage_dev) : 0;
         hipLaunchKernelGGL(fz_verify_kernel, dim3(d.n_cus * 4), dim3(64 * waves), lds, d.stream, sh.d_buf, fa, d.d_hits, recs,
                            counters);
         HIP_TRY(hipGetLastError());
     }
     if (copy_back) {
-        HIP_TRY(hipEventRecord(d.ev[2], d.stream));
-        d.first_copy = std::min<uint64_t>(std::min<uint64_t>(d.first_copy, kFirstCopyRecs), d.rec_cap);
-        HIP_TRY(hipMemcpyAsync(d.h_stage, d.d_out, kHeaderBytes + d.first_copy * sizeof(FzRec), hipMemcpyDeviceToHost,
-                               d.stream));
+        if (d.verify_launched) HIP_TRY(hipEventRecord(d.ev[2], d.stream));
+        if (!direct) {
+            d.first_copy = std::min<uint64_t>(std::min<uint64_t>(d.first_copy, kFirstCopyRecs), d.rec_cap);
+            HIP_TRY(hipMemcpyAsync(d.h_stage, d.d_out, kHeaderBytes + d.first_copy * sizeof(FzRec), hipMemcpyDeviceToHost,
+                                   d.stream));
+        }
         HIP_TRY(hipEventRecord(d.ev[3], d.stream));
         // zero the counters for the NEXT search now, off the critical path of that call
         HIP_TRY(hipMemsetAsync(d.d_out, 0, kHeaderBytes, d.stream));
@@ -303,7 +325,8 @@ int collect_shard(fz_ctx *ctx, const Shard &sh, bool with_verify, std::vector<Fz
     DevState &d = ctx->devs[sh.dev];
     HIP_TRY(hipSetDevice(d.device));
     Trace tr;
-    HIP_TRY(hipStreamSynchronize(d.stream));
+    // wait for the copy only: the memset that pre-zeroes the header for the next search runs behind it
+    HIP_TRY(hipEventSynchronize(d.ev[3]));
     tr.mark("  sync");
     const unsigned long long *cnt = reinterpret_cast<const unsigned long long *>(d.h_stage);
     uint64_t nh = cnt[0];
@@ -316,15 +339,17 @@ int collect_shard(fz_ctx *ctx, const Shard &sh, bool with_verify, std::vector<Fz
         if (rc) return rc;
         rerun = true;
     }
-    if (nr > d.rec_cap) {
+    if (d.last_direct && with_verify && nr > kHostRecs) d.direct = false;   // too many for the staging buffer
+    if (nr > (d.last_direct ? kHostRecs : d.rec_cap)) {
         int rc = ensure_recs(d, nr + nr / 8 + 1024);
         if (rc) return rc;
         rerun = true;
     }
+    if (!d.last_direct && nr * 4 < kHostRecs) d.direct = true;
     if (rerun) return FZ_OK;
     float f = 0, v = 0, t = 0;
     HIP_TRY(hipEventElapsedTime(&f, d.ev[0], d.ev[1]));
-    HIP_TRY(hipEventElapsedTime(&v, d.ev[1], d.ev[2]));
+    if (d.verify_launched) HIP_TRY(hipEventElapsedTime(&v, d.ev[1], d.ev[2]));
     HIP_TRY(hipEventElapsedTime(&t, d.ev[0], d.ev[3]));
     ctx->stats.filter_ms = std::max<double>(ctx->stats.filter_ms, f);
     ctx->stats.verify_ms = std::max<double>(ctx->stats.verify_ms, v);
@@ -335,7 +360,7 @@ int collect_shard(fz_ctx *ctx, const Shard &sh, bool with_verify, std::vector<Fz
         ctx->stats.raw_matches += nr;
         const size_t base = recs_out.size();
         recs_out.resize(base + nr);
-        const uint64_t first = std::min<uint64_t>(nr, d.first_copy);
+        const uint64_t first = d.last_direct ? nr : std::min<uint64_t>(nr, d.first_copy);
         if (first) memcpy(recs_out.data() + base, d.h_stage + kHeaderBytes, first * sizeof(FzRec));
         if (nr > first)
             HIP_TRY(hipMemcpy(recs_out.data() + base + first, d.d_out + kHeaderBytes + first * sizeof(FzRec),
@@ -537,20 +562,56 @@ void sort_gen_recs(std::vector<FzGenRec> &recs) {
     if (src != recs.data()) memcpy(recs.data(), src, n * sizeof(FzGenRec));
 }
 
-int emit_matches(const std::vector<FzRec> &recs, uint32_t L, fz_match **out, uint64_t *n) {
+// Records -> fz_match rows in (block, index) order == the reference's emission order.
+// The keys of one search differ in few bits (block number + an index range), so they are first
+// squeezed into <= 32 bits and sorted as (key32 << 32 | position) words with 11-bit LSD radix passes
+// (8-byte elements instead of 24-byte records); the records are then read once, in order.
+int emit_matches(std::vector<FzRec> &recs, uint32_t L, fz_match **out, uint64_t *n) {
+    const size_t cnt = recs.size();
     void *mem = nullptr;
-    int rc = alloc_out(recs.size(), sizeof(fz_match), &mem);
+    int rc = alloc_out(cnt, sizeof(fz_match), &mem);
     if (rc) return rc;
     fz_match *mo = static_cast<fz_match *>(mem);
-    for (size_t i = 0; i < recs.size(); ++i) {
-        const uint64_t idx = fz_hit_index(recs[i].key);
-        mo[i].start = (int64_t)(idx - recs[i].l);
-        mo[i].end = (int64_t)(idx + L + recs[i].r);
-        mo[i].dist = (int32_t)recs[i].dist;
-        mo[i].block = (int32_t)fz_hit_block(recs[i].key);
-    }
+    auto put = [&](size_t i, const FzRec &r) {
+        const uint64_t idx = fz_hit_index(r.key);
+        mo[i].start = (int64_t)(idx - r.l);
+        mo[i].end = (int64_t)(idx + L + r.r);
+        mo[i].dist = (int32_t)r.dist;
+        mo[i].block = (int32_t)fz_hit_block(r.key);
+    };
     *out = mo;
-    *n = recs.size();
+    *n = cnt;
+    if (cnt >= 64 && cnt < (1ull << 32)) {
+        uint64_t imin = ~0ull, imax = 0;
+        uint32_t gmax = 0;
+        for (size_t i = 0; i < cnt; ++i) {
+            const uint64_t idx = fz_hit_index(recs[i].key);
+            imin = std::min(imin, idx); imax = std::max(imax, idx);
+            gmax = std::max(gmax, fz_hit_block(recs[i].key));
+        }
+        int ibits = 0, gbits = 0;
+        while (ibits < 56 && ((imax - imin) >> ibits)) ++ibits;
+        while ((gmax >> gbits)) ++gbits;
+        if (ibits + gbits <= 32) {
+            std::vector<uint64_t> a(cnt), b(cnt);
+            for (size_t i = 0; i < cnt; ++i) {
+                const uint64_t k32 = ((uint64_t)fz_hit_block(recs[i].key) << ibits) | (fz_hit_index(recs[i].key) - imin);
+                a[i] = (k32 << 32) | (uint64_t)i;
+            }
+            uint64_t *src = a.data(), *dst = b.data();
+            for (int shift = 0; shift < ibits + gbits; shift += 11) {
+                uint32_t count[2049] = {0};
+                for (size_t i = 0; i < cnt; ++i) ++count[((src[i] >> (32 + shift)) & 0x7ff) + 1];
+                for (int d = 0; d < 2048; ++d) count[d + 1] += count[d];
+                for (size_t i = 0; i < cnt; ++i) dst[count[(src[i] >> (32 + shift)) & 0x7ff]++] = src[i];
+                std::swap(src, dst);
+            }
+            for (size_t i = 0; i < cnt; ++i) put(i, recs[(uint32_t)src[i]]);
+            return FZ_OK;
+        }
+    }
+    sort_recs(recs);
+    for (size_t i = 0; i < cnt; ++i) put(i, recs[i]);
     return FZ_OK;
 }
 
@@ -604,7 +665,8 @@ int fz_create(const int *device_ids, int n_devices, fz_ctx **out) {
             HIP_TRY(hipSetDevice(id));
             HIP_TRY(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
             for (auto &ev : d.ev) HIP_TRY(hipEventCreate(&ev));
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&d.h_stage), kHeaderBytes + kFirstCopyRecs * sizeof(FzRec), hipHostMallocDefault));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&d.h_stage), kHeaderBytes + kHostRecs * sizeof(FzRec), hipHostMallocMapped));
+            HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&d.h_stage_dev), d.h_stage, 0));
             return FZ_OK;
         };
         rc = init();
@@ -800,10 +862,8 @@ int fz_lev_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32
     rc = run_search(ctx, seq, q, true, recs, hits);
     if (rc) return rc;
     tr.mark("run_search");
-    sort_recs(recs);
-    tr.mark("sort");
     rc = emit_matches(recs, L, out, n);
-    tr.mark("emit");
+    tr.mark("sort+emit");
     return rc;
 }
 
@@ -831,7 +891,6 @@ int fz_subs_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint3
     std::vector<uint64_t> hits;
     rc = run_search(ctx, seq, q, true, recs, hits);
     if (rc) return rc;
-    sort_recs(recs);
     return emit_matches(recs, L, out, n);
 }
 

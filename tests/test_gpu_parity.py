@@ -140,6 +140,23 @@ def test_dense_and_degenerate_inputs(engine):
         h.release()
 
 
+def test_result_staging_mode_switches(engine):
+    """Small result sets are written by the kernels straight into pinned host memory, large ones go
+    through the device buffer + copy; alternate between the two and compare every call."""
+    dense = b'ACGT' * 30000                       # ~90 000 raw matches: beyond the host staging buffer
+    sparse = workloads.dna(1 << 18, 5).tobytes()
+    p, k = b'ACGTACGTACGTAC', 2
+    hd, hs = engine.upload(dense), engine.upload(sparse)
+    want_d, want_s = oracle.lev_ngrams_raw(p, dense, k), oracle.lev_ngrams_raw(p, sparse, k)
+    assert len(want_d) > 20000
+    for _ in range(3):
+        assert engine.lev_ngrams(hs, p, k) == want_s
+        assert engine.lev_ngrams(hd, p, k) == want_d
+        assert engine.subs_ngrams(hs, p, k) == oracle.subs_ngrams_raw(p, sparse, k)
+    assert engine.lev_ngrams(hs, p, k) == want_s
+    hd.release(); hs.release()
+
+
 def test_sharded_equals_unsharded(engine):
     """Two shards with (m + k) halos, hits owned by index == one sequence."""
     rnd = random.Random(21)
