@@ -174,11 +174,9 @@ def _match_dtype():
 def _take_matches_array(L, ptr, n):
     """-> numpy structured array (start, end, dist, block); one memcpy, then the C buffer is freed."""
     import numpy as np
-    if n == 0:
-        L.fz_free(ptr)
-        return np.empty(0, dtype=_match_dtype())
-    buf = (ctypes.c_char * (n * ctypes.sizeof(FzMatch))).from_address(ctypes.addressof(ptr.contents))
-    arr = np.frombuffer(buf, dtype=_match_dtype()).copy()
+    arr = np.empty(n, dtype=_match_dtype())
+    if n:
+        ctypes.memmove(arr.ctypes.data, ptr, n * ctypes.sizeof(FzMatch))
     L.fz_free(ptr)
     return arr
 
@@ -249,6 +247,8 @@ class Engine(object):
         self.devices = list(devices) if devices else [0]
         # a fz_ctx is not internally locked and ctypes drops the GIL during calls: serialise per engine
         self._lock = threading.Lock()
+        self._st = FzStats()
+        self._st_ref = ctypes.byref(self._st)
 
     def close(self):
         if self._h is not None:
@@ -318,19 +318,26 @@ class Engine(object):
         return self._match_call(self._lib.fz_generic_ngrams, seq, pattern, max_subs, max_ins, max_dels, max_l,
                                 as_array=as_array)
 
-    def lev_lp(self, seq, pattern, k):
-        return self._match_call(self._lib.fz_lev_lp, seq, pattern, k)
+    def lev_lp(self, seq, pattern, k, as_array=False):
+        return self._match_call(self._lib.fz_lev_lp, seq, pattern, k, as_array=as_array)
 
-    def subs_lp(self, seq, pattern, k):
-        return self._match_call(self._lib.fz_subs_lp, seq, pattern, k)
+    def subs_lp(self, seq, pattern, k, as_array=False):
+        return self._match_call(self._lib.fz_subs_lp, seq, pattern, k, as_array=as_array)
 
-    def generic_lp(self, seq, pattern, max_subs, max_ins, max_dels, max_l):
-        return self._match_call(self._lib.fz_generic_lp, seq, pattern, max_subs, max_ins, max_dels, max_l)
+    def generic_lp(self, seq, pattern, max_subs, max_ins, max_dels, max_l, as_array=False):
+        return self._match_call(self._lib.fz_generic_lp, seq, pattern, max_subs, max_ins, max_dels, max_l,
+                                as_array=as_array)
 
     def stats(self):
         st = FzStats()
         _check(self._lib.fz_stats(self._h, ctypes.byref(st)))
         return {f: getattr(st, f) for f, _ in FzStats._fields_}
+
+    def kernel_ms(self):
+        """(filter_ms, verify_ms, device_ms) of the last call: the cheap subset of stats()."""
+        st = self._st
+        _check(self._lib.fz_stats(self._h, self._st_ref))
+        return st.filter_ms, st.verify_ms, st.device_ms
 
 
 _default_engine = None

@@ -7,7 +7,8 @@ from .engine import prepare
 from .search_exact import search_exact
 
 __all__ = ['find_near_matches_generic', 'find_near_matches_generic_ngrams',
-           'find_near_matches_generic_linear_programming', 'GenericSearch']
+           'find_near_matches_generic_linear_programming', 'has_near_match_generic_ngrams',
+           'GenericSearch']
 
 
 def find_near_matches_generic_ngrams(subsequence, sequence, search_params):
@@ -49,6 +50,11 @@ def find_near_matches_generic_linear_programming(subsequence, sequence, search_p
         pr.release()
     seq = pr.original
     return [Match(s, e, d, matched=seq[s:e]) for (s, e, d, _g) in raw]
+
+
+def has_near_match_generic_ngrams(subsequence, sequence, search_params):
+    """generic_search.py:240-253."""
+    return len(find_near_matches_generic_ngrams(subsequence, sequence, search_params)) > 0
 
 
 class GenericSearch(FuzzySearchBase):

@@ -11,6 +11,8 @@ from .search_exact import search_exact
 
 __all__ = ['find_near_matches_substitutions', 'find_near_matches_substitutions_ngrams',
            'find_near_matches_substitutions_lp',
+           'has_near_match_substitutions', 'has_near_match_substitutions_ngrams',
+           'has_near_match_substitutions_lp',
            'SubstitutionsOnlySearch']
 
 
@@ -64,6 +66,39 @@ def find_near_matches_substitutions_lp(subsequence, sequence, max_substitutions)
         pr.release()
     seq = pr.original
     return [Match(s, e, d, matched=seq[s:e]) for (s, e, d, _g) in raw]
+
+
+def _any_raw(call, subsequence, sequence, max_substitutions):
+    pr = prepare(subsequence, sequence)
+    try:
+        return len(call(pr.engine)(pr.handle, pr.pattern, max_substitutions, as_array=True)) > 0
+    finally:
+        pr.release()
+
+
+def has_near_match_substitutions_ngrams(subsequence, sequence, max_substitutions):
+    """substitutions_only.py:218-233: does any window have at most max_substitutions mismatches?
+    (The reference stops at the first one; the GPU scan is one pass either way.)"""
+    _check_arguments(subsequence, sequence, max_substitutions)
+    if len(subsequence) // (max_substitutions + 1) == 0:
+        raise ValueError("The subsequence's length must be greater than max_substitutions!")
+    return _any_raw(lambda eng: eng.subs_ngrams, subsequence, sequence, max_substitutions)
+
+
+def has_near_match_substitutions_lp(subsequence, sequence, max_substitutions):
+    """substitutions_only.py:139-145."""
+    _check_arguments(subsequence, sequence, max_substitutions)
+    return _any_raw(lambda eng: eng.subs_lp, subsequence, sequence, max_substitutions)
+
+
+def has_near_match_substitutions(subsequence, sequence, max_substitutions):
+    """substitutions_only.py:18-34 (same dispatch rule as find_near_matches_substitutions)."""
+    _check_arguments(subsequence, sequence, max_substitutions)
+    if max_substitutions == 0:
+        return len(search_exact(subsequence, sequence)) > 0
+    if len(subsequence) // (max_substitutions + 1) >= 3:
+        return has_near_match_substitutions_ngrams(subsequence, sequence, max_substitutions)
+    return has_near_match_substitutions_lp(subsequence, sequence, max_substitutions)
 
 
 class SubstitutionsOnlySearch(FuzzySearchBase):

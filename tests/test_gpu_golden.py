@@ -84,6 +84,11 @@ def test_substitutions_golden(engine):
         assert len(got) == len(exp), (sub, seq, k)
         for g, e in zip(got, exp):           # group order pinned; in-group ties are hash-seed dependent
             assert g == e or (g[2] == e[2] and g[1] - g[0] == e[1] - e[0]), (sub, seq, k, got, exp)
+        # the has_near_match_* twins (substitutions_only.py:18-34, :139-145, :218-233)
+        has_fn = getattr(substitutions_only, rec["fn"].replace("find_near_matches", "has_near_match"))
+        assert has_fn(sub, seq, k) is (len(exp) > 0), (sub, seq, k)
+        if len(sub) // (k + 1) >= 1:
+            assert substitutions_only.has_near_match_substitutions_lp(sub, seq, k) is (len(exp) > 0)
         n += 1
     assert n >= 40
 
@@ -108,6 +113,7 @@ def test_generic_golden(engine):
             if len(sub) // (l + 1) == 0:
                 continue
             got = generic_search.find_near_matches_generic_ngrams(sub, seq, sp)
+            assert generic_search.has_near_match_generic_ngrams(sub, seq, sp) is (len(got) > 0)
         else:
             got = generic_search.find_near_matches_generic(sub, seq, sp)
         assert _matches(got) == _expect(rec), (sub, seq, params)
