@@ -56,7 +56,7 @@ __global__ __launch_bounds__(THREADS) void k_stream(const uint8_t *__restrict__ 
         for (int r = 0; r < ROWS; ++r) acc += v[r].x ^ v[r].y ^ v[r].z ^ v[r].w ^ h[r].x ^ h[r].y;
     }
     if (acc == 0x12345678u) atomicAdd(cnt, 1ull);
-    if (threadIdx.x == 0) { if (blockIdx.x == 0) { cnt[1] = clock64() - c0; cnt[2] = wall_clock64() - w0; } if (blockIdx.x < 8192) { cnt[8 + 2 * blockIdx.x] = w0; cnt[9 + 2 * blockIdx.x] = wall_clock64(); } }
+    if (threadIdx.x == 0) { if (blockIdx.x == 0) { cnt[1] = clock64() - c0; cnt[2] = wall_clock64() - w0; } if (blockIdx.x < 8192) { cnt[8 + 2 * blockIdx.x] = w0; cnt[9 + 2 * blockIdx.x] = wall_clock64(); cnt[8 + 2 * 8192 + 512 + blockIdx.x] = ((unsigned long long)__builtin_amdgcn_s_getreg(6164) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4); } }
 }
 
 // shared rare path: count the lanes (stand-in for queue push + drain)
@@ -178,7 +178,19 @@ __global__ __launch_bounds__(THREADS) void k_v3(const uint8_t *__restrict__ buf,
     // ASSIGN 2: each wave reads ROWS consecutive 1 KiB segments (4 KiB contiguous per wave)
     const uint32_t lane_off = ASSIGN == 2 ? (threadIdx.x >> 6) * (ROWS * 1024u) + (threadIdx.x & 63u) * 16u : threadIdx.x * 16u;
     constexpr uint32_t ROWSTEP = ASSIGN == 2 ? 1024u : ROWB;
-    for (uint64_t tile = t_begin; tile < t_end; tile += t_step) {
+    const uint32_t my_tiles = (uint32_t)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
+    uint32_t it = 0;
+    for (uint64_t tile = t_begin; tile < t_end; tile += t_step, ++it) {
+        if (ASSIGN == 3) {      // priority falls with progress: the least advanced wave issues first
+            const uint32_t q = it * 4 / my_tiles;
+            if (q == 0) __builtin_amdgcn_s_setprio(3); else if (q == 1) __builtin_amdgcn_s_setprio(2);
+            else if (q == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        }
+        if (ASSIGN == 4) {      // the opposite: the most advanced wave first
+            const uint32_t q = it * 4 / my_tiles;
+            if (q == 0) __builtin_amdgcn_s_setprio(0); else if (q == 1) __builtin_amdgcn_s_setprio(1);
+            else if (q == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
+        }
         // WRAPBITS < 63: all tiles alias a small L2-resident region -> compute-only time
         const uint8_t *src = buf + (tile & ((1ull << WRAPBITS) - 1)) * (uint64_t)(ROWB * ROWS) + lane_off;
         uint4 v[ROWS]; uint2 h[ROWS];
@@ -211,7 +223,7 @@ __global__ __launch_bounds__(THREADS) void k_v3(const uint8_t *__restrict__ buf,
         }
     }
     if ((threadIdx.x & 63) == 0 && qn) atomicAdd(cnt, (unsigned long long)qn);
-    if (threadIdx.x == 0) { if (blockIdx.x == 0) { cnt[1] = clock64() - c0; cnt[2] = wall_clock64() - w0; } if (blockIdx.x < 8192) { cnt[8 + 2 * blockIdx.x] = w0; cnt[9 + 2 * blockIdx.x] = wall_clock64(); } }
+    if (threadIdx.x == 0) { if (blockIdx.x == 0) { cnt[1] = clock64() - c0; cnt[2] = wall_clock64() - w0; } if (blockIdx.x < 8192) { cnt[8 + 2 * blockIdx.x] = w0; cnt[9 + 2 * blockIdx.x] = wall_clock64(); cnt[8 + 2 * 8192 + 512 + blockIdx.x] = ((unsigned long long)__builtin_amdgcn_s_getreg(6164) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4); } }
 }
 
 // ---- V5: hash, v_cmp + v_addc-style per-lane counter (no SALU), ballot per GROUP offsets ------
@@ -563,6 +575,150 @@ __global__ __launch_bounds__(THREADS) void k_v11(const uint8_t *__restrict__ buf
     if (threadIdx.x == 0 && blockIdx.x < 8192) { cnt[8 + 2 * blockIdx.x] = w0; cnt[9 + 2 * blockIdx.x] = wall_clock64(); if (blockIdx.x == 0) { cnt[1] = 1; cnt[2] = 1; } }
 }
 
+// ---- V12: v3 (1 or 3 blocks, hashes in VGPRs) with a per-tile timeline of ONE wave per CU-slot class:
+//      core-clock stamps after issuing the loads, when row 0 has arrived, and at the end of the tile.
+template <int NB, int WRAPBITS = 63>
+__global__ __launch_bounds__(THREADS) void k_v12(const uint8_t *__restrict__ buf, Args a, uint64_t ntiles, unsigned long long *cnt) {
+    uint32_t H[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) asm volatile("v_mov_b32 %0, %1" : "=v"(H[g]) : "s"(a.H[g]));
+    const uint32_t K = a.K;
+    uint32_t qn = 0;
+    unsigned long long t_wait = 0, t_comp = 0, t_issue = 0, n_t = 0;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint8_t *src = buf + (tile & ((1ull << WRAPBITS) - 1)) * (uint64_t)(ROWB * 4) + threadIdx.x * 16u;
+        uint4 v[4]; uint2 h[4];
+        const unsigned long long c0 = clock64();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] = *(const uint4 *)(src + r * ROWB); h[r] = *(const uint2 *)(src + r * ROWB + 16); }
+        const unsigned long long c1 = clock64();
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        const unsigned long long c2 = clock64();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t w[6] = {v[r].x, v[r].y, v[r].z, v[r].w, h[r].x, h[r].y};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t acc = 0xffffffffu;
+                uint32_t hv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int o = 4 * j + i;
+                    hv[i] = __umul24(WIN(w, o + 3), K) + WIN(w, o);
+                    if (NB == 3) { acc = min3u(acc, hv[i] ^ H[0], hv[i] ^ H[1]); acc = min(acc, hv[i] ^ H[2]); }
+                    else acc = min(acc, hv[i] ^ H[0]);
+                }
+                if (__ballot(acc == 0)) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int g = 0; g < NB; ++g) { const unsigned long long mm = __ballot(hv[i] == H[g]); if (mm) rare(mm, qn); }
+                }
+            }
+        }
+        const unsigned long long c3 = clock64();
+        t_issue += c1 - c0; t_wait += c2 - c1; t_comp += c3 - c2; ++n_t;
+    }
+    if ((threadIdx.x & 63) == 0 && qn) atomicAdd(cnt, (unsigned long long)qn);
+    if (threadIdx.x == 0) {      // per-CU-slot class = blockIdx / (gridDim/8): early vs late workgroups
+        const uint32_t cls = blockIdx.x * 8 / gridDim.x;
+        atomicAdd(&cnt[8 + cls * 4 + 0], t_issue); atomicAdd(&cnt[8 + cls * 4 + 1], t_wait);
+        atomicAdd(&cnt[8 + cls * 4 + 2], t_comp); atomicAdd(&cnt[8 + cls * 4 + 3], n_t);
+    }
+}
+
+// ---- V13: block hashes in a 64-slot table held in ONE VGPR (lane s = slot s); every offset fetches
+//      its slot (top 6 hash bits) with ds_bpermute_b32 and compares once: cost independent of #blocks ----
+template <int ROWS, int WRAPBITS = 63, int NLUT = 4>
+__global__ __launch_bounds__(THREADS) void k_v13(const uint8_t *__restrict__ buf, Args a, uint64_t ntiles, unsigned long long *cnt) {
+    const unsigned long long w0 = wall_clock64();
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t table = ((lane + 1u) & 63u) << 26;            // sentinel: a value that lives in another slot
+#pragma unroll
+    for (int g = 0; g < 3; ++g) if ((a.H[g] >> 26) == lane) table = a.H[g];
+    const uint32_t K = a.K;
+    uint32_t H[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) asm volatile("v_mov_b32 %0, %1" : "=v"(H[g]) : "s"(a.H[g]));
+    uint32_t qn = 0;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint8_t *src = buf + (tile & ((1ull << WRAPBITS) - 1)) * (uint64_t)(ROWB * ROWS) + threadIdx.x * 16u;
+        uint4 v[ROWS]; uint2 h[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) { v[r] = *(const uint4 *)(src + r * ROWB); h[r] = *(const uint2 *)(src + r * ROWB + 16); }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const uint32_t w[6] = {v[r].x, v[r].y, v[r].z, v[r].w, h[r].x, h[r].y};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t hv[4], t[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int o = 4 * j + i;
+                    hv[i] = __umul24(WIN(w, o + 3), K) + WIN(w, o);
+                    // NLUT of every 4 offsets go through the LDS crossbar, the rest through VALU compares
+                    if (i < NLUT) t[i] = hv[i] ^ (uint32_t)__builtin_amdgcn_ds_bpermute((int)(hv[i] >> 24), (int)table);
+                    else t[i] = min3u(hv[i] ^ H[0], hv[i] ^ H[1], hv[i] ^ H[2]);
+                }
+                const uint32_t acc = min(min3u(t[0], t[1], t[2]), t[3]);
+                if (__ballot(acc == 0)) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const unsigned long long mm = __ballot(t[i] == 0); if (mm) rare(mm, qn); }
+                }
+            }
+        }
+    }
+    if ((threadIdx.x & 63) == 0 && qn) atomicAdd(cnt, (unsigned long long)qn);
+    if (threadIdx.x == 0) { if (blockIdx.x == 0) { cnt[1] = 1; cnt[2] = 1; } if (blockIdx.x < 8192) { cnt[8 + 2 * blockIdx.x] = w0; cnt[9 + 2 * blockIdx.x] = wall_clock64(); } }
+}
+
+// ---- V14: like V13 but the 64-slot table sits in LDS and is read with ds_read_b32 (2 VALU ops for
+//      the address instead of 1, but a plain LDS read instead of the crossbar) ----------------------
+template <int ROWS, int WRAPBITS = 63, int NLUT = 4>
+__global__ __launch_bounds__(THREADS) void k_v14(const uint8_t *__restrict__ buf, Args a, uint64_t ntiles, unsigned long long *cnt) {
+    __shared__ uint32_t tab[64];
+    const unsigned long long w0 = wall_clock64();
+    if (threadIdx.x < 64) {
+        uint32_t t = ((threadIdx.x + 1u) & 63u) << 26;
+        for (int g = 0; g < 3; ++g) if ((a.H[g] >> 26) == threadIdx.x) t = a.H[g];
+        tab[threadIdx.x] = t;
+    }
+    __syncthreads();
+    const uint32_t K = a.K;
+    uint32_t H[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) asm volatile("v_mov_b32 %0, %1" : "=v"(H[g]) : "s"(a.H[g]));
+    uint32_t qn = 0;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint8_t *src = buf + (tile & ((1ull << WRAPBITS) - 1)) * (uint64_t)(ROWB * ROWS) + threadIdx.x * 16u;
+        uint4 v[ROWS]; uint2 h[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) { v[r] = *(const uint4 *)(src + r * ROWB); h[r] = *(const uint2 *)(src + r * ROWB + 16); }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const uint32_t w[6] = {v[r].x, v[r].y, v[r].z, v[r].w, h[r].x, h[r].y};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t hv[4], t[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int o = 4 * j + i;
+                    hv[i] = __umul24(WIN(w, o + 3), K) + WIN(w, o);
+                    if (i < NLUT) t[i] = hv[i] ^ *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(tab) + ((hv[i] >> 24) & 0xfcu));
+                    else t[i] = min3u(hv[i] ^ H[0], hv[i] ^ H[1], hv[i] ^ H[2]);
+                }
+                const uint32_t acc = min(min3u(t[0], t[1], t[2]), t[3]);
+                if (__ballot(acc == 0)) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const unsigned long long mm = __ballot(t[i] == 0); if (mm) rare(mm, qn); }
+                }
+            }
+        }
+    }
+    if ((threadIdx.x & 63) == 0 && qn) atomicAdd(cnt, (unsigned long long)qn);
+    if (threadIdx.x == 0) { if (blockIdx.x == 0) { cnt[1] = 1; cnt[2] = 1; } if (blockIdx.x < 8192) { cnt[8 + 2 * blockIdx.x] = w0; cnt[9 + 2 * blockIdx.x] = wall_clock64(); } }
+}
+
 // semantic probe of the (m)qsad instructions
 __global__ void k_probe(const uint64_t *s0, const uint32_t *s1, const uint64_t *s2, uint64_t *out_q, uint64_t *out_m) {
     const int i = threadIdx.x;
@@ -584,7 +740,7 @@ void run(const char *name, F launch, unsigned long long *d_cnt, uint64_t n, int 
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     std::vector<float> ms;
     unsigned long long h_cnt = 0, h_clk[3] = {0, 0, 0};
-    static std::vector<unsigned long long> h_t(8 + 2 * 8192);
+    static std::vector<unsigned long long> h_t(8 + 2 * 8192), h_id(8192);
     for (int it = 0; it < 7; ++it) {
         CHECK(hipMemset(d_cnt, 0, 64 + 8192 * 16 + 64 * 64));
         CHECK(hipEventRecord(e0));
@@ -596,6 +752,7 @@ void run(const char *name, F launch, unsigned long long *d_cnt, uint64_t n, int 
         ms.push_back(t);
         CHECK(hipMemcpy(h_clk, d_cnt, 24, hipMemcpyDeviceToHost));
         CHECK(hipMemcpy(h_t.data(), d_cnt, (8 + 2 * 8192) * 8, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(h_id.data(), d_cnt + 8 + 2 * 8192 + 512, 8192 * 8, hipMemcpyDeviceToHost));
         h_cnt = h_clk[0];
     }
     std::sort(ms.begin(), ms.end());
@@ -612,6 +769,15 @@ void run(const char *name, F launch, unsigned long long *d_cnt, uint64_t n, int 
         for (int q = 1; q < 10; q += 2) { const unsigned long long t = t0 + (t1 - t0) * q / 10; int act = 0;
             for (int b = 0; b < 8192; ++b) if (h_t[9 + 2 * b] && h_t[8 + 2 * b] <= t && h_t[9 + 2 * b] > t) ++act; printf(" %d", act); }
         printf("\n");
+        if (getenv("FV_XCD")) {
+            double sum[8] = {0}, endmax[8] = {0}; int nx[8] = {0};
+            for (int b = 0; b < 8192; ++b) if (h_t[9 + 2 * b]) { const int x = (int)((h_id[b] >> 32) & 7);
+                sum[x] += (h_t[9 + 2 * b] - h_t[8 + 2 * b]) / 100.0; endmax[x] = std::max(endmax[x], (h_t[9 + 2 * b] - t0) / 100.0); ++nx[x]; }
+            printf("    per XCD (WGs, mean WG duration us, last end us):");
+            for (int x = 0; x < 8; ++x) printf("  %d: %d %.0f %.0f |", x, nx[x], nx[x] ? sum[x] / nx[x] : 0.0, endmax[x]);
+            printf("\n    blockIdx 0..15 -> xcc:"); for (int b = 0; b < 16; ++b) printf(" %d", (int)((h_id[b] >> 32) & 7));
+            printf("  hw_id[0..3]: %08x %08x %08x %08x\n", (unsigned)h_id[0], (unsigned)h_id[1], (unsigned)h_id[8], (unsigned)h_id[16]);
+        }
     }
     if (h_clk[2]) printf("    WG0: %llu core cycles / %llu ticks@100MHz -> %.0f MHz\n", h_clk[1], h_clk[2], (double)h_clk[1] / h_clk[2] * 100.0);
 }
@@ -624,7 +790,7 @@ int main(int argc, char **argv) {
     hipLaunchKernelGGL(gen_dna, dim3(4096), dim3(256), 0, 0, buf, n, 12345ull);
     CHECK(hipDeviceSynchronize());
     unsigned long long *d_cnt;
-    CHECK(hipMalloc((void **)&d_cnt, 64 + 8192 * 16 + 64 * 64));
+    CHECK(hipMalloc((void **)&d_cnt, 64 + 8192 * 16 + 64 * 64 + 8192 * 8));
     const uint8_t pat[21] = "GATTACAGATTACACCGTTA";
     Args a{};
     a.K = 0x9E3779u; a.d2 = 2; a.dh = 3;
@@ -720,11 +886,48 @@ int main(int argc, char **argv) {
       a.d2 = 4; a.dh = 64; RUN("v11 dynamic 1blk C=4 P=64 g8", (k_v11<1>), 4, 8);
       a.d2 = 4; a.dh = 64; RUN("v11 dynamic 3blk C=4 P=64 g8 L2res", (k_v11<3, 8>), 4, 8);
       a = keep; }
+#define RUNT(NAME, KERN) { const uint64_t nt = n / (ROWB * 4); dim3 grid((unsigned)cus * 8); CHECK(hipMemset(d_cnt, 0, 64 + 8192 * 16)); \
+      hipLaunchKernelGGL(KERN, grid, dim3(THREADS), 0, 0, buf, a, nt, d_cnt); CHECK(hipDeviceSynchronize()); CHECK(hipMemset(d_cnt, 0, 64 + 8192 * 16)); \
+      hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0); hipLaunchKernelGGL(KERN, grid, dim3(THREADS), 0, 0, buf, a, nt, d_cnt); hipEventRecord(e1); CHECK(hipDeviceSynchronize()); \
+      float ms; hipEventElapsedTime(&ms, e0, e1); unsigned long long hc[8 + 32]; CHECK(hipMemcpy(hc, d_cnt, sizeof hc, hipMemcpyDeviceToHost)); \
+      printf("%-34s %.4f ms; per tile per wave-0 of a WG, by dispatch-order class (core cycles): issue / wait-row0 / compute\n", NAME, ms); \
+      for (int c = 0; c < 8; ++c) { const double nn = (double)hc[8 + c * 4 + 3]; if (nn > 0) printf("   class %d: %6.0f / %6.0f / %6.0f   (tiles %.0f)\n", c, hc[8 + c * 4] / nn, hc[8 + c * 4 + 1] / nn, hc[8 + c * 4 + 2] / nn, nn); } }
+    if (!getenv("FV_ONLY")) {
+    RUNT("v12 timeline 1 block HBM", (k_v12<1>));
+    RUNT("v12 timeline 1 block L2-res", (k_v12<1, 6>));
+    RUNT("v12 timeline 3 blocks HBM", (k_v12<3>));
+    RUNT("v12 timeline 3 blocks L2-res", (k_v12<3, 6>));
+    }
+    printf("slots of the 3 block hashes: %u %u %u\n", a.H[0] >> 26, a.H[1] >> 26, a.H[2] >> 26);
+    RUN("v13 bpermute LUT r4 g8", (k_v13<4>), 4, 8);
+    RUN("v13 bpermute LUT r4 g8 L2res", (k_v13<4, 6>), 4, 8);
+    RUN("v14 ds_read LUT 4/4 r4 g8", (k_v14<4, 63, 4>), 4, 8);
+    RUN("v14 ds_read LUT 4/4 r4 g8 L2res", (k_v14<4, 6, 4>), 4, 8);
+    RUN("v14 ds_read LUT 3/4 r4 g8", (k_v14<4, 63, 3>), 4, 8);
+    RUN("v14 ds_read LUT 3/4 r4 g8 L2res", (k_v14<4, 6, 3>), 4, 8);
+    RUN("v14 ds_read LUT 2/4 r4 g8", (k_v14<4, 63, 2>), 4, 8);
+    RUN("v14 ds_read LUT 2/4 r4 g8 L2res", (k_v14<4, 6, 2>), 4, 8);
+    RUN("v14 ds_read LUT 4/4 r8 g8", (k_v14<8, 63, 4>), 8, 8);
+    RUN("v13 hybrid 3/4 LUT r4 g8", (k_v13<4, 63, 3>), 4, 8);
+    RUN("v13 hybrid 2/4 LUT r4 g8", (k_v13<4, 63, 2>), 4, 8);
+    RUN("v13 hybrid 1/4 LUT r4 g8", (k_v13<4, 63, 1>), 4, 8);
+    RUN("v13 hybrid 2/4 LUT r4 g8 L2res", (k_v13<4, 6, 2>), 4, 8);
+    RUN("v13 hybrid 1/4 LUT r4 g8 L2res", (k_v13<4, 6, 1>), 4, 8);
+    RUN("v13 hybrid 2/4 LUT r8 g8", (k_v13<8, 63, 2>), 8, 8);
+    RUN("v13 bpermute LUT r8 g8", (k_v13<8>), 8, 8);
+    RUN("v13 bpermute LUT r4 g6", (k_v13<4>), 4, 6);
     RUN("v3 r4 g8 H-in-VGPR", (k_v3<4, 3, 4, 63, true>), 4, 8);
     RUN("v3 r4 g8 HV 1 block contiguous-per-WG", (k_v3<4, 3, 4, 63, true, 1, 1>), 4, 8);
     RUN("v3 r4 g8 HV 1 block wave-contig rows", (k_v3<4, 3, 4, 63, true, 1, 2>), 4, 8);
     RUN("v3 r4 g8 HV 3 block contiguous-per-WG", (k_v3<4, 3, 4, 63, true, 3, 1>), 4, 8);
     RUN("v3 r4 g8 HV 3 block wave-contig rows", (k_v3<4, 3, 4, 63, true, 3, 2>), 4, 8);
+    RUN("v3 r4 g8 HV 1 block prio-by-progress", (k_v3<4, 3, 4, 63, true, 1, 3>), 4, 8);
+    RUN("v3 r4 g8 HV 3 block prio-by-progress", (k_v3<4, 3, 4, 63, true, 3, 3>), 4, 8);
+    RUN("v3 r4 g8 HV 1 block prio-reverse", (k_v3<4, 3, 4, 63, true, 1, 4>), 4, 8);
+    RUN("v3 r4 g8 HV 3 block prio-reverse", (k_v3<4, 3, 4, 63, true, 3, 4>), 4, 8);
+    RUN("v3 r4 g16 HV 3 block prio-by-progress", (k_v3<4, 3, 4, 63, true, 3, 3>), 4, 16);
+    RUN("v3 r4 g32 HV 3 block prio-by-progress", (k_v3<4, 3, 4, 63, true, 3, 3>), 4, 32);
+    RUN("v3 r4 g32 HV 3 block", (k_v3<4, 3, 4, 63, true, 3, 0>), 4, 32);
     RUN("v3 r4 g8 HV 2 blocks", (k_v3<4, 3, 4, 63, true, 2>), 4, 8);
     RUN("v3 r4 g8 HV 1 block", (k_v3<4, 3, 4, 63, true, 1>), 4, 8);
     RUN("v3 r4 g8 HV 1 block L2res", (k_v3<4, 3, 4, 6, true, 1>), 4, 8);

@@ -21,7 +21,6 @@
 #define FZ_MAX_BLOCKS_PER_LAUNCH 8     // n-gram blocks tested by one filter launch
 #define FZ_MAX_M 1024                  // pattern bytes carried in the kernel argument block
 #define FZ_MAX_K 255                   // largest edit budget the verify kernels support
-#define FZ_HASH_K 0x9E3779u            // 24-bit multiplier of the window hash (v_mad_u32_u24)
 
 // What fz_lp_kernel iterates over.
 enum FzLpKind : uint32_t {
@@ -62,6 +61,8 @@ struct FzScanArgs {
     uint32_t cand_cap;                          // automaton kernels: candidate slots per list (LDS)
     uint32_t lp_kind;                           // FzLpKind of fz_lp_kernel
     uint32_t lp_starts;                         // tiled modes: start positions owned by one window
+    uint32_t hash_k;                            // odd multiplier of the window hash (24 bits when L > 4)
+    uint32_t lut_shift;                         // table slot of a hash h = (h >> lut_shift) & 63
     uint32_t H[FZ_MAX_BLOCKS_PER_LAUNCH];       // fast-path hash of each block's n-gram
     uint32_t A[FZ_MAX_BLOCKS_PER_LAUNCH];       // 1st window value per block (little endian)
     uint32_t B[FZ_MAX_BLOCKS_PER_LAUNCH];       // 2nd window value per block
@@ -89,11 +90,15 @@ FZ_HD uint32_t fz_hit_block(uint64_t h) { return (uint32_t)(h >> 56); }
 FZ_HD uint64_t fz_hit_index(uint64_t h) { return h & 0x00ffffffffffffffull; }
 
 // Hash of the first min(L, 8) bytes of an n-gram window as the filter's fast path computes it:
-//   x  = bytes [0, 4)                  (little-endian dword)
-//   yh = low 24 bits of the dword at byte min(L, 8) - 3, i.e. bytes [min(L,8)-3, min(L,8))
-//   h  = yh * FZ_HASH_K + x            (one v_mad_u32_u24)
-// For L <= 4 the masked dword itself is used.  Collisions only cost a visit to the exact re-check.
-FZ_HD uint32_t fz_hash_windows(uint32_t x, uint32_t yh) { return (yh & 0xffffffu) * FZ_HASH_K + x; }
+//   L > 4:  x  = bytes [0, 4)                  (little-endian dword)
+//           yh = low 24 bits of the dword at byte min(L, 8) - 3, i.e. bytes [min(L,8)-3, min(L,8))
+//           h  = yh * K + x                    (one v_mad_u32_u24; K < 2^24)
+//   L <= 4: h  = (x & mask) * K                (K odd: a bijection of the masked dword)
+// Collisions only cost a visit to the exact re-check.
+// Six bits of h, (h >> lut_shift) & 63, select the slot of the block-hash table; the host picks K and
+// lut_shift per launch so that different block hashes use different slots.
+FZ_HD uint32_t fz_hash_windows(uint32_t x, uint32_t yh, uint32_t k) { return (yh & 0xffffffu) * (k & 0xffffffu) + x; }
+FZ_HD uint32_t fz_hash_short(uint32_t x_masked, uint32_t k) { return x_masked * k; }
 
 // ---------------------------------------------------------------------------------------------
 // Bounded edit-distance expansion == c_expand_short == c_expand_long (SURVEY.md trap 2):

@@ -3,9 +3,10 @@
 //   fz_scan_kernel    ONE streaming pass over the resident sequence:
 //     K1 filter   every byte offset is tested against all G n-gram blocks at once (replaces G x
 //                 search_exact_byteslike passes, _common.c:75-102 / memmem.c:92-160): a one-op
-//                 hash of the first min(L,8) window bytes is compared with SGPR constants,
-//                 pure VALU (v_alignbyte / v_mad_u32_u24 / v_xor / v_min3), one ballot per 4
-//                 offsets; survivors go through a per-wave LDS queue to an exact re-check;
+//                 hash of the first min(L,8) window bytes (v_alignbyte / v_mad_u32_u24) selects one
+//                 of 64 slots of a table in LDS that holds the blocks' hashes (ds_read_b32), one
+//                 v_xor compares, v_min3 accumulates, one ballot per 4 offsets: the cost does not
+//                 depend on G; survivors go through a per-wave LDS queue to an exact re-check;
 //     K2 verify   confirmed hits wait in a per-wave LDS staging area and are verified 64 at a
 //                 time, one lane per hit, inside the same kernel: the <= m+2k window bytes are
 //                 fetched once into LDS, then the bounded edit-distance expansion right and left
@@ -37,12 +38,17 @@
 #define FZ_PAD_FRONT 256                                   // zero bytes before buf[0]
 #define FZ_PAD_BACK 64                                     // zero bytes the kernels may over-read
 #define FZ_QCAP 256                                        // fast-hit queue entries per wave
+#define FZ_LUT_SLOTS 64u                                   // slots of the block-hash table (6 hash bits)
+#define FZ_LUT_BYTES (FZ_LUT_SLOTS * 4u)
 
 // 32-bit little-endian window starting `b` bytes into the 64-bit value hi:lo (v_alignbyte_b32).
 __device__ __forceinline__ uint32_t fz_win(uint32_t lo, uint32_t hi, int b) {
     return b == 0 ? lo : __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)b);
 }
 #define FZ_WIN(w, o) fz_win((w)[(o) >> 2], (w)[((o) >> 2) + 1], (o) & 3)
+
+typedef __attribute__((address_space(3))) const uint32_t FzLdsU32;   // LDS seen through a raw 32-bit LDS address
+typedef __attribute__((address_space(3))) uint8_t FzLdsU8;
 
 __device__ __forceinline__ uint32_t fz_lane() { return threadIdx.x & 63u; }
 
@@ -211,14 +217,16 @@ __device__ __forceinline__ bool fz_confirm(const uint8_t *__restrict__ buf, cons
 // workgroup reads was produced by agent-scope atomics (performed memory-side), __syncthreads() makes
 // each wave wait for its own outstanding atomics (s_waitcnt vmcnt(0)) before the ticket is taken,
 // and the counters are read back with agent-scope atomic loads.
-__device__ __forceinline__ void fz_publish_header(const FzScanArgs &a, unsigned long long *__restrict__ counters) {
+// `flag` is one LDS dword the workgroup no longer needs (no static __shared__ here: it would move the
+// dynamic LDS base off 0 and cost the scan an address add per table lookup).
+__device__ __forceinline__ void fz_publish_header(const FzScanArgs &a, unsigned long long *__restrict__ counters,
+                                                  volatile uint32_t *flag) {
     if (!a.host_hdr) return;
-    __shared__ uint32_t is_last;
-    __syncthreads();                                       // all waves' counter atomics are complete
+    __syncthreads();                                       // all waves' counter atomics are complete, LDS is free
     if (threadIdx.x == 0)
-        is_last = atomicAdd(&counters[FZ_HDR_TICKET], 1ull) == (unsigned long long)gridDim.x - 1ull;
+        *flag = atomicAdd(&counters[FZ_HDR_TICKET], 1ull) == (unsigned long long)gridDim.x - 1ull;
     __syncthreads();
-    if (is_last) {
+    if (*flag) {
         unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.host_hdr);
         for (uint32_t i = threadIdx.x; i < FZ_HDR_WORDS; i += blockDim.x)
             dst[i] = __hip_atomic_load(&counters[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -274,11 +282,17 @@ __device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ b
     return confirmed;
 }
 
-// TG    : number of n-gram blocks compiled in (hash constants live in SGPRs); nblk <= TG are real.
-// NWIN  : 1 -> the (masked) dword at the offset is its own hash (L <= 4);
-//         2 -> hash = low24(dword at offset + DH) * K + dword at offset, DH = min(L, 8) - 3.
+// TG    : blocks the rare path tells apart (unrolled compares); nblk <= TG are real, the rest repeat block 0
+//         and are dropped by the range check.  The hot path does not depend on it.
+// NWIN  : 1 -> hash = (masked dword at the offset) * K               (L <= 4, v_mul_lo_u32);
+//         2 -> hash = low24(dword at offset + DH) * K + dword at offset (v_mad_u32_u24), DH = min(L, 8) - 3.
 // FUSED : verify candidates inside this kernel (records out) or emit exact hits (hit list out).
 // Each thread owns 16 consecutive byte offsets per row and reads 24 bytes (16 + 8 halo).
+// Block test: slot = top 6 bits of the hash; lut[slot] holds the hash of the block that lives there
+// (the host picks K so that different block hashes get different slots) or, for a free slot, a value
+// that belongs to another slot, so hash ^ lut[slot] == 0 <=> the window hashes like some block.
+// Measured against per-block VALU compares (benchmarks/filter_variants.hip, v3 vs v14, 3 blocks,
+// L2-resident data): 0.222 -> 0.175 ms per GiB, and no longer growing with the number of blocks.
 // Fast hits are queued per wave ACROSS tiles and processed 64 at a time (full lanes, one latency
 // chain per ~100 candidates instead of one per tile).  A tile denser than the queue is re-scanned
 // by enumeration ("slow tile": correctness path for pathological inputs).
@@ -288,16 +302,32 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) void fz_scan_kernel(
     uint64_t *__restrict__ hits, FzRec *__restrict__ recs, unsigned long long *__restrict__ counters) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t mpad = (a.m + 15u) & ~15u;
-    uint8_t *pat_lds = smem;
+    // [64] hash living in the slot.  The kernel has no static LDS, so the dynamic area, and with it this
+    // table, starts at LDS address 0 and a slot's byte offset is its address (saves one VALU add per
+    // lookup); trap if a toolchain ever lays LDS out differently.
+    uint32_t *lut = reinterpret_cast<uint32_t *>(smem);
+    if (reinterpret_cast<uintptr_t>((FzLdsU8 *)smem) != 0) __builtin_trap();
+    uint8_t *pat_lds = smem + FZ_LUT_BYTES;
     for (uint32_t i = threadIdx.x; i < a.m; i += FZ_FILTER_THREADS) pat_lds[i] = a.pat[i];
-    __syncthreads();
-    const FzWaveLds w = fz_wave_lds(smem + mpad, threadIdx.x >> 6, FUSED ? a.win_dwords : 0u,
-                                    FUSED ? a.band_w : 0u, a.vlanes, true);
-    // Block hashes live in VGPRs on purpose: on gfx950 a v_xor_b32 with an SGPR operand issues at
-    // ~4.5 cycles per wave, a VGPR-only one at ~2.6 (benchmarks/valu_rates.hip).
-    uint32_t H[TG];
+    if (threadIdx.x < FZ_LUT_SLOTS) {
+        uint32_t t = ((threadIdx.x + 1u) & (FZ_LUT_SLOTS - 1u)) << a.lut_shift;   // free slot: a value of the next slot
+        for (uint32_t g = 0; g < a.nblk; ++g)
+            if (((a.H[g] >> a.lut_shift) & (FZ_LUT_SLOTS - 1u)) == threadIdx.x) t = a.H[g];
+        lut[threadIdx.x] = t;
+    }
+    // lane g of hvec = hash of block g: the rare path reads it back with v_readlane (no memory latency)
+    uint32_t hvec = 0;
 #pragma unroll
-    for (int g = 0; g < TG; ++g) asm volatile("v_mov_b32 %0, %1" : "=v"(H[g]) : "s"(a.H[g]));
+    for (uint32_t g = 0; g < FZ_MAX_BLOCKS_PER_LAUNCH; ++g)
+        if (fz_lane() == g) hvec = a.H[g];
+    __syncthreads();
+    const FzWaveLds w = fz_wave_lds(smem + FZ_LUT_BYTES + mpad, threadIdx.x >> 6, FUSED ? a.win_dwords : 0u,
+                                    FUSED ? a.band_w : 0u, a.vlanes, true);
+    const uint32_t hash_k = a.hash_k;
+    // byte address of a hash's slot = (h >> (lut_shift - 2)) & 0xfc: two VGPR-only VALU ops (a shift
+    // amount in an SGPR or an SDWA byte select would issue at half the rate, benchmarks/valu_rates.hip)
+    uint32_t slot_shift;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(slot_shift) : "s"(a.lut_shift - 2u));
     const uint32_t mask1 = a.mask1;
     const uint32_t lane = fz_lane();
     const uint32_t lane_off = threadIdx.x * 16u;
@@ -342,28 +372,29 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) void fz_scan_kernel(
                         for (int i = 0; i < 4; ++i) {
                             const int o = 4 * j + i;
                             const uint32_t x = FZ_WIN(w6, o);
-                            if (NWIN == 1) hv[i] = x & mask1;
-                            else hv[i] = __umul24(FZ_WIN(w6, o + DH), FZ_HASH_K) + x;   // v_mad_u32_u24
-                            am[i] = 0xffffffffu;
-#pragma unroll
-                            for (int g = 0; g < TG; ++g) am[i] = min(am[i], hv[i] ^ H[g]);  // v_xor + v_min3
+                            if (NWIN == 1) hv[i] = (x & mask1) * hash_k;                             // v_mul_lo_u32
+                            else hv[i] = __umul24(FZ_WIN(w6, o + DH), hash_k) + x;                   // v_mad_u32_u24
+                            uint32_t slot4;
+                            asm("v_lshrrev_b32 %0, %1, %2\n\tv_and_b32 %0, 0xfc, %0" : "=v"(slot4) : "v"(slot_shift), "v"(hv[i]));
+                            am[i] = hv[i] ^ *reinterpret_cast<FzLdsU32 *>(slot4);   // lut sits at LDS address 0
                         }
                         const uint32_t acc = min(min(am[0], am[1]), min(am[2], am[3]));
-                        if (__builtin_expect(__ballot(acc == 0) != 0, 0)) {   // wave-uniform, rare: some lane, some offset, some block
+                        if (__builtin_expect(__ballot(acc == 0) != 0, 0)) {   // wave-uniform, rare: some lane, some offset
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
                                 if (__ballot(am[i] == 0)) {           // which offset (scalar branch)
 #pragma unroll
-                                    for (int g = 0; g < TG; ++g) {
-                                        const unsigned long long mk = __ballot(hv[i] == H[g]);
-                                        if (mk) {     // which block (scalar branch)
+                                    for (int g = 0; g < TG; ++g) {    // which block(s): equal n-grams share a slot
+                                        const uint32_t hg = (uint32_t)__builtin_amdgcn_readlane((int)hvec, g);
+                                        const unsigned long long mk = __ballot(hv[i] == hg);
+                                        if (mk) {
                                             const uint32_t slot = qn + fz_rank(mk);
-                                            // the empty asm keeps LICM from hoisting 64 * TG
-                                            // loop-invariant queue codes into VGPRs
+                                            // the empty asm keeps LICM from hoisting the loop-invariant
+                                            // queue codes into VGPRs
                                             uint32_t code = lane_off;
                                             asm volatile("" : "+v"(code));
                                             code = fz_code(code + (uint32_t)(r * FZ_ROW_BYTES + 4 * j + i), (uint32_t)g, titer);
-                                            if (hv[i] == H[g] && slot < FZ_QCAP) w.queue[slot] = code;
+                                            if (hv[i] == hg && slot < FZ_QCAP) w.queue[slot] = code;
                                             qn += (uint32_t)__popcll(mk);
                                         }
                                     }
@@ -387,7 +418,7 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) void fz_scan_kernel(
         if (!slow && tile >= ntiles) break;
     }
     if (FUSED && lane == 0 && confirmed) atomicAdd(&counters[8 + (blockIdx.x & 63u)], (unsigned long long)confirmed);
-    fz_publish_header(a, counters);
+    fz_publish_header(a, counters, lut);
 }
 
 // Verification of a hit list in HBM (parameter ranges whose LDS footprint does not fit beside the
@@ -411,7 +442,7 @@ __global__ void fz_verify_kernel(const uint8_t *__restrict__ buf, const FzScanAr
         const uint64_t hit = valid ? hits[q] : 0;
         fz_wave_verify<FZ_REG_BAND_MAX>(buf, a, pat_lds, w, hit, valid, recs, counters);
     }
-    fz_publish_header(a, counters);
+    fz_publish_header(a, counters, reinterpret_cast<uint32_t *>(smem));
 }
 
 // ---------------------------------------------------------------------------------------------

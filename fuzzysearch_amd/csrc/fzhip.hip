@@ -188,6 +188,12 @@ int pick_tg(uint32_t nblk) {
     return nblk <= 6 ? 6 : 8;
 }
 
+// Odd multipliers tried for the window hash (24-bit ones serve v_mad_u32_u24).  One search needs a
+// multiplier under which its (at most 8 per launch) distinct block hashes fall into distinct slots of
+// the 64-slot table: a random one works with probability 0.95 for 3 blocks, 0.63 for 8.
+const uint32_t kHashMultipliers[] = {0x9E3779u, 0x85EBCBu, 0xC2B2AFu, 0x27D4EBu, 0x165667u, 0xD3A264u | 1u, 0xFD7047u, 0xB55A4Fu,
+                                     0x7FEB35u, 0x846CA7u, 0x9E6C63u, 0x3243F7u, 0x517CC1u, 0xB7E151u, 0x6A09E7u, 0xBB67AFu};
+
 struct Search {
     uint32_t mode = 0, m = 0, k = 0;
     uint32_t max_subs = 0, max_ins = 0, max_dels = 0;      // generic search only
@@ -250,38 +256,67 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     // 64 lanes -> 31.6 KB LDS, 5 workgroups/CU, scan 0.540 ms; candidates are rare there anyway).
     static const uint32_t target = []() { const char *e = getenv("FZ_FUSED_TARGET_KB"); int v = e ? atoi(e) : 0; return (uint32_t)(v > 0 ? v : 18) * 1024u; }();
     fa.vlanes = 64;
-    while (fa.vlanes > 16 && mpad + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, fa.vlanes, true) > target)
+    while (fa.vlanes > 16 && mpad + FZ_LUT_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, fa.vlanes, true) > target)
         fa.vlanes >>= 1;
-    const uint32_t fused_lds = mpad + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, fa.vlanes, true);
+    const uint32_t fused_lds = mpad + FZ_LUT_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, fa.vlanes, true);
     // k > 4 (register band too wide for the scan kernel's VGPR budget) -> verify in fz_verify_kernel
     fa.fused = (with_verify && fused_lds <= kFusedLdsBudget && (q.mode != FZ_MODE_LEV || q.k <= 4)) ? 1u : 0u;
-    const uint32_t scan_lds = fa.fused ? fused_lds : mpad + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(0, 0, 64, true);
+    const uint32_t scan_lds = fa.fused ? fused_lds : mpad + FZ_LUT_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(0, 0, 64, true);
 
     uint32_t launches = 0;
-    for (uint32_t g0 = 0; g0 < G && ntiles > 0; g0 += FZ_MAX_BLOCKS_PER_LAUNCH) {
-        const uint32_t nblk = std::min<uint32_t>(FZ_MAX_BLOCKS_PER_LAUNCH, G - g0);
+    for (uint32_t g0 = 0; g0 < G && ntiles > 0;) {
+        // Blocks [g0, g0 + nblk) of this launch and the hash multiplier: the longest run of blocks (at
+        // most 8) whose distinct hashes land in distinct table slots under some multiplier.  One block
+        // always fits; equal n-grams (equal hashes) share a slot.
+        uint32_t nblk = 0;
+        for (uint32_t cand : kHashMultipliers) {
+            const uint32_t kk = nwin == 2 ? cand : (cand * 0x9E3779B1u) | 1u;
+            uint32_t hb[FZ_MAX_BLOCKS_PER_LAUNCH];
+            uint32_t nb = 0;
+            for (; nb < FZ_MAX_BLOCKS_PER_LAUNCH && g0 + nb < G; ++nb) {
+                const uint8_t *ng = q.p + q.plan.s[g0 + nb];
+                const uint32_t a1 = load_le32(ng, L) & fa.mask1;
+                hb[nb] = nwin == 2 ? fz_hash_windows(a1, load_le32(ng + dh, 3), kk) : fz_hash_short(a1, kk);
+            }
+            // h = yh * K + x mixes x only through the addition: which six bits tell the blocks apart
+            // depends on where their bytes differ, so the slot bits are a per-launch choice as well
+            for (int shift = 26; shift >= 2; shift -= 6) {
+                uint32_t slot_hash[FZ_LUT_SLOTS];
+                bool used[FZ_LUT_SLOTS] = {false};
+                uint32_t fit = 0;
+                for (; fit < nb; ++fit) {
+                    const uint32_t slot = (hb[fit] >> shift) & (FZ_LUT_SLOTS - 1u);
+                    if (used[slot] && slot_hash[slot] != hb[fit]) break;
+                    used[slot] = true;
+                    slot_hash[slot] = hb[fit];
+                }
+                if (fit > nblk) { nblk = fit; fa.hash_k = kk; fa.lut_shift = (uint32_t)shift; }
+            }
+            if (nblk == FZ_MAX_BLOCKS_PER_LAUNCH || g0 + nblk == G) break;
+        }
         fa.nblk = nblk;
         fa.g0 = g0;
-        const int tg = pick_tg(nblk);
-        for (int b = 0; b < tg; ++b) {
-            const uint32_t src = (uint32_t)b < nblk ? g0 + b : g0;   // pad with a copy of block 0
-            const uint8_t *ng = q.p + q.plan.s[src];
+        for (uint32_t b = 0; b < nblk; ++b) {
+            const uint8_t *ng = q.p + q.plan.s[g0 + b];
             fa.A[b] = load_le32(ng, L) & fa.mask1;
             fa.B[b] = nwin == 2 ? load_le32(ng + fa.d2, 4) : 0;
-            fa.H[b] = nwin == 2 ? fz_hash_windows(fa.A[b], load_le32(ng + dh, 3)) : fa.A[b];
-            fa.lo[b] = q.plan.lo[src];
-            fa.hi[b] = q.plan.hi[src];
-            fa.s[b] = q.plan.s[src];
+            fa.H[b] = nwin == 2 ? fz_hash_windows(fa.A[b], load_le32(ng + dh, 3), fa.hash_k) : fz_hash_short(fa.A[b], fa.hash_k);
+            fa.lo[b] = q.plan.lo[g0 + b];
+            fa.hi[b] = q.plan.hi[g0 + b];
+            fa.s[b] = q.plan.s[g0 + b];
         }
+        const int tg = pick_tg(nblk);
+        for (int b = (int)nblk; b < tg; ++b) fa.H[b] = fa.H[0];      // compiled-in spare blocks: dropped by the range check
         // the final kernel of the search publishes the counters to the host (direct mode)
         const bool verify_follows = with_verify && !fa.fused;
-        fa.host_hdr = (direct && !verify_follows && g0 + FZ_MAX_BLOCKS_PER_LAUNCH >= G) ? reinterpret_cast<uint64_t>(d.h_stage_dev) : 0;
+        fa.host_hdr = (direct && !verify_follows && g0 + nblk >= G) ? reinterpret_cast<uint64_t>(d.h_stage_dev) : 0;
         ScanKernel kern = scan_kernel(tg, nwin, dh, fa.fused != 0);
         static const uint32_t extra_lds = []() { const char *e = getenv("FZ_EXTRA_LDS_KB"); return e ? (uint32_t)atoi(e) * 1024u : 0u; }();
         hipLaunchKernelGGL(kern, grid, dim3(FZ_FILTER_THREADS), scan_lds + extra_lds, d.stream, sh.d_buf, fa, ntiles, d.d_hits, recs,
                            counters);
         HIP_TRY(hipGetLastError());
         ++launches;
+        g0 += nblk;
     }
     HIP_TRY(hipEventRecord(d.ev[1], d.stream));
     d.verify_launched = false;
