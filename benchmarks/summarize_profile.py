@@ -7,11 +7,24 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 base = os.path.join(root, "gpurun_out", "prof_" + tag)
 alg = int(sys.argv[2]) if len(sys.argv) > 2 else 2 ** 30
 stats = glob.glob(os.path.join(base, "stats", "*", "*_kernel_stats.csv"))[0]
-shutil.copy(stats, os.path.join(root, "profiles", tag + "_kernel_stats.csv"))
+shutil.copy(stats, os.path.join(root, "profiles", tag + "_rocprof_kernel_stats.csv"))
+# rocprofv3's own --stats table covered only the last few dispatches of the run (12 of 510 here), so the
+# per-kernel table that is committed is rebuilt from the full --kernel-trace of the same run
+trace = glob.glob(os.path.join(base, "stats", "*", "*_kernel_trace.csv"))[0]
+per = collections.defaultdict(list)
+for r in csv.DictReader(open(trace)):
+    per[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+total = sum(sum(v) for v in per.values())
+with open(os.path.join(root, "profiles", tag + "_kernel_stats.csv"), "w", newline="") as f:
+    wr = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)
+    wr.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "MedianNs"])
+    for name, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+        vs = sorted(v)
+        wr.writerow([name, len(v), sum(v), round(sum(v) / len(v), 1), round(100.0 * sum(v) / total, 2), vs[0], vs[-1], vs[len(vs) // 2]])
 avg_ns = None
-for r in csv.DictReader(open(stats)):
-    if "fz_scan" in r["Name"]:
-        avg_ns, kname, calls = float(r["AverageNs"]), r["Name"], int(r["Calls"])
+for name, v in per.items():
+    if "fz_scan" in name:
+        avg_ns, kname, calls = sum(v) / len(v), name, len(v)
 out = {}
 for d in sorted(glob.glob(os.path.join(base, "pmc*"))):
     if not os.path.isdir(d):
@@ -47,8 +60,7 @@ summary = {
         "salu_ops_per_sequence_byte_x64": out["SQ_INSTS_SALU"] * 64 / alg,
         "wave_cycle_split": {k: out[c] / out["SQ_WAVE_CYCLES"] for k, c in
                              (("active", "SQ_ACTIVE_INST_ANY"), ("wait_any", "SQ_WAIT_ANY"), ("wait_inst_any", "SQ_WAIT_INST_ANY"))},
-        "effective_clock_ghz_under_profiler": out["GRBM_GUI_ACTIVE"] / 8 / (avg_ns * 1e-9) / 1e9,
-        "achieved_GBps_under_profiler": alg / (avg_ns * 1e-9) / 1e9,
+        "achieved_GBps_kernel_trace": alg / (avg_ns * 1e-9) / 1e9,
     },
 }
 json.dump(summary, open(os.path.join(root, "profiles", tag + "_pmc_summary.json"), "w"), indent=1)
