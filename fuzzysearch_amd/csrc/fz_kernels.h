@@ -159,8 +159,17 @@ __device__ __forceinline__ uint32_t fz_wave_verify(const uint8_t *__restrict__ b
     }
     const uint32_t nd = valid ? (uint32_t)((whi - wbase + 3) >> 2) : 0u;
     const int64_t lbase = (int64_t)(wbase - a.geom.buf_off);
-    for (uint32_t d = 0; d < a.win_dwords; ++d)
-        if (d < nd) w.win[d * a.vlanes + lane] = *reinterpret_cast<const uint32_t *>(buf + lbase + (int64_t)d * 4);
+    // eight loads in flight per lane, then eight LDS stores (a load-store loop would pay the HBM/L2
+    // round trip once per dword: 8 - 21 serial round trips per flush)
+    for (uint32_t d0 = 0; d0 < a.win_dwords; d0 += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j)
+            v[j] = (d0 + j < nd) ? *reinterpret_cast<const uint32_t *>(buf + lbase + (int64_t)(d0 + j) * 4) : 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j)
+            if (d0 + j < nd) w.win[(d0 + j) * a.vlanes + lane] = v[j];
+    }
     fz_wave_lds_sync();
     FzRec rec;
     bool ok = false;

@@ -269,11 +269,15 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
         // most 8) whose distinct hashes land in distinct table slots under some multiplier.  One block
         // always fits; equal n-grams (equal hashes) share a slot.
         uint32_t nblk = 0;
+        // FZ_MAX_BLOCKS=n (test knob): at most n blocks per launch, to exercise the multi-launch path
+        const char *cap_env = getenv("FZ_MAX_BLOCKS");
+        const uint32_t max_blocks = cap_env && atoi(cap_env) > 0 ? std::min<uint32_t>((uint32_t)atoi(cap_env), FZ_MAX_BLOCKS_PER_LAUNCH)
+                                                                 : FZ_MAX_BLOCKS_PER_LAUNCH;
         for (uint32_t cand : kHashMultipliers) {
             const uint32_t kk = nwin == 2 ? cand : (cand * 0x9E3779B1u) | 1u;
             uint32_t hb[FZ_MAX_BLOCKS_PER_LAUNCH];
             uint32_t nb = 0;
-            for (; nb < FZ_MAX_BLOCKS_PER_LAUNCH && g0 + nb < G; ++nb) {
+            for (; nb < max_blocks && g0 + nb < G; ++nb) {
                 const uint8_t *ng = q.p + q.plan.s[g0 + nb];
                 const uint32_t a1 = load_le32(ng, L) & fa.mask1;
                 hb[nb] = nwin == 2 ? fz_hash_windows(a1, load_le32(ng + dh, 3), kk) : fz_hash_short(a1, kk);
@@ -292,7 +296,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
                 }
                 if (fit > nblk) { nblk = fit; fa.hash_k = kk; fa.lut_shift = (uint32_t)shift; }
             }
-            if (nblk == FZ_MAX_BLOCKS_PER_LAUNCH || g0 + nblk == G) break;
+            if (nblk == max_blocks || g0 + nblk == G) break;
         }
         fa.nblk = nblk;
         fa.g0 = g0;

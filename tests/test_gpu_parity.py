@@ -157,6 +157,25 @@ def test_result_staging_mode_switches(engine):
     hd.release(); hs.release()
 
 
+def test_blocks_split_over_several_launches(engine, monkeypatch):
+    """Blocks whose hashes cannot share the slot table go to separate scan launches; FZ_MAX_BLOCKS
+    forces that split (1 and 2 blocks per launch) for the fused, the emit + verify and the
+    substitutions paths; only the last launch publishes the counters."""
+    t = workloads.dna(1 << 20, 21).tobytes()
+    pats = [(workloads.dna(20, 1).tobytes(), 2), (workloads.dna(23, 5).tobytes(), 5), (workloads.dna(32, 3).tobytes(), 3)]
+    for p, _k in pats:
+        t = t[:5000] + p + t[5000:70000] + p[:7] + p[8:] + t[70000:]
+    h = engine.upload(t)
+    for cap in ("1", "2"):
+        monkeypatch.setenv("FZ_MAX_BLOCKS", cap)
+        for p, k in pats:
+            assert engine.lev_ngrams(h, p, k) == oracle.lev_ngrams_raw(p, t, k)
+            assert engine.subs_ngrams(h, p, k) == oracle.subs_ngrams_raw(p, t, k)
+        assert engine.stats()["filter_launches"] >= 2
+    monkeypatch.delenv("FZ_MAX_BLOCKS")
+    h.release()
+
+
 def test_sharded_equals_unsharded(engine):
     """Two shards with (m + k) halos, hits owned by index == one sequence."""
     rnd = random.Random(21)
