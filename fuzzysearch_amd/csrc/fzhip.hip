@@ -1235,6 +1235,26 @@ int fz_consolidate(const fz_match *in, uint64_t n, fz_match **out, uint64_t *n_o
     return FZ_OK;
 }
 
+int fz_merge_ranks(const fz_match *const *parts, const uint64_t *counts, const uint64_t *block_counts,
+                   uint32_t world, uint32_t nb, fz_match *out) {
+    if (!parts || !counts || !block_counts || !out) return fail(FZ_EINVAL, "null argument");
+    std::vector<uint64_t> pos(world, 0);                       // read position inside every rank's stream
+    for (uint32_t r = 0; r < world; ++r) {
+        uint64_t sum = 0;
+        for (uint32_t g = 0; g < nb; ++g) sum += block_counts[(size_t)r * nb + g];
+        if (sum != counts[r]) return fail(FZ_EINVAL, "rank %u: block counts do not add up to its record count", r);
+    }
+    uint64_t o = 0;
+    for (uint32_t g = 0; g < nb; ++g)
+        for (uint32_t r = 0; r < world; ++r) {
+            const uint64_t c = block_counts[(size_t)r * nb + g];
+            if (c) memcpy(out + o, parts[r] + pos[r], c * sizeof(fz_match));
+            o += c;
+            pos[r] += c;
+        }
+    return FZ_OK;
+}
+
 // Faithful group-list-order version (common.py:161-177), needed by the substitutions-only path.
 int fz_group_best(const fz_match *in, uint64_t n, fz_match **out, uint64_t *n_out) {
     if (!out || !n_out || (!in && n)) return fail(FZ_EINVAL, "null argument");

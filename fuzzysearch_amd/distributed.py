@@ -104,31 +104,33 @@ def _as_match_array(raw):
 def merge_rank_arrays(parts, block_counts=None):
     """parts[r] = rank r's fz_match array in reference order (block-major, index ascending within a
     block), ranks owning ascending index ranges -> one array in the global reference order: for every
-    block, the ranks' segments of that block back to back (no sort: O(total) copies on int64 views).
+    block, the ranks' segments of that block back to back (fz_merge_ranks: no sort, O(total) copies).
     block_counts[r][g] (optional) = number of rank r's records of block g."""
     world = len(parts)
+    parts = [np.ascontiguousarray(p, dtype=MATCH_DTYPE) for p in parts]
     if block_counts is None:
         nb = max([int(p["block"][-1]) + 1 for p in parts if len(p)] or [0])
-        block_counts = np.zeros((world, nb), dtype=np.int64)
+        block_counts = np.zeros((world, nb), dtype=np.uint64)
         for r, p in enumerate(parts):
             if len(p):
                 block_counts[r, :] = np.bincount(p["block"], minlength=nb)[:nb]
-    block_counts = np.asarray(block_counts, dtype=np.int64)
-    total = int(block_counts.sum())
-    out = np.empty((total, 3), dtype=np.int64)
-    if total:
-        src_off = np.zeros_like(block_counts)
-        src_off[:, 1:] = np.cumsum(block_counts, axis=1)[:, :-1]        # segment start inside rank r's array
-        dst_off = np.cumsum(block_counts.T.reshape(-1)) - block_counts.T.reshape(-1)   # (g, r) order
-        views = [np.ascontiguousarray(p).view(np.int64).reshape(-1, 3) if len(p) else None for p in parts]
-        nb = block_counts.shape[1]
-        for g in range(nb):
-            for r in range(world):
-                c = int(block_counts[r, g])
-                if c:
-                    d0, s0 = int(dst_off[g * world + r]), int(src_off[r, g])
-                    out[d0:d0 + c] = views[r][s0:s0 + c]
-    return out.reshape(-1).view(MATCH_DTYPE)
+    addrs = [p.__array_interface__["data"][0] for p in parts]
+    return _merge_native(addrs, [len(p) for p in parts], block_counts)
+
+
+def _merge_native(addrs, counts, block_counts):
+    """addrs[r] = address of rank r's first fz_match record (24-byte rows), counts[r] = how many."""
+    import ctypes
+    from . import _native
+    world = len(addrs)
+    bc = np.ascontiguousarray(block_counts, dtype=np.uint64).reshape(world, -1)
+    cnt = np.asarray(counts, dtype=np.uint64)
+    out = np.empty(int(cnt.sum()), dtype=MATCH_DTYPE)
+    ptrs = (ctypes.c_void_p * world)(*addrs)
+    _native._check(_native.load_library().fz_merge_ranks(
+        ptrs, cnt.__array_interface__["data"][0], bc.__array_interface__["data"][0], world, bc.shape[1],
+        out.__array_interface__["data"][0]))
+    return out
 
 
 _HDR_ROWS = 1 + 86        # row 0: [count, nblocks, 0]; rows 1..86: per-block counts, three per row (<= 255 blocks)
@@ -186,11 +188,18 @@ def allgather_matches(raw, group=None, as_array=False):
             dist.all_gather(list(st["h_recv"].unbind(0)), st["h_send"], group=group)
         host = st["h_recv"].numpy()
         counts = host[:, 0, 0]
-        if int(counts.max()) <= cap:
+        top = int(counts.max())
+        if top <= cap:
             nb = int(host[:, 0, 1].max())
             block_counts = host[:, 1:_HDR_ROWS].reshape(world, -1)[:, :nb]
-            parts = [host[r, _HDR_ROWS:_HDR_ROWS + int(counts[r])].reshape(-1).view(MATCH_DTYPE) for r in range(world)]
-            merged = merge_rank_arrays(parts, block_counts)
+            base = host.__array_interface__["data"][0]
+            stride = host.strides[0]
+            merged = _merge_native([base + r * stride + _HDR_ROWS * 24 for r in range(world)], counts, block_counts)
+            # keep the exchanged block near the size that is used (every rank sees the same counts, so
+            # every rank resizes identically): the collective and the D2H copy move `cap` rows per rank
+            want = max(256, -(-(top + top // 8) // 128) * 128)
+            if want * 4 <= cap * 3:
+                _gather_state[key] = {"cap": want, "world": -1}
             if as_array:
                 return merged
             out = np.empty((len(merged), 4), dtype=np.int64)

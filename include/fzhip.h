@@ -142,6 +142,14 @@ int fz_consolidate(const fz_match *in, uint64_t n, fz_match **out, uint64_t *n_o
  * substitutions_only.py:279-282 exposes.  Input order matters. */
 int fz_group_best(const fz_match *in, uint64_t n, fz_match **out, uint64_t *n_out);
 
+/* Multi-process jobs (one rank per GPU): merge the raw streams of `world` ranks,
+ * each already in reference order (block-major, index ascending) and owning an ascending index range,
+ * into the global reference order: for every block, the ranks' segments of that block back to back.
+ * No sort, O(total) copies.  parts[r] / counts[r] = rank r's records; block_counts[r * nb + g] = how
+ * many of them belong to block g.  `out` must hold sum(counts) records.  Needs no device. */
+int fz_merge_ranks(const fz_match *const *parts, const uint64_t *counts, const uint64_t *block_counts,
+                   uint32_t world, uint32_t nb, fz_match *out);
+
 int  fz_stats(fz_ctx *ctx, fz_stats_t *out);
 void fz_free(void *p);
 
