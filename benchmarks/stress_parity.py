@@ -1,0 +1,62 @@
+"""Opt-in randomized GPU-vs-oracle stress beyond the pytest suite (run on the GPU box):
+    python benchmarks/stress_parity.py [seconds] [seed]
+Random alphabets (2 .. 256 symbols, zero bytes included), pattern lengths up to 300, budgets up to 12,
+repeated / identical blocks, planted edits; Levenshtein, substitutions, exact and generic raw streams
+must equal the oracle's bit for bit and in order."""
+import os, random, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import oracle
+from fuzzysearch_amd import _native
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rnd = random.Random(seed)
+eng = _native.Engine([0])
+t_end = time.time() + budget
+n_cases = n_recs = n_unsupported = 0
+while time.time() < t_end:
+    sigma = rnd.choice([1, 2, 2, 3, 4, 4, 5, 20, 64, 256])
+    alpha = bytes(rnd.sample(range(256), sigma))
+    n = rnd.choice([0, 5, 50, 500, 5000, 60000, 300000])
+    t = bytes(rnd.choice(alpha) for _ in range(min(n, 3000)))
+    if n > 3000:
+        t = (t * (n // len(t) + 1))[:n] if rnd.random() < 0.3 else bytes(rnd.choices(alpha, k=n))
+    k = rnd.choice([0, 1, 1, 2, 2, 3, 4, 5, 7, 12])
+    m = rnd.randint(k + 1, max(k + 1, rnd.choice([8, 24, 64, 300])))
+    if rnd.random() < 0.5 and len(t) >= m:
+        st = rnd.randint(0, len(t) - m)
+        p = bytearray(t[st:st + m])
+        for _ in range(rnd.randint(0, k)):
+            q = rnd.randrange(len(p)); op = rnd.random()
+            if op < 0.4: p[q] = rnd.choice(alpha)
+            elif op < 0.7 and len(p) > k + 1: del p[q]
+            else: p.insert(q, rnd.choice(alpha))
+        p = bytes(p)
+    elif rnd.random() < 0.3:
+        blk = bytes(rnd.choice(alpha) for _ in range(max(1, m // (k + 1))))
+        p = (blk * (m // len(blk) + 1))[:m]                     # identical n-gram blocks
+    else:
+        p = bytes(rnd.choice(alpha) for _ in range(m))
+    if len(p) // (k + 1) == 0:
+        continue
+    h = eng.upload(t)
+    tag = (sigma, len(t), len(p), k)
+    got = eng.lev_ngrams(h, p, k); exp = oracle.lev_ngrams_raw(p, t, k)
+    assert got == exp, ("lev", tag, p, seed)
+    n_recs += len(got)
+    got = eng.subs_ngrams(h, p, k); exp = oracle.subs_ngrams_raw(p, t, k)
+    assert got == exp, ("subs", tag, p, seed)
+    if len(t) <= 60000:
+        assert eng.search_exact(h, p[:max(1, len(p) // 3)]) == oracle.search_exact(p[:max(1, len(p) // 3)], t), ("exact", tag)
+        if k and len(t) <= 5000:
+            lim = (rnd.randint(0, k), rnd.randint(0, k), rnd.randint(0, k), k)
+            try:
+                got = eng.generic_ngrams(h, p, *lim)
+            except NotImplementedError:                       # candidate sets beyond the LDS lists: documented limit
+                n_unsupported += 1
+            else:
+                assert got == oracle.generic_ngrams_raw(p, t, *lim), ("generic", tag, lim, p)
+    h.release()
+    n_cases += 1
+print("stress_parity: %d cases, %d Levenshtein records compared, %d generic cases beyond the LDS candidate lists, seed %d: all equal"
+      % (n_cases, n_recs, n_unsupported, seed))
