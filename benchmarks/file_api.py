@@ -9,6 +9,7 @@ workloads.plant_variants(seq, pat, 64 * mib // 64, 5)
 with tempfile.NamedTemporaryFile(delete=False) as f:
     f.write(seq.tobytes()); name = f.name
 try:
+    fa.find_near_matches(pat.tobytes(), seq[:1 << 20].tobytes(), max_l_dist=2)     # engine start-up is not file throughput
     for cs in (1 << 20, 1 << 24):
         with open(name, 'rb') as f:
             t0 = time.perf_counter(); r = fa.find_near_matches_in_file(pat.tobytes(), f, max_l_dist=2, _chunk_size=cs); dt = time.perf_counter() - t0
