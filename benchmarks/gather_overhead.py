@@ -26,10 +26,11 @@ t(lambda: st["d_send"].copy_(st["h_send"], non_blocking=True), "H2D staging (asy
 t(lambda: dist.all_gather(list(st["d_recv"].unbind(0)), st["d_send"]), "all_gather (list api)")
 t(lambda: dist.all_gather_into_tensor(st["d_recv"], st["d_send"]), "all_gather_into_tensor")
 t(lambda: (st["h_recv"].copy_(st["d_recv"], non_blocking=True), torch.cuda.current_stream().synchronize()), "D2H + sync")
-host = st["h_recv"].numpy()
-H = fzd._HDR_ROWS
-t(lambda: fzd.merge_rank_arrays([host[0, H:H + n].reshape(-1).view(fzd.MATCH_DTYPE)]), "merge (1 rank)")
-parts = [host[0, H:H + n].reshape(-1).view(fzd.MATCH_DTYPE)] * 8
-bc = np.tile(np.bincount(raw["block"], minlength=3), (8, 1))
-t(lambda: fzd.merge_rank_arrays(parts, bc), "merge (8 ranks, counts known)")
+import ctypes
+from fuzzysearch_amd import _native
+lib = _native.load_library()
+t(lambda: lib.fz_wire_pack(raw.__array_interface__["data"][0], n, st["cap"], st["send_ptr"]), "fz_wire_pack")
+out = np.empty(st["cap"], dtype=fzd.MATCH_DTYPE); tot, top = ctypes.c_uint64(), ctypes.c_uint64()
+t(lambda: lib.fz_wire_merge(st["recv_ptr"], 1, st["rows"], st["cap"], out.__array_interface__["data"][0], len(out),
+                            ctypes.byref(tot), ctypes.byref(top)), "fz_wire_merge (1 rank)")
 dist.destroy_process_group()

@@ -1255,6 +1255,69 @@ int fz_merge_ranks(const fz_match *const *parts, const uint64_t *counts, const u
     return FZ_OK;
 }
 
+namespace {
+struct WireRow { int64_t start; uint32_t len; uint16_t dist; uint16_t block; };
+struct WireHeader { uint64_t count, nblocks; uint32_t per_block[256]; };
+static_assert(sizeof(WireRow) == 16 && sizeof(WireHeader) == FZ_WIRE_HEADER_ROWS * 16, "wire layout");
+}  // namespace
+
+int fz_wire_pack(const fz_match *in, uint64_t n, uint64_t cap_rows, void *dst) {
+    if ((!in && n) || !dst) return fail(FZ_EINVAL, "null argument");
+    WireHeader *h = static_cast<WireHeader *>(dst);
+    WireRow *rows = reinterpret_cast<WireRow *>(h + 1);
+    memset(h, 0, sizeof *h);
+    h->count = n;
+    const uint64_t fit = std::min(n, cap_rows);
+    uint32_t nb = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const int32_t b = in[i].block;
+        if (b < 0 || b > 255 || in[i].end < in[i].start || in[i].end - in[i].start > 0xffffffffll || in[i].dist < 0 ||
+            in[i].dist > 0xffff)
+            return fail(FZ_EUNSUPPORTED, "record %llu does not fit the wire format", (unsigned long long)i);
+        ++h->per_block[b];
+        nb = std::max(nb, (uint32_t)b + 1);
+        if (i < fit) rows[i] = WireRow{in[i].start, (uint32_t)(in[i].end - in[i].start), (uint16_t)in[i].dist, (uint16_t)b};
+    }
+    h->nblocks = nb;
+    return FZ_OK;
+}
+
+int fz_wire_merge(const void *recv, uint32_t world, uint64_t rows_per_rank, uint64_t cap_rows,
+                  fz_match *out, uint64_t out_cap, uint64_t *n_out, uint64_t *max_count) {
+    if (!recv || !n_out || !max_count || rows_per_rank < FZ_WIRE_HEADER_ROWS + cap_rows) return fail(FZ_EINVAL, "bad argument");
+    const uint8_t *base = static_cast<const uint8_t *>(recv);
+    uint64_t total = 0, top = 0;
+    uint32_t nb = 0;
+    for (uint32_t r = 0; r < world; ++r) {
+        const WireHeader *h = reinterpret_cast<const WireHeader *>(base + (size_t)r * rows_per_rank * 16);
+        if (h->nblocks > 256) return fail(FZ_EINVAL, "rank %u: corrupt header", r);
+        total += h->count;
+        top = std::max(top, h->count);
+        nb = std::max(nb, (uint32_t)h->nblocks);
+    }
+    *n_out = total;
+    *max_count = top;
+    if (top > cap_rows) return FZ_OK;                          // caller re-gathers with a larger capacity
+    if (total > out_cap || (total && !out)) return fail(FZ_EINVAL, "output too small for %llu records", (unsigned long long)total);
+    std::vector<uint64_t> pos(world, 0);
+    uint64_t o = 0;
+    for (uint32_t g = 0; g < nb; ++g)
+        for (uint32_t r = 0; r < world; ++r) {
+            const WireHeader *h = reinterpret_cast<const WireHeader *>(base + (size_t)r * rows_per_rank * 16);
+            const WireRow *rows = reinterpret_cast<const WireRow *>(h + 1) + pos[r];
+            const uint32_t c = h->per_block[g];
+            if (pos[r] + c > h->count) return fail(FZ_EINVAL, "rank %u: block counts exceed its record count", r);
+            for (uint32_t i = 0; i < c; ++i, ++o) {
+                out[o].start = rows[i].start;
+                out[o].end = rows[i].start + (int64_t)rows[i].len;
+                out[o].dist = rows[i].dist;
+                out[o].block = rows[i].block;
+            }
+            pos[r] += c;
+        }
+    return FZ_OK;
+}
+
 // Faithful group-list-order version (common.py:161-177), needed by the substitutions-only path.
 int fz_group_best(const fz_match *in, uint64_t n, fz_match **out, uint64_t *n_out) {
     if (!out || !n_out || (!in && n)) return fail(FZ_EINVAL, "null argument");

@@ -133,7 +133,7 @@ def _merge_native(addrs, counts, block_counts):
     return out
 
 
-_HDR_ROWS = 1 + 86        # row 0: [count, nblocks, 0]; rows 1..86: per-block counts, three per row (<= 255 blocks)
+WIRE_HEADER_ROWS = 65     # FZ_WIRE_HEADER_ROWS of include/fzhip.h: count, nblocks, 256 per-block counts
 
 
 def allgather_matches(raw, group=None, as_array=False):
@@ -142,43 +142,38 @@ def allgather_matches(raw, group=None, as_array=False):
     -> the merged stream in the reference's global order on every rank, as an (M, 4) int64 array
     (or the fz_match structured array with as_array=True).
 
-    ONE collective per call in the common case: every rank contributes a fixed-capacity block
-    [header: count, per-block counts | 24-byte fz_match records] (the counts ride along, so there is no
-    separate count exchange and the merge needs no sort), staged through persistent pinned host
-    buffers with a single stream synchronisation.  If some rank's count exceeds the agreed capacity
-    every rank sees it in the gathered headers, the capacity is raised identically everywhere and the
-    gather is repeated."""
+    ONE collective per call in the common case: every rank contributes a fixed-capacity block in the
+    16-byte wire format of include/fzhip.h (header: count + per-block counts, then the records; the
+    counts ride along, so there is no separate count exchange and the merge needs no sort), packed and
+    merged by the C library, staged through persistent pinned host buffers with a single stream
+    synchronisation.  If some rank's count exceeds the agreed capacity every rank sees it in the
+    gathered headers, the capacity is raised identically everywhere and the gather is repeated; the
+    capacity also follows the counts down."""
+    import ctypes
     import torch
     import torch.distributed as dist
+    from . import _native
+    lib = _native.load_library()
     world = dist.get_world_size(group)
     dev = _device_for(group)
     mine = _as_match_array(raw)
-    nb_mine = int(mine["block"][-1]) + 1 if len(mine) else 0
-    if nb_mine > 255:
-        raise ValueError("more than 255 n-gram blocks")
     key = id(group) if group is not None else 0
     while True:
         st = _gather_state.get(key)
         if st is None or st["world"] != world:
             cap = st["cap"] if st else 4096
             pin = dev.type == "cuda"
-            rows = _HDR_ROWS + cap
-            st = {"cap": cap, "world": world,
-                  "h_send": torch.zeros((rows, 3), dtype=torch.int64, pin_memory=pin),
-                  "h_recv": torch.zeros((world, rows, 3), dtype=torch.int64, pin_memory=pin)}
+            rows = WIRE_HEADER_ROWS + cap
+            st = {"cap": cap, "world": world, "rows": rows,
+                  "h_send": torch.zeros((rows, 2), dtype=torch.int64, pin_memory=pin),
+                  "h_recv": torch.zeros((world, rows, 2), dtype=torch.int64, pin_memory=pin)}
+            st["send_ptr"], st["recv_ptr"] = st["h_send"].data_ptr(), st["h_recv"].data_ptr()
             if pin:
-                st["d_send"] = torch.zeros((rows, 3), dtype=torch.int64, device=dev)
-                st["d_recv"] = torch.zeros((world, rows, 3), dtype=torch.int64, device=dev)
+                st["d_send"] = torch.zeros((rows, 2), dtype=torch.int64, device=dev)
+                st["d_recv"] = torch.zeros((world, rows, 2), dtype=torch.int64, device=dev)
             _gather_state[key] = st
         cap = st["cap"]
-        send = st["h_send"].numpy()
-        send[0, 0], send[0, 1] = len(mine), nb_mine
-        hdr = send[1:_HDR_ROWS].reshape(-1)
-        hdr[:] = 0
-        if nb_mine:
-            hdr[:nb_mine] = np.bincount(mine["block"], minlength=nb_mine)
-        fit = min(len(mine), cap)
-        send[_HDR_ROWS:_HDR_ROWS + fit] = mine[:fit].view(np.int64).reshape(-1, 3)   # 24-byte records as 3 x int64
+        _native._check(lib.fz_wire_pack(mine.__array_interface__["data"][0], len(mine), cap, st["send_ptr"]))
         if dev.type == "cuda":
             st["d_send"].copy_(st["h_send"], non_blocking=True)
             dist.all_gather_into_tensor(st["d_recv"], st["d_send"], group=group)
@@ -186,18 +181,16 @@ def allgather_matches(raw, group=None, as_array=False):
             torch.cuda.current_stream().synchronize()
         else:
             dist.all_gather(list(st["h_recv"].unbind(0)), st["h_send"], group=group)
-        host = st["h_recv"].numpy()
-        counts = host[:, 0, 0]
-        top = int(counts.max())
-        if top <= cap:
-            nb = int(host[:, 0, 1].max())
-            block_counts = host[:, 1:_HDR_ROWS].reshape(world, -1)[:, :nb]
-            base = host.__array_interface__["data"][0]
-            stride = host.strides[0]
-            merged = _merge_native([base + r * stride + _HDR_ROWS * 24 for r in range(world)], counts, block_counts)
+        total, top = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        # first pass: totals only (out_cap 0 is fine when a re-gather is needed or nothing matched)
+        merged = np.empty(world * cap, dtype=MATCH_DTYPE)
+        _native._check(lib.fz_wire_merge(st["recv_ptr"], world, st["rows"], cap, merged.__array_interface__["data"][0],
+                                         len(merged), ctypes.byref(total), ctypes.byref(top)))
+        if top.value <= cap:
+            merged = merged[:total.value]
             # keep the exchanged block near the size that is used (every rank sees the same counts, so
             # every rank resizes identically): the collective and the D2H copy move `cap` rows per rank
-            want = max(256, -(-(top + top // 8) // 128) * 128)
+            want = max(256, -(-(top.value + top.value // 8) // 128) * 128)
             if want * 4 <= cap * 3:
                 _gather_state[key] = {"cap": want, "world": -1}
             if as_array:
@@ -206,6 +199,6 @@ def allgather_matches(raw, group=None, as_array=False):
             out[:, 0], out[:, 1], out[:, 2], out[:, 3] = merged["start"], merged["end"], merged["dist"], merged["block"]
             return out
         new_cap = cap
-        while new_cap < int(counts.max()):
+        while new_cap < top.value:
             new_cap *= 2
         _gather_state[key] = {"cap": new_cap, "world": -1}               # rebuild buffers at the new capacity

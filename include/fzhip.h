@@ -150,6 +150,19 @@ int fz_group_best(const fz_match *in, uint64_t n, fz_match **out, uint64_t *n_ou
 int fz_merge_ranks(const fz_match *const *parts, const uint64_t *counts, const uint64_t *block_counts,
                    uint32_t world, uint32_t nb, fz_match *out);
 
+/* Wire format of one rank's contribution to the all-gather of match lists (16-byte rows so that the
+ * collective and the D2H copy move 2/3 of the bytes of raw fz_match rows):
+ *   header, FZ_WIRE_HEADER_ROWS rows: u64 count, u64 nblocks, u32 per_block_count[256]
+ *   then `count` rows: i64 start, u32 end - start, u16 dist, u16 block   (at most cap_rows are stored)
+ * fz_wire_pack fills `dst` (>= FZ_WIRE_HEADER_ROWS + cap_rows rows) from a stream in reference order.
+ * fz_wire_merge reads `world` such blocks, each rows_per_rank rows apart, and writes the merged stream
+ * (global reference order, like fz_merge_ranks) to `out`; *n_out = total.  If some rank stored fewer
+ * rows than its count (count > cap), nothing is written and *max_count tells the capacity needed. */
+#define FZ_WIRE_HEADER_ROWS 65
+int fz_wire_pack(const fz_match *in, uint64_t n, uint64_t cap_rows, void *dst);
+int fz_wire_merge(const void *recv, uint32_t world, uint64_t rows_per_rank, uint64_t cap_rows,
+                  fz_match *out, uint64_t out_cap, uint64_t *n_out, uint64_t *max_count);
+
 int  fz_stats(fz_ctx *ctx, fz_stats_t *out);
 void fz_free(void *p);
 
