@@ -4,8 +4,9 @@
 Metric (BASELINE.json): GB/s of sequence scanned (and matches/s) at |p| = 20, max_l_dist = 2.
 Workload at N = 1: BASELINE configs[1] — 1 GiB of iid random DNA bytes with 1 024 planted variants
 of a 20-byte pattern (tests/workloads.py::cfg2, SURVEY.md §8(d)), resident in HBM before the timed
-region.  One "step" = one fz_lev_ngrams() call through the C-ABI over the resident sequence:
-filter kernel + verify kernel + D2H of the raw match stream + host ordering.
+region.  One "step" = one fz_lev_ngrams() call through the C-ABI over the resident sequence: the scan
+kernel (filter + fused verification, records and counters written to pinned host memory) + host
+ordering of the raw match stream.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling — every rank owns one
 1 GiB shard of an N GiB global sequence, holds (m + k)-byte halos of its neighbours' bytes, scans
