@@ -6,11 +6,12 @@ tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 base = os.path.join(root, "gpurun_out", "prof_" + tag)
 alg = int(sys.argv[2]) if len(sys.argv) > 2 else 2 ** 30
-stats = glob.glob(os.path.join(base, "stats", "*", "*_kernel_stats.csv"))[0]
+newest = lambda pattern: max(glob.glob(pattern), key=os.path.getmtime)   # gpurun merges runs: take the last one
+stats = newest(os.path.join(base, "stats", "*", "*_kernel_stats.csv"))
 shutil.copy(stats, os.path.join(root, "profiles", tag + "_rocprof_kernel_stats.csv"))
 # rocprofv3's own --stats table covered only the last few dispatches of the run (12 of 510 here), so the
 # per-kernel table that is committed is rebuilt from the full --kernel-trace of the same run
-trace = glob.glob(os.path.join(base, "stats", "*", "*_kernel_trace.csv"))[0]
+trace = newest(os.path.join(base, "stats", "*", "*_kernel_trace.csv"))
 per = collections.defaultdict(list)
 for r in csv.DictReader(open(trace)):
     per[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
@@ -29,7 +30,7 @@ out = {}
 for d in sorted(glob.glob(os.path.join(base, "pmc*"))):
     if not os.path.isdir(d):
         continue
-    f = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0]
+    f = newest(os.path.join(d, "*", "*_counter_collection.csv"))
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if "fz_scan" in r["Kernel_Name"]:
