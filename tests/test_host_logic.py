@@ -180,3 +180,41 @@ def test_file_api_chunk_geometry_with_a_recording_search_class():
         fa.choose_search_class = orig
     with pytest.raises(ValueError):
         fa.find_near_matches_in_file(b"", io.BytesIO(data), max_l_dist=1)
+
+
+def test_wire_format_pack_and_merge_round_trip():
+    """fz_wire_pack / fz_wire_merge (host-only C entry points of the multi-rank gather) against a sort:
+    random rank streams in reference order, header-only overflow signalling, rejected records."""
+    import ctypes
+    import numpy as np
+    from fuzzysearch_amd import distributed as fzd
+    lib = _native.load_library()
+    rnd = random.Random(9)
+    H = fzd.WIRE_HEADER_ROWS
+    for _ in range(100):
+        world, nblocks, cap = rnd.randint(1, 6), rnd.randint(1, 5), rnd.choice([4, 16, 64])
+        rows = H + cap
+        recv = np.zeros((world, rows, 2), dtype=np.int64)
+        parts, base = [], 0
+        for r in range(world):
+            rec = []
+            for g in range(nblocks):
+                for _i in range(rnd.randint(0, 5)):
+                    st = base + rnd.randint(0, 400)
+                    rec.append((st, st + rnd.randint(0, 30), rnd.randint(0, 7), g))
+            rec.sort(key=lambda x: (x[3], x[0], x[1]))
+            arr = fzd._as_match_array(rec) if rec else np.empty(0, dtype=fzd.MATCH_DTYPE)
+            parts.append(rec)
+            _native._check(lib.fz_wire_pack(arr.ctypes.data, len(arr), cap, recv[r].ctypes.data))
+            base += 1000
+        out = np.empty(world * cap, dtype=fzd.MATCH_DTYPE)
+        total, top = ctypes.c_uint64(), ctypes.c_uint64()
+        _native._check(lib.fz_wire_merge(recv.ctypes.data, world, rows, cap, out.ctypes.data, len(out),
+                                         ctypes.byref(total), ctypes.byref(top)))
+        assert total.value == sum(len(p) for p in parts) and top.value == max(len(p) for p in parts)
+        if top.value > cap:
+            continue                                              # the caller would re-gather with a larger capacity
+        exp = [x for g in range(nblocks) for p in parts for x in p if x[3] == g]
+        assert [tuple(x) for x in out[:total.value].tolist()] == exp
+    bad = fzd._as_match_array([(10, 5, 0, 0)])                    # end < start cannot be encoded
+    assert lib.fz_wire_pack(bad.ctypes.data, 1, 4, np.zeros((H + 4, 2), dtype=np.int64).ctypes.data) != 0
