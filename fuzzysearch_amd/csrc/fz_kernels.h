@@ -394,9 +394,9 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
                                 if (__ballot(am[i] == 0)) {           // which offset (scalar branch)
-#pragma unroll
-                                    for (int g = 0; g < TG; ++g) {    // which block(s): equal n-grams share a slot
-                                        const uint32_t hg = (uint32_t)__builtin_amdgcn_readlane((int)hvec, g);
+                                    // which block(s): equal n-grams share a slot
+                                    auto push = [&](uint32_t g) {
+                                        const uint32_t hg = (uint32_t)__builtin_amdgcn_readlane((int)hvec, (int)g);
                                         const unsigned long long mk = __ballot(hv[i] == hg);
                                         if (mk) {
                                             const uint32_t slot = qn + fz_rank(mk);
@@ -404,10 +404,17 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                                             // queue codes into VGPRs
                                             uint32_t code = lane_off;
                                             asm volatile("" : "+v"(code));
-                                            code = fz_code(code + (uint32_t)(r * FZ_ROW_BYTES + 4 * j + i), (uint32_t)g, titer);
+                                            code = fz_code(code + (uint32_t)(r * FZ_ROW_BYTES + 4 * j + i), g, titer);
                                             if (hv[i] == hg && slot < FZ_QCAP) w.queue[slot] = code;
                                             qn += (uint32_t)__popcll(mk);
                                         }
+                                    };
+                                    if constexpr (TG <= 4) {          // unrolled: 6 % faster at 17 % firing groups (DNA, L = 6)
+#pragma unroll
+                                        for (int g = 0; g < TG; ++g) push((uint32_t)g);
+                                    } else {                          // rolled: 64 x 8 unrolled copies stop the row loop from unrolling
+#pragma unroll 1
+                                        for (uint32_t g = 0; g < (uint32_t)TG; ++g) push(g);
                                     }
                                 }
                             }
