@@ -305,27 +305,39 @@ struct FzGOut {
     uint32_t nmatch;
 };
 
+// Appends with compile-time indices only: a dynamically indexed member array would move the whole
+// struct to scratch memory on the GPU (78 scratch accesses in the automaton kernel's inner loop).
+FZ_HD void fz_gout_succ(FzGOut &o, const FzGCand &x) {
+    if (o.nsucc == 0) o.succ[0] = x;
+    else if (o.nsucc == 1) o.succ[1] = x;
+    else o.succ[2] = x;
+    ++o.nsucc;
+}
+FZ_HD void fz_gout_match(FzGOut &o, uint32_t start, uint32_t end, uint32_t dist) {
+    if (o.nmatch == 0) { o.mstart[0] = start; o.mend[0] = end; o.mdist[0] = dist; }
+    else { o.mstart[1] = start; o.mend[1] = end; o.mdist[1] = dist; }
+    ++o.nmatch;
+}
+
 template <class PatF>
 FZ_HD void fz_generic_step(const FzGCand &c, uint8_t ch, uint32_t index, uint32_t m, PatF pat,
                            uint32_t max_subs, uint32_t max_ins, uint32_t max_dels, uint32_t max_l, FzGOut &o) {
     o.nsucc = 0; o.nmatch = 0;
-    auto match = [&](uint32_t end, uint32_t dist) {
-        o.mstart[o.nmatch] = c.start; o.mend[o.nmatch] = end; o.mdist[o.nmatch] = dist; ++o.nmatch;
-    };
+    auto match = [&](uint32_t end, uint32_t dist) { fz_gout_match(o, c.start, end, dist); };
     if (ch == pat(c.j)) {                                              // py:85-94
         if (c.j + 1u == m) match(index + 1, c.l);
-        else { FzGCand x = c; x.j = (uint16_t)(c.j + 1); o.succ[o.nsucc++] = x; }
+        else { FzGCand x = c; x.j = (uint16_t)(c.j + 1); fz_gout_succ(o, x); }
         return;
     }
     if (c.l == max_l) return;                                          // py:101-102
     if (c.ni < max_ins) {                                              // py:104-109: skip a sequence char
-        FzGCand x = c; x.ni++; x.l++; o.succ[o.nsucc++] = x;
+        FzGCand x = c; x.ni++; x.l++; fz_gout_succ(o, x);
     }
     if (c.j + 1u < m) {                                                // py:111-128
         if (c.ns < max_subs) {
-            FzGCand x = c; x.ns++; x.j++; x.l++; o.succ[o.nsucc++] = x;
+            FzGCand x = c; x.ns++; x.j++; x.l++; fz_gout_succ(o, x);
         } else if (c.nd < max_dels && c.ni < max_ins) {
-            FzGCand x = c; x.ni++; x.nd++; x.j++; x.l++; o.succ[o.nsucc++] = x;
+            FzGCand x = c; x.ni++; x.nd++; x.j++; x.l++; fz_gout_succ(o, x);
         }
     } else if (c.ns < max_subs || (c.nd < max_dels && c.ni < max_ins)) {   // py:129-138
         match(index + 1, c.l + 1u);
@@ -338,7 +350,7 @@ FZ_HD void fz_generic_step(const FzGCand &c, uint8_t ch, uint32_t index, uint32_
             if (c.j + sk + 1u == m) match(index, c.l + sk);
             else {
                 FzGCand x = c; x.nd = (uint8_t)(c.nd + sk); x.j = (uint16_t)(c.j + 1u + sk); x.l = (uint8_t)(c.l + sk);
-                o.succ[o.nsucc++] = x;
+                fz_gout_succ(o, x);
             }
             break;
         }
@@ -351,24 +363,22 @@ template <class PatF>
 FZ_HD void fz_levlp_step(const FzGCand &c, uint8_t ch, uint32_t index, bool more_seq, uint32_t m, PatF pat,
                          uint32_t k, FzGOut &o) {
     o.nsucc = 0; o.nmatch = 0;
-    auto match = [&](uint32_t end, uint32_t dist) {
-        o.mstart[o.nmatch] = c.start; o.mend[o.nmatch] = end; o.mdist[o.nmatch] = dist; ++o.nmatch;
-    };
+    auto match = [&](uint32_t end, uint32_t dist) { fz_gout_match(o, c.start, end, dist); };
     if (pat(c.j) == ch) {                                              // :84-92
         if (c.j + 1u == m) match(index + 1, c.l);
-        else { FzGCand x = c; x.j = (uint16_t)(c.j + 1); o.succ[o.nsucc++] = x; }
+        else { FzGCand x = c; x.j = (uint16_t)(c.j + 1); fz_gout_succ(o, x); }
         return;
     }
     if (c.l == k) return;                                              // :99-100
-    { FzGCand x = c; x.l++; o.succ[o.nsucc++] = x; }                   // :103 skip a sequence char
+    { FzGCand x = c; x.l++; fz_gout_succ(o, x); }                   // :103 skip a sequence char
     if (more_seq && c.j + 1u < m) {                                    // :105-111 skip both
-        FzGCand x = c; x.l++; x.j++; o.succ[o.nsucc++] = x;
+        FzGCand x = c; x.l++; x.j++; fz_gout_succ(o, x);
     }
     for (uint32_t sk = 1; sk <= k - c.l; ++sk) {                       // :114-137 skip pattern chars
         if (c.j + sk == m) { match(index + 1, c.l + sk); break; }
         if (pat(c.j + sk) == ch) {
             if (c.j + sk + 1u == m) match(index + 1, c.l + sk);
-            else { FzGCand x = c; x.l = (uint8_t)(c.l + sk); x.j = (uint16_t)(c.j + 1u + sk); o.succ[o.nsucc++] = x; }
+            else { FzGCand x = c; x.l = (uint8_t)(c.l + sk); x.j = (uint16_t)(c.j + 1u + sk); fz_gout_succ(o, x); }
             break;
         }
     }

@@ -608,10 +608,14 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
                 const uint32_t tot_s = tot & 0xffffu, tot_m = tot >> 16;
                 if (nnext + tot_s > a.cand_cap) { overflow = true; break; }
                 if (mb + tot_m > FZ_GEN_MCAP) flush_matches();
-                for (uint32_t i = 0; i < o.nsucc; ++i) nxt[nnext + (excl & 0xffffu) + i] = o.succ[i];
-                for (uint32_t i = 0; i < o.nmatch; ++i)
-                    mbuf[mb + (excl >> 16) + i] = (uint64_t)(o.mstart[i] | (o.mend[i] << 16)) | ((uint64_t)o.mdist[i] << 32) |
-                                                  ((uint64_t)index << 48);
+#pragma unroll
+                for (uint32_t i = 0; i < 3; ++i)
+                    if (i < o.nsucc) nxt[nnext + (excl & 0xffffu) + i] = o.succ[i];
+#pragma unroll
+                for (uint32_t i = 0; i < 2; ++i)
+                    if (i < o.nmatch)
+                        mbuf[mb + (excl >> 16) + i] = (uint64_t)(o.mstart[i] | (o.mend[i] << 16)) | ((uint64_t)o.mdist[i] << 32) |
+                                                      ((uint64_t)index << 48);
                 nnext += tot_s;
                 mb += tot_m;
             }
