@@ -112,6 +112,10 @@ struct fz_ctx {
     std::vector<DevState> devs;
     fz_stats_t stats{};
     bool last_fused = false;
+    // Candidate slots per list of the per-hit automaton kernel.  Small lists let every wave of the launch
+    // be resident at once (256 slots: 8 KB of LDS per wave, 19 waves per CU; 1024: 7 per CU); a search
+    // that overflows them re-runs with 4x the slots and the context remembers.
+    uint32_t gen_cand_cap = 256;
 };
 
 struct fz_seq {
@@ -460,8 +464,8 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
     memset(&ctx->stats, 0, sizeof ctx->stats);
     ctx->stats.n_devices = (uint32_t)ctx->devs.size();
     static_assert(sizeof(FzGenRec) == sizeof(FzRec), "record buffers are shared");
-    uint32_t cand_cap = 1024;
-    for (int attempt = 0; attempt < 6; ++attempt) {
+    uint32_t cand_cap = ctx->gen_cand_cap;
+    for (int attempt = 0; attempt < 7; ++attempt) {
         recs_out.clear();
         bool rerun = false;
         ctx->stats.filter_launches = 0;
@@ -498,6 +502,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
                                    hipMemcpyDeviceToHost, d.stream));
             HIP_TRY(hipEventRecord(d.ev[3], d.stream));
         }
+        bool lists_overflowed = false;
         for (const Shard &sh : seq->shards) {
             DevState &d = ctx->devs[sh.dev];
             HIP_TRY(hipSetDevice(d.device));
@@ -506,7 +511,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             const uint64_t nh = cnt[0], nr = cnt[1], novf = cnt[2];
             if (nh > d.hit_cap) { int rc = ensure_hits(d, nh + nh / 8 + 1024); if (rc) return rc; rerun = true; }
             if (nr > d.rec_cap) { int rc = ensure_recs(d, nr + nr / 8 + 1024); if (rc) return rc; rerun = true; }
-            if (novf) { cand_cap *= 4; rerun = true; }
+            if (novf) { lists_overflowed = true; rerun = true; }
             if (rerun) continue;
             float f = 0, v = 0, t = 0;
             HIP_TRY(hipEventElapsedTime(&f, d.ev[0], d.ev[1]));
@@ -525,6 +530,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
                 HIP_TRY(hipMemcpy(recs_out.data() + base + first, d.d_out + kHeaderBytes + first * sizeof(FzGenRec),
                                   (nr - first) * sizeof(FzGenRec), hipMemcpyDeviceToHost));
         }
+        if (lists_overflowed) { cand_cap *= 4; ctx->gen_cand_cap = cand_cap; }
         if (!rerun) return FZ_OK;
     }
     return fail(FZ_EUNSUPPORTED, "generic search: candidate lists / result buffers kept overflowing");
