@@ -116,6 +116,10 @@ struct fz_ctx {
     // be resident at once (256 slots: 8 KB of LDS per wave, 19 waves per CU; 1024: 7 per CU); a search
     // that overflows them re-runs with 4x the slots and the context remembers.
     uint32_t gen_cand_cap = 256;
+    // Single-shard searches in direct mode leave their records in the pinned staging buffer and only
+    // publish a view of them (valid until the next search of this context): saves a 24 B x nr memcpy.
+    const FzRec *view = nullptr;
+    uint64_t view_n = 0;
 };
 
 struct fz_seq {
@@ -363,7 +367,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
 }
 
 // Wait for a shard, handle overflow (returns 1 = capacities grown, caller must re-run), collect.
-int collect_shard(fz_ctx *ctx, const Shard &sh, bool with_verify, std::vector<FzRec> &recs_out,
+int collect_shard(fz_ctx *ctx, const Shard &sh, bool with_verify, bool view_ok, std::vector<FzRec> &recs_out,
                   std::vector<uint64_t> &hits_out, bool &rerun) {
     DevState &d = ctx->devs[sh.dev];
     HIP_TRY(hipSetDevice(d.device));
@@ -399,7 +403,11 @@ int collect_shard(fz_ctx *ctx, const Shard &sh, bool with_verify, std::vector<Fz
     ctx->stats.device_ms = std::max<double>(ctx->stats.device_ms, t);
     ctx->stats.bytes_scanned += sh.geom.buf_len;
     ctx->stats.ngram_hits += nh;
-    if (with_verify) {
+    if (with_verify && view_ok && d.last_direct) {
+        ctx->stats.raw_matches += nr;
+        ctx->view = reinterpret_cast<const FzRec *>(d.h_stage + kHeaderBytes);
+        ctx->view_n = nr;
+    } else if (with_verify) {
         ctx->stats.raw_matches += nr;
         const size_t base = recs_out.size();
         recs_out.resize(base + nr);
@@ -436,6 +444,8 @@ int run_search(fz_ctx *ctx, fz_seq *seq, const Search &q, bool with_verify, std:
     for (int attempt = 0; attempt < 4; ++attempt) {
         recs.clear();
         hits.clear();
+        ctx->view = nullptr;
+        ctx->view_n = 0;
         ctx->stats.filter_launches = 0;
         ctx->stats.bytes_scanned = ctx->stats.ngram_hits = ctx->stats.raw_matches = 0;
         ctx->stats.filter_ms = ctx->stats.verify_ms = ctx->stats.device_ms = 0;
@@ -448,7 +458,7 @@ int run_search(fz_ctx *ctx, fz_seq *seq, const Search &q, bool with_verify, std:
         bool any_rerun = false;
         for (const Shard &sh : seq->shards) {
             bool rr = false;
-            int rc = collect_shard(ctx, sh, with_verify, recs, hits, rr);
+            int rc = collect_shard(ctx, sh, with_verify, seq->shards.size() == 1, recs, hits, rr);
             if (rc) return rc;
             any_rerun |= rr;
         }
@@ -577,8 +587,7 @@ void sort_recs(std::vector<FzRec> &recs) {
 // The keys of one search differ in few bits (block number + an index range), so they are first
 // squeezed into <= 32 bits and sorted as (key32 << 32 | position) words with 11-bit LSD radix passes
 // (8-byte elements instead of 24-byte records); the records are then read once, in order.
-int emit_matches(std::vector<FzRec> &recs, uint32_t L, fz_match **out, uint64_t *n) {
-    const size_t cnt = recs.size();
+int emit_matches(const FzRec *recs, size_t cnt, uint32_t L, fz_match **out, uint64_t *n) {
     void *mem = nullptr;
     int rc = alloc_out(cnt, sizeof(fz_match), &mem);
     if (rc) return rc;
@@ -621,9 +630,15 @@ int emit_matches(std::vector<FzRec> &recs, uint32_t L, fz_match **out, uint64_t 
             return FZ_OK;
         }
     }
-    sort_recs(recs);
-    for (size_t i = 0; i < cnt; ++i) put(i, recs[i]);
+    std::vector<FzRec> copy(recs, recs + cnt);
+    sort_recs(copy);
+    for (size_t i = 0; i < cnt; ++i) put(i, copy[i]);
     return FZ_OK;
+}
+
+// the records of the search that just ran: the staging-buffer view or the collected vector
+int emit_matches(const fz_ctx *ctx, const std::vector<FzRec> &recs, uint32_t L, fz_match **out, uint64_t *n) {
+    return ctx->view ? emit_matches(ctx->view, (size_t)ctx->view_n, L, out, n) : emit_matches(recs.data(), recs.size(), L, out, n);
 }
 
 }  // namespace
@@ -873,7 +888,7 @@ int fz_lev_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32
     rc = run_search(ctx, seq, q, true, recs, hits);
     if (rc) return rc;
     tr.mark("run_search");
-    rc = emit_matches(recs, L, out, n);
+    rc = emit_matches(ctx, recs, L, out, n);
     tr.mark("sort+emit");
     return rc;
 }
@@ -902,7 +917,7 @@ int fz_subs_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint3
     std::vector<uint64_t> hits;
     rc = run_search(ctx, seq, q, true, recs, hits);
     if (rc) return rc;
-    return emit_matches(recs, L, out, n);
+    return emit_matches(ctx, recs, L, out, n);
 }
 
 int fz_generic_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t max_subs, uint32_t max_ins,
