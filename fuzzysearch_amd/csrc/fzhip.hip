@@ -95,6 +95,7 @@ struct DevState {
     uint64_t first_copy = 512;                   // records fetched with the header (tracks the last count)
     bool header_zeroed = false;                  // the counters were already zeroed after the last D2H copy
     bool verify_launched = false;                // the last enqueue ran fz_verify_kernel (ev[2] recorded)
+    int scan_end_event = 1;                      // which event marks the end of the last scan (1 or 3)
     int n_cus = 256;
 };
 
@@ -330,7 +331,10 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
         ++launches;
         g0 += nblk;
     }
-    HIP_TRY(hipEventRecord(d.ev[1], d.stream));
+    // ev[1] = end of the scan.  When the results need no copy and no verify kernel follows, ev[3] is
+    // recorded at the same point of the stream: one event packet less on the critical path.
+    d.scan_end_event = (copy_back && direct && !(with_verify && !fa.fused)) ? 3 : 1;
+    if (d.scan_end_event == 1) HIP_TRY(hipEventRecord(d.ev[1], d.stream));
     d.verify_launched = false;
     if (with_verify && !fa.fused) {
         d.verify_launched = true;
@@ -395,7 +399,7 @@ int collect_shard(fz_ctx *ctx, const Shard &sh, bool with_verify, bool view_ok, 
     if (!d.last_direct && nr * 4 < kHostRecs) d.direct = true;
     if (rerun) return FZ_OK;
     float f = 0, v = 0, t = 0;
-    HIP_TRY(hipEventElapsedTime(&f, d.ev[0], d.ev[1]));
+    HIP_TRY(hipEventElapsedTime(&f, d.ev[0], d.ev[d.scan_end_event]));
     if (d.verify_launched) HIP_TRY(hipEventElapsedTime(&v, d.ev[1], d.ev[2]));
     HIP_TRY(hipEventElapsedTime(&t, d.ev[0], d.ev[3]));
     ctx->stats.filter_ms = std::max<double>(ctx->stats.filter_ms, f);
