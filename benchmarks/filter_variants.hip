@@ -719,6 +719,61 @@ __global__ __launch_bounds__(THREADS) void k_v14(const uint8_t *__restrict__ buf
     if (threadIdx.x == 0) { if (blockIdx.x == 0) { cnt[1] = 1; cnt[2] = 1; } if (blockIdx.x < 8192) { cnt[8 + 2 * blockIdx.x] = w0; cnt[9 + 2 * blockIdx.x] = wall_clock64(); } }
 }
 
+// ---- V15: V14 with the 8-byte halo taken from the next lane (DPP wave_shl:1) instead of a second load; lane 63 loads it.
+// ---- (V14 text:) like V13 but the 64-slot table sits in LDS and is read with ds_read_b32 (2 VALU ops for
+//      the address instead of 1, but a plain LDS read instead of the crossbar) ----------------------
+template <int ROWS, int WRAPBITS = 63, int NLUT = 4>
+__global__ __launch_bounds__(THREADS) void k_v15(const uint8_t *__restrict__ buf, Args a, uint64_t ntiles, unsigned long long *cnt) {
+    __shared__ uint32_t tab[64];
+    const unsigned long long w0 = wall_clock64();
+    if (threadIdx.x < 64) {
+        uint32_t t = ((threadIdx.x + 1u) & 63u) << 26;
+        for (int g = 0; g < 3; ++g) if ((a.H[g] >> 26) == threadIdx.x) t = a.H[g];
+        tab[threadIdx.x] = t;
+    }
+    __syncthreads();
+    const uint32_t K = a.K;
+    uint32_t H[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) asm volatile("v_mov_b32 %0, %1" : "=v"(H[g]) : "s"(a.H[g]));
+    uint32_t qn = 0;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint8_t *src = buf + (tile & ((1ull << WRAPBITS) - 1)) * (uint64_t)(ROWB * ROWS) + threadIdx.x * 16u;
+        uint4 v[ROWS]; uint2 h[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) { v[r] = *(const uint4 *)(src + r * ROWB); h[r] = uint2{0u, 0u}; if ((threadIdx.x & 63u) == 63u) h[r] = *(const uint2 *)(src + r * ROWB + 16); }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            // lane l takes v.x, v.y of lane l + 1 (lane 63 keeps its loaded halo: bound_ctrl off, old value kept)
+            h[r].x = (uint32_t)__builtin_amdgcn_update_dpp((int)h[r].x, (int)v[r].x, 0x130, 0xf, 0xf, false);
+            h[r].y = (uint32_t)__builtin_amdgcn_update_dpp((int)h[r].y, (int)v[r].y, 0x130, 0xf, 0xf, false);
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const uint32_t w[6] = {v[r].x, v[r].y, v[r].z, v[r].w, h[r].x, h[r].y};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t hv[4], t[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int o = 4 * j + i;
+                    hv[i] = __umul24(WIN(w, o + 3), K) + WIN(w, o);
+                    if (i < NLUT) t[i] = hv[i] ^ *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(tab) + ((hv[i] >> 24) & 0xfcu));
+                    else t[i] = min3u(hv[i] ^ H[0], hv[i] ^ H[1], hv[i] ^ H[2]);
+                }
+                const uint32_t acc = min(min3u(t[0], t[1], t[2]), t[3]);
+                if (__ballot(acc == 0)) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const unsigned long long mm = __ballot(t[i] == 0); if (mm) rare(mm, qn); }
+                }
+            }
+        }
+    }
+    if ((threadIdx.x & 63) == 0 && qn) atomicAdd(cnt, (unsigned long long)qn);
+    if (threadIdx.x == 0) { if (blockIdx.x == 0) { cnt[1] = 1; cnt[2] = 1; } if (blockIdx.x < 8192) { cnt[8 + 2 * blockIdx.x] = w0; cnt[9 + 2 * blockIdx.x] = wall_clock64(); } }
+}
+
+
 // semantic probe of the (m)qsad instructions
 __global__ void k_probe(const uint64_t *s0, const uint32_t *s1, const uint64_t *s2, uint64_t *out_q, uint64_t *out_m) {
     const int i = threadIdx.x;
@@ -902,6 +957,9 @@ int main(int argc, char **argv) {
     RUN("v13 bpermute LUT r4 g8", (k_v13<4>), 4, 8);
     RUN("v13 bpermute LUT r4 g8 L2res", (k_v13<4, 6>), 4, 8);
     RUN("v14 ds_read LUT 4/4 r4 g8", (k_v14<4, 63, 4>), 4, 8);
+    RUN("v15 LUT + DPP halo r4 g8", (k_v15<4, 63, 4>), 4, 8);
+    RUN("v15 LUT + DPP halo r4 g8 L2res", (k_v15<4, 6, 4>), 4, 8);
+    RUN("v15 LUT + DPP halo r8 g8", (k_v15<8, 63, 4>), 8, 8);
     RUN("v14 ds_read LUT 4/4 r4 g8 L2res", (k_v14<4, 6, 4>), 4, 8);
     RUN("v14 ds_read LUT 3/4 r4 g8", (k_v14<4, 63, 3>), 4, 8);
     RUN("v14 ds_read LUT 3/4 r4 g8 L2res", (k_v14<4, 6, 3>), 4, 8);
