@@ -297,9 +297,10 @@ __device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ b
 //         2 -> hash = low24(dword at offset + DH) * K + dword at offset (v_mad_u32_u24), DH = min(L, 8) - 3.
 // FUSED : verify candidates inside this kernel (records out) or emit exact hits (hit list out).
 // Each thread owns 16 consecutive byte offsets per row and reads 24 bytes (16 + 8 halo).
-// Block test: slot = top 6 bits of the hash; lut[slot] holds the hash of the block that lives there
-// (the host picks K so that different block hashes get different slots) or, for a free slot, a value
-// that belongs to another slot, so hash ^ lut[slot] == 0 <=> the window hashes like some block.
+// Block test: slot = (hash >> lut_shift) & 63; lut[slot] holds the hash of the block that lives there
+// (the host picks K and lut_shift so that different block hashes get different slots) or, for a free
+// slot, a value that belongs to another slot, so hash ^ lut[slot] == 0 <=> the window hashes like
+// some block.
 // Measured against per-block VALU compares (benchmarks/filter_variants.hip, v3 vs v14, 3 blocks,
 // L2-resident data): 0.222 -> 0.175 ms per GiB, and no longer growing with the number of blocks.
 // Fast hits are queued per wave ACROSS tiles and processed 64 at a time (full lanes, one latency
