@@ -41,6 +41,8 @@ def timeit(fn, reps=100, warm=60):
 
 rows = []
 cases = [
+    ("cfg0 DNA m=20 exact (search_exact, max_l_dist=0)", lambda: workloads.cfg2(n, 1024 * mib // 1024 or 64)[:2],
+     lambda h, p: eng.search_exact(h, p), lambda p, t: oracle.search_exact(p, t)),
     ("cfg1 DNA m=20 k=2 (levenshtein_ngram)", lambda: workloads.cfg2(n, 1024 * mib // 1024 or 64)[:2],
      lambda h, p: eng.lev_ngrams(h, p, 2, as_array=True), lambda p, t: oracle.lev_ngrams_raw(p, t, 2)),
     ("cfg2 ASCII m=32 subs<=3 (substitutions_only)", None,
@@ -66,7 +68,8 @@ for name, gen, run, orc in cases:
     t0 = time.perf_counter()
     exp = orc(p, seq.tobytes())
     t_cpu = time.perf_counter() - t0
-    got = [tuple(int(x) for x in r) for r in (res.tolist() if hasattr(res, "tolist") else res)]
+    res = res.tolist() if hasattr(res, "tolist") else res
+    got = [tuple(int(x) for x in r) if isinstance(r, (tuple, list)) else int(r) for r in res]
     ok = got == exp
     rows.append({"config": name, "MiB": mib, "ms_per_call": round(dt * 1e3, 4), "GB_per_s": round(n / dt / 1e9, 1),
                  "scan_kernel_ms": round(st["filter_ms"], 4), "kernel_GB_per_s": round(n / st["filter_ms"] / 1e6, 1),

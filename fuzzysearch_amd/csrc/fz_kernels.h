@@ -237,8 +237,11 @@ __device__ __forceinline__ void fz_publish_header(const FzScanArgs &a, unsigned 
     __syncthreads();
     if (*flag) {
         unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.host_hdr);
-        for (uint32_t i = threadIdx.x; i < FZ_HDR_WORDS; i += blockDim.x)
+        for (uint32_t i = threadIdx.x; i < FZ_HDR_WORDS; i += blockDim.x) {
             dst[i] = __hip_atomic_load(&counters[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // ... and leaves the counters zeroed for the next search (no memset command on the stream)
+            __hip_atomic_store(&counters[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 

@@ -361,8 +361,9 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
                                    d.stream));
         }
         HIP_TRY(hipEventRecord(d.ev[3], d.stream));
-        // zero the counters for the NEXT search now, off the critical path of that call
-        HIP_TRY(hipMemsetAsync(d.d_out, 0, kHeaderBytes, d.stream));
+        // the counters are zeroed for the NEXT search now, off the critical path of that call: by the
+        // publishing workgroup itself in direct mode, by a memset behind the copy otherwise
+        if (!direct) HIP_TRY(hipMemsetAsync(d.d_out, 0, kHeaderBytes, d.stream));
         d.header_zeroed = true;
     }
     ctx->stats.filter_launches += launches;
