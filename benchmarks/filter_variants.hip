@@ -719,6 +719,55 @@ __global__ __launch_bounds__(THREADS) void k_v14(const uint8_t *__restrict__ buf
     if (threadIdx.x == 0) { if (blockIdx.x == 0) { cnt[1] = 1; cnt[2] = 1; } if (blockIdx.x < 8192) { cnt[8 + 2 * blockIdx.x] = w0; cnt[9 + 2 * blockIdx.x] = wall_clock64(); } }
 }
 
+// ---- V16: V14 with a 32-slot table (one slot per LDS bank: no bank conflicts).
+// ---- (V14 text:) like V13 but the 64-slot table sits in LDS and is read with ds_read_b32 (2 VALU ops for
+//      the address instead of 1, but a plain LDS read instead of the crossbar) ----------------------
+template <int ROWS, int WRAPBITS = 63, int NLUT = 4>
+__global__ __launch_bounds__(THREADS) void k_v16(const uint8_t *__restrict__ buf, Args a, uint64_t ntiles, unsigned long long *cnt) {
+    __shared__ uint32_t tab[32];
+    const unsigned long long w0 = wall_clock64();
+    if (threadIdx.x < 32) {
+        uint32_t t = ((threadIdx.x + 1u) & 31u) << 27;
+        for (int g = 0; g < 3; ++g) if ((a.H[g] >> 27) == threadIdx.x) t = a.H[g];
+        tab[threadIdx.x] = t;
+    }
+    __syncthreads();
+    const uint32_t K = a.K;
+    uint32_t H[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) asm volatile("v_mov_b32 %0, %1" : "=v"(H[g]) : "s"(a.H[g]));
+    uint32_t qn = 0;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint8_t *src = buf + (tile & ((1ull << WRAPBITS) - 1)) * (uint64_t)(ROWB * ROWS) + threadIdx.x * 16u;
+        uint4 v[ROWS]; uint2 h[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) { v[r] = *(const uint4 *)(src + r * ROWB); h[r] = *(const uint2 *)(src + r * ROWB + 16); }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const uint32_t w[6] = {v[r].x, v[r].y, v[r].z, v[r].w, h[r].x, h[r].y};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t hv[4], t[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int o = 4 * j + i;
+                    hv[i] = __umul24(WIN(w, o + 3), K) + WIN(w, o);
+                    if (i < NLUT) t[i] = hv[i] ^ *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(tab) + ((hv[i] >> 25) & 0x7cu));
+                    else t[i] = min3u(hv[i] ^ H[0], hv[i] ^ H[1], hv[i] ^ H[2]);
+                }
+                const uint32_t acc = min(min3u(t[0], t[1], t[2]), t[3]);
+                if (__ballot(acc == 0)) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const unsigned long long mm = __ballot(t[i] == 0); if (mm) rare(mm, qn); }
+                }
+            }
+        }
+    }
+    if ((threadIdx.x & 63) == 0 && qn) atomicAdd(cnt, (unsigned long long)qn);
+    if (threadIdx.x == 0) { if (blockIdx.x == 0) { cnt[1] = 1; cnt[2] = 1; } if (blockIdx.x < 8192) { cnt[8 + 2 * blockIdx.x] = w0; cnt[9 + 2 * blockIdx.x] = wall_clock64(); } }
+}
+
+
 // ---- V15: V14 with the 8-byte halo taken from the next lane (DPP wave_shl:1) instead of a second load; lane 63 loads it.
 // ---- (V14 text:) like V13 but the 64-slot table sits in LDS and is read with ds_read_b32 (2 VALU ops for
 //      the address instead of 1, but a plain LDS read instead of the crossbar) ----------------------
@@ -957,6 +1006,9 @@ int main(int argc, char **argv) {
     RUN("v13 bpermute LUT r4 g8", (k_v13<4>), 4, 8);
     RUN("v13 bpermute LUT r4 g8 L2res", (k_v13<4, 6>), 4, 8);
     RUN("v14 ds_read LUT 4/4 r4 g8", (k_v14<4, 63, 4>), 4, 8);
+    printf("32-slot indices of the 3 block hashes: %u %u %u\n", a.H[0] >> 27, a.H[1] >> 27, a.H[2] >> 27);
+    RUN("v16 32-slot LUT r4 g8", (k_v16<4, 63, 4>), 4, 8);
+    RUN("v16 32-slot LUT r4 g8 L2res", (k_v16<4, 6, 4>), 4, 8);
     RUN("v15 LUT + DPP halo r4 g8", (k_v15<4, 63, 4>), 4, 8);
     RUN("v15 LUT + DPP halo r4 g8 L2res", (k_v15<4, 6, 4>), 4, 8);
     RUN("v15 LUT + DPP halo r8 g8", (k_v15<8, 63, 4>), 8, 8);
