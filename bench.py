@@ -11,7 +11,8 @@ ordering of the raw match stream.
 N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling — every rank owns one
 1 GiB shard of an N GiB global sequence, holds (m + k)-byte halos of its neighbours' bytes, scans
 its shard with no data-path collective and the ranks' match lists are all-gathered over RCCL
-(SURVEY.md §8(e)); value = N GiB / max-over-ranks time.
+(SURVEY.md §8(e)); the all-gather of step i runs while the scan of step i + 1 is on the GPU
+(fz_lev_ngrams_begin / _end, separate HIP streams); value = N GiB / max-over-ranks time.
 
 Prints ONE JSON line on rank 0.
 """
@@ -148,7 +149,7 @@ def main():
         # C-ABI's fz_match array; no per-record Python objects inside the timed region)
         raw = engine.lev_ngrams(handle, p, k, as_array=True)
         if use_dist:
-            return fzd.allgather_matches(raw, as_array=True)   # ONE RCCL all_gather: counts + padded records
+            return fzd.allgather_matches(raw, as_array=True)   # ONE RCCL all_gather: counts + packed records
         return raw
 
     # setup self-check + clock settle (untimed): repeated searches must return the identical stream
@@ -162,12 +163,28 @@ def main():
     filter_ms, verify_ms, device_ms = [], [], []
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        matches = step()
-        f_, v_, d_ = engine.kernel_ms()                # hipEvent spans of this step's kernels
-        filter_ms.append(f_)
-        verify_ms.append(v_)
-        device_ms.append(d_)
+    if not use_dist:
+        for _ in range(args.steps):
+            matches = step()
+            f_, v_, d_ = engine.kernel_ms()                # hipEvent spans of this step's kernels
+            filter_ms.append(f_)
+            verify_ms.append(v_)
+            device_ms.append(d_)
+    else:
+        # N > 1: the collective of step i overlaps the scan of step i + 1 (fz_lev_ngrams_begin / _end;
+        # the scan runs on the engine's own HIP stream, RCCL and its staging copies on torch's).  Every
+        # step still ends with its merged, ordered match list on this rank's host, and all K searches
+        # and K all-gathers complete inside the timed region.
+        engine.lev_ngrams_begin(handle, p, k)
+        for i in range(args.steps):
+            raw = engine.lev_ngrams_end(as_array=True)
+            f_, v_, d_ = engine.kernel_ms()
+            filter_ms.append(f_)
+            verify_ms.append(v_)
+            device_ms.append(d_)
+            if i + 1 < args.steps:
+                engine.lev_ngrams_begin(handle, p, k)
+            matches = fzd.allgather_matches(raw, as_array=True)
     sync()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -201,7 +218,8 @@ def main():
             "config": {"workload": "%d MiB iid random DNA bytes per GPU, |pattern|=20, max_l_dist=2, "
                                    "1024 planted variants per GiB (BASELINE configs[1]); resident in HBM" % args.mib,
                        "bytes_per_gpu": shard_bytes, "pattern_len": m, "max_l_dist": k,
-                       "sharding": "none" if not use_dist else "contiguous shards, (m+k)-byte halo, RCCL all_gather of matches"},
+                       "sharding": "none" if not use_dist else "contiguous shards, (m+k)-byte halo, RCCL all_gather of "
+                                   "matches; the all_gather of step i overlaps the scan of step i+1"},
             "matches_per_s": round(len(matches) * args.steps / elapsed, 1),
             "raw_matches": len(matches),
             "consolidated_matches": len(consolidated),

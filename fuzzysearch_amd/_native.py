@@ -17,7 +17,7 @@ UINT64_MAX = (1 << 64) - 1
 EXPORTED_SYMBOLS = (
     "fz_abi_version", "fz_last_error", "fz_device_count", "fz_create", "fz_destroy",
     "fz_seq_upload", "fz_seq_upload_shard", "fz_seq_len", "fz_seq_release",
-    "fz_search_exact", "fz_lev_ngrams", "fz_subs_ngrams", "fz_generic_ngrams",
+    "fz_search_exact", "fz_lev_ngrams", "fz_lev_ngrams_begin", "fz_lev_ngrams_end", "fz_subs_ngrams", "fz_generic_ngrams",
     "fz_lev_lp", "fz_subs_lp", "fz_generic_lp",
     "fz_consolidate", "fz_group_best", "fz_merge_ranks", "fz_wire_pack", "fz_wire_merge", "fz_stats", "fz_free",
 )
@@ -80,6 +80,10 @@ def load_library():
         L.fz_search_exact.argtypes = [vp, vp, u8p, u32, u64, u64, ctypes.POINTER(u64p), u64p]
         L.fz_lev_ngrams.restype = ci
         L.fz_lev_ngrams.argtypes = [vp, vp, u8p, u32, u32, mpp, u64p]
+        L.fz_lev_ngrams_begin.restype = ci
+        L.fz_lev_ngrams_begin.argtypes = [vp, vp, u8p, u32, u32]
+        L.fz_lev_ngrams_end.restype = ci
+        L.fz_lev_ngrams_end.argtypes = [vp, mpp, u64p]
         L.fz_subs_ngrams.restype = ci
         L.fz_subs_ngrams.argtypes = [vp, vp, u8p, u32, u32, mpp, u64p]
         L.fz_generic_ngrams.restype = ci
@@ -316,6 +320,25 @@ class Engine(object):
         tuples, or a numpy structured array with those fields (as_array=True, no per-record
         Python objects)."""
         return self._match_call(self._lib.fz_lev_ngrams, seq, pattern, k, as_array=as_array)
+
+    def lev_ngrams_begin(self, seq, pattern, k):
+        """Launch lev_ngrams and return; lev_ngrams_end() delivers the result.  One search in flight per
+        engine; the host and other streams (a collective, a copy) can work meanwhile."""
+        if type(pattern) is bytes:
+            paddr, m, keep = pattern, len(pattern), None
+        else:
+            paddr, m, keep = _buffer_address(pattern)
+        with self._lock:
+            _check(self._lib.fz_lev_ngrams_begin(self._h, seq._h, paddr, m, k))
+
+    def lev_ngrams_end(self, as_array=False):
+        ptr = ctypes.POINTER(FzMatch)()
+        cnt = ctypes.c_uint64(0)
+        with self._lock:
+            _check(self._lib.fz_lev_ngrams_end(self._h, ctypes.byref(ptr), ctypes.byref(cnt)))
+        if as_array:
+            return _take_matches_array(self._lib, ptr, cnt.value)
+        return _take_matches(self._lib, ptr, cnt.value)
 
     def subs_ngrams(self, seq, pattern, k, as_array=False):
         return self._match_call(self._lib.fz_subs_ngrams, seq, pattern, k, as_array=as_array)

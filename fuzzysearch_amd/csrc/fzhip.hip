@@ -121,6 +121,13 @@ struct fz_ctx {
     // publish a view of them (valid until the next search of this context): saves a 24 B x nr memcpy.
     const FzRec *view = nullptr;
     uint64_t view_n = 0;
+    // fz_lev_ngrams_begin .. _end: the one search that may be in flight
+    struct Pending {
+        bool active = false;
+        fz_seq *seq = nullptr;
+        std::vector<uint8_t> pattern;
+        uint32_t m = 0, k = 0;
+    } pending;
 };
 
 struct fz_seq {
@@ -442,24 +449,28 @@ int check_halo(const fz_seq *seq, uint64_t need) {
     return FZ_OK;
 }
 
-int run_search(fz_ctx *ctx, fz_seq *seq, const Search &q, bool with_verify, std::vector<FzRec> &recs,
-               std::vector<uint64_t> &hits) {
-    memset(&ctx->stats, 0, sizeof ctx->stats);
-    ctx->stats.n_devices = (uint32_t)ctx->devs.size();
+// Launch a search on every shard (no host synchronisation).
+int search_enqueue(fz_ctx *ctx, fz_seq *seq, const Search &q, bool with_verify) {
+    ctx->view = nullptr;
+    ctx->view_n = 0;
+    ctx->stats.filter_launches = 0;
+    ctx->stats.bytes_scanned = ctx->stats.ngram_hits = ctx->stats.raw_matches = 0;
+    ctx->stats.filter_ms = ctx->stats.verify_ms = ctx->stats.device_ms = 0;
+    for (const Shard &sh : seq->shards) {
+        int rc = enqueue_shard(ctx, sh, q, with_verify);
+        if (rc) return rc;
+    }
+    return FZ_OK;
+}
+
+// Wait for the search launched by search_enqueue and collect it; on an overflow the buffers have
+// been grown and the search is launched again (deterministic, at most three times).
+int search_collect(fz_ctx *ctx, fz_seq *seq, const Search &q, bool with_verify, std::vector<FzRec> &recs,
+                   std::vector<uint64_t> &hits) {
     for (int attempt = 0; attempt < 4; ++attempt) {
         recs.clear();
         hits.clear();
-        ctx->view = nullptr;
-        ctx->view_n = 0;
-        ctx->stats.filter_launches = 0;
-        ctx->stats.bytes_scanned = ctx->stats.ngram_hits = ctx->stats.raw_matches = 0;
-        ctx->stats.filter_ms = ctx->stats.verify_ms = ctx->stats.device_ms = 0;
         Trace tr;
-        for (const Shard &sh : seq->shards) {
-            int rc = enqueue_shard(ctx, sh, q, with_verify);
-            if (rc) return rc;
-        }
-        tr.mark(" enqueue");
         bool any_rerun = false;
         for (const Shard &sh : seq->shards) {
             bool rr = false;
@@ -469,8 +480,22 @@ int run_search(fz_ctx *ctx, fz_seq *seq, const Search &q, bool with_verify, std:
         }
         tr.mark(" collect");
         if (!any_rerun) return FZ_OK;
+        int rc = search_enqueue(ctx, seq, q, with_verify);
+        if (rc) return rc;
     }
     return fail(FZ_EDEVICE, "result buffers kept overflowing");
+}
+
+int run_search(fz_ctx *ctx, fz_seq *seq, const Search &q, bool with_verify, std::vector<FzRec> &recs,
+               std::vector<uint64_t> &hits) {
+    if (ctx->pending.active) return fail(FZ_EINVAL, "a search started with fz_lev_ngrams_begin is still in flight");
+    memset(&ctx->stats, 0, sizeof ctx->stats);
+    ctx->stats.n_devices = (uint32_t)ctx->devs.size();
+    Trace tr;
+    int rc = search_enqueue(ctx, seq, q, with_verify);
+    if (rc) return rc;
+    tr.mark(" enqueue");
+    return search_collect(ctx, seq, q, with_verify, recs, hits);
 }
 
 // Generic search: scan (emit exact hits) -> fz_generic_kernel (one wave per hit) -> records.
@@ -559,6 +584,7 @@ int alloc_out(uint64_t n, size_t elem, void **out) {
 
 int validate(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m) {
     if (!ctx || !seq || seq->ctx != ctx) return fail(FZ_EINVAL, "bad ctx/seq handle");
+    if (ctx->pending.active) return fail(FZ_EINVAL, "a search started with fz_lev_ngrams_begin is still in flight");
     if (!p || m == 0) return fail(FZ_EINVAL, "subsequence must not be empty");
     if (m > FZ_MAX_M) return fail(FZ_EUNSUPPORTED, "subsequence longer than %d bytes", FZ_MAX_M);
     return FZ_OK;
@@ -694,7 +720,14 @@ int fz_create(const int *device_ids, int n_devices, fz_ctx **out) {
         int rc = FZ_OK;
         auto init = [&]() -> int {
             HIP_TRY(hipSetDevice(id));
-            HIP_TRY(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+            // Lowest priority: a different hardware queue than the default-priority streams of the rest of
+            // the process, and the dispatcher prefers their workgroups.  Measured with RCCL on torch's
+            // stream: at default priority an all_gather launched while a scan was running only started
+            // after it (250 us); the scan alone is not slower at low priority.
+            int prio_least = 0, prio_greatest = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+            static const bool default_prio = getenv("FZ_STREAM_DEFAULT_PRIORITY") != nullptr;
+            HIP_TRY(hipStreamCreateWithPriority(&d.stream, hipStreamNonBlocking, default_prio ? 0 : prio_least));
             for (auto &ev : d.ev) HIP_TRY(hipEventCreate(&ev));
             HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&d.h_stage), kHeaderBytes + kHostRecs * sizeof(FzRec), hipHostMallocMapped));
             HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&d.h_stage_dev), d.h_stage, 0));
@@ -865,9 +898,8 @@ int fz_search_exact(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint
     return FZ_OK;
 }
 
-int fz_lev_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, fz_match **out, uint64_t *n) {
-    if (!out || !n) return fail(FZ_EINVAL, "null argument");
-    *out = nullptr; *n = 0;
+// Argument checks and the block plan of find_near_matches_levenshtein_ngrams (levenshtein_ngram.py:159-176).
+static int lev_plan(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, Search &q) {
     int rc = validate(ctx, seq, p, m);
     if (rc) return rc;
     const uint32_t L = m / (k + 1);
@@ -876,7 +908,6 @@ int fz_lev_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32
     rc = check_halo(seq, (uint64_t)m + k);
     if (rc) return rc;
     const int64_t N = (int64_t)seq->n;
-    Search q;
     q.mode = FZ_MODE_LEV; q.m = m; q.k = k; q.p = p;
     q.plan.L = L;
     for (uint32_t s = 0; s + L <= m; s += L) {              // levenshtein_ngram.py:171-176
@@ -887,15 +918,57 @@ int fz_lev_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32
         q.plan.hi.push_back((uint64_t)hi);
     }
     if (q.plan.s.size() > 255) return fail(FZ_EUNSUPPORTED, "more than 255 n-gram blocks");
+    return FZ_OK;
+}
+
+int fz_lev_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, fz_match **out, uint64_t *n) {
+    if (!out || !n) return fail(FZ_EINVAL, "null argument");
+    *out = nullptr; *n = 0;
+    Search q;
+    int rc = lev_plan(ctx, seq, p, m, k, q);
+    if (rc) return rc;
     std::vector<FzRec> recs;
     std::vector<uint64_t> hits;
     Trace tr;
     rc = run_search(ctx, seq, q, true, recs, hits);
     if (rc) return rc;
     tr.mark("run_search");
-    rc = emit_matches(ctx, recs, L, out, n);
+    rc = emit_matches(ctx, recs, q.plan.L, out, n);
     tr.mark("sort+emit");
     return rc;
+}
+
+int fz_lev_ngrams_begin(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k) {
+    if (ctx && ctx->pending.active) return fail(FZ_EINVAL, "a search is already in flight on this context");
+    Search q;
+    int rc = lev_plan(ctx, seq, p, m, k, q);
+    if (rc) return rc;
+    ctx->pending.pattern.assign(p, p + m);                   // the caller's buffer is only borrowed for this call
+    ctx->pending.seq = seq;
+    ctx->pending.m = m;
+    ctx->pending.k = k;
+    q.p = ctx->pending.pattern.data();
+    memset(&ctx->stats, 0, sizeof ctx->stats);
+    ctx->stats.n_devices = (uint32_t)ctx->devs.size();
+    rc = search_enqueue(ctx, seq, q, true);
+    if (rc) return rc;
+    ctx->pending.active = true;
+    return FZ_OK;
+}
+
+int fz_lev_ngrams_end(fz_ctx *ctx, fz_match **out, uint64_t *n) {
+    if (!ctx || !out || !n) return fail(FZ_EINVAL, "null argument");
+    *out = nullptr; *n = 0;
+    if (!ctx->pending.active) return fail(FZ_EINVAL, "no search in flight");
+    ctx->pending.active = false;
+    Search q;
+    int rc = lev_plan(ctx, ctx->pending.seq, ctx->pending.pattern.data(), ctx->pending.m, ctx->pending.k, q);
+    if (rc) return rc;
+    std::vector<FzRec> recs;
+    std::vector<uint64_t> hits;
+    rc = search_collect(ctx, ctx->pending.seq, q, true, recs, hits);
+    if (rc) return rc;
+    return emit_matches(ctx, recs, q.plan.L, out, n);
 }
 
 int fz_subs_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, fz_match **out, uint64_t *n) {

@@ -109,6 +109,13 @@ int fz_search_exact(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m,
 int fz_lev_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k,
                   fz_match **out, uint64_t *n);
 
+/* The same search split in two so that the host (and other streams: a collective, a copy) can work
+ * while the scan runs: _begin launches it and returns, _end waits and delivers exactly what
+ * fz_lev_ngrams would.  One search in flight per ctx; `p` is copied, `seq` must stay alive; every
+ * other search call on the ctx fails with FZ_EINVAL until _end has been called. */
+int fz_lev_ngrams_begin(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k);
+int fz_lev_ngrams_end(fz_ctx *ctx, fz_match **out, uint64_t *n);
+
 /* Raw stream of the substitutions-only n-gram search: (i, i+m, min(Hamming, k+1), block) in the
  * reference's discovery order, cross-block duplicates preserved. */
 int fz_subs_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k,

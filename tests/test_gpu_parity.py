@@ -176,6 +176,31 @@ def test_blocks_split_over_several_launches(engine, monkeypatch):
     h.release()
 
 
+def test_begin_end_split_equals_the_synchronous_call(engine):
+    """fz_lev_ngrams_begin / _end: same stream as fz_lev_ngrams, also across a result-buffer overflow;
+    other searches are refused while one is in flight."""
+    from fuzzysearch_amd import _native
+    t = workloads.dna(1 << 20, 31).tobytes()
+    p = t[5000:5020]
+    dense = b'ACGT' * 30000
+    h, hd = engine.upload(t), engine.upload(dense)
+    want = oracle.lev_ngrams_raw(p, t, 2)
+    for _ in range(3):
+        engine.lev_ngrams_begin(h, p, 2)
+        with pytest.raises(ValueError):
+            engine.lev_ngrams(h, p, 2)
+        with pytest.raises(ValueError):
+            engine.lev_ngrams_begin(h, p, 2)
+        assert engine.lev_ngrams_end() == want
+    with pytest.raises(ValueError):
+        engine.lev_ngrams_end()
+    pd = b'ACGTACGTACGTAC'
+    engine.lev_ngrams_begin(hd, bytearray(pd), 2)              # the pattern buffer is copied by _begin
+    assert engine.lev_ngrams_end() == oracle.lev_ngrams_raw(pd, dense, 2)
+    assert engine.lev_ngrams(h, p, 2) == want
+    h.release(); hd.release()
+
+
 def test_sharded_equals_unsharded(engine):
     """Two shards with (m + k) halos, hits owned by index == one sequence."""
     rnd = random.Random(21)
