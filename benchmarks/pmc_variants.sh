@@ -1,5 +1,7 @@
 #!/bin/bash
 # PMC passes over selected filter_variants kernels (run on the GPU box) -> gpurun_out/pmc_fv/
+# NOTE: only the SQ_* pass completed on this pool; the TCP_*/TCC_* passes ran into the 200 s timeout
+# (10 GPU-minutes for nothing) — keep them out unless the box is yours for longer.
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/pmc_fv; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
