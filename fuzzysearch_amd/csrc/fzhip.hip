@@ -88,6 +88,11 @@ struct DevState {
     // the counts are small again.
     bool direct = true;
     bool last_direct = false;                    // mode of the search being collected
+    // Large record sets of the automaton kernels (10^5 .. 10^6 records): a pinned, device-mapped host
+    // buffer that grows on demand; the kernel's stores cross PCIe while it runs instead of a D2H copy
+    // into pageable memory afterwards.
+    uint8_t *h_big = nullptr, *h_big_dev = nullptr;
+    uint64_t big_cap = 0;                        // records
     // one recycled sequence allocation (chunked file reads upload / release 1 MiB buffers in a loop;
     // hipMalloc + hipFree per chunk would dominate)
     uint8_t *spare_alloc = nullptr;
@@ -121,6 +126,8 @@ struct fz_ctx {
     // publish a view of them (valid until the next search of this context): saves a 24 B x nr memcpy.
     const FzRec *view = nullptr;
     uint64_t view_n = 0;
+    const FzGenRec *gen_view = nullptr;          // same for the per-hit automaton's records (pinned h_big)
+    uint64_t gen_view_n = 0;
     // fz_lev_ngrams_begin .. _end: the one search that may be in flight
     struct Pending {
         bool active = false;
@@ -144,6 +151,16 @@ int ensure_hits(DevState &d, uint64_t cap) {
     if (d.d_hits) { HIP_TRY(hipFree(d.d_hits)); d.d_hits = nullptr; d.hit_cap = 0; }
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d.d_hits), cap * sizeof(uint64_t)));
     d.hit_cap = cap;
+    return FZ_OK;
+}
+
+int ensure_big(DevState &d, uint64_t cap) {
+    if (d.big_cap >= cap) return FZ_OK;
+    HIP_TRY(hipSetDevice(d.device));
+    if (d.h_big) { HIP_TRY(hipStreamSynchronize(d.stream)); HIP_TRY(hipHostFree(d.h_big)); d.h_big = nullptr; d.big_cap = 0; }
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&d.h_big), cap * sizeof(FzRec), hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&d.h_big_dev), d.h_big, 0));
+    d.big_cap = cap;
     return FZ_OK;
 }
 
@@ -507,6 +524,8 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
     uint32_t cand_cap = ctx->gen_cand_cap;
     for (int attempt = 0; attempt < 7; ++attempt) {
         recs_out.clear();
+        ctx->gen_view = nullptr;
+        ctx->gen_view_n = 0;
         bool rerun = false;
         ctx->stats.filter_launches = 0;
         ctx->stats.bytes_scanned = ctx->stats.ngram_hits = ctx->stats.raw_matches = 0;
@@ -526,11 +545,13 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             fa.cand_cap = cand_cap;
             fa.lp_kind = FZ_LP_GENERIC_HIT;
             fa.lp_starts = 0;
+            rc = ensure_big(d, 1u << 16);
+            if (rc) return rc;
             fa.hit_cap = d.hit_cap;
-            fa.rec_cap = d.rec_cap;
+            fa.rec_cap = d.big_cap;
             memcpy(fa.pat, q.p, q.m);
             unsigned long long *counters = reinterpret_cast<unsigned long long *>(d.d_out);
-            FzGenRec *recs = reinterpret_cast<FzGenRec *>(d.d_out + kHeaderBytes);
+            FzGenRec *recs = reinterpret_cast<FzGenRec *>(d.h_big_dev);      // records go straight to pinned host memory
             if (lds > 64 * 1024)
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fz_lp_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -538,8 +559,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
                                (uint64_t)0, recs, counters);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(d.ev[2], d.stream));
-            HIP_TRY(hipMemcpyAsync(d.h_stage, d.d_out, kHeaderBytes + kFirstCopyRecs * sizeof(FzRec),
-                                   hipMemcpyDeviceToHost, d.stream));
+            HIP_TRY(hipMemcpyAsync(d.h_stage, d.d_out, kHeaderBytes, hipMemcpyDeviceToHost, d.stream));
             HIP_TRY(hipEventRecord(d.ev[3], d.stream));
         }
         bool lists_overflowed = false;
@@ -550,7 +570,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             const unsigned long long *cnt = reinterpret_cast<const unsigned long long *>(d.h_stage);
             const uint64_t nh = cnt[0], nr = cnt[1], novf = cnt[2];
             if (nh > d.hit_cap) { int rc = ensure_hits(d, nh + nh / 8 + 1024); if (rc) return rc; rerun = true; }
-            if (nr > d.rec_cap) { int rc = ensure_recs(d, nr + nr / 8 + 1024); if (rc) return rc; rerun = true; }
+            if (nr > d.big_cap) { int rc = ensure_big(d, nr + nr / 8 + 1024); if (rc) return rc; rerun = true; }
             if (novf) { lists_overflowed = true; rerun = true; }
             if (rerun) continue;
             float f = 0, v = 0, t = 0;
@@ -562,13 +582,14 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             ctx->stats.device_ms = std::max<double>(ctx->stats.device_ms, t);
             ctx->stats.bytes_scanned += sh.geom.buf_len;
             ctx->stats.ngram_hits += nh;
-            const size_t base = recs_out.size();
-            recs_out.resize(base + nr);
-            const uint64_t first = std::min<uint64_t>(nr, kFirstCopyRecs);
-            if (first) memcpy(recs_out.data() + base, d.h_stage + kHeaderBytes, first * sizeof(FzGenRec));
-            if (nr > first)
-                HIP_TRY(hipMemcpy(recs_out.data() + base + first, d.d_out + kHeaderBytes + first * sizeof(FzGenRec),
-                                  (nr - first) * sizeof(FzGenRec), hipMemcpyDeviceToHost));
+            if (seq->shards.size() == 1) {                    // read in place (valid until the next search)
+                ctx->gen_view = reinterpret_cast<const FzGenRec *>(d.h_big);
+                ctx->gen_view_n = nr;
+            } else {
+                const size_t base = recs_out.size();
+                recs_out.resize(base + nr);
+                if (nr) memcpy(recs_out.data() + base, d.h_big, nr * sizeof(FzGenRec));
+            }
         }
         if (lists_overflowed) { cand_cap *= 4; ctx->gen_cand_cap = cand_cap; }
         if (!rerun) return FZ_OK;
@@ -751,6 +772,7 @@ void fz_destroy(fz_ctx *ctx) {
         if (d.d_out) (void)hipFree(d.d_out);
         if (d.spare_alloc) (void)hipFree(d.spare_alloc);
         if (d.h_stage) (void)hipHostFree(d.h_stage);
+        if (d.h_big) (void)hipHostFree(d.h_big);
         for (auto &ev : d.ev) if (ev) (void)hipEventDestroy(ev);
         if (d.stream) (void)hipStreamDestroy(d.stream);
     }
@@ -1023,8 +1045,8 @@ int fz_generic_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, ui
         q.plan.hi.push_back((uint64_t)hi);
     }
     if (q.plan.s.size() > 255) return fail(FZ_EUNSUPPORTED, "more than 255 n-gram blocks");
-    std::vector<FzGenRec> recs;
-    rc = run_generic(ctx, seq, q, recs);
+    std::vector<FzGenRec> recs_vec;
+    rc = run_generic(ctx, seq, q, recs_vec);
     if (rc) return rc;
     // Reference order: hits in (block, idx) order, each hit's matches in automaton emission order.
     // A wave writes the matches of its hit in contiguous runs (one bulk append per <= 512 matches) that
@@ -1032,15 +1054,17 @@ int fz_generic_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, ui
     // and the 24-byte records are read once: 2.1e5 records order in ~0.4 ms instead of ~2 ms.
     struct Run { uint64_t key; uint32_t seq0; uint32_t len; size_t first; };
     std::vector<Run> runs;
-    for (size_t i = 0; i < recs.size();) {
+    const FzGenRec *recs = ctx->gen_view ? ctx->gen_view : recs_vec.data();
+    const size_t nrecs = ctx->gen_view ? (size_t)ctx->gen_view_n : recs_vec.size();
+    for (size_t i = 0; i < nrecs;) {
         size_t j = i + 1;
-        while (j < recs.size() && recs[j].key == recs[i].key && recs[j].seq == recs[j - 1].seq + 1) ++j;
+        while (j < nrecs && recs[j].key == recs[i].key && recs[j].seq == recs[j - 1].seq + 1) ++j;
         runs.push_back(Run{recs[i].key, recs[i].seq, (uint32_t)(j - i), i});
         i = j;
     }
     std::sort(runs.begin(), runs.end(), [](const Run &x, const Run &y) { return x.key != y.key ? x.key < y.key : x.seq0 < y.seq0; });
     void *mem = nullptr;
-    rc = alloc_out(recs.size(), sizeof(fz_match), &mem);
+    rc = alloc_out(nrecs, sizeof(fz_match), &mem);
     if (rc) return rc;
     fz_match *mo = static_cast<fz_match *>(mem);
     size_t o = 0;
@@ -1057,8 +1081,8 @@ int fz_generic_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, ui
         }
     }
     *out = mo;
-    *n = recs.size();
-    ctx->stats.raw_matches = recs.size();
+    *n = nrecs;
+    ctx->stats.raw_matches = nrecs;
     return FZ_OK;
 }
 
