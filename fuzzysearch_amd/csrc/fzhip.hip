@@ -591,8 +591,11 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
                 if (nr) memcpy(recs_out.data() + base, d.h_big, nr * sizeof(FzGenRec));
             }
         }
-        if (lists_overflowed) { cand_cap *= 4; ctx->gen_cand_cap = cand_cap; }
-        if (!rerun) return FZ_OK;
+        if (lists_overflowed) cand_cap *= 4;
+        if (!rerun) {
+            ctx->gen_cand_cap = std::min<uint32_t>(cand_cap, 4096);   // remember what worked (never an unusable size)
+            return FZ_OK;
+        }
     }
     return fail(FZ_EUNSUPPORTED, "generic search: candidate lists / result buffers kept overflowing");
 }
@@ -637,8 +640,9 @@ void sort_recs(std::vector<FzRec> &recs) {
 
 // Records -> fz_match rows in (block, index) order == the reference's emission order.
 // The keys of one search differ in few bits (block number + an index range), so they are first
-// squeezed into <= 32 bits and sorted as (key32 << 32 | position) words with 11-bit LSD radix passes
-// (8-byte elements instead of 24-byte records); the records are then read once, in order.
+// squeezed next to the record's position into one 64-bit word and those words are sorted with 11-bit
+// LSD radix passes over the key bits only (8-byte elements instead of 24-byte records); the records
+// are then read once, in order.
 int emit_matches(const FzRec *recs, size_t cnt, uint32_t L, fz_match **out, uint64_t *n) {
     void *mem = nullptr;
     int rc = alloc_out(cnt, sizeof(fz_match), &mem);
@@ -653,7 +657,7 @@ int emit_matches(const FzRec *recs, size_t cnt, uint32_t L, fz_match **out, uint
     };
     *out = mo;
     *n = cnt;
-    if (cnt >= 64 && cnt < (1ull << 32)) {
+    if (cnt >= 64) {
         uint64_t imin = ~0ull, imax = 0;
         uint32_t gmax = 0;
         for (size_t i = 0; i < cnt; ++i) {
@@ -661,24 +665,26 @@ int emit_matches(const FzRec *recs, size_t cnt, uint32_t L, fz_match **out, uint
             imin = std::min(imin, idx); imax = std::max(imax, idx);
             gmax = std::max(gmax, fz_hit_block(recs[i].key));
         }
-        int ibits = 0, gbits = 0;
+        int ibits = 0, gbits = 0, pbits = 0;                   // index range, block number, record position
         while (ibits < 56 && ((imax - imin) >> ibits)) ++ibits;
         while ((gmax >> gbits)) ++gbits;
-        if (ibits + gbits <= 32) {
+        while (((cnt - 1) >> pbits)) ++pbits;
+        if (ibits + gbits + pbits <= 64) {
             std::vector<uint64_t> a(cnt), b(cnt);
             for (size_t i = 0; i < cnt; ++i) {
-                const uint64_t k32 = ((uint64_t)fz_hit_block(recs[i].key) << ibits) | (fz_hit_index(recs[i].key) - imin);
-                a[i] = (k32 << 32) | (uint64_t)i;
+                const uint64_t key = ((uint64_t)fz_hit_block(recs[i].key) << ibits) | (fz_hit_index(recs[i].key) - imin);
+                a[i] = (key << pbits) | (uint64_t)i;
             }
             uint64_t *src = a.data(), *dst = b.data();
-            for (int shift = 0; shift < ibits + gbits; shift += 11) {
+            for (int shift = pbits; shift < pbits + ibits + gbits; shift += 11) {
                 uint32_t count[2049] = {0};
-                for (size_t i = 0; i < cnt; ++i) ++count[((src[i] >> (32 + shift)) & 0x7ff) + 1];
+                for (size_t i = 0; i < cnt; ++i) ++count[((src[i] >> shift) & 0x7ff) + 1];
                 for (int d = 0; d < 2048; ++d) count[d + 1] += count[d];
-                for (size_t i = 0; i < cnt; ++i) dst[count[(src[i] >> (32 + shift)) & 0x7ff]++] = src[i];
+                for (size_t i = 0; i < cnt; ++i) dst[count[(src[i] >> shift) & 0x7ff]++] = src[i];
                 std::swap(src, dst);
             }
-            for (size_t i = 0; i < cnt; ++i) put(i, recs[(uint32_t)src[i]]);
+            const uint64_t pmask = pbits ? ((1ull << pbits) - 1) : 0;
+            for (size_t i = 0; i < cnt; ++i) put(i, recs[src[i] & pmask]);
             return FZ_OK;
         }
     }
