@@ -56,7 +56,23 @@ while time.time() < t_end:
                 n_unsupported += 1
             else:
                 assert got == oracle.generic_ngrams_raw(p, t, *lim), ("generic", tag, lim, p)
+    if len(t) <= 5000 and len(p) <= 40:                       # the linear-programming fallbacks (short patterns)
+        try:
+            got = eng.lev_lp(h, p, k)
+        except NotImplementedError:
+            n_unsupported += 1
+        else:
+            assert got == oracle.lev_lp_raw(p, t, k), ("lev_lp", tag, p)
+        assert eng.subs_lp(h, p, k) == oracle.subs_lp_raw(p, t, k), ("subs_lp", tag, p)
+        if k:
+            lim = (rnd.randint(0, k), rnd.randint(0, k), rnd.randint(0, k), k)
+            try:
+                got = eng.generic_lp(h, p, *lim)
+            except NotImplementedError:
+                n_unsupported += 1
+            else:
+                assert got == oracle.generic_lp_raw(p, t, *lim), ("generic_lp", tag, lim, p)
     h.release()
     n_cases += 1
-print("stress_parity: %d cases, %d Levenshtein records compared, %d generic cases beyond the LDS candidate lists, seed %d: all equal"
+print("stress_parity: %d cases, %d Levenshtein records compared, %d automaton cases beyond the LDS candidate lists, seed %d: all equal"
       % (n_cases, n_recs, n_unsupported, seed))
