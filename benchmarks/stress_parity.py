@@ -15,7 +15,7 @@ eng = _native.Engine([0])
 t_end = time.time() + budget
 n_cases = n_recs = n_unsupported = 0
 while time.time() < t_end:
-    sigma = rnd.choice([1, 2, 2, 3, 4, 4, 5, 20, 64, 256])
+    sigma = rnd.choice([2, 3, 4, 4, 5, 20, 64, 256])   # 1-2 letter alphabets with large budgets take seconds per case (HBM candidate lists)
     alpha = bytes(rnd.sample(range(256), sigma))
     n = rnd.choice([0, 5, 50, 500, 5000, 60000, 300000])
     t = bytes(rnd.choice(alpha) for _ in range(min(n, 3000)))

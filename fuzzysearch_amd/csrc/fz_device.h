@@ -58,7 +58,9 @@ struct FzScanArgs {
     uint32_t win_dwords;                        // window dwords staged per lane ((m + 2k + 6) / 4 + 1)
     uint32_t vlanes;                            // lanes of a wave that verify at once (64, 32 or 16): LDS vs lane use
     uint32_t max_subs, max_ins, max_dels;       // generic search limits (k = max_l_dist there)
-    uint32_t cand_cap;                          // automaton kernels: candidate slots per list (LDS)
+    uint32_t cand_cap;                          // automaton kernels: candidate slots per list
+    uint64_t cand_scratch;                      // 0: both lists in LDS; else device address of per-wave lists in HBM
+                                                // (2 * cand_cap slots per workgroup; pathological inputs only)
     uint32_t lp_kind;                           // FzLpKind of fz_lp_kernel
     uint32_t lp_starts;                         // tiled modes: start positions owned by one window
     uint32_t hash_k;                            // odd multiplier of the window hash (24 bits when L > 4)

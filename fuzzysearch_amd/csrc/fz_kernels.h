@@ -498,9 +498,13 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
     const uint32_t wpad = (wmax + 15u) & ~15u;
     uint8_t *pat = smem;
     uint8_t *win = smem + mpad;
-    FzGCand *cur = reinterpret_cast<FzGCand *>(smem + mpad + wpad);
+    // Candidate lists: LDS normally; for inputs whose candidate sets outgrow it (two-letter alphabets with
+    // large budgets) per-workgroup lists in HBM.  One wave per workgroup, so the workgroup-scope fences
+    // of fz_wave_lds_sync order its global accesses just as they order the LDS ones.
+    FzGCand *cur = a.cand_scratch ? reinterpret_cast<FzGCand *>(a.cand_scratch) + (size_t)blockIdx.x * 2u * a.cand_cap
+                                  : reinterpret_cast<FzGCand *>(smem + mpad + wpad);
     FzGCand *nxt = cur + a.cand_cap;
-    uint64_t *mbuf = reinterpret_cast<uint64_t *>(nxt + a.cand_cap);
+    uint64_t *mbuf = reinterpret_cast<uint64_t *>(smem + mpad + wpad + (a.cand_scratch ? 0u : 2u * a.cand_cap * (uint32_t)sizeof(FzGCand)));
     for (uint32_t i = lane; i < a.m; i += 64u) pat[i] = a.pat[i];
     fz_wave_lds_sync();
     auto patf = [&](uint32_t i) -> uint8_t { return pat[i]; };

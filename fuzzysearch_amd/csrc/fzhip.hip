@@ -91,6 +91,8 @@ struct DevState {
     // Large record sets of the automaton kernels (10^5 .. 10^6 records): a pinned, device-mapped host
     // buffer that grows on demand; the kernel's stores cross PCIe while it runs instead of a D2H copy
     // into pageable memory afterwards.
+    uint8_t *d_cand = nullptr;                   // HBM candidate lists of the automaton kernels (rare fallback)
+    uint64_t cand_bytes = 0;
     uint8_t *h_big = nullptr, *h_big_dev = nullptr;
     uint64_t big_cap = 0;                        // records
     // one recycled sequence allocation (chunked file reads upload / release 1 MiB buffers in a loop;
@@ -151,6 +153,30 @@ int ensure_hits(DevState &d, uint64_t cap) {
     if (d.d_hits) { HIP_TRY(hipFree(d.d_hits)); d.d_hits = nullptr; d.hit_cap = 0; }
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d.d_hits), cap * sizeof(uint64_t)));
     d.hit_cap = cap;
+    return FZ_OK;
+}
+
+constexpr uint32_t kCandLdsMax = 4096;            // candidate slots per list that still live in LDS
+constexpr uint32_t kCandMax = 1u << 18;           // ... and in the HBM fallback (4 MiB per workgroup)
+constexpr unsigned kCandScratchGrid = 256;        // workgroups of a launch that uses the HBM lists
+
+// LDS bytes and (if the lists do not fit LDS) the HBM scratch of one automaton launch.
+int cand_lists(DevState &d, uint32_t cand_cap, size_t fixed_lds, size_t &lds, uint64_t &scratch) {
+    lds = fixed_lds + 2 * (size_t)cand_cap * sizeof(FzGCand);
+    scratch = 0;
+    const char *knob = getenv("FZ_CAND_LDS_MAX");              // test knob: force the HBM lists at small sizes
+    const uint32_t lds_max = knob && atoi(knob) > 0 ? (uint32_t)atoi(knob) : kCandLdsMax;
+    if (cand_cap <= lds_max && lds <= 160 * 1024) return FZ_OK;
+    if (cand_cap > kCandMax) return fail(FZ_EUNSUPPORTED, "automaton candidate sets beyond %u entries", kCandMax);
+    lds = fixed_lds;
+    const uint64_t need = (uint64_t)kCandScratchGrid * 2 * cand_cap * sizeof(FzGCand);
+    if (d.cand_bytes < need) {
+        HIP_TRY(hipSetDevice(d.device));
+        if (d.d_cand) { HIP_TRY(hipFree(d.d_cand)); d.d_cand = nullptr; d.cand_bytes = 0; }
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d.d_cand), need));
+        d.cand_bytes = need;
+    }
+    scratch = reinterpret_cast<uint64_t>(d.d_cand);
     return FZ_OK;
 }
 
@@ -522,7 +548,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
     ctx->stats.n_devices = (uint32_t)ctx->devs.size();
     static_assert(sizeof(FzGenRec) == sizeof(FzRec), "record buffers are shared");
     uint32_t cand_cap = ctx->gen_cand_cap;
-    for (int attempt = 0; attempt < 7; ++attempt) {
+    for (int attempt = 0; attempt < 9; ++attempt) {
         recs_out.clear();
         ctx->gen_view = nullptr;
         ctx->gen_view_n = 0;
@@ -531,18 +557,21 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
         ctx->stats.bytes_scanned = ctx->stats.ngram_hits = ctx->stats.raw_matches = 0;
         ctx->stats.filter_ms = ctx->stats.verify_ms = ctx->stats.device_ms = 0;
         const uint32_t mpad = (q.m + 15u) & ~15u, wpad = (q.m + 2 * q.k + 15u) & ~15u;
-        const size_t lds = mpad + wpad + 2 * (size_t)cand_cap * sizeof(FzGCand) + FZ_GEN_MCAP * 8;
-        if (lds > 160 * 1024) return fail(FZ_EUNSUPPORTED, "generic search: candidate lists do not fit LDS");
         for (const Shard &sh : seq->shards) {
             int rc = enqueue_shard(ctx, sh, q, /*with_verify=*/false, /*copy_back=*/false);
             if (rc) return rc;
             DevState &d = ctx->devs[sh.dev];
+            size_t lds = 0;
+            uint64_t scratch = 0;
+            rc = cand_lists(d, cand_cap, mpad + wpad + FZ_GEN_MCAP * 8, lds, scratch);
+            if (rc) return rc;
             FzScanArgs fa;
             memset(&fa, 0, sizeof fa);
             fa.geom = sh.geom;
             fa.mode = q.mode; fa.m = q.m; fa.k = q.k; fa.L = q.plan.L;
             fa.max_subs = q.max_subs; fa.max_ins = q.max_ins; fa.max_dels = q.max_dels;
             fa.cand_cap = cand_cap;
+            fa.cand_scratch = scratch;
             fa.lp_kind = FZ_LP_GENERIC_HIT;
             fa.lp_starts = 0;
             rc = ensure_big(d, 1u << 16);
@@ -555,8 +584,8 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             if (lds > 64 * 1024)
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fz_lp_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(fz_lp_kernel, dim3(d.n_cus * 16), dim3(64), lds, d.stream, sh.d_buf, fa, d.d_hits,
-                               (uint64_t)0, recs, counters);
+            hipLaunchKernelGGL(fz_lp_kernel, dim3(scratch ? kCandScratchGrid : d.n_cus * 16), dim3(64), lds, d.stream, sh.d_buf,
+                               fa, d.d_hits, (uint64_t)0, recs, counters);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(d.ev[2], d.stream));
             HIP_TRY(hipMemcpyAsync(d.h_stage, d.d_out, kHeaderBytes, hipMemcpyDeviceToHost, d.stream));
@@ -593,7 +622,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
         }
         if (lists_overflowed) cand_cap *= 4;
         if (!rerun) {
-            ctx->gen_cand_cap = std::min<uint32_t>(cand_cap, 4096);   // remember what worked (never an unusable size)
+            ctx->gen_cand_cap = std::min<uint32_t>(cand_cap, kCandLdsMax);   // remember what worked, never the HBM fallback
             return FZ_OK;
         }
     }
@@ -779,6 +808,7 @@ void fz_destroy(fz_ctx *ctx) {
         if (d.spare_alloc) (void)hipFree(d.spare_alloc);
         if (d.h_stage) (void)hipHostFree(d.h_stage);
         if (d.h_big) (void)hipHostFree(d.h_big);
+        if (d.d_cand) (void)hipFree(d.d_cand);
         for (auto &ev : d.ev) if (ev) (void)hipEventDestroy(ev);
         if (d.stream) (void)hipStreamDestroy(d.stream);
     }
@@ -1109,15 +1139,17 @@ int run_lp(fz_ctx *ctx, fz_seq *seq, const Search &q, uint32_t lp_kind, std::vec
     memset(&ctx->stats, 0, sizeof ctx->stats);
     ctx->stats.n_devices = (uint32_t)ctx->devs.size();
     uint32_t cand_cap = 1024;
-    for (int attempt = 0; attempt < 6; ++attempt) {
+    for (int attempt = 0; attempt < 8; ++attempt) {
         out.clear();
         bool rerun = false;
         const uint32_t mpad = (q.m + 15u) & ~15u, wpad = (q.m + 2 * q.k + kLpStarts + 15u) & ~15u;
-        const size_t lds = mpad + wpad + 2 * (size_t)cand_cap * sizeof(FzGCand) + FZ_GEN_MCAP * 8;
-        if (lds > 160 * 1024) return fail(FZ_EUNSUPPORTED, "automaton candidate lists do not fit LDS");
         for (const Shard &sh : seq->shards) {
             DevState &d = ctx->devs[sh.dev];
             HIP_TRY(hipSetDevice(d.device));
+            size_t lds = 0;
+            uint64_t scratch = 0;
+            int rc_lists = cand_lists(d, cand_cap, mpad + wpad + FZ_GEN_MCAP * 8, lds, scratch);
+            if (rc_lists) return rc_lists;
             unsigned long long *counters = reinterpret_cast<unsigned long long *>(d.d_out);
             FzGenRec *recs = reinterpret_cast<FzGenRec *>(d.d_out + kHeaderBytes);
             HIP_TRY(hipMemsetAsync(d.d_out, 0, kHeaderBytes, d.stream));
@@ -1129,6 +1161,7 @@ int run_lp(fz_ctx *ctx, fz_seq *seq, const Search &q, uint32_t lp_kind, std::vec
             fa.mode = q.mode; fa.m = q.m; fa.k = q.k; fa.L = 0;
             fa.max_subs = q.max_subs; fa.max_ins = q.max_ins; fa.max_dels = q.max_dels;
             fa.cand_cap = cand_cap;
+            fa.cand_scratch = scratch;
             fa.lp_kind = lp_kind;
             fa.lp_starts = kLpStarts;
             fa.rec_cap = d.rec_cap;
@@ -1139,7 +1172,7 @@ int run_lp(fz_ctx *ctx, fz_seq *seq, const Search &q, uint32_t lp_kind, std::vec
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fz_lp_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             if (nwin) {
-                const unsigned grid = (unsigned)std::min<uint64_t>(nwin, (uint64_t)d.n_cus * 64);
+                const unsigned grid = (unsigned)std::min<uint64_t>(nwin, scratch ? kCandScratchGrid : (uint64_t)d.n_cus * 64);
                 hipLaunchKernelGGL(fz_lp_kernel, dim3(grid), dim3(64), lds, d.stream, sh.d_buf, fa, d.d_hits, nwin, recs,
                                    counters);
                 HIP_TRY(hipGetLastError());

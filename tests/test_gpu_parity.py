@@ -201,29 +201,26 @@ def test_begin_end_split_equals_the_synchronous_call(engine):
     h.release(); hd.release()
 
 
-def test_generic_search_recovers_after_candidate_list_overflow(engine):
-    """A generic search whose candidate sets outgrow LDS fails loudly (FZ_EUNSUPPORTED) and must not
-    poison the context: the next ordinary generic search runs with normal list sizes again."""
+def test_automaton_candidate_lists_in_hbm(engine, monkeypatch):
+    """Candidate sets that outgrow LDS move to per-workgroup lists in HBM (slow, pathological inputs
+    only).  FZ_CAND_LDS_MAX forces that path at ordinary sizes; afterwards the context goes back to
+    LDS lists."""
     rnd = random.Random(5)
+    t = bytes(rnd.choice(b'ab') for _ in range(600))
+    p = bytes(rnd.choice(b'ab') for _ in range(30))
     t_ok = workloads.dna(1 << 16, 9).tobytes()
     p_ok = t_ok[300:340]
-    want = oracle.generic_ngrams_raw(p_ok, t_ok, 2, 1, 1, 2)
-    h_ok = engine.upload(t_ok)
-    failed = 0
-    for _ in range(12):
-        t = bytes(rnd.choice(b'ab') for _ in range(4000))
-        p = bytes(rnd.choice(b'ab') for _ in range(rnd.randint(40, 90)))
-        k = rnd.randint(6, 12)
-        h = engine.upload(t)
-        try:
-            got = engine.generic_ngrams(h, p, k, k, k, k)
-        except NotImplementedError:
-            failed += 1
-        else:
-            assert got == oracle.generic_ngrams_raw(p, t, k, k, k, k)
-        h.release()
-        assert engine.generic_ngrams(h_ok, p_ok, 2, 1, 1, 2) == want
-    h_ok.release()
+    h, h_ok = engine.upload(t), engine.upload(t_ok)
+    want_ok = oracle.generic_ngrams_raw(p_ok, t_ok, 2, 1, 1, 2)
+    monkeypatch.setenv("FZ_CAND_LDS_MAX", "16")
+    assert engine.generic_ngrams(h, p, 3, 3, 3, 3) == oracle.generic_ngrams_raw(p, t, 3, 3, 3, 3)
+    assert engine.generic_ngrams(h_ok, p_ok, 2, 1, 1, 2) == want_ok
+    assert engine.lev_lp(h, p[:8], 3) == oracle.lev_lp_raw(p[:8], t, 3)
+    assert engine.generic_lp(h, p[:8], 2, 2, 2, 3) == oracle.generic_lp_raw(p[:8], t, 2, 2, 2, 3)
+    monkeypatch.delenv("FZ_CAND_LDS_MAX")
+    assert engine.generic_ngrams(h_ok, p_ok, 2, 1, 1, 2) == want_ok
+    assert engine.generic_ngrams(h, p, 3, 3, 3, 3) == oracle.generic_ngrams_raw(p, t, 3, 3, 3, 3)
+    h.release(); h_ok.release()
 
 
 def test_sharded_equals_unsharded(engine):
