@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = (
     "fz_seq_upload", "fz_seq_upload_shard", "fz_seq_len", "fz_seq_release",
     "fz_search_exact", "fz_lev_ngrams", "fz_lev_ngrams_begin", "fz_lev_ngrams_end", "fz_subs_ngrams", "fz_generic_ngrams",
     "fz_lev_lp", "fz_subs_lp", "fz_generic_lp",
-    "fz_consolidate", "fz_group_best", "fz_merge_ranks", "fz_wire_pack", "fz_wire_merge", "fz_stats", "fz_free",
+    "fz_consolidate", "fz_group_best", "fz_merge_ranks", "fz_wire_pack", "fz_wire_merge", "fz_debug_launch_plan", "fz_stats", "fz_free",
 )
 
 
@@ -102,6 +102,8 @@ def load_library():
         L.fz_wire_pack.argtypes = [ctypes.c_void_p, u64, u64, ctypes.c_void_p]
         L.fz_wire_merge.restype = ci
         L.fz_wire_merge.argtypes = [ctypes.c_void_p, u32, u64, u64, ctypes.c_void_p, u64, u64p, u64p]
+        L.fz_debug_launch_plan.restype = ci
+        L.fz_debug_launch_plan.argtypes = [u8p, u32, u32, ctypes.POINTER(u32), u32, ctypes.POINTER(u32)]
         L.fz_merge_ranks.restype = ci
         L.fz_merge_ranks.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, u32, u32, ctypes.c_void_p]
         L.fz_stats.restype = ci

@@ -253,6 +253,55 @@ int pick_tg(uint32_t nblk) {
 const uint32_t kHashMultipliers[] = {0x9E3779u, 0x85EBCBu, 0xC2B2AFu, 0x27D4EBu, 0x165667u, 0xD3A264u | 1u, 0xFD7047u, 0xB55A4Fu,
                                      0x7FEB35u, 0x846CA7u, 0x9E6C63u, 0x3243F7u, 0x517CC1u, 0xB7E151u, 0x6A09E7u, 0xBB67AFu};
 
+// Window geometry of the filter's hash for n-gram length L (see fz_hash_windows / fz_hash_short).
+struct HashGeom {
+    int nwin;            // 1: L <= 4 (masked dword * K);  2: dword + 24 bits at offset dh
+    int dh;
+    uint32_t mask1;
+    explicit HashGeom(uint32_t L)
+        : nwin(L <= 4 ? 1 : 2), dh(L <= 4 ? 0 : (int)std::min<uint32_t>(L, 8) - 3),
+          mask1(L >= 4 ? 0xffffffffu : ((1u << (8 * L)) - 1u)) {}
+    uint32_t hash(const uint8_t *ng, uint32_t L, uint32_t k) const {
+        const uint32_t a1 = load_le32(ng, L) & mask1;
+        return nwin == 2 ? fz_hash_windows(a1, load_le32(ng + dh, 3), k) : fz_hash_short(a1, k);
+    }
+};
+
+// Blocks [g0, g0 + n) of one scan launch, the hash multiplier and the slot bits: the longest run of
+// blocks (at most 8) whose distinct hashes land in distinct slots of the 64-slot table under some
+// (multiplier, shift).  One block always fits; equal n-grams (equal hashes) share a slot.
+// h = yh * K + x mixes x only through the addition: which six bits tell the blocks apart depends on
+// where their bytes differ, so the slot bits are a per-launch choice as well.
+uint32_t choose_launch_blocks(const uint8_t *p, const uint32_t *starts, uint32_t g0, uint32_t G, uint32_t L,
+                              uint32_t &hash_k, uint32_t &lut_shift) {
+    const HashGeom hg(L);
+    // FZ_MAX_BLOCKS=n (test knob): at most n blocks per launch, to exercise the multi-launch path
+    const char *cap_env = getenv("FZ_MAX_BLOCKS");
+    const uint32_t max_blocks = cap_env && atoi(cap_env) > 0 ? std::min<uint32_t>((uint32_t)atoi(cap_env), FZ_MAX_BLOCKS_PER_LAUNCH)
+                                                             : FZ_MAX_BLOCKS_PER_LAUNCH;
+    uint32_t nblk = 0;
+    for (uint32_t cand : kHashMultipliers) {
+        const uint32_t kk = hg.nwin == 2 ? cand : (cand * 0x9E3779B1u) | 1u;
+        uint32_t hb[FZ_MAX_BLOCKS_PER_LAUNCH];
+        uint32_t nb = 0;
+        for (; nb < max_blocks && g0 + nb < G; ++nb) hb[nb] = hg.hash(p + starts[g0 + nb], L, kk);
+        for (int shift = 26; shift >= 2; shift -= 6) {
+            uint32_t slot_hash[FZ_LUT_SLOTS];
+            bool used[FZ_LUT_SLOTS] = {false};
+            uint32_t fit = 0;
+            for (; fit < nb; ++fit) {
+                const uint32_t slot = (hb[fit] >> shift) & (FZ_LUT_SLOTS - 1u);
+                if (used[slot] && slot_hash[slot] != hb[fit]) break;
+                used[slot] = true;
+                slot_hash[slot] = hb[fit];
+            }
+            if (fit > nblk) { nblk = fit; hash_k = kk; lut_shift = (uint32_t)shift; }
+        }
+        if (nblk == max_blocks || g0 + nblk == G) break;
+    }
+    return nblk;
+}
+
 struct Search {
     uint32_t mode = 0, m = 0, k = 0;
     uint32_t max_subs = 0, max_ins = 0, max_dels = 0;      // generic search only
@@ -299,10 +348,10 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     fa.m = q.m;
     fa.k = q.k;
     fa.L = L;
-    const int nwin = L <= 4 ? 1 : 2;
-    const int dh = nwin == 2 ? (int)std::min<uint32_t>(L, 8) - 3 : 0;
+    const HashGeom hgeom(L);
+    const int nwin = hgeom.nwin, dh = hgeom.dh;
     fa.d2 = nwin == 2 ? std::min<uint32_t>(L, 8) - 4 : 0;
-    fa.mask1 = L >= 4 ? 0xffffffffu : ((1u << (8 * L)) - 1u);
+    fa.mask1 = hgeom.mask1;
     fa.mask2 = 0xffffffffu;
     fa.band_w = q.mode == FZ_MODE_LEV ? 2 * q.k + 2 : 0;
     fa.win_dwords = (q.m + 2 * q.k + 6) / 4 + 1;
@@ -327,36 +376,10 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
         // Blocks [g0, g0 + nblk) of this launch and the hash multiplier: the longest run of blocks (at
         // most 8) whose distinct hashes land in distinct table slots under some multiplier.  One block
         // always fits; equal n-grams (equal hashes) share a slot.
-        uint32_t nblk = 0;
-        // FZ_MAX_BLOCKS=n (test knob): at most n blocks per launch, to exercise the multi-launch path
-        const char *cap_env = getenv("FZ_MAX_BLOCKS");
-        const uint32_t max_blocks = cap_env && atoi(cap_env) > 0 ? std::min<uint32_t>((uint32_t)atoi(cap_env), FZ_MAX_BLOCKS_PER_LAUNCH)
-                                                                 : FZ_MAX_BLOCKS_PER_LAUNCH;
-        for (uint32_t cand : kHashMultipliers) {
-            const uint32_t kk = nwin == 2 ? cand : (cand * 0x9E3779B1u) | 1u;
-            uint32_t hb[FZ_MAX_BLOCKS_PER_LAUNCH];
-            uint32_t nb = 0;
-            for (; nb < max_blocks && g0 + nb < G; ++nb) {
-                const uint8_t *ng = q.p + q.plan.s[g0 + nb];
-                const uint32_t a1 = load_le32(ng, L) & fa.mask1;
-                hb[nb] = nwin == 2 ? fz_hash_windows(a1, load_le32(ng + dh, 3), kk) : fz_hash_short(a1, kk);
-            }
-            // h = yh * K + x mixes x only through the addition: which six bits tell the blocks apart
-            // depends on where their bytes differ, so the slot bits are a per-launch choice as well
-            for (int shift = 26; shift >= 2; shift -= 6) {
-                uint32_t slot_hash[FZ_LUT_SLOTS];
-                bool used[FZ_LUT_SLOTS] = {false};
-                uint32_t fit = 0;
-                for (; fit < nb; ++fit) {
-                    const uint32_t slot = (hb[fit] >> shift) & (FZ_LUT_SLOTS - 1u);
-                    if (used[slot] && slot_hash[slot] != hb[fit]) break;
-                    used[slot] = true;
-                    slot_hash[slot] = hb[fit];
-                }
-                if (fit > nblk) { nblk = fit; fa.hash_k = kk; fa.lut_shift = (uint32_t)shift; }
-            }
-            if (nblk == max_blocks || g0 + nblk == G) break;
-        }
+        uint32_t hash_k = 0, lut_shift = 0;
+        const uint32_t nblk = choose_launch_blocks(q.p, q.plan.s.data(), g0, G, L, hash_k, lut_shift);
+        fa.hash_k = hash_k;
+        fa.lut_shift = lut_shift;
         fa.nblk = nblk;
         fa.g0 = g0;
         for (uint32_t b = 0; b < nblk; ++b) {
@@ -1477,6 +1500,24 @@ int fz_wire_merge(const void *recv, uint32_t world, uint64_t rows_per_rank, uint
             }
             pos[r] += c;
         }
+    return FZ_OK;
+}
+
+int fz_debug_launch_plan(const uint8_t *p, uint32_t m, uint32_t L, uint32_t *out, uint32_t cap, uint32_t *n_launches) {
+    if (!p || !out || !n_launches || L == 0 || L > m) return fail(FZ_EINVAL, "bad argument");
+    std::vector<uint32_t> starts;
+    for (uint32_t s = 0; s + L <= m; s += L) starts.push_back(s);
+    const uint32_t G = (uint32_t)starts.size();
+    uint32_t nl = 0;
+    for (uint32_t g0 = 0; g0 < G;) {
+        uint32_t hk = 0, sh = 0;
+        const uint32_t nb = choose_launch_blocks(p, starts.data(), g0, G, L, hk, sh);
+        if (nb == 0) return fail(FZ_EDEVICE, "internal: a launch without blocks");
+        if (nl < cap) { out[4 * nl] = g0; out[4 * nl + 1] = nb; out[4 * nl + 2] = hk; out[4 * nl + 3] = sh; }
+        ++nl;
+        g0 += nb;
+    }
+    *n_launches = nl;
     return FZ_OK;
 }
 

@@ -170,6 +170,11 @@ int fz_wire_pack(const fz_match *in, uint64_t n, uint64_t cap_rows, void *dst);
 int fz_wire_merge(const void *recv, uint32_t world, uint64_t rows_per_rank, uint64_t cap_rows,
                   fz_match *out, uint64_t out_cap, uint64_t *n_out, uint64_t *max_count);
 
+/* Test hook (no device needed): how the scan would split the n-gram blocks of pattern p (block
+ * length L, blocks at 0, L, 2L, ...) into launches.  out[4i .. 4i+3] = first block, number of blocks,
+ * hash multiplier, slot shift of launch i (at most `cap` launches are written); *n_launches = total. */
+int fz_debug_launch_plan(const uint8_t *p, uint32_t m, uint32_t L, uint32_t *out, uint32_t cap, uint32_t *n_launches);
+
 int  fz_stats(fz_ctx *ctx, fz_stats_t *out);
 void fz_free(void *p);
 

@@ -218,3 +218,45 @@ def test_wire_format_pack_and_merge_round_trip():
         assert [tuple(x) for x in out[:total.value].tolist()] == exp
     bad = fzd._as_match_array([(10, 5, 0, 0)])                    # end < start cannot be encoded
     assert lib.fz_wire_pack(bad.ctypes.data, 1, 4, np.zeros((H + 4, 2), dtype=np.int64).ctypes.data) != 0
+
+
+def test_scan_launch_plan_separates_block_hashes():
+    """fz_debug_launch_plan (host-only): every launch holds at most 8 consecutive blocks whose distinct
+    hashes occupy distinct slots of the 64-slot table under the chosen multiplier and slot bits; the
+    launches cover all blocks once, in order; equal n-grams may share a launch (and a slot)."""
+    import ctypes
+    lib = _native.load_library()
+    rnd = random.Random(21)
+
+    def le(b, n):
+        return int.from_bytes(bytes(b[:n]).ljust(4, b"\0")[:4], "little") & ((1 << (8 * n)) - 1 if n < 4 else 0xffffffff)
+
+    def block_hash(ng, L, k):
+        if L <= 4:
+            return (le(ng, L) * k) & 0xffffffff
+        dh = min(L, 8) - 3
+        return ((le(ng[dh:], 3) & 0xffffff) * (k & 0xffffff) + le(ng, 4)) & 0xffffffff
+
+    n_multi = 0
+    for _ in range(600):
+        sigma = rnd.choice([1, 2, 4, 4, 20, 256])
+        alpha = bytes(rnd.sample(range(256), sigma))
+        L = rnd.choice([1, 2, 3, 4, 5, 6, 7, 8, 10, 16])
+        G = rnd.randint(1, 40)
+        m = L * G + rnd.randint(0, L - 1)
+        p = bytes(rnd.choice(alpha) for _ in range(m))
+        out = (ctypes.c_uint32 * (4 * 64))()
+        nl = ctypes.c_uint32(0)
+        _native._check(lib.fz_debug_launch_plan(p, m, L, out, 64, ctypes.byref(nl)))
+        nxt = 0
+        for i in range(nl.value):
+            g0, nb, hk, shift = out[4 * i:4 * i + 4]
+            assert g0 == nxt and 1 <= nb <= 8 and shift in (26, 20, 14, 8, 2) and hk & 1
+            slots = {}
+            for b in range(g0, g0 + nb):
+                h = block_hash(p[b * L:b * L + L], L, hk)
+                assert slots.setdefault((h >> shift) & 63, h) == h, (p, L, i)
+            nxt = g0 + nb
+        assert nxt == m // L
+        n_multi += nl.value > -(-(m // L) // 8)
+    assert n_multi < 200            # splitting beyond ceil(G / 8) launches is the exception (low-entropy patterns)
