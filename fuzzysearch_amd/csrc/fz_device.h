@@ -33,22 +33,69 @@ enum FzMode : uint32_t { FZ_MODE_EXACT = 0, FZ_MODE_LEV = 1, FZ_MODE_SUBS = 2, F
 
 // Geometry of the resident (shard of the) sequence.  All match arithmetic is in GLOBAL
 // coordinates; `buf` holds global bytes [buf_off, buf_off + buf_len).
+//
+// Segments (find_near_matches_in_file, __init__.py:129-200): the reference searches a file chunk by
+// chunk, every chunk as an INDEPENDENT sequence (window clamps use the chunk's own ends), so the
+// result depends on the chunk geometry.  A whole batch of chunks is resident at
+// once here and every chunk is a "segment" with its own clamps:
+//     segment j = [seg_org + j*S - pre, seg_org + (j+1)*S + post)  clipped to  [seg_org, n)
+// binary files (:129-171): S = chunk_size - keep, pre = 0, post = keep;
+// text files   (:174-200): S = chunk_size,        pre = keep, post = 0     (keep = m - 1 + extra).
+// seg_stride == 0: one segment, the whole sequence [0, n).  With pre, post <= S / 2 a position lies in
+// at most two segments: its core segment (idx - seg_org) / S and the neighbour the extension
+// reaches into.  A launch owns the segments [seg_j0, seg_j1).
 struct FzGeom {
     uint64_t n;         // global sequence length (every clamp of App. A uses this)
     uint64_t buf_off;   // global index of buf[0]
     uint64_t buf_len;   // valid bytes in buf (the allocation is zero-padded on both sides)
     uint64_t own_lo;    // this shard owns n-gram hits with own_lo <= idx < own_hi
     uint64_t own_hi;
+    uint64_t seg_stride;   // S; 0 = unsegmented
+    uint64_t seg_org;      // global index where segment 0's core starts
+    uint64_t seg_j0, seg_j1;   // segments owned by this launch
+    uint32_t seg_pre, seg_post;
 };
 
+// One segment's bounds [sa, se).
+struct FzSeg { uint64_t sa, se; uint32_t j; uint32_t ok; };
+
+// Candidate segment number c (0 or 1) of position idx; ok = 0 if there is no such segment in this launch.
+FZ_HD FzSeg fz_segment(const FzGeom &g, uint64_t idx, uint32_t c) {
+    FzSeg r;
+    r.j = 0;
+    if (g.seg_stride == 0) { r.sa = 0; r.se = g.n; r.ok = c == 0 ? 1u : 0u; return r; }
+    r.sa = r.se = 0; r.ok = 0;
+    if (idx < g.seg_org) return r;
+    uint64_t j = (idx - g.seg_org) / g.seg_stride;
+    if (c == 1) {
+        if (g.seg_post) { if (j == 0) return r; --j; }       // the previous segment's extension reaches here
+        else if (g.seg_pre) ++j;                              // the next segment starts `pre` bytes early
+        else return r;
+    }
+    if (j < g.seg_j0 || j >= g.seg_j1) return r;
+    const uint64_t core = g.seg_org + j * g.seg_stride;
+    r.sa = (core - g.seg_org >= g.seg_pre) ? core - g.seg_pre : g.seg_org;
+    r.se = core + g.seg_stride + g.seg_post;
+    if (r.se > g.n) r.se = g.n;
+    r.j = (uint32_t)j;
+    r.ok = (idx >= r.sa && idx < r.se) ? 1u : 0u;
+    return r;
+}
+FZ_HD uint32_t fz_segment_candidates(const FzGeom &g) { return (g.seg_stride && (g.seg_pre || g.seg_post)) ? 2u : 1u; }
+
 // One scan launch: up to 8 n-gram blocks of length L.  A hit of block b at global index idx is
-// accepted iff lo[b] <= idx && idx + L <= hi[b] && own_lo <= idx < own_hi.
+// accepted for the segment [sa, se) iff
+//     sa + lo_rel[b] <= idx  &&  idx + L <= se - hi_sub[b]  &&  abs_lo <= idx  &&  idx + L <= abs_hi
+//     &&  own_lo <= idx < own_hi
+// (levenshtein_ngram.py:171-176: lo_rel = max(0, s - k), hi_sub = max(0, m - s - L - k);
+//  _substitutions_only_ngrams_template.h:97-101: lo_rel = s, hi_sub = m - s - L;
+//  search_exact.py:70-71: abs_lo / abs_hi = the clamped start / end index).
 struct FzScanArgs {
     FzGeom   geom;
     uint32_t mode;                              // FzMode: what happens to confirmed hits
     uint32_t m, k;                              // pattern length, edit / substitution budget
     uint32_t L;                                 // n-gram length
-    uint32_t nblk;                              // real blocks in this launch (<= template TG)
+    uint32_t nblk;                              // real blocks in this launch
     uint32_t g0;                                // global block index of block 0 of this launch
     uint32_t d2;                                // byte offset of the 2nd exact-compare window
     uint32_t mask1;                             // mask of the 1st window ((1 << 8L) - 1 when L < 4)
@@ -64,13 +111,18 @@ struct FzScanArgs {
     uint32_t lp_kind;                           // FzLpKind of fz_lp_kernel
     uint32_t lp_starts;                         // tiled modes: start positions owned by one window
     uint32_t hash_k;                            // odd multiplier of the window hash (24 bits when L > 4)
-    uint32_t lut_shift;                         // table slot of a hash h = (h >> lut_shift) & 63
+    uint32_t lut_shift;                         // table slot of a hash h = (h >> lut_shift) & 31
+    uint32_t gw;                                // wavefront verification: lanes per candidate (16, 32 or 64)
+    uint32_t pad0;
     uint32_t H[FZ_MAX_BLOCKS_PER_LAUNCH];       // fast-path hash of each block's n-gram
     uint32_t A[FZ_MAX_BLOCKS_PER_LAUNCH];       // 1st window value per block (little endian)
     uint32_t B[FZ_MAX_BLOCKS_PER_LAUNCH];       // 2nd window value per block
-    uint64_t lo[FZ_MAX_BLOCKS_PER_LAUNCH];
-    uint64_t hi[FZ_MAX_BLOCKS_PER_LAUNCH];
+    uint32_t lo_rel[FZ_MAX_BLOCKS_PER_LAUNCH];  // accepted hit range of a block, relative to the segment ends
+    uint32_t hi_sub[FZ_MAX_BLOCKS_PER_LAUNCH];
     uint32_t s[FZ_MAX_BLOCKS_PER_LAUNCH];       // ngram_start of each block inside the pattern
+    uint64_t abs_lo, abs_hi;                    // absolute index range (exact search with start / end index)
+    uint64_t nchunks;                           // scan: 4 KiB chunks of the buffer
+    uint64_t dom_chunks;                        // scan: chunks per ticket domain
     uint64_t hit_cap;                           // capacity of the hit list
     uint64_t rec_cap;                           // capacity of the record list
     uint64_t host_hdr;                          // device-visible address of the host copy of the counters
@@ -84,7 +136,7 @@ struct FzRec {
     uint32_t l;          // bytes consumed to the left of idx   (start = idx - l)
     uint32_t r;          // bytes consumed right of the n-gram  (end   = idx + L + r)
     uint32_t dist;
-    uint32_t aux;
+    uint32_t aux;        // segment number (file API), else 0
 };
 
 FZ_HD uint64_t fz_hit_pack(uint32_t g, uint64_t idx) { return ((uint64_t)g << 56) | idx; }
@@ -237,17 +289,51 @@ FZ_HD bool fz_expand_any(Sc &sc, uint32_t k, SubF sub, uint32_t sublen, WinF win
     return fz_expand(sc, sub, sublen, win, winlen, budget, dist, consumed);
 }
 
-// levenshtein_ngram.py:177-198 for one hit (block starting at s in the pattern, hit at idx).
+// Accepted hit range of the block starting at pattern offset s, relative to the ends of the sequence /
+// segment: sa + lo_rel <= idx and idx + L <= se - hi_sub.
+FZ_HD void fz_block_range(uint32_t mode, uint32_t m, uint32_t k, uint32_t L, uint32_t s, uint32_t &lo_rel, uint32_t &hi_sub) {
+    if (mode == FZ_MODE_SUBS) { lo_rel = s; hi_sub = m - s - L; }                  // template.h:97-101
+    else if (mode == FZ_MODE_EXACT) { lo_rel = 0; hi_sub = 0; }
+    else {                                                                         // levenshtein_ngram.py:171-176
+        lo_rel = s > k ? s - k : 0;
+        hi_sub = m - s - L > k ? m - s - L - k : 0;
+    }
+}
+
+// Index-range test of a candidate against one segment (block's accepted hit range, absolute range,
+// shard ownership) — the `for index in search_exact(ngram, sequence, start, end)` bounds of
+// levenshtein_ngram.py:171-176 / generic_search.py:221-228 / _substitutions_only_ngrams_template.h:97-101.
+FZ_HD bool fz_hit_in_range(const FzScanArgs &a, uint32_t blk, uint64_t idx, const FzSeg &sg) {
+    if (!sg.ok || blk >= a.nblk) return false;
+    if (idx < sg.sa + a.lo_rel[blk]) return false;
+    if (sg.se < a.hi_sub[blk] || idx + a.L > sg.se - a.hi_sub[blk]) return false;
+    if (idx < a.abs_lo || idx + a.L > a.abs_hi) return false;
+    return idx >= a.geom.own_lo && idx < a.geom.own_hi;
+}
+
+// The same test for a hit of ANY block of the search (kernels that run after the scan launches).
+FZ_HD bool fz_hit_in_range_s(const FzScanArgs &a, uint32_t s, uint64_t idx, const FzSeg &sg) {
+    if (!sg.ok) return false;
+    uint32_t lo_rel, hi_sub;
+    fz_block_range(a.mode, a.m, a.k, a.L, s, lo_rel, hi_sub);
+    if (idx < sg.sa + lo_rel) return false;
+    if (sg.se < hi_sub || idx + a.L > sg.se - hi_sub) return false;
+    if (idx < a.abs_lo || idx + a.L > a.abs_hi) return false;
+    return idx >= a.geom.own_lo && idx < a.geom.own_hi;
+}
+
+// levenshtein_ngram.py:177-198 for one hit (block starting at s in the pattern, hit at idx) inside the
+// sequence / segment [sa, se) (sa = 0, se = n for an in-memory search).
 // `t.at(g)` returns the sequence byte at GLOBAL index g; only indices inside
-// [max(0, idx-s-k), min(n, idx-s+m+k)) are ever requested.
+// [max(sa, idx-s-k), min(se, idx-s+m+k)) are ever requested.
 template <int MAXK, class Sc, class Seq>
-FZ_HD bool fz_verify_lev(Sc &sc, const Seq &t, uint64_t n, const uint8_t *p, uint32_t m,
+FZ_HD bool fz_verify_lev(Sc &sc, const Seq &t, uint64_t sa, uint64_t se, const uint8_t *p, uint32_t m,
                          uint32_t k, uint32_t L, uint32_t s, uint64_t idx, FzRec &rec) {
-    // right: p[s+L:] vs t[idx+L : min(n, idx-s+m+k)]      (idx >= s-k guarantees idx-s+m+k >= 0)
+    // right: p[s+L:] vs t[idx+L : min(se, idx-s+m+k)]      (idx >= sa+s-k guarantees idx-s+m+k >= sa)
     const uint32_t rlen = m - s - L;
     uint64_t rbeg = idx + L;
-    uint64_t rend = idx + m + k - s; if (rend > n) rend = n;
-    if (rbeg > n) rbeg = n;
+    uint64_t rend = idx + m + k - s; if (rend > se) rend = se;
+    if (rbeg > se) rbeg = se;
     if (rend < rbeg) rend = rbeg;
     uint32_t dR = 0, r = 0;
     {
@@ -256,10 +342,10 @@ FZ_HD bool fz_verify_lev(Sc &sc, const Seq &t, uint64_t n, const uint8_t *p, uin
         auto win = [&](uint32_t j) -> uint8_t { return t.at(rbeg + j); };
         if (!fz_expand_any<MAXK>(sc, k, sub, rlen, win, (uint32_t)(rend - rbeg), k, dR, r)) return false;
     }
-    // left: reversed p[:s] vs reversed t[max(0, idx-s-(k-dR)) : idx], budget k - dR
+    // left: reversed p[:s] vs reversed t[max(sa, idx-s-(k-dR)) : idx], budget k - dR
     const uint32_t bl = k - dR;
     uint64_t want = (uint64_t)s + bl;
-    uint64_t lbeg = (idx > want) ? (idx - want) : 0;
+    uint64_t lbeg = (idx - sa > want) ? (idx - want) : sa;
     uint32_t dL = 0, l = 0;
     {
         auto sub = [&](uint32_t i) -> uint8_t { return p[s - 1 - i]; };

@@ -4,17 +4,26 @@
 //     K1 filter   every byte offset is tested against all G n-gram blocks at once (replaces G x
 //                 search_exact_byteslike passes, _common.c:75-102 / memmem.c:92-160): a one-op
 //                 hash of the first min(L,8) window bytes (v_alignbyte / v_mad_u32_u24) selects one
-//                 of 64 slots of a table in LDS that holds the blocks' hashes (ds_read_b32), one
-//                 v_xor compares, v_min3 accumulates, one ballot per 4 offsets: the cost does not
-//                 depend on G; survivors go through a per-wave LDS queue to an exact re-check;
-//     K2 verify   confirmed hits wait in a per-wave LDS staging area and are verified 64 at a
-//                 time, one lane per hit, inside the same kernel: the <= m+2k window bytes are
-//                 fetched once into LDS, then the bounded edit-distance expansion right and left
-//                 (c_expand_*, _levenshtein_ngrams.pyx:9-154) or the Hamming count
-//                 (_substitutions_only_ngrams_template.h:103-121) runs on a ring of 2k+2 LDS score
-//                 slots per lane.  Only match records leave the chip.
-//   fz_verify_kernel  the same wave-level verification over a hit list in HBM, for parameter
-//                 ranges that do not fit beside the filter (k > 4, or large m + 2k).
+//                 of 32 slots of a table in LDS that holds the blocks' hashes (ds_read_b32: one slot
+//                 per bank, so the lookup is bank-conflict free by construction), one v_xor
+//                 compares, v_min3 accumulates, one ballot per 4 offsets: the cost does not depend
+//                 on G.  A firing 4-offset group only pushes its POSITION onto a per-wave LDS queue
+//                 (8 wave-instructions); which offset and which block fired is worked out later, 64
+//                 groups at a time with full lanes;
+//     K2 verify   queued groups are resolved 64 at a time (exact compare of every offset with every
+//                 block), then verified one lane per candidate inside the same kernel: the <= m+2k
+//                 window bytes are fetched once into LDS, then the bounded edit-distance expansion
+//                 right and left (c_expand_*, _levenshtein_ngrams.pyx:9-154) or the Hamming count
+//                 (_substitutions_only_ngrams_template.h:103-121).  Only match records leave the chip.
+//     work split  a wave's unit of work is a 4 KiB chunk drawn from one of 256 ticket counters
+//                 (global atomics, the next ticket is fetched while the current chunk is processed):
+//                 waves that the SIMD's oldest-first issue favours simply draw more chunks, so all
+//                 waves of the persistent grid finish together (no tail of half-empty CUs).
+//   fz_verify_kernel  the lane-per-candidate verification over a hit list in HBM, for parameter
+//                 ranges that do not fit beside the filter (large m + 2k, budgets above 31).
+//   fz_verify_wf_kernel  budgets 5..31: lane-per-DP-cell.  GW = 16 / 32 / 64 lanes own the 2k+1 band
+//                 cells of one candidate's DP row; the left-neighbour recurrence is a prefix-min
+//                 over the lanes (DPP row shifts), the upper neighbour one DPP shift.
 //   fz_lp_kernel      one wave per work item: the reference's greedy candidate-set automata
 //                 (generic search per n-gram hit; generic / Levenshtein linear-programming fallbacks
 //                 tiled over the whole sequence), candidate lists in LDS, order preserved.
@@ -22,24 +31,30 @@
 //
 // HBM-bound integer/byte work: no MFMA.  What matters (MI355X guide): 16-byte coalesced loads,
 // >= 2048 workgroups' worth of loads in flight, no per-byte branching, n-gram constants in a
-// 256-byte LDS table, wave-uniform rare paths, ONE global atomic per bulk append (a single counter
+// 128-byte LDS table, wave-uniform rare paths, ONE global atomic per bulk append (a single counter
 // word sustains only ~90 atomics/us chip-wide), no agent-scope fences.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstddef>
 #include "fz_device.h"
 
 #define FZ_FILTER_THREADS 256
 #define FZ_WAVES_PER_BLOCK (FZ_FILTER_THREADS / 64)
-#define FZ_FILTER_ROWS 4                                   // 16-byte rows per thread per tile
-#define FZ_ROW_BYTES (FZ_FILTER_THREADS * 16)              // 4 KiB
-#define FZ_TILE_BYTES (FZ_ROW_BYTES * FZ_FILTER_ROWS)      // 16 KiB (4 rows) / 32 KiB (8 rows)
-#define FZ_TILE_BITS (FZ_FILTER_ROWS == 8 ? 15 : 14)       // log2(FZ_TILE_BYTES)
-#define FZ_TITER_MAX ((1u << (32 - FZ_TILE_BITS - 3)) - 1) // tile iterations a queue code can carry
+#define FZ_FILTER_ROWS 4                                   // 16-byte rows per lane per chunk
+#define FZ_ROW_BYTES 1024                                  // one wave-row: 64 lanes x 16 B
+#define FZ_CHUNK_BYTES (FZ_ROW_BYTES * FZ_FILTER_ROWS)     // 4 KiB: one wave's unit of work
+#define FZ_CHUNK_BITS 12
+#define FZ_GROUP_BITS (FZ_CHUNK_BITS - 2)                  // a queue code's low bits: 4-offset group inside the chunk
+#define FZ_CODE_CHUNKS (1u << (32 - FZ_GROUP_BITS))        // chunks a queue code can tell apart
 #define FZ_PAD_FRONT 256                                   // zero bytes before buf[0]
 #define FZ_PAD_BACK 64                                     // zero bytes the kernels may over-read
-#define FZ_QCAP 256                                        // fast-hit queue entries per wave
-#define FZ_LUT_SLOTS 64u                                   // slots of the block-hash table (6 hash bits)
+#define FZ_QCAP 256                                        // queue entries per wave
+#define FZ_LUT_SLOTS 32u                                   // slots of the block-hash table: one per LDS bank
 #define FZ_LUT_BYTES (FZ_LUT_SLOTS * 4u)
+#define FZ_NDOM 256u                                       // ticket counters (domains of consecutive chunks)
+#define FZ_TICKET_STRIDE 16u                               // 64-bit words between two ticket counters (128 B)
+#define FZ_STEALS 3u                                       // other domains a wave tries when its own is drained
+#define FZ_ARGS_LDS_BYTES ((uint32_t)((offsetof(FzScanArgs, pat) + 15u) & ~15u))   // LDS copy of the launch arguments
 
 // 32-bit little-endian window starting `b` bytes into the 64-bit value hi:lo (v_alignbyte_b32).
 __device__ __forceinline__ uint32_t fz_win(uint32_t lo, uint32_t hi, int b) {
@@ -74,7 +89,7 @@ __device__ __forceinline__ uint32_t fz_load_win(const uint8_t *__restrict__ buf,
 
 // Per-wave LDS areas, carved from dynamic LDS by fz_wave_lds().
 struct FzWaveLds {
-    uint32_t *queue;      // [FZ_QCAP]  fast hits: tile-local offset | block << 14 | tile iteration << 17
+    uint32_t *queue;      // [FZ_QCAP]  fired 4-offset groups: group inside the chunk | (chunk - queue base) << 10
     uint32_t *win;        // [win_dwords * 64]  sequence window of each lane's hit (dword d of lane l at d*64+l)
     uint16_t *scores;     // [band_w * 64]      ring of DP score slots (slot s of lane l at s*64+l)
 };
@@ -121,25 +136,19 @@ __device__ __forceinline__ unsigned long long fz_bcast64(unsigned long long v) {
            __builtin_amdgcn_readfirstlane((uint32_t)v);
 }
 
-// Index-range tests of a candidate (block's accepted hit range, shard ownership).
-__device__ __forceinline__ bool fz_in_range(const FzScanArgs &a, uint32_t blk, uint64_t idx) {
-    if (blk >= a.nblk) return false;
-    if (idx < a.lo[blk] || idx + a.L > a.hi[blk]) return false;
-    return idx >= a.geom.own_lo && idx < a.geom.own_hi;
-}
-
 // ---------------------------------------------------------------------------------------------
-// Wave-level verification of up to 64 candidates: each lane owns one (hit = block | idx).
+// Wave-level verification of up to 64 candidates: each lane owns one (hit = block | idx) and the
+// segment it is verified in.
 //  1. every lane fetches the <= m + 2k window bytes around its candidate into LDS with independent
 //     aligned dword loads (one HBM/L2 round trip instead of one per byte),
-//  2. confirms the n-gram exactly (the filter only compared a hash), then runs the reference's
-//     per-hit logic (fz_verify_lev / fz_verify_subs) out of LDS,
+//  2. confirms the n-gram exactly (the filter only compared its first min(L, 8) bytes), then runs the
+//     reference's per-hit logic (fz_verify_lev / fz_verify_subs) out of LDS,
 //  3. the wave appends its records with ONE global atomic.
 // Returns the number of exactly-confirmed n-gram hits (wave-uniform, statistics).
 template <int MAXK>
 __device__ __forceinline__ uint32_t fz_wave_verify(const uint8_t *__restrict__ buf, const FzScanArgs &a,
                                                    const uint8_t *pat_lds, const FzWaveLds &w,
-                                                   uint64_t hit, bool valid,
+                                                   uint64_t hit, const FzSeg &sg, bool valid,
                                                    FzRec *__restrict__ recs, unsigned long long *__restrict__ counters) {
     const uint32_t lane = fz_lane();
     const uint32_t g = fz_hit_block(hit);
@@ -149,12 +158,12 @@ __device__ __forceinline__ uint32_t fz_wave_verify(const uint8_t *__restrict__ b
     uint64_t wlo = 0, whi = 0, wbase = 0;
     if (valid) {
         const uint64_t reach = (uint64_t)s + a.k;
-        wlo = idx > reach ? idx - reach : 0;
+        wlo = idx - sg.sa > reach ? idx - reach : sg.sa;
         if (wlo < a.geom.buf_off) wlo = a.geom.buf_off;
         whi = idx - s + a.m + a.k;
         const uint64_t lim = a.geom.buf_off + a.geom.buf_len;
         if (whi > lim) whi = lim;
-        if (whi > a.geom.n) whi = a.geom.n;
+        if (whi > sg.se) whi = sg.se;
         wbase = a.geom.buf_off + ((wlo - a.geom.buf_off) & ~(uint64_t)3);   // dword-aligned in the buffer
     }
     const uint32_t nd = valid ? (uint32_t)((whi - wbase + 3) >> 2) : 0u;
@@ -183,7 +192,7 @@ __device__ __forceinline__ uint32_t fz_wave_verify(const uint8_t *__restrict__ b
     if (valid) {
         if (a.mode == FZ_MODE_LEV) {
             FzLdsScores sc{w.scores + lane, a.vlanes};
-            ok = fz_verify_lev<MAXK>(sc, t, a.geom.n, pat_lds, a.m, a.k, a.L, s, idx, rec);
+            ok = fz_verify_lev<MAXK>(sc, t, sg.sa, sg.se, pat_lds, a.m, a.k, a.L, s, idx, rec);
         } else {
             ok = fz_verify_subs(t, pat_lds, a.m, a.k, a.L, s, idx, rec);
         }
@@ -195,6 +204,7 @@ __device__ __forceinline__ uint32_t fz_wave_verify(const uint8_t *__restrict__ b
         base = fz_bcast64(base);
         if (ok) {
             rec.key = hit;
+            rec.aux = sg.j;
             const unsigned long long slot = base + fz_rank(mask);
             if (slot < a.rec_cap) recs[slot] = rec;
         }
@@ -203,24 +213,22 @@ __device__ __forceinline__ uint32_t fz_wave_verify(const uint8_t *__restrict__ b
     return confirmed;
 }
 
-// Exact test of one (local position, block) candidate against the buffer in HBM (emit mode).
-__device__ __forceinline__ bool fz_confirm(const uint8_t *__restrict__ buf, const FzScanArgs &a, uint32_t blk,
-                                           uint64_t local) {
-    if ((fz_load_win(buf, (int64_t)local) & a.mask1) != a.A[blk]) return false;
-    if (a.L > 4 && (fz_load_win(buf, (int64_t)local + a.d2) & a.mask2) != a.B[blk]) return false;
+// Bytes 8 .. L-1 of a block's n-gram against the buffer in HBM (the first min(L, 8) were compared exactly).
+__device__ __forceinline__ bool fz_confirm_tail(const uint8_t *__restrict__ buf, const FzScanArgs &a, const uint8_t *pat_lds,
+                                                uint32_t blk, uint64_t local) {
     for (uint32_t b = 8; b < a.L; ++b)
-        if (buf[local + b] != a.pat[a.s[blk] + b]) return false;
+        if (buf[local + b] != pat_lds[a.s[blk] + b]) return false;
     return true;
 }
 
-
 #define FZ_HDR_WORDS 128                                   // 64-bit counters in the result header
-#define FZ_HDR_TICKET 3                                    // counters[3]: workgroups that finished (final launch)
+#define FZ_HDR_TICKET 3                                    // counters[3]: workgroups that finished (this launch)
 
-// End of the final kernel of a search: the LAST workgroup to get here copies the counters into
-// host-visible memory (a.host_hdr), so the host needs no D2H copy command after the kernel (the
-// records themselves are then written straight to pinned host memory as well).  Every thread of
-// the workgroup must call it.
+// End of a kernel: the LAST workgroup to get here
+//  * zeroes the chunk-ticket counters for the next scan launch (no memset command on the stream),
+//  * and, in the final kernel of a search, copies the counters into host-visible memory
+//    (a.host_hdr), so the host needs no D2H copy command after the kernel (the records themselves are
+//    then written straight to pinned host memory as well).  Every thread of the workgroup must call it.
 // No agent-scope fence on purpose: on this multi-XCD part __threadfence() writes back the XCD's L2,
 // and one per workgroup made the scan 1.7x slower.  It is not needed either: everything the last
 // workgroup reads was produced by agent-scope atomics (performed memory-side), __syncthreads() makes
@@ -228,65 +236,110 @@ __device__ __forceinline__ bool fz_confirm(const uint8_t *__restrict__ buf, cons
 // and the counters are read back with agent-scope atomic loads.
 // `flag` is one LDS dword the workgroup no longer needs (no static __shared__ here: it would move the
 // dynamic LDS base off 0 and cost the scan an address add per table lookup).
-__device__ __forceinline__ void fz_publish_header(const FzScanArgs &a, unsigned long long *__restrict__ counters,
-                                                  volatile uint32_t *flag) {
-    if (!a.host_hdr) return;
+__device__ __forceinline__ void fz_finish_launch(const FzScanArgs &a, unsigned long long *__restrict__ counters,
+                                                 unsigned long long *__restrict__ tickets, volatile uint32_t *flag) {
     __syncthreads();                                       // all waves' counter atomics are complete, LDS is free
     if (threadIdx.x == 0)
         *flag = atomicAdd(&counters[FZ_HDR_TICKET], 1ull) == (unsigned long long)gridDim.x - 1ull;
     __syncthreads();
     if (*flag) {
-        unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.host_hdr);
-        for (uint32_t i = threadIdx.x; i < FZ_HDR_WORDS; i += blockDim.x) {
-            dst[i] = __hip_atomic_load(&counters[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // ... and leaves the counters zeroed for the next search (no memset command on the stream)
-            __hip_atomic_store(&counters[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tickets)
+            for (uint32_t i = threadIdx.x; i < FZ_NDOM; i += blockDim.x)
+                __hip_atomic_store(&tickets[i * FZ_TICKET_STRIDE], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.host_hdr) {
+            unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.host_hdr);
+            for (uint32_t i = threadIdx.x; i < FZ_HDR_WORDS; i += blockDim.x) {
+                dst[i] = __hip_atomic_load(&counters[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // ... and leaves the counters zeroed for the next search (no memset command on the stream)
+                __hip_atomic_store(&counters[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else if (threadIdx.x == 0) {
+            __hip_atomic_store(&counters[FZ_HDR_TICKET], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
 
-// Candidate code of the queue: tile-local byte offset (14 bits) | block (3 bits) | tile iteration.
-__device__ __forceinline__ uint32_t fz_code(uint32_t off, uint32_t blk, uint32_t titer) {
-    return off | (blk << FZ_TILE_BITS) | (titer << (FZ_TILE_BITS + 3));
-}
-
-// Process queue entries [0, qn): range-check, then verify in place (FUSED) or confirm against HBM
-// and bulk-append to the global hit list.  Returns the number of confirmed n-gram hits.
+// Process queue entries [0, qn): every entry is a 4-offset group some lane's filter fired on.
+//  A  64 groups at a time: fetch the group's 12 bytes and compare each of its 4 offsets exactly with
+//     the first min(L, 8) bytes of every block of the launch -> a bit per (offset, block);
+//  B  while some lane still has a bit: every lane takes its lowest one as a candidate, range-checks it
+//     against each segment it may belong to and verifies in place (FUSED) or confirms the n-gram's
+//     tail against HBM and bulk-appends the hit to the global hit list.
+// Nearly every group carries exactly one bit, so B normally runs once with all lanes busy; inputs with
+// overlapping n-gram occurrences just take more rounds.  Returns the number of confirmed n-gram hits.
+// A real function call on purpose: inlined, the flush (two expansions per budget, window staging)
+// dominates the kernel's register allocation and the hot loop of the scan pays for it (spilled loop
+// constants, LDS lookups issued one at a time).  Out of line the hot loop is allocated on its own and
+// only the rare call saves what is live.  `ap` points at the workgroup's LDS copy of the launch
+// arguments (everything but the pattern, which lives in pat_lds): the by-value kernel argument has no
+// address a function could take without a 1.4 KB private copy per lane.
 template <bool FUSED>
-__device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ buf, const FzScanArgs &a,
-                                                   const uint8_t *pat_lds, const FzWaveLds &w, uint32_t qn,
-                                                   uint64_t *__restrict__ hits, FzRec *__restrict__ recs,
-                                                   unsigned long long *__restrict__ counters) {
+__device__ __noinline__ uint32_t fz_queue_flush(
+    const uint8_t *__restrict__ buf, const FzScanArgs *ap, const uint8_t *pat_lds, uint32_t *queue, uint32_t *win,
+    uint16_t *scores, uint32_t qn, uint64_t qbase, uint64_t *__restrict__ hits, FzRec *__restrict__ recs,
+    unsigned long long *__restrict__ counters) {
+    const FzScanArgs &a = *ap;
+    FzWaveLds w;
+    w.queue = queue; w.win = win; w.scores = scores;
     const uint32_t lane = fz_lane();
     uint32_t confirmed = 0;
     fz_wave_lds_sync();
-    const uint32_t width = FUSED ? a.vlanes : 64u;          // candidates handled per pass
-    for (uint32_t e0 = 0; e0 < qn; e0 += width) {
+    const uint32_t ncand = fz_segment_candidates(a.geom);
+    for (uint32_t e0 = 0; e0 < qn; e0 += 64u) {
         const uint32_t e = e0 + lane;
-        bool valid = lane < width && e < qn;
-        uint64_t hit = 0;
         uint64_t local = 0;
-        uint32_t blk = 0;
-        if (valid) {
+        uint32_t bits = 0;
+        if (e < qn) {
             const uint32_t code = w.queue[e];
-            blk = (code >> FZ_TILE_BITS) & 7u;
-            const uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)(code >> (FZ_TILE_BITS + 3)) * gridDim.x;
-            local = tile * (uint64_t)FZ_TILE_BYTES + (code & (FZ_TILE_BYTES - 1u));
-            const uint64_t idx = a.geom.buf_off + local;
-            valid = fz_in_range(a, blk, idx);
-            hit = fz_hit_pack(a.g0 + blk, idx);
+            local = (qbase + (uint64_t)(code >> FZ_GROUP_BITS)) * (uint64_t)FZ_CHUNK_BYTES +
+                    (uint64_t)((code & ((1u << FZ_GROUP_BITS) - 1u)) << 2);
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(buf + local);
+            const uint32_t w4[4] = {src[0], src[1], src[2], 0u};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t x = FZ_WIN(w4, i) & a.mask1;
+                for (uint32_t b = 0; b < a.nblk; ++b) {
+                    bool eq = x == a.A[b];
+                    if (eq && a.L > 4) {
+                        // second window: n-gram bytes d2 .. d2+3 (d2 = min(L, 8) - 4 in 1..4)
+                        const uint32_t o2 = (uint32_t)i + a.d2;          // 1 .. 7
+                        const uint32_t lo = o2 < 4 ? w4[0] : w4[1], mid = o2 < 4 ? w4[1] : w4[2];
+                        const uint32_t y2 = (o2 & 3u) ? __builtin_amdgcn_alignbyte(mid, lo, o2 & 3u) : lo;
+                        eq = (y2 & a.mask2) == a.B[b];
+                    }
+                    if (eq) bits |= 1u << (i * 8 + (int)b);
+                }
+            }
         }
-        if (FUSED) {
-            confirmed += fz_wave_verify<4>(buf, a, pat_lds, w, hit, valid, recs, counters);
-        } else {
-            if (valid) valid = fz_confirm(buf, a, blk, local);
-            const unsigned long long mask = __ballot(valid);
-            if (mask) {
-                unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(&counters[0], (unsigned long long)__popcll(mask));
-                base = fz_bcast64(base);
-                const unsigned long long slot = base + fz_rank(mask);
-                if (valid && slot < a.hit_cap) hits[slot] = hit;
+        while (__ballot(bits != 0)) {
+            const bool has = bits != 0;
+            const uint32_t tz = has ? (uint32_t)__builtin_ctz(bits) : 0u;
+            bits &= bits - 1u;
+            const uint32_t blk = tz & 7u;
+            const uint64_t loc = local + (tz >> 3);
+            const uint64_t idx = a.geom.buf_off + loc;
+            const uint64_t hit = fz_hit_pack(a.g0 + blk, idx);
+            if (FUSED) {
+                for (uint32_t c = 0; c < ncand; ++c) {
+                    const FzSeg sg = fz_segment(a.geom, idx, c);
+                    const bool valid = has && fz_hit_in_range(a, blk, idx, sg);
+                    if (!__ballot(valid)) continue;
+                    confirmed += fz_wave_verify<4>(buf, a, pat_lds, w, hit, sg, valid, recs, counters);
+                }
+            } else {
+                bool valid = false;
+                if (has) {
+                    for (uint32_t c = 0; c < ncand; ++c) valid = valid || fz_hit_in_range(a, blk, idx, fz_segment(a.geom, idx, c));
+                    if (valid) valid = fz_confirm_tail(buf, a, pat_lds, blk, loc);
+                }
+                const unsigned long long mask = __ballot(valid);
+                if (mask) {
+                    unsigned long long base = 0;
+                    if (lane == 0) base = atomicAdd(&counters[0], (unsigned long long)__popcll(mask));
+                    base = fz_bcast64(base);
+                    const unsigned long long slot = base + fz_rank(mask);
+                    if (valid && slot < a.hit_cap) hits[slot] = hit;
+                }
             }
         }
     }
@@ -294,157 +347,189 @@ __device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ b
     return confirmed;
 }
 
-// TG    : blocks the rare path tells apart (unrolled compares); nblk <= TG are real, the rest repeat block 0
-//         and are dropped by the range check.  The hot path does not depend on it.
+// Draw the next chunk of domain `dom` (one returning global atomic, lane 0).
+__device__ __forceinline__ uint32_t fz_ticket_issue(unsigned long long *__restrict__ tickets, uint32_t dom) {
+    uint32_t t = 0;
+    if (fz_lane() == 0) t = atomicAdd(reinterpret_cast<unsigned int *>(&tickets[dom * FZ_TICKET_STRIDE]), 1u);
+    return t;
+}
+__device__ __forceinline__ uint32_t fz_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
 // NWIN  : 1 -> hash = (masked dword at the offset) * K               (L <= 4, v_mul_lo_u32);
 //         2 -> hash = low24(dword at offset + DH) * K + dword at offset (v_mad_u32_u24), DH = min(L, 8) - 3.
 // FUSED : verify candidates inside this kernel (records out) or emit exact hits (hit list out).
-// Each thread owns 16 consecutive byte offsets per row and reads 24 bytes (16 + 8 halo).
-// Block test: slot = (hash >> lut_shift) & 63; lut[slot] holds the hash of the block that lives there
+// Each lane owns 16 consecutive byte offsets per row and reads 24 bytes (16 + 8 halo).
+// Block test: slot = (hash >> lut_shift) & 31; lut[slot] holds the hash of the block that lives there
 // (the host picks K and lut_shift so that different block hashes get different slots) or, for a free
 // slot, a value that belongs to another slot, so hash ^ lut[slot] == 0 <=> the window hashes like
-// some block.
-// Measured against per-block VALU compares (benchmarks/filter_variants.hip, v3 vs v14, 3 blocks,
-// L2-resident data): 0.222 -> 0.175 ms per GiB, and no longer growing with the number of blocks.
-// Fast hits are queued per wave ACROSS tiles and processed 64 at a time (full lanes, one latency
-// chain per ~100 candidates instead of one per tile).  A tile denser than the queue is re-scanned
-// by enumeration ("slow tile": correctness path for pathological inputs).
-// 7 waves per SIMD (72 VGPRs): measured 2-3 % faster than the natural 79-VGPR / 6-wave allocation;
-// 8 waves (64 VGPRs) spills 27 VGPRs in the verify path and is 50 % slower.
-template <int TG, int NWIN, int DH, bool FUSED>
+// some block.  32 slots of 4 bytes = one slot per LDS bank: lanes that read different slots never
+// collide, lanes that read the same slot are served by one broadcast.
+// A firing group is only queued (position, 32-bit code); offsets and blocks are resolved at the flush.
+// A chunk denser than the queue is re-queued group by group ("slow chunk": correctness path for
+// pathological inputs).
+// 7 waves per SIMD (72 VGPRs): measured 2-3 % faster than the natural 79-VGPR / 6-wave allocation.
+template <int NWIN, int DH, bool FUSED>
 __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_eu(7, 7))) void fz_scan_kernel(
-    const uint8_t *__restrict__ buf, const FzScanArgs a, uint64_t ntiles,
+    const uint8_t *__restrict__ buf, const FzScanArgs a, unsigned long long *__restrict__ tickets,
     uint64_t *__restrict__ hits, FzRec *__restrict__ recs, unsigned long long *__restrict__ counters) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t mpad = (a.m + 15u) & ~15u;
-    // [64] hash living in the slot.  The kernel has no static LDS, so the dynamic area, and with it this
+    // [32] hash living in the slot.  The kernel has no static LDS, so the dynamic area, and with it this
     // table, starts at LDS address 0 and a slot's byte offset is its address (saves one VALU add per
     // lookup); trap if a toolchain ever lays LDS out differently.
     uint32_t *lut = reinterpret_cast<uint32_t *>(smem);
     if (reinterpret_cast<uintptr_t>((FzLdsU8 *)smem) != 0) __builtin_trap();
     uint8_t *pat_lds = smem + FZ_LUT_BYTES;
     for (uint32_t i = threadIdx.x; i < a.m; i += FZ_FILTER_THREADS) pat_lds[i] = a.pat[i];
+    // the launch arguments (all but the pattern) for the out-of-line flush, copied from the kernarg segment
+    FzScanArgs *args_lds = reinterpret_cast<FzScanArgs *>(smem + FZ_LUT_BYTES + mpad);
+    {
+        typedef __attribute__((address_space(4))) const uint32_t FzConstU32;
+        FzConstU32 *src = (FzConstU32 *)__builtin_amdgcn_kernarg_segment_ptr() + 2;   // `a` follows `buf`
+        for (uint32_t i = threadIdx.x; i < FZ_ARGS_LDS_BYTES / 4u; i += FZ_FILTER_THREADS)
+            reinterpret_cast<uint32_t *>(args_lds)[i] = src[i];
+    }
     if (threadIdx.x < FZ_LUT_SLOTS) {
         uint32_t t = ((threadIdx.x + 1u) & (FZ_LUT_SLOTS - 1u)) << a.lut_shift;   // free slot: a value of the next slot
         for (uint32_t g = 0; g < a.nblk; ++g)
             if (((a.H[g] >> a.lut_shift) & (FZ_LUT_SLOTS - 1u)) == threadIdx.x) t = a.H[g];
         lut[threadIdx.x] = t;
     }
-    // lane g of hvec = hash of block g: the rare path reads it back with v_readlane (no memory latency)
-    uint32_t hvec = 0;
-#pragma unroll
-    for (uint32_t g = 0; g < FZ_MAX_BLOCKS_PER_LAUNCH; ++g)
-        if (fz_lane() == g) hvec = a.H[g];
     __syncthreads();
-    const FzWaveLds w = fz_wave_lds(smem + FZ_LUT_BYTES + mpad, threadIdx.x >> 6, FUSED ? a.win_dwords : 0u,
-                                    FUSED ? a.band_w : 0u, a.vlanes, true);
-    const uint32_t hash_k = a.hash_k;
-    // byte address of a hash's slot = (h >> (lut_shift - 2)) & 0xfc: two VGPR-only VALU ops (a shift
-    // amount in an SGPR or an SDWA byte select would issue at half the rate, benchmarks/valu_rates.hip)
-    uint32_t slot_shift;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(slot_shift) : "s"(a.lut_shift - 2u));
-    const uint32_t mask1 = a.mask1;
+    // The loop keeps as little state as it can (32-bit, wave-uniform -> SGPRs): whatever is live across
+    // the hot loop takes registers away from it.  Chunk numbers are 32-bit (16 TiB of sequence).
+    const uint32_t wave = fz_uniform(threadIdx.x >> 6);
     const uint32_t lane = fz_lane();
-    const uint32_t lane_off = threadIdx.x * 16u;
-    uint32_t qn = 0;                                  // wave-uniform queue fill
-    uint32_t confirmed = 0;                           // wave-uniform statistics
-    uint32_t titer = 0;                               // tile iteration of this workgroup
-    uint64_t tile = blockIdx.x;
-    bool slow = false;                                // a tile is being re-scanned by enumeration
+    const uint32_t nchunks = (uint32_t)a.nchunks, dom_chunks = (uint32_t)a.dom_chunks;
+    uint32_t qn = 0;                                  // queue fill
+    uint32_t qbase = 0;                               // chunk the queue codes are relative to
+
+    // chunk tickets: this wave's home domain, then up to FZ_STEALS others (spread over the XCDs)
+    const uint32_t home = fz_uniform((blockIdx.x * FZ_WAVES_PER_BLOCK + wave) % FZ_NDOM);
+    uint32_t steal = 0;
+    uint32_t dom = home;
+    uint32_t tk = fz_ticket_issue(tickets, dom);      // lane 0: the drawn ticket (chunk number inside the domain)
+    uint32_t chunk = 0;
+    bool have = false;                                // `chunk` is drawn but not processed yet
+    bool slow = false;                                // `chunk` is being re-queued group by group
+    bool done = false;
     uint32_t slow_pos = 0;
 
+    // One flush site only (the flush is large: inlined several times it pushed the hot loop into scratch).
     for (;;) {
         if (slow) {
-            // enumerate (row, offset, block) candidates of tile `tile`, 64 lanes at a time
-            const uint32_t steps = FZ_FILTER_ROWS * 16u * a.nblk;
-            while (slow_pos < steps && qn + 64u <= FZ_QCAP) {
-                const uint32_t blk = slow_pos % a.nblk;
-                const uint32_t ro = slow_pos / a.nblk;
-                w.queue[qn + lane] = fz_code((ro >> 4) * FZ_ROW_BYTES + lane_off + (ro & 15u), blk, titer);
+            // the chunk overflowed the queue: queue every one of its 1024 groups instead, 64 at a time
+            // (the flush tests them exactly)
+            if (qn == 0) qbase = chunk;
+            uint32_t *queue = fz_wave_lds(smem + FZ_LUT_BYTES + mpad + FZ_ARGS_LDS_BYTES, wave, FUSED ? a.win_dwords : 0u,
+                                          FUSED ? a.band_w : 0u, a.vlanes, true).queue;
+            while (slow_pos < FZ_FILTER_ROWS * 4u && qn + 64u <= FZ_QCAP) {
+                queue[qn + lane] = ((lane << 2) + ((slow_pos >> 2) * 256u + (slow_pos & 3u))) | ((chunk - qbase) << FZ_GROUP_BITS);
                 qn += 64u;
                 ++slow_pos;
             }
-            if (slow_pos >= steps) { slow = false; tile += gridDim.x; ++titer; }
-        } else {
-            while (tile < ntiles && qn <= FZ_QCAP / 2) {
-                const uint64_t tile_base = tile * (uint64_t)FZ_TILE_BYTES;
+            if (slow_pos == FZ_FILTER_ROWS * 4u) slow = false;
+        } else if (!done) {
+            if (!have) {
+                const uint32_t dom_lo = dom * dom_chunks;
+                const uint32_t dom_hi = dom_lo + dom_chunks < nchunks ? dom_lo + dom_chunks : nchunks;
+                const uint32_t c = dom_lo + fz_uniform(tk);
+                if (dom_lo < dom_hi && c < dom_hi) {
+                    chunk = c;
+                    have = true;
+                } else if (steal == FZ_STEALS) {
+                    done = true;                      // own domain and the steal targets are drained
+                } else {
+                    ++steal;
+                    dom = (home + steal * 4u * 9u) % FZ_NDOM;   // 4 waves per workgroup, consecutive workgroups on consecutive XCDs
+                    tk = fz_ticket_issue(tickets, dom);
+                    continue;
+                }
+            }
+            // the queue codes are relative to qbase: a chunk outside their range waits for the flush below
+            if (have && !(qn && (chunk < qbase || chunk - qbase >= FZ_CODE_CHUNKS))) {
+                if (qn == 0) qbase = chunk;
+                // Per-chunk constants are set up here, not before the loop: kept live across the (large)
+                // flush they were the first values the register allocator pushed to scratch.
+                const uint32_t hash_k = a.hash_k;
+                const uint32_t mask1 = a.mask1;
+                // byte address of a hash's slot = (h >> (lut_shift - 2)) & 0x7c: two VGPR-only VALU ops (a shift
+                // amount in an SGPR or an SDWA byte select would issue at half the rate, benchmarks/valu_rates.hip)
+                uint32_t slot_shift;
+                asm volatile("v_mov_b32 %0, %1" : "=v"(slot_shift) : "s"(a.lut_shift - 2u));
+                uint32_t lane_code = lane << 2;        // this lane's part of a queue code: its first group in a row
+                asm volatile("" : "+v"(lane_code));
+                uint32_t queue_lds;                    // LDS byte address of this wave's queue
+                {
+                    uint8_t *qp = reinterpret_cast<uint8_t *>(
+                        fz_wave_lds(smem + FZ_LUT_BYTES + mpad + FZ_ARGS_LDS_BYTES, wave, FUSED ? a.win_dwords : 0u,
+                                    FUSED ? a.band_w : 0u, a.vlanes, true).queue);
+                    queue_lds = fz_uniform((uint32_t)(uintptr_t)((FzLdsU8 *)qp));
+                }
+                const uint8_t *src0 = buf + (uint64_t)chunk * FZ_CHUNK_BYTES + lane * 16u;
                 uint4 v[FZ_FILTER_ROWS];
                 uint2 h[FZ_FILTER_ROWS];
 #pragma unroll
                 for (int r = 0; r < FZ_FILTER_ROWS; ++r) {
-                    const uint8_t *src = buf + tile_base + lane_off + (uint64_t)r * FZ_ROW_BYTES;
+                    const uint8_t *src = src0 + (uint64_t)r * FZ_ROW_BYTES;
                     v[r] = *reinterpret_cast<const uint4 *>(src);
                     h[r] = *reinterpret_cast<const uint2 *>(src + 16);
                 }
-                const uint32_t q_tile = qn;
+                tk = fz_ticket_issue(tickets, dom);   // next ticket: its latency hides behind this chunk
+                have = false;
+                const uint32_t q_chunk = qn;
+                const uint32_t code_chunk = (chunk - qbase) << FZ_GROUP_BITS;
 #pragma unroll
                 for (int r = 0; r < FZ_FILTER_ROWS; ++r) {
                     const uint32_t w6[6] = {v[r].x, v[r].y, v[r].z, v[r].w, h[r].x, h[r].y};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {     // 4 byte offsets per ballot
-                        uint32_t hv[4], am[4];
+                        uint32_t am[4];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const int o = 4 * j + i;
                             const uint32_t x = FZ_WIN(w6, o);
-                            if (NWIN == 1) hv[i] = (x & mask1) * hash_k;                             // v_mul_lo_u32
-                            else hv[i] = __umul24(FZ_WIN(w6, o + DH), hash_k) + x;                   // v_mad_u32_u24
+                            uint32_t hv;
+                            if (NWIN == 1) hv = (x & mask1) * hash_k;                             // v_mul_lo_u32
+                            else hv = __umul24(FZ_WIN(w6, o + DH), hash_k) + x;                   // v_mad_u32_u24
                             uint32_t slot4;
-                            asm("v_lshrrev_b32 %0, %1, %2\n\tv_and_b32 %0, 0xfc, %0" : "=v"(slot4) : "v"(slot_shift), "v"(hv[i]));
-                            am[i] = hv[i] ^ *reinterpret_cast<FzLdsU32 *>(slot4);   // lut sits at LDS address 0
+                            asm("v_lshrrev_b32 %0, %1, %2\n\tv_and_b32 %0, 0x7c, %0" : "=v"(slot4) : "v"(slot_shift), "v"(hv));
+                            am[i] = hv ^ *reinterpret_cast<FzLdsU32 *>(slot4);   // lut sits at LDS address 0
                         }
                         const uint32_t acc = min(min(am[0], am[1]), min(am[2], am[3]));
-                        if (__builtin_expect(__ballot(acc == 0) != 0, 0)) {   // wave-uniform, rare: some lane, some offset
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                if (__ballot(am[i] == 0)) {           // which offset (scalar branch)
-                                    // which block(s): equal n-grams share a slot
-                                    auto push = [&](uint32_t g) {
-                                        const uint32_t hg = (uint32_t)__builtin_amdgcn_readlane((int)hvec, (int)g);
-                                        const unsigned long long mk = __ballot(hv[i] == hg);
-                                        if (mk) {
-                                            const uint32_t slot = qn + fz_rank(mk);
-                                            // the empty asm keeps LICM from hoisting the loop-invariant
-                                            // queue codes into VGPRs
-                                            uint32_t code = lane_off;
-                                            asm volatile("" : "+v"(code));
-                                            code = fz_code(code + (uint32_t)(r * FZ_ROW_BYTES + 4 * j + i), g, titer);
-                                            if (hv[i] == hg && slot < FZ_QCAP) w.queue[slot] = code;
-                                            qn += (uint32_t)__popcll(mk);
-                                        }
-                                    };
-                                    if constexpr (TG <= 4) {          // unrolled: 6 % faster at 17 % firing groups (DNA, L = 6)
-#pragma unroll
-                                        for (int g = 0; g < TG; ++g) push((uint32_t)g);
-                                    } else {                          // rolled: 64 x 8 unrolled copies stop the row loop from unrolling
-#pragma unroll 1
-                                        for (uint32_t g = 0; g < (uint32_t)TG; ++g) push(g);
-                                    }
-                                }
-                            }
+                        const unsigned long long fired = __ballot(acc == 0);
+                        if (__builtin_expect(fired != 0, 0)) {   // wave-uniform, rare: some lane, some offset of this group
+                            const uint32_t slot = qn + fz_rank(fired);
+                            if (acc == 0 && slot < FZ_QCAP)
+                                *reinterpret_cast<__attribute__((address_space(3))) uint32_t *>(queue_lds + slot * 4u) =
+                                    (lane_code + (uint32_t)(r * 256 + j)) | code_chunk;
+                            qn += (uint32_t)__popcll(fired);
                         }
                     }
                 }
-                if (qn > FZ_QCAP) {                   // this tile overflowed the queue: drop its
-                    qn = q_tile;                      // partial entries and re-scan it by enumeration
+                if (qn > FZ_QCAP) {                   // denser than the queue: drop the partial entries, re-queue by enumeration
+                    qn = q_chunk;
                     slow = true;
                     slow_pos = 0;
-                    break;
                 }
-                tile += gridDim.x;
-                ++titer;
             }
         }
-        if (qn) confirmed += fz_queue_flush<FUSED>(buf, a, pat_lds, w, qn, hits, recs, counters);
-        qn = 0;
-        if (!slow && tile >= ntiles) break;
+        if (qn && (done || have || slow || qn > FZ_QCAP / 2 || qn + 64u > FZ_QCAP)) {
+            const FzWaveLds w = fz_wave_lds(smem + FZ_LUT_BYTES + mpad + FZ_ARGS_LDS_BYTES, wave, FUSED ? a.win_dwords : 0u,
+                                            FUSED ? a.band_w : 0u, a.vlanes, true);
+            const uint32_t confirmed = fz_queue_flush<FUSED>(buf, args_lds, pat_lds, w.queue, w.win, w.scores, qn, qbase, hits, recs,
+                                                             counters);
+            if (FUSED && lane == 0 && confirmed) atomicAdd(&counters[8 + (blockIdx.x & 63u)], (unsigned long long)confirmed);
+            qn = 0;
+        }
+        if (done) break;
     }
-    if (FUSED && lane == 0 && confirmed) atomicAdd(&counters[8 + (blockIdx.x & 63u)], (unsigned long long)confirmed);
-    fz_publish_header(a, counters, lut);
+    fz_finish_launch(a, counters, tickets, lut);
 }
 
-// Verification of a hit list in HBM (parameter ranges whose LDS footprint does not fit beside the
-// filter).  One wave verifies 64 hits at a time.  Dynamic LDS: pattern + per-wave window/score areas.
+// Verification of a hit list in HBM, one lane per candidate (parameter ranges whose LDS footprint does
+// not fit beside the filter, substitutions with large budgets, Levenshtein budgets above 31).  One wave
+// verifies 64 hits at a time.  Dynamic LDS: pattern + per-wave window/score areas.
 __global__ void fz_verify_kernel(const uint8_t *__restrict__ buf, const FzScanArgs a,
                                  const uint64_t *__restrict__ hits, FzRec *__restrict__ recs,
                                  unsigned long long *__restrict__ counters) {
@@ -458,13 +543,195 @@ __global__ void fz_verify_kernel(const uint8_t *__restrict__ buf, const FzScanAr
     if (nh > a.hit_cap) nh = a.hit_cap;
     const uint64_t waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t ncand = fz_segment_candidates(a.geom);
     for (uint64_t q0 = wave * a.vlanes; q0 < nh; q0 += waves * a.vlanes) {
         const uint64_t q = q0 + fz_lane();
-        const bool valid = fz_lane() < a.vlanes && q < nh;
-        const uint64_t hit = valid ? hits[q] : 0;
-        fz_wave_verify<FZ_REG_BAND_MAX>(buf, a, pat_lds, w, hit, valid, recs, counters);
+        const bool have = fz_lane() < a.vlanes && q < nh;
+        const uint64_t hit = have ? hits[q] : 0;
+        for (uint32_t c = 0; c < ncand; ++c) {
+            const FzSeg sg = fz_segment(a.geom, fz_hit_index(hit), c);
+            const bool valid = have && fz_hit_in_range_s(a, fz_hit_block(hit) * a.L, fz_hit_index(hit), sg);
+            if (!__ballot(valid)) continue;
+            fz_wave_verify<FZ_REG_BAND_MAX>(buf, a, pat_lds, w, hit, sg, valid, recs, counters);
+        }
     }
-    fz_publish_header(a, counters, reinterpret_cast<uint32_t *>(smem));
+    fz_finish_launch(a, counters, nullptr, reinterpret_cast<uint32_t *>(smem));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Lane-per-DP-cell verification (the north star's wavefront form), for budgets 5 .. 31 where one
+// lane per candidate is a long serial chain.  GW lanes own one candidate; lane gl holds the band
+// cell D[i][i + gl - K] of the current row i (K = max_l_dist).  Row i + 1 needs
+//   the diagonal  D[i][i+d]      = the lane's own cell,
+//   the upper     D[i][i+1+d]    = the cell of lane gl + 1          (one DPP row shift),
+//   the left      D[i+1][i+d]    = the NEW cell of lane gl - 1:  v[gl] = min_{e <= gl} (a[e] + gl - e),
+//                                  a prefix-min over the lanes of a[e] - e (log2 GW DPP steps).
+// Same table as fz_expand_band / c_expand_*: band K >= budget holds every cell <= budget, bottom row
+// scanned for the LAST arg-min from the column-0 baseline (pyx:33-34, :67-69).
+template <int GW>
+__device__ __forceinline__ uint32_t fz_xl_shl1(uint32_t v, uint32_t fill, uint32_t gl) {
+    if constexpr (GW == 16) {
+        return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x101, 0xf, 0xf, false);   // row_shl:1
+    } else {
+        const uint32_t o = (uint32_t)__shfl_down((int)v, 1, 64);
+        return gl == (uint32_t)GW - 1u ? fill : o;
+    }
+}
+
+template <int GW>
+__device__ __forceinline__ uint32_t fz_xl_prefix_min(uint32_t v, uint32_t gl) {
+    if constexpr (GW == 16) {
+        v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xf, 0xf, false));   // row_shr:1
+        v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x112, 0xf, 0xf, false));
+        v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114, 0xf, 0xf, false));
+        v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118, 0xf, 0xf, false));
+    } else {
+#pragma unroll
+        for (int n = 1; n < GW; n <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)v, n, 64);
+            if (gl >= (uint32_t)n) v = min(v, o);
+        }
+    }
+    return v;
+}
+
+// One bounded expansion for every candidate of the wave.  All arguments but gl are uniform inside a
+// group.  sub(i) = lds[sub_addr + i * sub_step], win(j) = lds[win_addr + j * win_step] (bytes in LDS;
+// reads one element outside either range land in this workgroup's LDS and only feed cells that are
+// forced anyway).  -> ok / dist / consumed, uniform inside the group.
+template <int GW>
+__device__ __forceinline__ bool fz_wf_expand(const uint8_t *lds, uint32_t gl, uint32_t K, int sub_addr, int sub_step,
+                                             uint32_t sublen, int win_addr, int win_step, uint32_t winlen,
+                                             uint32_t budget, bool valid, uint32_t &dist, uint32_t &consumed) {
+    constexpr uint32_t INF = 0x3fffu;
+    const int d = (int)gl - (int)K;
+    const bool act = valid && gl <= 2u * K;
+    uint32_t jv = act ? (uint32_t)d : 0x7fff0000u;          // column j = i + d of this lane (row 0); "negative" = huge
+    uint32_t cell = jv <= winlen ? jv : INF;                // row 0: D[0][j] = j
+    if (!valid) { win_addr = sub_addr = 0; win_step = sub_step = 0; }
+    int caddr = win_addr + win_step * d;                    // row i compares win(i + d - 1)
+    if (!act) caddr = win_addr;
+    int paddr = sub_addr;
+    uint32_t chr = lds[caddr], pc = lds[paddr];
+    const uint32_t bias = (uint32_t)GW - gl;
+    for (uint32_t i = 1;; ++i) {
+        const bool live = valid && i <= sublen;
+        if (!__ballot(live)) break;
+        caddr += win_step;
+        paddr += sub_step;
+        const uint32_t nchr = lds[caddr], npc = lds[paddr];   // next row's characters: their latency hides behind this row
+        jv += 1u;
+        const uint32_t up = fz_xl_shl1<GW>(cell, INF, gl);
+        uint32_t v = min(cell + (chr != pc ? 1u : 0u), up + 1u);
+        if (jv == 0u) v = i;                                  // column 0: D[i][0] = i
+        const bool bad = jv > winlen;
+        v = bad ? INF : v;
+        v = fz_xl_prefix_min<GW>(v + bias, gl) - bias;
+        v = bad ? INF : v;
+        if (live) cell = v;
+        chr = nchr;
+        pc = npc;
+        // row minima never decrease: once no live candidate has a cell within its budget, nothing can pass
+        if ((i & 3u) == 0u && !__ballot(live && cell <= budget)) break;
+    }
+    const int jb = (int)sublen + d;
+    const bool validj = act && jb >= 1 && jb <= (int)winlen;
+    uint32_t key = validj ? ((cell << 8) | (255u - gl)) : 0xffffffffu;     // min cell, then the LARGEST column
+    key = fz_xl_prefix_min<GW>(key, gl);
+    key = (uint32_t)__shfl((int)key, (int)((fz_lane() & ~((uint32_t)GW - 1u)) + (uint32_t)GW - 1u), 64);
+    uint32_t best = sublen, arg = 0;
+    if (key != 0xffffffffu && (key >> 8) <= sublen) {
+        best = key >> 8;
+        arg = (uint32_t)((int)sublen + (int)(255u - (key & 255u)) - (int)K);
+    }
+    dist = best;
+    consumed = arg;
+    return valid && best <= budget;
+}
+
+// Levenshtein verification of a hit list, GW lanes per hit (64 / GW hits per wave at a time).
+// Dynamic LDS: pattern + per-wave window areas (one contiguous byte window per group).
+template <int GW>
+__global__ __launch_bounds__(256) void fz_verify_wf_kernel(const uint8_t *__restrict__ buf, const FzScanArgs a,
+                                                           const uint64_t *__restrict__ hits, FzRec *__restrict__ recs,
+                                                           unsigned long long *__restrict__ counters) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr uint32_t NG = 64u / (uint32_t)GW;                         // candidates per wave
+    const uint32_t mpad = (a.m + 15u) & ~15u;
+    uint8_t *pat_lds = smem + 16;                                       // 16 bytes of slack below p[0] (reversed reads)
+    for (uint32_t i = threadIdx.x; i < a.m; i += blockDim.x) pat_lds[i] = a.pat[i];
+    __syncthreads();
+    const uint32_t lane = fz_lane();
+    const uint32_t grp = lane / (uint32_t)GW, gl = lane % (uint32_t)GW;
+    const uint32_t wbytes = a.win_dwords * 4u;
+    uint8_t *gwin = smem + 16 + mpad + 16 + ((threadIdx.x >> 6) * NG + grp) * (wbytes + 16u);
+    unsigned long long nh = counters[0];
+    if (nh > a.hit_cap) nh = a.hit_cap;
+    const uint64_t waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t ncand = fz_segment_candidates(a.geom);
+    for (uint64_t q0 = wave * NG; q0 < nh; q0 += waves * NG) {
+        const uint64_t q = q0 + grp;
+        const bool have = q < nh;
+        const uint64_t hit = have ? hits[q] : 0;
+        const uint32_t g = fz_hit_block(hit);
+        const uint64_t idx = fz_hit_index(hit);
+        const uint32_t s = g * a.L;
+        for (uint32_t c = 0; c < ncand; ++c) {
+            const FzSeg sg = fz_segment(a.geom, idx, c);
+            const bool valid = have && fz_hit_in_range_s(a, s, idx, sg);
+            if (!__ballot(valid)) continue;
+            // the group's window [wlo, whi), staged as plain bytes: byte g of the sequence at gwin[g - wbase]
+            uint64_t wlo = 0, whi = 0, wbase = 0;
+            if (valid) {
+                const uint64_t reach = (uint64_t)s + a.k;
+                wlo = idx - sg.sa > reach ? idx - reach : sg.sa;
+                if (wlo < a.geom.buf_off) wlo = a.geom.buf_off;
+                whi = idx - s + a.m + a.k;
+                const uint64_t lim = a.geom.buf_off + a.geom.buf_len;
+                if (whi > lim) whi = lim;
+                if (whi > sg.se) whi = sg.se;
+                wbase = a.geom.buf_off + ((wlo - a.geom.buf_off) & ~(uint64_t)3);
+            }
+            const uint32_t nd = valid ? (uint32_t)((whi - wbase + 3) >> 2) : 0u;
+            const int64_t lbase = (int64_t)(wbase - a.geom.buf_off);
+            for (uint32_t dd = gl; dd < nd; dd += (uint32_t)GW)
+                reinterpret_cast<uint32_t *>(gwin)[dd] = *reinterpret_cast<const uint32_t *>(buf + lbase + (int64_t)dd * 4);
+            fz_wave_lds_sync();
+            // LDS byte offsets relative to smem (invalid groups read offset 0)
+            const int wrel = (int)(gwin - smem);
+            auto lds_of = [&](uint64_t gidx) -> int { return valid ? wrel + (int)(int64_t)(gidx - wbase) : 0; };
+            // right: p[s+L:] vs t[idx+L : min(se, idx-s+m+k)]
+            uint64_t rbeg = idx + a.L, rend = idx + a.m + a.k - s;
+            if (rend > sg.se) rend = sg.se;
+            if (rbeg > sg.se) rbeg = sg.se;
+            if (rend < rbeg) rend = rbeg;
+            uint32_t dR = 0, r = 0, dL = 0, l = 0;
+            const bool ok1 = fz_wf_expand<GW>(smem, gl, a.k, (int)(pat_lds - smem) + (int)(s + a.L), 1, a.m - s - a.L,
+                                              lds_of(rbeg), 1, (uint32_t)(rend - rbeg), a.k, valid, dR, r);
+            // left: reversed p[:s] vs reversed t[max(sa, idx-s-(k-dR)) : idx], budget k - dR
+            const uint32_t bl = ok1 ? a.k - dR : 0u;
+            const uint64_t want = (uint64_t)s + bl;
+            const uint64_t lbeg = (idx - sg.sa > want) ? idx - want : sg.sa;
+            const bool ok = fz_wf_expand<GW>(smem, gl, a.k, (int)(pat_lds - smem) + (int)s - 1, -1, s,
+                                             lds_of(idx) - 1, -1, ok1 ? (uint32_t)(idx - lbeg) : 0u, bl, ok1, dL, l);
+            const bool emit = ok && gl == 0;
+            const unsigned long long mask = __ballot(emit);
+            if (mask) {
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(&counters[1], (unsigned long long)__popcll(mask));
+                base = fz_bcast64(base);
+                if (emit) {
+                    FzRec rec;
+                    rec.key = hit; rec.l = l; rec.r = r; rec.dist = dL + dR; rec.aux = sg.j;
+                    const unsigned long long slot = base + fz_rank(mask);
+                    if (slot < a.rec_cap) recs[slot] = rec;
+                }
+            }
+            fz_wave_lds_sync();
+        }
+    }
+    fz_finish_launch(a, counters, nullptr, reinterpret_cast<uint32_t *>(smem));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -513,21 +780,26 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
 
     unsigned long long nitems = n_items;
     if (per_hit) { nitems = counters[0]; if (nitems > a.hit_cap) nitems = a.hit_cap; }
-    for (uint64_t q = blockIdx.x; q < nitems; q += gridDim.x) {
+    const uint32_t ncand = per_hit ? fz_segment_candidates(a.geom) : 1u;
+    for (uint64_t qc = blockIdx.x; qc < nitems * ncand; qc += gridDim.x) {
+        const uint64_t q = qc / ncand;
         uint64_t key_base, w0, w1;
-        uint32_t spawn_len;
+        uint32_t spawn_len, seg_j = 0;
         bool flush_end;
         if (per_hit) {
             const uint64_t hit = hits[q];
             const uint32_t s = fz_hit_block(hit) * a.L;
             const uint64_t idx = fz_hit_index(hit);
+            const FzSeg sg = fz_segment(a.geom, idx, (uint32_t)(qc % ncand));
+            if (!fz_hit_in_range_s(a, s, idx, sg)) continue;           // wave-uniform: one hit per wave
             const uint64_t reach = (uint64_t)s + a.k;
-            w0 = idx > reach ? idx - reach : 0;                        // generic_search.py:231
+            w0 = idx - sg.sa > reach ? idx - reach : sg.sa;            // generic_search.py:231
             w1 = idx - s + a.m + a.k;
-            if (w1 > a.geom.n) w1 = a.geom.n;
+            if (w1 > sg.se) w1 = sg.se;
             spawn_len = (uint32_t)(w1 - w0);
             flush_end = true;                                          // the window IS the sequence there
             key_base = hit;
+            seg_j = sg.j;
         } else {
             w0 = a.geom.own_lo + q * a.lp_starts;
             const uint64_t own_end = a.geom.own_hi < a.geom.n ? a.geom.own_hi : a.geom.n;
@@ -555,7 +827,7 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
                     const uint64_t v = mbuf[e];
                     FzGenRec r;
                     r.key = per_hit ? key_base : key_base + (v >> 48);
-                    r.seq = mseq + e; r.se = (uint32_t)v; r.dist = (uint32_t)(v >> 32) & 0xffffu; r.win = (uint32_t)q;
+                    r.seq = mseq + e; r.se = (uint32_t)v; r.dist = (uint32_t)(v >> 32) & 0xffffu; r.win = per_hit ? seg_j : (uint32_t)q;
                     recs[base + e] = r;
                 }
             }
@@ -593,7 +865,7 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
                     }
                 }
             }
-            const bool more_seq = w0 + index + 1 < a.geom.n;
+            const bool more_seq = w0 + index + 1 < a.geom.n;   // tiled Levenshtein mode only
             for (uint32_t c0 = 0; c0 < ncur; c0 += 64u) {
                 const bool valid = c0 + lane < ncur;
                 FzGOut o;

@@ -1,8 +1,8 @@
 // fzhip.hip — host side of libfzhip.so: the C-ABI of include/fzhip.h over the gfx950 kernels.
 //
 // Data layout in HBM (per device shard):
-//   [FZ_PAD_FRONT zero bytes][buf_len sequence bytes][zero bytes up to a whole tile + FZ_PAD_BACK]
-// so the scan can read whole 16 KiB tiles and 8-byte halos without bounds checks; zero padding can
+//   [FZ_PAD_FRONT zero bytes][buf_len sequence bytes][zero bytes up to a whole 4 KiB chunk + FZ_PAD_BACK]
+// so the scan can read whole chunks and 8-byte halos without bounds checks; zero padding can
 // never create an accepted hit because every candidate is range-checked against the global length.
 //   d_out  : [1 KiB header: counters][records, 24 B each] in one allocation, so the usual result
 //            comes back in ONE D2H copy (header + about as many records as the previous call had)
@@ -91,6 +91,8 @@ struct DevState {
     // Large record sets of the automaton kernels (10^5 .. 10^6 records): a pinned, device-mapped host
     // buffer that grows on demand; the kernel's stores cross PCIe while it runs instead of a D2H copy
     // into pageable memory afterwards.
+    unsigned long long *d_tickets = nullptr;     // FZ_NDOM chunk-ticket counters of the scan, one per 128 bytes;
+                                                 // zero between launches (the last workgroup of a scan resets them)
     uint8_t *d_cand = nullptr;                   // HBM candidate lists of the automaton kernels (rare fallback)
     uint64_t cand_bytes = 0;
     uint8_t *h_big = nullptr, *h_big_dev = nullptr;
@@ -209,47 +211,30 @@ uint32_t load_le32(const uint8_t *p, uint32_t avail) {
 // Describes one whole search as a list of n-gram blocks.
 struct BlockPlan {
     uint32_t L = 0;
-    std::vector<uint32_t> s;       // ngram_start per block
-    std::vector<uint64_t> lo, hi;  // accepted hit range per block: lo <= idx, idx + L <= hi
+    std::vector<uint32_t> s;       // ngram_start per block (the accepted hit range follows from it: fz_block_range)
+    uint64_t abs_lo = 0, abs_hi = ~0ull;   // absolute index range (exact search with start / end index)
 };
 
-using ScanKernel = void (*)(const uint8_t *, const FzScanArgs, uint64_t, uint64_t *, FzRec *, unsigned long long *);
-
-template <int TG, bool FUSED>
-ScanKernel scan_kernel_tg(int nwin, int dh) {
-    if (nwin == 1) return fz_scan_kernel<TG, 1, 0, FUSED>;
-    switch (dh) {
-        case 2: return fz_scan_kernel<TG, 2, 2, FUSED>;
-        case 3: return fz_scan_kernel<TG, 2, 3, FUSED>;
-        case 4: return fz_scan_kernel<TG, 2, 4, FUSED>;
-        default: return fz_scan_kernel<TG, 2, 5, FUSED>;
-    }
-}
+using ScanKernel = void (*)(const uint8_t *, const FzScanArgs, unsigned long long *, uint64_t *, FzRec *, unsigned long long *);
 
 template <bool FUSED>
-ScanKernel scan_kernel_f(int tg, int nwin, int dh) {
-    switch (tg) {
-        case 1: return scan_kernel_tg<1, FUSED>(nwin, dh);
-        case 2: return scan_kernel_tg<2, FUSED>(nwin, dh);
-        case 3: return scan_kernel_tg<3, FUSED>(nwin, dh);
-        case 4: return scan_kernel_tg<4, FUSED>(nwin, dh);
-        case 6: return scan_kernel_tg<6, FUSED>(nwin, dh);
-        default: return scan_kernel_tg<8, FUSED>(nwin, dh);
+ScanKernel scan_kernel_f(int nwin, int dh) {
+    if (nwin == 1) return fz_scan_kernel<1, 0, FUSED>;
+    switch (dh) {
+        case 2: return fz_scan_kernel<2, 2, FUSED>;
+        case 3: return fz_scan_kernel<2, 3, FUSED>;
+        case 4: return fz_scan_kernel<2, 4, FUSED>;
+        default: return fz_scan_kernel<2, 5, FUSED>;
     }
 }
 
-ScanKernel scan_kernel(int tg, int nwin, int dh, bool fused) {
-    return fused ? scan_kernel_f<true>(tg, nwin, dh) : scan_kernel_f<false>(tg, nwin, dh);
-}
-
-int pick_tg(uint32_t nblk) {
-    if (nblk <= 4) return (int)nblk;
-    return nblk <= 6 ? 6 : 8;
+ScanKernel scan_kernel(int nwin, int dh, bool fused) {
+    return fused ? scan_kernel_f<true>(nwin, dh) : scan_kernel_f<false>(nwin, dh);
 }
 
 // Odd multipliers tried for the window hash (24-bit ones serve v_mad_u32_u24).  One search needs a
 // multiplier under which its (at most 8 per launch) distinct block hashes fall into distinct slots of
-// the 64-slot table: a random one works with probability 0.95 for 3 blocks, 0.63 for 8.
+// the 32-slot table: a random one works with probability 0.91 for 3 blocks, 0.39 for 8.
 const uint32_t kHashMultipliers[] = {0x9E3779u, 0x85EBCBu, 0xC2B2AFu, 0x27D4EBu, 0x165667u, 0xD3A264u | 1u, 0xFD7047u, 0xB55A4Fu,
                                      0x7FEB35u, 0x846CA7u, 0x9E6C63u, 0x3243F7u, 0x517CC1u, 0xB7E151u, 0x6A09E7u, 0xBB67AFu};
 
@@ -268,9 +253,9 @@ struct HashGeom {
 };
 
 // Blocks [g0, g0 + n) of one scan launch, the hash multiplier and the slot bits: the longest run of
-// blocks (at most 8) whose distinct hashes land in distinct slots of the 64-slot table under some
+// blocks (at most 8) whose distinct hashes land in distinct slots of the 32-slot table under some
 // (multiplier, shift).  One block always fits; equal n-grams (equal hashes) share a slot.
-// h = yh * K + x mixes x only through the addition: which six bits tell the blocks apart depends on
+// h = yh * K + x mixes x only through the addition: which five bits tell the blocks apart depends on
 // where their bytes differ, so the slot bits are a per-launch choice as well.
 uint32_t choose_launch_blocks(const uint8_t *p, const uint32_t *starts, uint32_t g0, uint32_t G, uint32_t L,
                               uint32_t &hash_k, uint32_t &lut_shift) {
@@ -285,7 +270,7 @@ uint32_t choose_launch_blocks(const uint8_t *p, const uint32_t *starts, uint32_t
         uint32_t hb[FZ_MAX_BLOCKS_PER_LAUNCH];
         uint32_t nb = 0;
         for (; nb < max_blocks && g0 + nb < G; ++nb) hb[nb] = hg.hash(p + starts[g0 + nb], L, kk);
-        for (int shift = 26; shift >= 2; shift -= 6) {
+        for (int shift = 27; shift >= 2; shift -= 5) {
             uint32_t slot_hash[FZ_LUT_SLOTS];
             bool used[FZ_LUT_SLOTS] = {false};
             uint32_t fit = 0;
@@ -302,6 +287,9 @@ uint32_t choose_launch_blocks(const uint8_t *p, const uint32_t *starts, uint32_t
     return nblk;
 }
 
+int emit_generic(fz_ctx *ctx, fz_seq *seq, const std::vector<FzGenRec> &recs_vec, uint32_t L, uint32_t k, fz_match **out,
+                 uint64_t *n, uint32_t **seg_out);
+
 struct Search {
     uint32_t mode = 0, m = 0, k = 0;
     uint32_t max_subs = 0, max_ins = 0, max_dels = 0;      // generic search only
@@ -310,6 +298,23 @@ struct Search {
 };
 
 static const uint32_t kFusedLdsBudget = []() { const char *e = getenv("FZ_FUSED_LDS_KB"); int v = e ? atoi(e) : 0; return (uint32_t)(v > 0 ? v : 64) * 1024u; }();   // dynamic LDS per scan workgroup when verification is fused
+
+// Fields of FzScanArgs that every kernel of a search shares.
+void fill_common_args(FzScanArgs &fa, const Shard &sh, const Search &q) {
+    memset(&fa, 0, sizeof fa);
+    fa.geom = sh.geom;
+    fa.mode = q.mode;
+    fa.m = q.m;
+    fa.k = q.k;
+    fa.L = q.plan.L;
+    fa.max_subs = q.max_subs; fa.max_ins = q.max_ins; fa.max_dels = q.max_dels;
+    fa.abs_lo = q.plan.abs_lo;
+    fa.abs_hi = q.plan.abs_hi;
+    memcpy(fa.pat, q.p, q.m);
+}
+
+// Lanes per candidate of the lane-per-cell verification: the 2k + 1 band cells of a row must fit.
+int wavefront_group(uint32_t k) { return 2 * k + 1 <= 16 ? 16 : 2 * k + 1 <= 32 ? 32 : 64; }
 
 // Enqueue scan (+ separate verify when it cannot be fused) for one shard on its device stream.
 // No host synchronisation.
@@ -329,25 +334,17 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
 
     const uint32_t L = q.plan.L;
     const uint32_t G = (uint32_t)q.plan.s.size();
-    const uint64_t ntiles = (sh.geom.buf_len + FZ_TILE_BYTES - 1) / FZ_TILE_BYTES;
-    // Grid: every workgroup strides over ~16 tiles (256 KiB).  Measured on MI355X at 1 GiB: 6 / 8 /
-    // 12 / 16 / 20 / 32 / 64 workgroups per CU -> 0.302 / 0.302 / 0.276 / 0.267 / 0.265 / 0.280 /
-    // 0.333 ms: several rounds of short workgroups overlap one workgroup's end-of-life verification
-    // (latency-bound) with the others' streaming; too many pay the per-workgroup fixed cost.  At least
-    // 6 per CU (the co-resident count at this kernel's SGPR use) so small inputs still fill the chip.
-    static const int tiles_per_wg = []() { const char *e = getenv("FZ_TILES_PER_WG"); int v = e ? atoi(e) : 0; return v > 0 ? v : 16; }();
-    const uint64_t max_grid = std::max<uint64_t>((uint64_t)d.n_cus * 6, ntiles / tiles_per_wg);
-    // the queue codes carry a bounded per-workgroup tile iteration
-    const uint64_t min_grid = (ntiles + FZ_TITER_MAX - 1) / FZ_TITER_MAX;
-    dim3 grid((unsigned)std::max<uint64_t>(std::max<uint64_t>(1, min_grid), std::min<uint64_t>(ntiles, max_grid)));
+    const uint64_t nchunks = (sh.geom.buf_len + FZ_CHUNK_BYTES - 1) / FZ_CHUNK_BYTES;
+    // Persistent grid: as many workgroups as the chip holds at once (7 per CU at this kernel's register
+    // use; one more per CU does no harm — a workgroup that finds every ticket domain drained leaves at
+    // once).  The waves draw 4 KiB chunks from 256 ticket counters, so the grid size only has to cover
+    // the domains: 4 * grid >= min(256, chunks).
+    static const int wg_per_cu = []() { const char *e = getenv("FZ_WG_PER_CU"); int v = e ? atoi(e) : 0; return v > 0 ? v : 7; }();
+    const uint64_t max_grid = (uint64_t)d.n_cus * wg_per_cu;
+    dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nchunks + FZ_WAVES_PER_BLOCK - 1) / FZ_WAVES_PER_BLOCK, max_grid)));
 
     FzScanArgs fa;
-    memset(&fa, 0, sizeof fa);
-    fa.geom = sh.geom;
-    fa.mode = q.mode;
-    fa.m = q.m;
-    fa.k = q.k;
-    fa.L = L;
+    fill_common_args(fa, sh, q);
     const HashGeom hgeom(L);
     const int nwin = hgeom.nwin, dh = hgeom.dh;
     fa.d2 = nwin == 2 ? std::min<uint32_t>(L, 8) - 4 : 0;
@@ -357,22 +354,23 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     fa.win_dwords = (q.m + 2 * q.k + 6) / 4 + 1;
     fa.hit_cap = d.hit_cap;
     fa.rec_cap = direct ? kHostRecs : d.rec_cap;
-    memcpy(fa.pat, q.p, q.m);
+    fa.nchunks = nchunks;
+    fa.dom_chunks = (nchunks + FZ_NDOM - 1) / FZ_NDOM;
     const uint32_t mpad = (q.m + 15u) & ~15u;
     // Lanes that verify at once: all 64 while the staged windows stay small; fewer for long patterns
     // so that the scan keeps ~8 workgroups per CU resident (measured at m = 64, k = 5 on 1 GiB of text:
     // 64 lanes -> 31.6 KB LDS, 5 workgroups/CU, scan 0.540 ms; candidates are rare there anyway).
     static const uint32_t target = []() { const char *e = getenv("FZ_FUSED_TARGET_KB"); int v = e ? atoi(e) : 0; return (uint32_t)(v > 0 ? v : 18) * 1024u; }();
     fa.vlanes = 64;
-    while (fa.vlanes > 16 && mpad + FZ_LUT_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, fa.vlanes, true) > target)
+    while (fa.vlanes > 16 && mpad + FZ_LUT_BYTES + FZ_ARGS_LDS_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, fa.vlanes, true) > target)
         fa.vlanes >>= 1;
-    const uint32_t fused_lds = mpad + FZ_LUT_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, fa.vlanes, true);
-    // k > 4 (register band too wide for the scan kernel's VGPR budget) -> verify in fz_verify_kernel
+    const uint32_t fused_lds = mpad + FZ_LUT_BYTES + FZ_ARGS_LDS_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, fa.vlanes, true);
+    // k > 4 (register band too wide for the scan kernel's VGPR budget) -> verify in a kernel of its own
     fa.fused = (with_verify && fused_lds <= kFusedLdsBudget && (q.mode != FZ_MODE_LEV || q.k <= 4)) ? 1u : 0u;
-    const uint32_t scan_lds = fa.fused ? fused_lds : mpad + FZ_LUT_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(0, 0, 64, true);
+    const uint32_t scan_lds = fa.fused ? fused_lds : mpad + FZ_LUT_BYTES + FZ_ARGS_LDS_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(0, 0, 64, true);
 
     uint32_t launches = 0;
-    for (uint32_t g0 = 0; g0 < G && ntiles > 0;) {
+    for (uint32_t g0 = 0; g0 < G && nchunks > 0;) {
         // Blocks [g0, g0 + nblk) of this launch and the hash multiplier: the longest run of blocks (at
         // most 8) whose distinct hashes land in distinct table slots under some multiplier.  One block
         // always fits; equal n-grams (equal hashes) share a slot.
@@ -387,19 +385,16 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
             fa.A[b] = load_le32(ng, L) & fa.mask1;
             fa.B[b] = nwin == 2 ? load_le32(ng + fa.d2, 4) : 0;
             fa.H[b] = nwin == 2 ? fz_hash_windows(fa.A[b], load_le32(ng + dh, 3), fa.hash_k) : fz_hash_short(fa.A[b], fa.hash_k);
-            fa.lo[b] = q.plan.lo[g0 + b];
-            fa.hi[b] = q.plan.hi[g0 + b];
             fa.s[b] = q.plan.s[g0 + b];
+            fz_block_range(q.mode, q.m, q.k, L, fa.s[b], fa.lo_rel[b], fa.hi_sub[b]);
         }
-        const int tg = pick_tg(nblk);
-        for (int b = (int)nblk; b < tg; ++b) fa.H[b] = fa.H[0];      // compiled-in spare blocks: dropped by the range check
         // the final kernel of the search publishes the counters to the host (direct mode)
         const bool verify_follows = with_verify && !fa.fused;
         fa.host_hdr = (direct && !verify_follows && g0 + nblk >= G) ? reinterpret_cast<uint64_t>(d.h_stage_dev) : 0;
-        ScanKernel kern = scan_kernel(tg, nwin, dh, fa.fused != 0);
+        ScanKernel kern = scan_kernel(nwin, dh, fa.fused != 0);
         static const uint32_t extra_lds = []() { const char *e = getenv("FZ_EXTRA_LDS_KB"); return e ? (uint32_t)atoi(e) * 1024u : 0u; }();
-        hipLaunchKernelGGL(kern, grid, dim3(FZ_FILTER_THREADS), scan_lds + extra_lds, d.stream, sh.d_buf, fa, ntiles, d.d_hits, recs,
-                           counters);
+        hipLaunchKernelGGL(kern, grid, dim3(FZ_FILTER_THREADS), scan_lds + extra_lds, d.stream, sh.d_buf, fa, d.d_tickets, d.d_hits,
+                           recs, counters);
         HIP_TRY(hipGetLastError());
         ++launches;
         g0 += nblk;
@@ -409,21 +404,36 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     d.scan_end_event = (copy_back && direct && !(with_verify && !fa.fused)) ? 3 : 1;
     if (d.scan_end_event == 1) HIP_TRY(hipEventRecord(d.ev[1], d.stream));
     d.verify_launched = false;
-    if (with_verify && !fa.fused) {
+    if (with_verify && !fa.fused && nchunks > 0 && G > 0) {
         d.verify_launched = true;
-        // LDS: pattern + per-wave window and score ring; shrink the block until it fits.
-        unsigned waves = 4;
-        fa.vlanes = 64;
-        while (waves > 1 && mpad + waves * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, 64, false) > 64 * 1024) waves >>= 1;
-        const size_t lds = mpad + (size_t)waves * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, 64, false);
-        if (lds > 160 * 1024) return fail(FZ_EUNSUPPORTED, "pattern/budget too large for the verify kernel (m=%u, k=%u)", q.m, q.k);
-        if (lds > 64 * 1024)
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fz_verify_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         fa.nblk = 0;
+        fa.g0 = 0;
         fa.host_hdr = direct ? reinterpret_cast<uint64_t>(d.h_stage_dev) : 0;
-        hipLaunchKernelGGL(fz_verify_kernel, dim3(d.n_cus * 4), dim3(64 * waves), lds, d.stream, sh.d_buf, fa, d.d_hits, recs,
-                           counters);
+        static const bool no_wf = getenv("FZ_NO_WAVEFRONT") != nullptr;
+        if (q.mode == FZ_MODE_LEV && q.k >= 5 && q.k <= 31 && !no_wf) {
+            // lane-per-cell: 64 / gw candidates per wave, one contiguous byte window per candidate
+            const int gw = wavefront_group(q.k);
+            fa.gw = (uint32_t)gw;
+            const uint32_t per_wave = (64u / gw) * (fa.win_dwords * 4u + 16u);
+            const size_t lds = 16 + mpad + 16 + 4 * per_wave;
+            if (lds > 64 * 1024) return fail(FZ_EUNSUPPORTED, "pattern too long for the verify kernel (m=%u, k=%u)", q.m, q.k);
+            const dim3 vgrid(d.n_cus * 4), vblock(256);
+            if (gw == 16) hipLaunchKernelGGL(fz_verify_wf_kernel<16>, vgrid, vblock, lds, d.stream, sh.d_buf, fa, d.d_hits, recs, counters);
+            else if (gw == 32) hipLaunchKernelGGL(fz_verify_wf_kernel<32>, vgrid, vblock, lds, d.stream, sh.d_buf, fa, d.d_hits, recs, counters);
+            else hipLaunchKernelGGL(fz_verify_wf_kernel<64>, vgrid, vblock, lds, d.stream, sh.d_buf, fa, d.d_hits, recs, counters);
+        } else {
+            // LDS: pattern + per-wave window and score ring; shrink the block until it fits.
+            unsigned waves = 4;
+            fa.vlanes = 64;
+            while (waves > 1 && mpad + waves * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, 64, false) > 64 * 1024) waves >>= 1;
+            const size_t lds = mpad + (size_t)waves * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, 64, false);
+            if (lds > 160 * 1024) return fail(FZ_EUNSUPPORTED, "pattern/budget too large for the verify kernel (m=%u, k=%u)", q.m, q.k);
+            if (lds > 64 * 1024)
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fz_verify_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(fz_verify_kernel, dim3(d.n_cus * 4), dim3(64 * waves), lds, d.stream, sh.d_buf, fa, d.d_hits, recs,
+                               counters);
+        }
         HIP_TRY(hipGetLastError());
     }
     if (copy_back) {
@@ -589,10 +599,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             rc = cand_lists(d, cand_cap, mpad + wpad + FZ_GEN_MCAP * 8, lds, scratch);
             if (rc) return rc;
             FzScanArgs fa;
-            memset(&fa, 0, sizeof fa);
-            fa.geom = sh.geom;
-            fa.mode = q.mode; fa.m = q.m; fa.k = q.k; fa.L = q.plan.L;
-            fa.max_subs = q.max_subs; fa.max_ins = q.max_ins; fa.max_dels = q.max_dels;
+            fill_common_args(fa, sh, q);
             fa.cand_cap = cand_cap;
             fa.cand_scratch = scratch;
             fa.lp_kind = FZ_LP_GENERIC_HIT;
@@ -601,7 +608,6 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             if (rc) return rc;
             fa.hit_cap = d.hit_cap;
             fa.rec_cap = d.big_cap;
-            memcpy(fa.pat, q.p, q.m);
             unsigned long long *counters = reinterpret_cast<unsigned long long *>(d.d_out);
             FzGenRec *recs = reinterpret_cast<FzGenRec *>(d.h_big_dev);      // records go straight to pinned host memory
             if (lds > 64 * 1024)
@@ -746,6 +752,34 @@ int emit_matches(const FzRec *recs, size_t cnt, uint32_t L, fz_match **out, uint
     return FZ_OK;
 }
 
+// Segmented searches (file API): reference order = segment (chunk) major, then (block, index).
+int emit_matches_seg(const FzRec *recs, size_t cnt, uint32_t L, fz_match **out, uint64_t *n, uint32_t **seg_out) {
+    void *mem = nullptr, *smem_ = nullptr;
+    int rc = alloc_out(cnt, sizeof(fz_match), &mem);
+    if (rc) return rc;
+    rc = alloc_out(cnt, sizeof(uint32_t), &smem_);
+    if (rc) { free(mem); return rc; }
+    fz_match *mo = static_cast<fz_match *>(mem);
+    uint32_t *so = static_cast<uint32_t *>(smem_);
+    std::vector<uint32_t> order(cnt);
+    for (size_t i = 0; i < cnt; ++i) order[i] = (uint32_t)i;
+    std::sort(order.begin(), order.end(), [recs](uint32_t x, uint32_t y) {
+        if (recs[x].aux != recs[y].aux) return recs[x].aux < recs[y].aux;
+        return recs[x].key < recs[y].key;
+    });
+    for (size_t i = 0; i < cnt; ++i) {
+        const FzRec &r = recs[order[i]];
+        const uint64_t idx = fz_hit_index(r.key);
+        mo[i].start = (int64_t)(idx - r.l);
+        mo[i].end = (int64_t)(idx + L + r.r);
+        mo[i].dist = (int32_t)r.dist;
+        mo[i].block = (int32_t)fz_hit_block(r.key);
+        so[i] = r.aux;
+    }
+    *out = mo; *n = cnt; *seg_out = so;
+    return FZ_OK;
+}
+
 // the records of the search that just ran: the staging-buffer view or the collected vector
 int emit_matches(const fz_ctx *ctx, const std::vector<FzRec> &recs, uint32_t L, fz_match **out, uint64_t *n) {
     return ctx->view ? emit_matches(ctx->view, (size_t)ctx->view_n, L, out, n) : emit_matches(recs.data(), recs.size(), L, out, n);
@@ -810,6 +844,8 @@ int fz_create(const int *device_ids, int n_devices, fz_ctx **out) {
             for (auto &ev : d.ev) HIP_TRY(hipEventCreate(&ev));
             HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&d.h_stage), kHeaderBytes + kHostRecs * sizeof(FzRec), hipHostMallocMapped));
             HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&d.h_stage_dev), d.h_stage, 0));
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d.d_tickets), FZ_NDOM * FZ_TICKET_STRIDE * sizeof(unsigned long long)));
+            HIP_TRY(hipMemsetAsync(d.d_tickets, 0, FZ_NDOM * FZ_TICKET_STRIDE * sizeof(unsigned long long), d.stream));
             return FZ_OK;
         };
         rc = init();
@@ -832,6 +868,7 @@ void fz_destroy(fz_ctx *ctx) {
         if (d.h_stage) (void)hipHostFree(d.h_stage);
         if (d.h_big) (void)hipHostFree(d.h_big);
         if (d.d_cand) (void)hipFree(d.d_cand);
+        if (d.d_tickets) (void)hipFree(d.d_tickets);
         for (auto &ev : d.ev) if (ev) (void)hipEventDestroy(ev);
         if (d.stream) (void)hipStreamDestroy(d.stream);
     }
@@ -841,8 +878,8 @@ void fz_destroy(fz_ctx *ctx) {
 static int upload_one(fz_ctx *ctx, int dev_index, const uint8_t *host_buf, const FzGeom &geom, Shard &sh) {
     DevState &d = ctx->devs[dev_index];
     HIP_TRY(hipSetDevice(d.device));
-    const uint64_t tiles = (geom.buf_len + FZ_TILE_BYTES - 1) / FZ_TILE_BYTES;
-    const uint64_t body = std::max<uint64_t>(1, tiles) * FZ_TILE_BYTES;
+    const uint64_t chunks = (geom.buf_len + FZ_CHUNK_BYTES - 1) / FZ_CHUNK_BYTES;
+    const uint64_t body = std::max<uint64_t>(1, chunks) * FZ_CHUNK_BYTES;
     sh.dev = dev_index;
     sh.alloc_bytes = FZ_PAD_FRONT + body + FZ_PAD_BACK;
     sh.geom = geom;
@@ -875,7 +912,7 @@ int fz_seq_upload(fz_ctx *ctx, const uint8_t *host, uint64_t n, fz_seq **out) {
     const uint64_t R = ctx->devs.size();
     const uint64_t halo = 2 * FZ_MAX_M + 64;          // >= m + k for every supported query
     for (uint64_t r = 0; r < R; ++r) {
-        FzGeom g;
+        FzGeom g{};
         g.n = n;
         g.own_lo = n / R * r + std::min<uint64_t>(r, n % R);
         g.own_hi = n / R * (r + 1) + std::min<uint64_t>(r + 1, n % R);
@@ -910,7 +947,7 @@ int fz_seq_upload_shard(fz_ctx *ctx, const uint8_t *host_buf, uint64_t buf_len, 
     if (!seq) return fail(FZ_ENOMEM, "out of memory");
     seq->ctx = ctx;
     seq->n = global_n;
-    FzGeom g;
+    FzGeom g{};
     g.n = global_n;
     g.buf_off = buf_global_off;
     g.buf_len = buf_len;
@@ -962,8 +999,8 @@ int fz_search_exact(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint
     q.mode = FZ_MODE_EXACT; q.m = m; q.k = 0; q.p = p;
     q.plan.L = m;
     q.plan.s = {0};
-    q.plan.lo = {lo};
-    q.plan.hi = {hi};
+    q.plan.abs_lo = lo;
+    q.plan.abs_hi = hi;
     std::vector<FzRec> recs;
     std::vector<uint64_t> hits;
     rc = run_search(ctx, seq, q, /*with_verify=*/false, recs, hits);
@@ -988,16 +1025,9 @@ static int lev_plan(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint
     if (k > FZ_MAX_K) return fail(FZ_EUNSUPPORTED, "max_l_dist above %d is not supported by the verify kernels", FZ_MAX_K);
     rc = check_halo(seq, (uint64_t)m + k);
     if (rc) return rc;
-    const int64_t N = (int64_t)seq->n;
     q.mode = FZ_MODE_LEV; q.m = m; q.k = k; q.p = p;
     q.plan.L = L;
-    for (uint32_t s = 0; s + L <= m; s += L) {              // levenshtein_ngram.py:171-176
-        int64_t lo = (int64_t)s - (int64_t)k; if (lo < 0) lo = 0; if (lo > N) lo = N;
-        int64_t hi = N - (int64_t)m + s + L + k; if (hi > N) hi = N; if (hi < lo) hi = lo;
-        q.plan.s.push_back(s);
-        q.plan.lo.push_back((uint64_t)lo);
-        q.plan.hi.push_back((uint64_t)hi);
-    }
+    for (uint32_t s = 0; s + L <= m; s += L) q.plan.s.push_back(s);   // levenshtein_ngram.py:171-176 (ranges: fz_block_range)
     if (q.plan.s.size() > 255) return fail(FZ_EUNSUPPORTED, "more than 255 n-gram blocks");
     return FZ_OK;
 }
@@ -1066,11 +1096,7 @@ int fz_subs_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint3
     Search q;
     q.mode = FZ_MODE_SUBS; q.m = m; q.k = k; q.p = p;
     q.plan.L = L;
-    for (uint32_t s = 0; s + L <= m; s += L) {                  // template :92-101
-        q.plan.s.push_back(s);
-        q.plan.lo.push_back(s);
-        q.plan.hi.push_back(N - (m - s - L));
-    }
+    for (uint32_t s = 0; s + L <= m; s += L) q.plan.s.push_back(s);   // template :92-101 (ranges: fz_block_range)
     if (q.plan.s.size() > 255) return fail(FZ_EUNSUPPORTED, "more than 255 n-gram blocks");
     std::vector<FzRec> recs;
     std::vector<uint64_t> hits;
@@ -1091,61 +1117,81 @@ int fz_generic_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, ui
     if (L == 0) return fail(FZ_EINVAL, "the subsequence length must be greater than max_l_dist");
     rc = check_halo(seq, (uint64_t)m + k);
     if (rc) return rc;
-    const int64_t N = (int64_t)seq->n;
     Search q;
     q.mode = FZ_MODE_GENERIC; q.m = m; q.k = k; q.p = p;
     q.max_subs = std::min(max_subs, 255u); q.max_ins = std::min(max_ins, 255u); q.max_dels = std::min(max_dels, 255u);
     q.plan.L = L;
-    for (uint32_t s = 0; s + L <= m; s += L) {              // generic_search.py:221-228
-        int64_t lo = (int64_t)s - (int64_t)k; if (lo < 0) lo = 0; if (lo > N) lo = N;
-        int64_t hi = N - (int64_t)m + s + L + k; if (hi > N) hi = N; if (hi < lo) hi = lo;
-        q.plan.s.push_back(s);
-        q.plan.lo.push_back((uint64_t)lo);
-        q.plan.hi.push_back((uint64_t)hi);
-    }
+    for (uint32_t s = 0; s + L <= m; s += L) q.plan.s.push_back(s);   // generic_search.py:221-228 (ranges: fz_block_range)
     if (q.plan.s.size() > 255) return fail(FZ_EUNSUPPORTED, "more than 255 n-gram blocks");
     std::vector<FzGenRec> recs_vec;
     rc = run_generic(ctx, seq, q, recs_vec);
     if (rc) return rc;
-    // Reference order: hits in (block, idx) order, each hit's matches in automaton emission order.
-    // A wave writes the matches of its hit in contiguous runs (one bulk append per <= 512 matches) that
-    // are already in emission order, so only the runs are ordered, by (key, first emission number),
-    // and the 24-byte records are read once: 2.1e5 records order in ~0.4 ms instead of ~2 ms.
-    struct Run { uint64_t key; uint32_t seq0; uint32_t len; size_t first; };
+    return emit_generic(ctx, seq, recs_vec, L, k, out, n, nullptr);
+}
+
+}  // extern "C"
+
+namespace {
+
+// Reference order: (segment,) hits in (block, idx) order, each hit's matches in automaton emission order.
+// A wave writes the matches of its hit in contiguous runs (one bulk append per <= 512 matches) that
+// are already in emission order, so only the runs are ordered, by (segment, key, first emission number),
+// and the 24-byte records are read once: 2.1e5 records order in ~0.4 ms instead of ~2 ms.
+int emit_generic(fz_ctx *ctx, fz_seq *seq, const std::vector<FzGenRec> &recs_vec, uint32_t L, uint32_t k, fz_match **out,
+                 uint64_t *n, uint32_t **seg_out) {
+    struct Run { uint64_t key; uint32_t seg; uint32_t seq0; uint32_t len; size_t first; };
     std::vector<Run> runs;
     const FzGenRec *recs = ctx->gen_view ? ctx->gen_view : recs_vec.data();
     const size_t nrecs = ctx->gen_view ? (size_t)ctx->gen_view_n : recs_vec.size();
     for (size_t i = 0; i < nrecs;) {
         size_t j = i + 1;
-        while (j < nrecs && recs[j].key == recs[i].key && recs[j].seq == recs[j - 1].seq + 1) ++j;
-        runs.push_back(Run{recs[i].key, recs[i].seq, (uint32_t)(j - i), i});
+        while (j < nrecs && recs[j].key == recs[i].key && recs[j].win == recs[i].win && recs[j].seq == recs[j - 1].seq + 1) ++j;
+        runs.push_back(Run{recs[i].key, recs[i].win, recs[i].seq, (uint32_t)(j - i), i});
         i = j;
     }
-    std::sort(runs.begin(), runs.end(), [](const Run &x, const Run &y) { return x.key != y.key ? x.key < y.key : x.seq0 < y.seq0; });
+    std::sort(runs.begin(), runs.end(), [](const Run &x, const Run &y) {
+        if (x.seg != y.seg) return x.seg < y.seg;
+        return x.key != y.key ? x.key < y.key : x.seq0 < y.seq0;
+    });
     void *mem = nullptr;
-    rc = alloc_out(nrecs, sizeof(fz_match), &mem);
+    int rc = alloc_out(nrecs, sizeof(fz_match), &mem);
     if (rc) return rc;
     fz_match *mo = static_cast<fz_match *>(mem);
+    uint32_t *so = nullptr;
+    if (seg_out) {
+        void *smem_ = nullptr;
+        rc = alloc_out(nrecs, sizeof(uint32_t), &smem_);
+        if (rc) { free(mem); return rc; }
+        so = static_cast<uint32_t *>(smem_);
+    }
+    const FzGeom &geom = seq->shards.empty() ? FzGeom{} : seq->shards[0].geom;
     size_t o = 0;
     for (const Run &run : runs) {
         const uint64_t idx = fz_hit_index(run.key);
         const uint32_t blk = fz_hit_block(run.key);
         const uint64_t reach = (uint64_t)blk * L + k;
-        const uint64_t w0 = idx > reach ? idx - reach : 0;
+        uint64_t sa = 0;
+        if (geom.seg_stride) {                                 // start of segment run.seg (fz_segment)
+            const uint64_t core = geom.seg_org + (uint64_t)run.seg * geom.seg_stride;
+            sa = core - geom.seg_org >= geom.seg_pre ? core - geom.seg_pre : geom.seg_org;
+        }
+        const uint64_t w0 = idx - sa > reach ? idx - reach : sa;
         for (size_t i = run.first; i < run.first + run.len; ++i, ++o) {
             mo[o].start = (int64_t)(w0 + (recs[i].se & 0xffffu));
             mo[o].end = (int64_t)(w0 + (recs[i].se >> 16));
             mo[o].dist = (int32_t)recs[i].dist;
             mo[o].block = (int32_t)blk;
+            if (so) so[o] = run.seg;
         }
     }
+    if (seg_out) *seg_out = so;
     *out = mo;
     *n = nrecs;
     ctx->stats.raw_matches = nrecs;
     return FZ_OK;
 }
 
-}  // extern "C"
+}  // namespace
 
 // ---- (f)3: the reference's linear-programming fallbacks for short patterns, on the GPU ---------
 namespace {

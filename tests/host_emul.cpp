@@ -51,7 +51,7 @@ int64_t emul_search(int mode, const uint8_t *p, uint32_t m, const uint8_t *t, ui
             if ((uint64_t)idx < own_lo || (uint64_t)idx >= own_hi) continue;
             if (memcmp(t + idx, p + s, L) != 0) continue;
             FzRec rec;
-            bool ok = mode == 1 ? fz_verify_lev<FZ_REG_BAND_MAX>(sc, view, n, p, m, k, L, s, (uint64_t)idx, rec)
+            bool ok = mode == 1 ? fz_verify_lev<FZ_REG_BAND_MAX>(sc, view, 0, n, p, m, k, L, s, (uint64_t)idx, rec)
                                 : fz_verify_subs(view, p, m, k, L, s, (uint64_t)idx, rec);
             if (!ok) continue;
             if (cnt < cap) {

@@ -222,7 +222,7 @@ def test_wire_format_pack_and_merge_round_trip():
 
 def test_scan_launch_plan_separates_block_hashes():
     """fz_debug_launch_plan (host-only): every launch holds at most 8 consecutive blocks whose distinct
-    hashes occupy distinct slots of the 64-slot table under the chosen multiplier and slot bits; the
+    hashes occupy distinct slots of the 32-slot table under the chosen multiplier and slot bits; the
     launches cover all blocks once, in order; equal n-grams may share a launch (and a slot)."""
     import ctypes
     lib = _native.load_library()
@@ -251,11 +251,11 @@ def test_scan_launch_plan_separates_block_hashes():
         nxt = 0
         for i in range(nl.value):
             g0, nb, hk, shift = out[4 * i:4 * i + 4]
-            assert g0 == nxt and 1 <= nb <= 8 and shift in (26, 20, 14, 8, 2) and hk & 1
+            assert g0 == nxt and 1 <= nb <= 8 and shift in (27, 22, 17, 12, 7, 2) and hk & 1
             slots = {}
             for b in range(g0, g0 + nb):
                 h = block_hash(p[b * L:b * L + L], L, hk)
-                assert slots.setdefault((h >> shift) & 63, h) == h, (p, L, i)
+                assert slots.setdefault((h >> shift) & 31, h) == h, (p, L, i)
             nxt = g0 + nb
         assert nxt == m // L
         n_multi += nl.value > -(-(m // L) // 8)
