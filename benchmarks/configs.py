@@ -19,15 +19,7 @@ n = mib << 20
 eng = _native.Engine([0])
 
 
-def utf8_text(n, seed):
-    """65-symbol ASCII mixed with ~5 % 2-byte UTF-8 code points, as bytes (SURVEY.md §8(d) cfg 4)."""
-    rng = np.random.default_rng(seed)
-    base = workloads.text65(n, seed)
-    pos = np.flatnonzero(rng.random(n - 1) < 0.025)
-    pos = pos[np.diff(np.concatenate([[-2], pos])) > 1]
-    base[pos] = 0xC3
-    base[pos + 1] = 0xA0 + rng.integers(0, 32, len(pos), dtype=np.uint8)
-    return base
+utf8_text = workloads.utf8_text
 
 
 def timeit(fn, reps=100, warm=60):

@@ -8,7 +8,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfzhip.so")
+# FUZZYSEARCH_HIP_LIB: another build of the same C-ABI (A/B benchmarking of kernel versions)
+LIB_PATH = os.environ.get("FUZZYSEARCH_HIP_LIB") or os.path.join(_HERE, "libfzhip.so")
 
 FZ_OK, FZ_EINVAL, FZ_ENOMEM, FZ_EDEVICE, FZ_EUNSUPPORTED, FZ_EHALO = 0, -1, -2, -3, -4, -5
 UINT64_MAX = (1 << 64) - 1

@@ -53,7 +53,7 @@
 #define FZ_LUT_BYTES (FZ_LUT_SLOTS * 4u)
 #define FZ_NDOM 256u                                       // ticket counters (domains of consecutive chunks)
 #define FZ_TICKET_STRIDE 16u                               // 64-bit words between two ticket counters (128 B)
-#define FZ_STEALS 3u                                       // other domains a wave tries when its own is drained
+#define FZ_STEALS 2u                                       // other domains a wave tries when its own is drained
 #define FZ_ARGS_LDS_BYTES ((uint32_t)((offsetof(FzScanArgs, pat) + 15u) & ~15u))   // LDS copy of the launch arguments
 
 // 32-bit little-endian window starting `b` bytes into the 64-bit value hi:lo (v_alignbyte_b32).
@@ -137,8 +137,8 @@ __device__ __forceinline__ unsigned long long fz_bcast64(unsigned long long v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Wave-level verification of up to 64 candidates: each lane owns one (hit = block | idx) and the
-// segment it is verified in.
+// Wave-level verification of up to a.vlanes candidates: each valid lane owns one (hit = block | idx),
+// the segment it is verified in and the slot vl < a.vlanes of the staging areas.
 //  1. every lane fetches the <= m + 2k window bytes around its candidate into LDS with independent
 //     aligned dword loads (one HBM/L2 round trip instead of one per byte),
 //  2. confirms the n-gram exactly (the filter only compared its first min(L, 8) bytes), then runs the
@@ -147,7 +147,7 @@ __device__ __forceinline__ unsigned long long fz_bcast64(unsigned long long v) {
 // Returns the number of exactly-confirmed n-gram hits (wave-uniform, statistics).
 template <int MAXK>
 __device__ __forceinline__ uint32_t fz_wave_verify(const uint8_t *__restrict__ buf, const FzScanArgs &a,
-                                                   const uint8_t *pat_lds, const FzWaveLds &w,
+                                                   const uint8_t *pat_lds, const FzWaveLds &w, uint32_t vl,
                                                    uint64_t hit, const FzSeg &sg, bool valid,
                                                    FzRec *__restrict__ recs, unsigned long long *__restrict__ counters) {
     const uint32_t lane = fz_lane();
@@ -177,12 +177,12 @@ __device__ __forceinline__ uint32_t fz_wave_verify(const uint8_t *__restrict__ b
             v[j] = (d0 + j < nd) ? *reinterpret_cast<const uint32_t *>(buf + lbase + (int64_t)(d0 + j) * 4) : 0u;
 #pragma unroll
         for (uint32_t j = 0; j < 8; ++j)
-            if (d0 + j < nd) w.win[(d0 + j) * a.vlanes + lane] = v[j];
+            if (d0 + j < nd) w.win[(d0 + j) * a.vlanes + vl] = v[j];
     }
     fz_wave_lds_sync();
     FzRec rec;
     bool ok = false;
-    FzLdsWindow t{reinterpret_cast<const uint8_t *>(w.win + lane), wbase, a.vlanes * 4u};
+    FzLdsWindow t{reinterpret_cast<const uint8_t *>(w.win + vl), wbase, a.vlanes * 4u};
     if (valid) {
         const uint8_t *ng = pat_lds + s;
         for (uint32_t b = 0; b < a.L; ++b)
@@ -191,7 +191,7 @@ __device__ __forceinline__ uint32_t fz_wave_verify(const uint8_t *__restrict__ b
     const uint32_t confirmed = (uint32_t)__popcll(__ballot(valid));
     if (valid) {
         if (a.mode == FZ_MODE_LEV) {
-            FzLdsScores sc{w.scores + lane, a.vlanes};
+            FzLdsScores sc{w.scores + vl, a.vlanes};
             ok = fz_verify_lev<MAXK>(sc, t, sg.sa, sg.se, pat_lds, a.m, a.k, a.L, s, idx, rec);
         } else {
             ok = fz_verify_subs(t, pat_lds, a.m, a.k, a.L, s, idx, rec);
@@ -275,12 +275,17 @@ __device__ __forceinline__ void fz_finish_launch(const FzScanArgs &a, unsigned l
 // address a function could take without a 1.4 KB private copy per lane.
 template <bool FUSED>
 __device__ __noinline__ uint32_t fz_queue_flush(
-    const uint8_t *__restrict__ buf, const FzScanArgs *ap, const uint8_t *pat_lds, uint32_t *queue, uint32_t *win,
-    uint16_t *scores, uint32_t qn, uint64_t qbase, uint64_t *__restrict__ hits, FzRec *__restrict__ recs,
+    const uint8_t *__restrict__ buf, uint32_t args_off, uint32_t pat_off, uint32_t queue_off, uint32_t win_off,
+    uint32_t scores_off, uint32_t qn, uint32_t qbase, uint64_t *__restrict__ hits, FzRec *__restrict__ recs,
     unsigned long long *__restrict__ counters) {
-    const FzScanArgs &a = *ap;
+    // LDS byte offsets -> pointers built from address-space-3 pointers here, inside the function, so that
+    // the compiler knows every access below is an LDS access (ds_read / ds_write, not flat_load)
+    const FzScanArgs &a = *(const FzScanArgs *)(__attribute__((address_space(3))) const FzScanArgs *)(uintptr_t)args_off;
+    const uint8_t *pat_lds = (const uint8_t *)(FzLdsU8 *)(uintptr_t)pat_off;
     FzWaveLds w;
-    w.queue = queue; w.win = win; w.scores = scores;
+    w.queue = (uint32_t *)(__attribute__((address_space(3))) uint32_t *)(uintptr_t)queue_off;
+    w.win = (uint32_t *)(__attribute__((address_space(3))) uint32_t *)(uintptr_t)win_off;
+    w.scores = (uint16_t *)(__attribute__((address_space(3))) uint16_t *)(uintptr_t)scores_off;
     const uint32_t lane = fz_lane();
     uint32_t confirmed = 0;
     fz_wave_lds_sync();
@@ -291,7 +296,7 @@ __device__ __noinline__ uint32_t fz_queue_flush(
         uint32_t bits = 0;
         if (e < qn) {
             const uint32_t code = w.queue[e];
-            local = (qbase + (uint64_t)(code >> FZ_GROUP_BITS)) * (uint64_t)FZ_CHUNK_BYTES +
+            local = ((uint64_t)qbase + (uint64_t)(code >> FZ_GROUP_BITS)) * (uint64_t)FZ_CHUNK_BYTES +
                     (uint64_t)((code & ((1u << FZ_GROUP_BITS) - 1u)) << 2);
             const uint32_t *src = reinterpret_cast<const uint32_t *>(buf + local);
             const uint32_t w4[4] = {src[0], src[1], src[2], 0u};
@@ -311,34 +316,40 @@ __device__ __noinline__ uint32_t fz_queue_flush(
                 }
             }
         }
+        // the staged windows hold a.vlanes lanes: lanes [sub, sub + vlanes) verify together
+        const uint32_t vl_n = FUSED ? a.vlanes : 64u;
         while (__ballot(bits != 0)) {
-            const bool has = bits != 0;
-            const uint32_t tz = has ? (uint32_t)__builtin_ctz(bits) : 0u;
-            bits &= bits - 1u;
-            const uint32_t blk = tz & 7u;
-            const uint64_t loc = local + (tz >> 3);
-            const uint64_t idx = a.geom.buf_off + loc;
-            const uint64_t hit = fz_hit_pack(a.g0 + blk, idx);
-            if (FUSED) {
-                for (uint32_t c = 0; c < ncand; ++c) {
-                    const FzSeg sg = fz_segment(a.geom, idx, c);
-                    const bool valid = has && fz_hit_in_range(a, blk, idx, sg);
-                    if (!__ballot(valid)) continue;
-                    confirmed += fz_wave_verify<4>(buf, a, pat_lds, w, hit, sg, valid, recs, counters);
-                }
-            } else {
-                bool valid = false;
-                if (has) {
-                    for (uint32_t c = 0; c < ncand; ++c) valid = valid || fz_hit_in_range(a, blk, idx, fz_segment(a.geom, idx, c));
-                    if (valid) valid = fz_confirm_tail(buf, a, pat_lds, blk, loc);
-                }
-                const unsigned long long mask = __ballot(valid);
-                if (mask) {
-                    unsigned long long base = 0;
-                    if (lane == 0) base = atomicAdd(&counters[0], (unsigned long long)__popcll(mask));
-                    base = fz_bcast64(base);
-                    const unsigned long long slot = base + fz_rank(mask);
-                    if (valid && slot < a.hit_cap) hits[slot] = hit;
+            for (uint32_t sub = 0; sub < 64u; sub += vl_n) {
+                const bool mine = lane >= sub && lane < sub + vl_n;
+                const bool has = mine && bits != 0;
+                if (!__ballot(has)) continue;
+                const uint32_t tz = has ? (uint32_t)__builtin_ctz(bits) : 0u;
+                if (mine) bits &= bits - 1u;
+                const uint32_t blk = tz & 7u;
+                const uint64_t loc = local + (tz >> 3);
+                const uint64_t idx = a.geom.buf_off + loc;
+                const uint64_t hit = fz_hit_pack(a.g0 + blk, idx);
+                if (FUSED) {
+                    for (uint32_t c = 0; c < ncand; ++c) {
+                        const FzSeg sg = fz_segment(a.geom, idx, c);
+                        const bool valid = has && fz_hit_in_range(a, blk, idx, sg);
+                        if (!__ballot(valid)) continue;
+                        confirmed += fz_wave_verify<4>(buf, a, pat_lds, w, lane - sub, hit, sg, valid, recs, counters);
+                    }
+                } else {
+                    bool valid = false;
+                    if (has) {
+                        for (uint32_t c = 0; c < ncand; ++c) valid = valid || fz_hit_in_range(a, blk, idx, fz_segment(a.geom, idx, c));
+                        if (valid) valid = fz_confirm_tail(buf, a, pat_lds, blk, loc);
+                    }
+                    const unsigned long long mask = __ballot(valid);
+                    if (mask) {
+                        unsigned long long base = 0;
+                        if (lane == 0) base = atomicAdd(&counters[0], (unsigned long long)__popcll(mask));
+                        base = fz_bcast64(base);
+                        const unsigned long long slot = base + fz_rank(mask);
+                        if (valid && slot < a.hit_cap) hits[slot] = hit;
+                    }
                 }
             }
         }
@@ -400,7 +411,8 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
     // the hot loop takes registers away from it.  Chunk numbers are 32-bit (16 TiB of sequence).
     const uint32_t wave = fz_uniform(threadIdx.x >> 6);
     const uint32_t lane = fz_lane();
-    const uint32_t nchunks = (uint32_t)a.nchunks, dom_chunks = (uint32_t)a.dom_chunks;
+    const uint32_t nchunks = (uint32_t)a.nchunks;
+    const bool static_split = (a.flags & 1u) != 0;    // tuning knob: chunks dealt round-robin, no tickets
     uint32_t qn = 0;                                  // queue fill
     uint32_t qbase = 0;                               // chunk the queue codes are relative to
 
@@ -408,7 +420,8 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
     const uint32_t home = fz_uniform((blockIdx.x * FZ_WAVES_PER_BLOCK + wave) % FZ_NDOM);
     uint32_t steal = 0;
     uint32_t dom = home;
-    uint32_t tk = fz_ticket_issue(tickets, dom);      // lane 0: the drawn ticket (chunk number inside the domain)
+    // lane 0: the drawn ticket (the domain's next chunk is ticket * FZ_NDOM + dom)
+    uint32_t tk = static_split ? blockIdx.x * FZ_WAVES_PER_BLOCK + wave : fz_ticket_issue(tickets, dom);
     uint32_t chunk = 0;
     bool have = false;                                // `chunk` is drawn but not processed yet
     bool slow = false;                                // `chunk` is being re-queued group by group
@@ -431,13 +444,14 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
             if (slow_pos == FZ_FILTER_ROWS * 4u) slow = false;
         } else if (!done) {
             if (!have) {
-                const uint32_t dom_lo = dom * dom_chunks;
-                const uint32_t dom_hi = dom_lo + dom_chunks < nchunks ? dom_lo + dom_chunks : nchunks;
-                const uint32_t c = dom_lo + fz_uniform(tk);
-                if (dom_lo < dom_hi && c < dom_hi) {
+                // domain d owns the chunks c with c % FZ_NDOM == d: the 256 domains advance together, so at any
+                // time the chip reads one moving window of the buffer (contiguous domains put 256 read fronts at
+                // equal offsets 4 MiB apart, i.e. onto the same memory channels)
+                const uint32_t c = static_split ? tk : fz_uniform(tk) * FZ_NDOM + dom;
+                if (c < nchunks) {
                     chunk = c;
                     have = true;
-                } else if (steal == FZ_STEALS) {
+                } else if (static_split || steal == FZ_STEALS) {
                     done = true;                      // own domain and the steal targets are drained
                 } else {
                     ++steal;
@@ -475,7 +489,8 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                     v[r] = *reinterpret_cast<const uint4 *>(src);
                     h[r] = *reinterpret_cast<const uint2 *>(src + 16);
                 }
-                tk = fz_ticket_issue(tickets, dom);   // next ticket: its latency hides behind this chunk
+                // next ticket: its latency hides behind this chunk
+                tk = static_split ? chunk + gridDim.x * FZ_WAVES_PER_BLOCK : fz_ticket_issue(tickets, dom);
                 have = false;
                 const uint32_t q_chunk = qn;
                 const uint32_t code_chunk = (chunk - qbase) << FZ_GROUP_BITS;
@@ -517,8 +532,11 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
         if (qn && (done || have || slow || qn > FZ_QCAP / 2 || qn + 64u > FZ_QCAP)) {
             const FzWaveLds w = fz_wave_lds(smem + FZ_LUT_BYTES + mpad + FZ_ARGS_LDS_BYTES, wave, FUSED ? a.win_dwords : 0u,
                                             FUSED ? a.band_w : 0u, a.vlanes, true);
-            const uint32_t confirmed = fz_queue_flush<FUSED>(buf, args_lds, pat_lds, w.queue, w.win, w.scores, qn, qbase, hits, recs,
-                                                             counters);
+            // the dynamic LDS area starts at LDS address 0: offsets into smem are LDS addresses
+            const uint32_t confirmed = fz_queue_flush<FUSED>(
+                buf, FZ_LUT_BYTES + mpad, FZ_LUT_BYTES, (uint32_t)(reinterpret_cast<uint8_t *>(w.queue) - smem),
+                (uint32_t)(reinterpret_cast<uint8_t *>(w.win) - smem), (uint32_t)(reinterpret_cast<uint8_t *>(w.scores) - smem), qn,
+                qbase, hits, recs, counters);
             if (FUSED && lane == 0 && confirmed) atomicAdd(&counters[8 + (blockIdx.x & 63u)], (unsigned long long)confirmed);
             qn = 0;
         }
@@ -552,7 +570,7 @@ __global__ void fz_verify_kernel(const uint8_t *__restrict__ buf, const FzScanAr
             const FzSeg sg = fz_segment(a.geom, fz_hit_index(hit), c);
             const bool valid = have && fz_hit_in_range_s(a, fz_hit_block(hit) * a.L, fz_hit_index(hit), sg);
             if (!__ballot(valid)) continue;
-            fz_wave_verify<FZ_REG_BAND_MAX>(buf, a, pat_lds, w, hit, sg, valid, recs, counters);
+            fz_wave_verify<FZ_REG_BAND_MAX>(buf, a, pat_lds, w, fz_lane(), hit, sg, valid, recs, counters);
         }
     }
     fz_finish_launch(a, counters, nullptr, reinterpret_cast<uint32_t *>(smem));

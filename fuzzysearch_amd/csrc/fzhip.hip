@@ -355,7 +355,8 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     fa.hit_cap = d.hit_cap;
     fa.rec_cap = direct ? kHostRecs : d.rec_cap;
     fa.nchunks = nchunks;
-    fa.dom_chunks = (nchunks + FZ_NDOM - 1) / FZ_NDOM;
+    static const uint32_t scan_flags = []() { const char *e = getenv("FZ_SCAN_FLAGS"); return e ? (uint32_t)atoi(e) : 0u; }();
+    fa.flags = scan_flags;
     const uint32_t mpad = (q.m + 15u) & ~15u;
     // Lanes that verify at once: all 64 while the staged windows stay small; fewer for long patterns
     // so that the scan keeps ~8 workgroups per CU resident (measured at m = 64, k = 5 on 1 GiB of text:

@@ -50,6 +50,42 @@ def test_lev_ngrams_raw_random(engine):
     assert n_cases > 1000
 
 
+def test_lev_ngrams_wide_budgets_random(engine):
+    """Budgets 5 .. 31 run the lane-per-cell wavefront kernel (16 / 32 / 64 lanes per candidate), larger
+    ones the lane-per-candidate LDS ring: every group width, ragged sequence ends, dense repeats."""
+    rnd = random.Random(17)
+    n_cases = {16: 0, 32: 0, 64: 0, 0: 0}
+    for it in range(900):
+        sigma = rnd.choice([2, 3, 4, 4, 20])
+        alpha = bytes(rnd.sample(range(33, 127), sigma))
+        k = rnd.choice([5, 5, 6, 7, 7, 8, 9, 12, 15, 16, 20, 31, 32, 40])
+        m = rnd.randint(k + 1, min(4 * (k + 1) + 20, 140))
+        n = rnd.randint(0, 500)
+        t = bytearray(rnd.choice(alpha) for _ in range(n))
+        p = bytes(rnd.choice(alpha) for _ in range(m))
+        if n > m + 10 and rnd.random() < 0.7:          # plant an edited copy
+            v = bytearray(p)
+            for _ in range(rnd.randint(0, k)):
+                q = rnd.randrange(len(v))
+                op = rnd.random()
+                if op < 0.4:
+                    v[q] = rnd.choice(alpha)
+                elif op < 0.7 and len(v) > 2:
+                    del v[q]
+                else:
+                    v.insert(q, rnd.choice(alpha))
+            st = rnd.choice([0, 1, n - len(v) - 1, n - len(v), rnd.randint(0, max(0, n - len(v)))])
+            st = max(0, min(st, n - len(v)))
+            t[st:st + len(v)] = v
+        t = bytes(t)
+        seq = engine.upload(t)
+        got = engine.lev_ngrams(seq, p, k)
+        seq.release()
+        assert got == oracle.lev_ngrams_raw(p, t, k), (p, t, k)
+        n_cases[16 if k <= 7 else 32 if k <= 15 else 64 if k <= 31 else 0] += 1
+    assert all(v > 50 for v in n_cases.values()), n_cases
+
+
 def test_subs_ngrams_raw_random(engine):
     rnd = random.Random(12)
     for _ in range(1000):
@@ -81,7 +117,7 @@ def test_search_exact_random(engine):
         assert got_all == oracle.search_exact(p, t), (p, t)
 
 
-@pytest.mark.parametrize("m,k", [(20, 2), (9, 2), (12, 1), (32, 3), (23, 5), (64, 5), (10, 0 + 1), (40, 12)])
+@pytest.mark.parametrize("m,k", [(20, 2), (9, 2), (12, 1), (32, 3), (23, 5), (64, 5), (10, 0 + 1), (40, 12), (64, 8), (100, 20)])
 def test_lev_ngrams_medium_dna(engine, m, k):
     """4 MiB of DNA with planted variants: every n-gram length / block count regime."""
     n = 4 << 20

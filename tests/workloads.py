@@ -13,6 +13,17 @@ def text65(n, seed):
     return TEXT65[np.random.default_rng(seed).integers(0, 65, n, dtype=np.uint8)]
 
 
+def utf8_text(n, seed):
+    """65-symbol ASCII mixed with ~5 % 2-byte UTF-8 code points, as bytes (SURVEY.md §8(d) cfg 4)."""
+    rng = np.random.default_rng(seed)
+    base = text65(n, seed)
+    pos = np.flatnonzero(rng.random(n - 1) < 0.025)
+    pos = pos[np.diff(np.concatenate([[-2], pos])) > 1]
+    base[pos] = 0xC3
+    base[pos + 1] = 0xA0 + rng.integers(0, 32, len(pos), dtype=np.uint8)
+    return base
+
+
 def plant_variants(seq, pattern, n_plant, seed, alphabet=DNA):
     """Overwrite `seq` (uint8 array, in place) with n_plant variants of `pattern` at sorted random
     positions at least 64 apart: variant i % 4 in {exact, 1 substitution, 1 deletion, 1 insertion}.
@@ -42,6 +53,20 @@ def plant_variants(seq, pattern, n_plant, seed, alphabet=DNA):
         seq[p0:p0 + len(v)] = np.frombuffer(bytes(v), dtype=np.uint8)
         out.append((p0, kind))
     return out
+
+
+def cfg3(n=2 ** 30, n_plant=1024):
+    """BASELINE config 3: n bytes over 65 ASCII symbols, |p| = 32, <= 3 substitutions."""
+    seq, pattern = text65(n, 3), text65(32, 33)
+    planted = plant_variants(seq, pattern, n_plant, 8, TEXT65)
+    return seq, pattern, planted
+
+
+def cfg4(n=2 ** 30, n_plant=1024):
+    """BASELINE config 4: n bytes of UTF-8 text (as bytes), |p| = 64, k = 5 (4a) / limits (5, 2, 2, 5) (4b)."""
+    seq, pattern = utf8_text(n, 4), utf8_text(64, 44)
+    planted = plant_variants(seq, pattern, n_plant, 9, TEXT65)
+    return seq, pattern, planted
 
 
 def cfg2(n=2 ** 30, n_plant=1024):
