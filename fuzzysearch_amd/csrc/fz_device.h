@@ -122,6 +122,8 @@ struct FzScanArgs {
     uint32_t s[FZ_MAX_BLOCKS_PER_LAUNCH];       // ngram_start of each block inside the pattern
     uint64_t abs_lo, abs_hi;                    // absolute index range (exact search with start / end index)
     uint64_t nchunks;                           // scan: 4 KiB chunks of the buffer
+    uint32_t wave_budget;                       // scan: chunks a wave processes before it retires (0: persistent grid, no limit)
+    uint32_t pad1;
     uint64_t hit_cap;                           // capacity of the hit list
     uint64_t rec_cap;                           // capacity of the record list
     uint64_t host_hdr;                          // device-visible address of the host copy of the counters

@@ -289,6 +289,7 @@ __device__ __noinline__ uint32_t fz_queue_flush(
     const uint32_t lane = fz_lane();
     uint32_t confirmed = 0;
     fz_wave_lds_sync();
+    if (a.flags & 2u) return 0;                       // timing knob: drop every candidate
     const uint32_t ncand = fz_segment_candidates(a.geom);
     for (uint32_t e0 = 0; e0 < qn; e0 += 64u) {
         const uint32_t e = e0 + lane;
@@ -318,6 +319,7 @@ __device__ __noinline__ uint32_t fz_queue_flush(
         }
         // the staged windows hold a.vlanes lanes: lanes [sub, sub + vlanes) verify together
         const uint32_t vl_n = FUSED ? a.vlanes : 64u;
+        if (a.flags & 4u) bits = 0;                   // timing knob: resolve the groups, verify nothing
         while (__ballot(bits != 0)) {
             for (uint32_t sub = 0; sub < 64u; sub += vl_n) {
                 const bool mine = lane >= sub && lane < sub + vl_n;
@@ -413,6 +415,12 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
     const uint32_t lane = fz_lane();
     const uint32_t nchunks = (uint32_t)a.nchunks;
     const bool static_split = (a.flags & 1u) != 0;    // tuning knob: chunks dealt round-robin, no tickets
+    // Every wave processes at most `budget` chunks, then flushes its queue and retires: the (latency-bound)
+    // end-of-life flushes are spread over the kernel and overlap with the streaming of the workgroups the
+    // dispatcher starts in their place.  The host sizes the grid so that the home waves of every domain
+    // can take all of its chunks (grid * 4 a multiple of FZ_NDOM, waves per domain * budget >= chunks
+    // per domain): a wave only stops early when its domain is drained.
+    uint32_t budget = a.wave_budget ? a.wave_budget : 0xffffffffu;
     uint32_t qn = 0;                                  // queue fill
     uint32_t qbase = 0;                               // chunk the queue codes are relative to
 
@@ -448,10 +456,11 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                 // time the chip reads one moving window of the buffer (contiguous domains put 256 read fronts at
                 // equal offsets 4 MiB apart, i.e. onto the same memory channels)
                 const uint32_t c = static_split ? tk : fz_uniform(tk) * FZ_NDOM + dom;
-                if (c < nchunks) {
+                if (c < nchunks && budget) {
                     chunk = c;
                     have = true;
-                } else if (static_split || steal == FZ_STEALS) {
+                    --budget;
+                } else if (static_split || steal == FZ_STEALS || !budget || a.wave_budget) {
                     done = true;                      // own domain and the steal targets are drained
                 } else {
                     ++steal;
@@ -489,8 +498,9 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                     v[r] = *reinterpret_cast<const uint4 *>(src);
                     h[r] = *reinterpret_cast<const uint2 *>(src + 16);
                 }
-                // next ticket: its latency hides behind this chunk
-                tk = static_split ? chunk + gridDim.x * FZ_WAVES_PER_BLOCK : fz_ticket_issue(tickets, dom);
+                // next ticket: its latency hides behind this chunk (none when this was the wave's last chunk:
+                // a drawn ticket must be processed)
+                if (budget) tk = static_split ? chunk + gridDim.x * FZ_WAVES_PER_BLOCK : fz_ticket_issue(tickets, dom);
                 have = false;
                 const uint32_t q_chunk = qn;
                 const uint32_t code_chunk = (chunk - qbase) << FZ_GROUP_BITS;

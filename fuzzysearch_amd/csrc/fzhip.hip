@@ -340,9 +340,17 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     // once).  The waves draw 4 KiB chunks from 256 ticket counters, so the grid size only has to cover
     // the domains: 4 * grid >= min(256, chunks).
     static const int wg_per_cu = []() { const char *e = getenv("FZ_WG_PER_CU"); int v = e ? atoi(e) : 0; return v > 0 ? v : 7; }();
-    const uint64_t max_grid = (uint64_t)d.n_cus * wg_per_cu;
-    dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nchunks + FZ_WAVES_PER_BLOCK - 1) / FZ_WAVES_PER_BLOCK, max_grid)));
-
+    static const int wave_budget = []() { const char *e = getenv("FZ_CHUNKS_PER_WAVE"); int v = e ? atoi(e) : -1; return v >= 0 ? v : 0; }();
+    const uint64_t resident = (uint64_t)d.n_cus * wg_per_cu;
+    uint64_t want = (nchunks + FZ_WAVES_PER_BLOCK - 1) / FZ_WAVES_PER_BLOCK;
+    if (wave_budget) {
+        // waves per domain * budget >= chunks per domain, and grid * 4 a multiple of the domain count
+        const uint64_t per_dom = (nchunks + FZ_NDOM - 1) / FZ_NDOM;
+        want = std::max<uint64_t>(1, (per_dom + wave_budget - 1) / wave_budget) * (FZ_NDOM / FZ_WAVES_PER_BLOCK);
+    } else {
+        want = std::min<uint64_t>(want, resident);
+    }
+    dim3 grid((unsigned)std::max<uint64_t>(1, want));
     FzScanArgs fa;
     fill_common_args(fa, sh, q);
     const HashGeom hgeom(L);
@@ -357,6 +365,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     fa.nchunks = nchunks;
     static const uint32_t scan_flags = []() { const char *e = getenv("FZ_SCAN_FLAGS"); return e ? (uint32_t)atoi(e) : 0u; }();
     fa.flags = scan_flags;
+    fa.wave_budget = (uint32_t)wave_budget;
     const uint32_t mpad = (q.m + 15u) & ~15u;
     // Lanes that verify at once: all 64 while the staged windows stay small; fewer for long patterns
     // so that the scan keeps ~8 workgroups per CU resident (measured at m = 64, k = 5 on 1 GiB of text:
