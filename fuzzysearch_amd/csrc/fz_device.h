@@ -113,7 +113,7 @@ struct FzScanArgs {
     uint32_t hash_k;                            // odd multiplier of the window hash (24 bits when L > 4)
     uint32_t lut_shift;                         // table slot of a hash h = (h >> lut_shift) & 31
     uint32_t gw;                                // wavefront verification: lanes per candidate (16, 32 or 64)
-    uint32_t flags;                             // bit 0: scan deals chunks round-robin instead of by tickets (tuning knob)
+    uint32_t flags;                             // tuning knobs (0 in production)
     uint32_t H[FZ_MAX_BLOCKS_PER_LAUNCH];       // fast-path hash of each block's n-gram
     uint32_t A[FZ_MAX_BLOCKS_PER_LAUNCH];       // 1st window value per block (little endian)
     uint32_t B[FZ_MAX_BLOCKS_PER_LAUNCH];       // 2nd window value per block
@@ -121,9 +121,6 @@ struct FzScanArgs {
     uint32_t hi_sub[FZ_MAX_BLOCKS_PER_LAUNCH];
     uint32_t s[FZ_MAX_BLOCKS_PER_LAUNCH];       // ngram_start of each block inside the pattern
     uint64_t abs_lo, abs_hi;                    // absolute index range (exact search with start / end index)
-    uint64_t nchunks;                           // scan: 4 KiB chunks of the buffer
-    uint32_t wave_budget;                       // scan: chunks a wave processes before it retires (0: persistent grid, no limit)
-    uint32_t pad1;
     uint64_t hit_cap;                           // capacity of the hit list
     uint64_t rec_cap;                           // capacity of the record list
     uint64_t host_hdr;                          // device-visible address of the host copy of the counters

@@ -7,18 +7,17 @@
 //                 of 32 slots of a table in LDS that holds the blocks' hashes (ds_read_b32: one slot
 //                 per bank, so the lookup is bank-conflict free by construction), one v_xor
 //                 compares, v_min3 accumulates, one ballot per 4 offsets: the cost does not depend
-//                 on G.  A firing 4-offset group only pushes its POSITION onto a per-wave LDS queue
-//                 (8 wave-instructions); which offset and which block fired is worked out later, 64
-//                 groups at a time with full lanes;
-//     K2 verify   queued groups are resolved 64 at a time (exact compare of every offset with every
-//                 block), then verified one lane per candidate inside the same kernel: the <= m+2k
-//                 window bytes are fetched once into LDS, then the bounded edit-distance expansion
-//                 right and left (c_expand_*, _levenshtein_ngrams.pyx:9-154) or the Hamming count
-//                 (_substitutions_only_ngrams_template.h:103-121).  Only match records leave the chip.
-//     work split  a wave's unit of work is a 4 KiB chunk drawn from one of 256 ticket counters
-//                 (global atomics, the next ticket is fetched while the current chunk is processed):
-//                 waves that the SIMD's oldest-first issue favours simply draw more chunks, so all
-//                 waves of the persistent grid finish together (no tail of half-empty CUs).
+//                 on G; survivors go through a per-wave LDS queue to an exact re-check;
+//     K2 verify   confirmed hits wait in a per-wave LDS staging area and are verified 64 at a
+//                 time, one lane per hit, inside the same kernel: the <= m+2k window bytes are
+//                 fetched once into LDS, then the bounded edit-distance expansion right and left
+//                 (c_expand_*, _levenshtein_ngrams.pyx:9-154) or the Hamming count
+//                 (_substitutions_only_ngrams_template.h:103-121) runs out of LDS / registers.
+//                 Only match records leave the chip.
+//                 (Measured and rejected in round 2, DESIGN.md §4: a persistent grid whose waves draw
+//                 4 KiB chunks from ticket counters, and queueing only a fired group's position with
+//                 the offset/block resolved at the flush — equal without candidates, 0.04 ms slower on
+//                 DNA: every wave then flushes at the same time, at the end.)
 //   fz_verify_kernel  the lane-per-candidate verification over a hit list in HBM, for parameter
 //                 ranges that do not fit beside the filter (large m + 2k, budgets above 31).
 //   fz_verify_wf_kernel  budgets 5..31: lane-per-DP-cell.  GW = 16 / 32 / 64 lanes own the 2k+1 band
@@ -40,21 +39,19 @@
 
 #define FZ_FILTER_THREADS 256
 #define FZ_WAVES_PER_BLOCK (FZ_FILTER_THREADS / 64)
-#define FZ_FILTER_ROWS 4                                   // 16-byte rows per lane per chunk
-#define FZ_ROW_BYTES 1024                                  // one wave-row: 64 lanes x 16 B
-#define FZ_CHUNK_BYTES (FZ_ROW_BYTES * FZ_FILTER_ROWS)     // 4 KiB: one wave's unit of work
-#define FZ_CHUNK_BITS 12
-#define FZ_GROUP_BITS (FZ_CHUNK_BITS - 2)                  // a queue code's low bits: 4-offset group inside the chunk
-#define FZ_CODE_CHUNKS (1u << (32 - FZ_GROUP_BITS))        // chunks a queue code can tell apart
+#define FZ_FILTER_ROWS 4                                   // 16-byte rows per thread per tile
+#define FZ_ROW_BYTES (FZ_FILTER_THREADS * 16)              // 4 KiB
+#define FZ_TILE_BYTES (FZ_ROW_BYTES * FZ_FILTER_ROWS)      // 16 KiB (4 rows)
+#define FZ_TILE_BITS 14                                    // log2(FZ_TILE_BYTES)
+#define FZ_TITER_MAX ((1u << (32 - FZ_TILE_BITS - 3)) - 1) // tile iterations a queue code can carry
 #define FZ_PAD_FRONT 256                                   // zero bytes before buf[0]
 #define FZ_PAD_BACK 64                                     // zero bytes the kernels may over-read
-#define FZ_QCAP 256                                        // queue entries per wave
+#define FZ_QCAP 256                                        // fast-hit queue entries per wave
+#ifndef FZ_LUT_SLOTS
 #define FZ_LUT_SLOTS 32u                                   // slots of the block-hash table: one per LDS bank
+#endif
 #define FZ_LUT_BYTES (FZ_LUT_SLOTS * 4u)
-#define FZ_NDOM 256u                                       // ticket counters (domains of consecutive chunks)
-#define FZ_TICKET_STRIDE 16u                               // 64-bit words between two ticket counters (128 B)
-#define FZ_STEALS 2u                                       // other domains a wave tries when its own is drained
-#define FZ_ARGS_LDS_BYTES ((uint32_t)((offsetof(FzScanArgs, pat) + 15u) & ~15u))   // LDS copy of the launch arguments
+#define FZ_LUT_ADDR_MASK_STR "0x7c"                        // (FZ_LUT_SLOTS - 1) * 4: byte address of a slot
 
 // 32-bit little-endian window starting `b` bytes into the 64-bit value hi:lo (v_alignbyte_b32).
 __device__ __forceinline__ uint32_t fz_win(uint32_t lo, uint32_t hi, int b) {
@@ -89,7 +86,7 @@ __device__ __forceinline__ uint32_t fz_load_win(const uint8_t *__restrict__ buf,
 
 // Per-wave LDS areas, carved from dynamic LDS by fz_wave_lds().
 struct FzWaveLds {
-    uint32_t *queue;      // [FZ_QCAP]  fired 4-offset groups: group inside the chunk | (chunk - queue base) << 10
+    uint32_t *queue;      // [FZ_QCAP]  fast hits: tile-local offset | block << 14 | tile iteration << 17
     uint32_t *win;        // [win_dwords * 64]  sequence window of each lane's hit (dword d of lane l at d*64+l)
     uint16_t *scores;     // [band_w * 64]      ring of DP score slots (slot s of lane l at s*64+l)
 };
@@ -213,22 +210,23 @@ __device__ __forceinline__ uint32_t fz_wave_verify(const uint8_t *__restrict__ b
     return confirmed;
 }
 
-// Bytes 8 .. L-1 of a block's n-gram against the buffer in HBM (the first min(L, 8) were compared exactly).
-__device__ __forceinline__ bool fz_confirm_tail(const uint8_t *__restrict__ buf, const FzScanArgs &a, const uint8_t *pat_lds,
-                                                uint32_t blk, uint64_t local) {
+// Exact test of one (local position, block) candidate against the buffer in HBM (emit mode).
+__device__ __forceinline__ bool fz_confirm(const uint8_t *__restrict__ buf, const FzScanArgs &a, uint32_t blk,
+                                           uint64_t local) {
+    if ((fz_load_win(buf, (int64_t)local) & a.mask1) != a.A[blk]) return false;
+    if (a.L > 4 && (fz_load_win(buf, (int64_t)local + a.d2) & a.mask2) != a.B[blk]) return false;
     for (uint32_t b = 8; b < a.L; ++b)
-        if (buf[local + b] != pat_lds[a.s[blk] + b]) return false;
+        if (buf[local + b] != a.pat[a.s[blk] + b]) return false;
     return true;
 }
 
 #define FZ_HDR_WORDS 128                                   // 64-bit counters in the result header
-#define FZ_HDR_TICKET 3                                    // counters[3]: workgroups that finished (this launch)
+#define FZ_HDR_TICKET 3                                    // counters[3]: workgroups that finished (final launch)
 
-// End of a kernel: the LAST workgroup to get here
-//  * zeroes the chunk-ticket counters for the next scan launch (no memset command on the stream),
-//  * and, in the final kernel of a search, copies the counters into host-visible memory
-//    (a.host_hdr), so the host needs no D2H copy command after the kernel (the records themselves are
-//    then written straight to pinned host memory as well).  Every thread of the workgroup must call it.
+// End of the final kernel of a search: the LAST workgroup to get here copies the counters into
+// host-visible memory (a.host_hdr), so the host needs no D2H copy command after the kernel (the
+// records themselves are then written straight to pinned host memory as well).  Every thread of
+// the workgroup must call it.
 // No agent-scope fence on purpose: on this multi-XCD part __threadfence() writes back the XCD's L2,
 // and one per workgroup made the scan 1.7x slower.  It is not needed either: everything the last
 // workgroup reads was produced by agent-scope atomics (performed memory-side), __syncthreads() makes
@@ -237,122 +235,78 @@ __device__ __forceinline__ bool fz_confirm_tail(const uint8_t *__restrict__ buf,
 // `flag` is one LDS dword the workgroup no longer needs (no static __shared__ here: it would move the
 // dynamic LDS base off 0 and cost the scan an address add per table lookup).
 __device__ __forceinline__ void fz_finish_launch(const FzScanArgs &a, unsigned long long *__restrict__ counters,
-                                                 unsigned long long *__restrict__ tickets, volatile uint32_t *flag) {
+                                                 volatile uint32_t *flag) {
+    if (!a.host_hdr) return;
     __syncthreads();                                       // all waves' counter atomics are complete, LDS is free
     if (threadIdx.x == 0)
         *flag = atomicAdd(&counters[FZ_HDR_TICKET], 1ull) == (unsigned long long)gridDim.x - 1ull;
     __syncthreads();
     if (*flag) {
-        if (tickets)
-            for (uint32_t i = threadIdx.x; i < FZ_NDOM; i += blockDim.x)
-                __hip_atomic_store(&tickets[i * FZ_TICKET_STRIDE], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (a.host_hdr) {
-            unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.host_hdr);
-            for (uint32_t i = threadIdx.x; i < FZ_HDR_WORDS; i += blockDim.x) {
-                dst[i] = __hip_atomic_load(&counters[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // ... and leaves the counters zeroed for the next search (no memset command on the stream)
-                __hip_atomic_store(&counters[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        } else if (threadIdx.x == 0) {
-            __hip_atomic_store(&counters[FZ_HDR_TICKET], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.host_hdr);
+        for (uint32_t i = threadIdx.x; i < FZ_HDR_WORDS; i += blockDim.x) {
+            dst[i] = __hip_atomic_load(&counters[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // ... and leaves the counters zeroed for the next search (no memset command on the stream)
+            __hip_atomic_store(&counters[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
 
-// Process queue entries [0, qn): every entry is a 4-offset group some lane's filter fired on.
-//  A  64 groups at a time: fetch the group's 12 bytes and compare each of its 4 offsets exactly with
-//     the first min(L, 8) bytes of every block of the launch -> a bit per (offset, block);
-//  B  while some lane still has a bit: every lane takes its lowest one as a candidate, range-checks it
-//     against each segment it may belong to and verifies in place (FUSED) or confirms the n-gram's
-//     tail against HBM and bulk-appends the hit to the global hit list.
-// Nearly every group carries exactly one bit, so B normally runs once with all lanes busy; inputs with
-// overlapping n-gram occurrences just take more rounds.  Returns the number of confirmed n-gram hits.
-// A real function call on purpose: inlined, the flush (two expansions per budget, window staging)
-// dominates the kernel's register allocation and the hot loop of the scan pays for it (spilled loop
-// constants, LDS lookups issued one at a time).  Out of line the hot loop is allocated on its own and
-// only the rare call saves what is live.  `ap` points at the workgroup's LDS copy of the launch
-// arguments (everything but the pattern, which lives in pat_lds): the by-value kernel argument has no
-// address a function could take without a 1.4 KB private copy per lane.
+// Candidate code of the queue: tile-local byte offset (14 bits) | block (3 bits) | tile iteration.
+__device__ __forceinline__ uint32_t fz_code(uint32_t off, uint32_t blk, uint32_t titer) {
+    return off | (blk << FZ_TILE_BITS) | (titer << (FZ_TILE_BITS + 3));
+}
+
+// Process queue entries [0, qn): range-check against every segment the position may belong to (one,
+// or two with the file API's overlapping chunks), then verify in place (FUSED) or confirm against HBM
+// and bulk-append to the global hit list.  Returns the number of confirmed n-gram hits.
 template <bool FUSED>
-__device__ __noinline__ uint32_t fz_queue_flush(
-    const uint8_t *__restrict__ buf, uint32_t args_off, uint32_t pat_off, uint32_t queue_off, uint32_t win_off,
-    uint32_t scores_off, uint32_t qn, uint32_t qbase, uint64_t *__restrict__ hits, FzRec *__restrict__ recs,
-    unsigned long long *__restrict__ counters) {
-    // LDS byte offsets -> pointers built from address-space-3 pointers here, inside the function, so that
-    // the compiler knows every access below is an LDS access (ds_read / ds_write, not flat_load)
-    const FzScanArgs &a = *(const FzScanArgs *)(__attribute__((address_space(3))) const FzScanArgs *)(uintptr_t)args_off;
-    const uint8_t *pat_lds = (const uint8_t *)(FzLdsU8 *)(uintptr_t)pat_off;
-    FzWaveLds w;
-    w.queue = (uint32_t *)(__attribute__((address_space(3))) uint32_t *)(uintptr_t)queue_off;
-    w.win = (uint32_t *)(__attribute__((address_space(3))) uint32_t *)(uintptr_t)win_off;
-    w.scores = (uint16_t *)(__attribute__((address_space(3))) uint16_t *)(uintptr_t)scores_off;
+__device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ buf, const FzScanArgs &a,
+                                                   const uint8_t *pat_lds, const FzWaveLds &w, uint32_t qn,
+                                                   uint64_t *__restrict__ hits, FzRec *__restrict__ recs,
+                                                   unsigned long long *__restrict__ counters) {
     const uint32_t lane = fz_lane();
     uint32_t confirmed = 0;
     fz_wave_lds_sync();
-    if (a.flags & 2u) return 0;                       // timing knob: drop every candidate
-    const uint32_t ncand = fz_segment_candidates(a.geom);
-    for (uint32_t e0 = 0; e0 < qn; e0 += 64u) {
+    const uint32_t width = FUSED ? a.vlanes : 64u;          // candidates handled per pass
+    const uint32_t ncand = FUSED ? fz_segment_candidates(a.geom) : 1u;
+    // one loop over (batch, candidate segment): a single inlined copy of the verification
+    for (uint32_t it = 0; it * width < qn * ncand; ++it) {
+        const uint32_t e0 = (it / ncand) * width, c = it % ncand;
         const uint32_t e = e0 + lane;
+        bool valid = lane < width && e < qn;
+        uint64_t hit = 0;
         uint64_t local = 0;
-        uint32_t bits = 0;
-        if (e < qn) {
+        uint32_t blk = 0;
+        FzSeg sg;
+        sg.sa = sg.se = 0; sg.j = 0; sg.ok = 0;
+        if (valid) {
             const uint32_t code = w.queue[e];
-            local = ((uint64_t)qbase + (uint64_t)(code >> FZ_GROUP_BITS)) * (uint64_t)FZ_CHUNK_BYTES +
-                    (uint64_t)((code & ((1u << FZ_GROUP_BITS) - 1u)) << 2);
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(buf + local);
-            const uint32_t w4[4] = {src[0], src[1], src[2], 0u};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t x = FZ_WIN(w4, i) & a.mask1;
-                for (uint32_t b = 0; b < a.nblk; ++b) {
-                    bool eq = x == a.A[b];
-                    if (eq && a.L > 4) {
-                        // second window: n-gram bytes d2 .. d2+3 (d2 = min(L, 8) - 4 in 1..4)
-                        const uint32_t o2 = (uint32_t)i + a.d2;          // 1 .. 7
-                        const uint32_t lo = o2 < 4 ? w4[0] : w4[1], mid = o2 < 4 ? w4[1] : w4[2];
-                        const uint32_t y2 = (o2 & 3u) ? __builtin_amdgcn_alignbyte(mid, lo, o2 & 3u) : lo;
-                        eq = (y2 & a.mask2) == a.B[b];
-                    }
-                    if (eq) bits |= 1u << (i * 8 + (int)b);
-                }
+            blk = (code >> FZ_TILE_BITS) & 7u;
+            const uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)(code >> (FZ_TILE_BITS + 3)) * gridDim.x;
+            local = tile * (uint64_t)FZ_TILE_BYTES + (code & (FZ_TILE_BYTES - 1u));
+            const uint64_t idx = a.geom.buf_off + local;
+            if (FUSED) {
+                sg = fz_segment(a.geom, idx, c);
+                valid = fz_hit_in_range(a, blk, idx, sg);
+            } else {                                          // hit list: accepted by ANY segment (the verify kernel re-checks)
+                valid = false;
+                for (uint32_t cc = 0; cc < fz_segment_candidates(a.geom); ++cc)
+                    valid = valid || fz_hit_in_range(a, blk, idx, fz_segment(a.geom, idx, cc));
             }
+            hit = fz_hit_pack(a.g0 + blk, idx);
         }
-        // the staged windows hold a.vlanes lanes: lanes [sub, sub + vlanes) verify together
-        const uint32_t vl_n = FUSED ? a.vlanes : 64u;
-        if (a.flags & 4u) bits = 0;                   // timing knob: resolve the groups, verify nothing
-        while (__ballot(bits != 0)) {
-            for (uint32_t sub = 0; sub < 64u; sub += vl_n) {
-                const bool mine = lane >= sub && lane < sub + vl_n;
-                const bool has = mine && bits != 0;
-                if (!__ballot(has)) continue;
-                const uint32_t tz = has ? (uint32_t)__builtin_ctz(bits) : 0u;
-                if (mine) bits &= bits - 1u;
-                const uint32_t blk = tz & 7u;
-                const uint64_t loc = local + (tz >> 3);
-                const uint64_t idx = a.geom.buf_off + loc;
-                const uint64_t hit = fz_hit_pack(a.g0 + blk, idx);
-                if (FUSED) {
-                    for (uint32_t c = 0; c < ncand; ++c) {
-                        const FzSeg sg = fz_segment(a.geom, idx, c);
-                        const bool valid = has && fz_hit_in_range(a, blk, idx, sg);
-                        if (!__ballot(valid)) continue;
-                        confirmed += fz_wave_verify<4>(buf, a, pat_lds, w, lane - sub, hit, sg, valid, recs, counters);
-                    }
-                } else {
-                    bool valid = false;
-                    if (has) {
-                        for (uint32_t c = 0; c < ncand; ++c) valid = valid || fz_hit_in_range(a, blk, idx, fz_segment(a.geom, idx, c));
-                        if (valid) valid = fz_confirm_tail(buf, a, pat_lds, blk, loc);
-                    }
-                    const unsigned long long mask = __ballot(valid);
-                    if (mask) {
-                        unsigned long long base = 0;
-                        if (lane == 0) base = atomicAdd(&counters[0], (unsigned long long)__popcll(mask));
-                        base = fz_bcast64(base);
-                        const unsigned long long slot = base + fz_rank(mask);
-                        if (valid && slot < a.hit_cap) hits[slot] = hit;
-                    }
-                }
+        if (FUSED) {
+            if (c && !__ballot(valid)) continue;
+            confirmed += fz_wave_verify<4>(buf, a, pat_lds, w, lane, hit, sg, valid, recs, counters);
+        } else {
+            if (valid) valid = fz_confirm(buf, a, blk, local);
+            const unsigned long long mask = __ballot(valid);
+            if (mask) {
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(&counters[0], (unsigned long long)__popcll(mask));
+                base = fz_bcast64(base);
+                const unsigned long long slot = base + fz_rank(mask);
+                if (valid && slot < a.hit_cap) hits[slot] = hit;
             }
         }
     }
@@ -360,30 +314,27 @@ __device__ __noinline__ uint32_t fz_queue_flush(
     return confirmed;
 }
 
-// Draw the next chunk of domain `dom` (one returning global atomic, lane 0).
-__device__ __forceinline__ uint32_t fz_ticket_issue(unsigned long long *__restrict__ tickets, uint32_t dom) {
-    uint32_t t = 0;
-    if (fz_lane() == 0) t = atomicAdd(reinterpret_cast<unsigned int *>(&tickets[dom * FZ_TICKET_STRIDE]), 1u);
-    return t;
-}
-__device__ __forceinline__ uint32_t fz_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-
+// TG    : blocks the rare path tells apart (unrolled compares); nblk <= TG are real, the rest repeat block 0
+//         and are dropped by the range check.  The hot path does not depend on it.
 // NWIN  : 1 -> hash = (masked dword at the offset) * K               (L <= 4, v_mul_lo_u32);
 //         2 -> hash = low24(dword at offset + DH) * K + dword at offset (v_mad_u32_u24), DH = min(L, 8) - 3.
 // FUSED : verify candidates inside this kernel (records out) or emit exact hits (hit list out).
-// Each lane owns 16 consecutive byte offsets per row and reads 24 bytes (16 + 8 halo).
+// Each thread owns 16 consecutive byte offsets per row and reads 24 bytes (16 + 8 halo).
 // Block test: slot = (hash >> lut_shift) & 31; lut[slot] holds the hash of the block that lives there
 // (the host picks K and lut_shift so that different block hashes get different slots) or, for a free
 // slot, a value that belongs to another slot, so hash ^ lut[slot] == 0 <=> the window hashes like
 // some block.  32 slots of 4 bytes = one slot per LDS bank: lanes that read different slots never
 // collide, lanes that read the same slot are served by one broadcast.
-// A firing group is only queued (position, 32-bit code); offsets and blocks are resolved at the flush.
-// A chunk denser than the queue is re-queued group by group ("slow chunk": correctness path for
-// pathological inputs).
-// 7 waves per SIMD (72 VGPRs): measured 2-3 % faster than the natural 79-VGPR / 6-wave allocation.
-template <int NWIN, int DH, bool FUSED>
+// Measured against per-block VALU compares (benchmarks/filter_variants.hip, v3 vs v14, 3 blocks,
+// L2-resident data): 0.222 -> 0.175 ms per GiB, and no longer growing with the number of blocks.
+// Fast hits are queued per wave ACROSS tiles and processed 64 at a time (full lanes, one latency
+// chain per ~100 candidates instead of one per tile).  A tile denser than the queue is re-scanned
+// by enumeration ("slow tile": correctness path for pathological inputs).
+// 7 waves per SIMD (72 VGPRs): measured 2-3 % faster than the natural 79-VGPR / 6-wave allocation;
+// 8 waves (64 VGPRs) spills 27 VGPRs in the verify path and is 50 % slower.
+template <int TG, int NWIN, int DH, bool FUSED>
 __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_eu(7, 7))) void fz_scan_kernel(
-    const uint8_t *__restrict__ buf, const FzScanArgs a, unsigned long long *__restrict__ tickets,
+    const uint8_t *__restrict__ buf, const FzScanArgs a, uint64_t ntiles,
     uint64_t *__restrict__ hits, FzRec *__restrict__ recs, unsigned long long *__restrict__ counters) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t mpad = (a.m + 15u) & ~15u;
@@ -394,165 +345,126 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
     if (reinterpret_cast<uintptr_t>((FzLdsU8 *)smem) != 0) __builtin_trap();
     uint8_t *pat_lds = smem + FZ_LUT_BYTES;
     for (uint32_t i = threadIdx.x; i < a.m; i += FZ_FILTER_THREADS) pat_lds[i] = a.pat[i];
-    // the launch arguments (all but the pattern) for the out-of-line flush, copied from the kernarg segment
-    FzScanArgs *args_lds = reinterpret_cast<FzScanArgs *>(smem + FZ_LUT_BYTES + mpad);
-    {
-        typedef __attribute__((address_space(4))) const uint32_t FzConstU32;
-        FzConstU32 *src = (FzConstU32 *)__builtin_amdgcn_kernarg_segment_ptr() + 2;   // `a` follows `buf`
-        for (uint32_t i = threadIdx.x; i < FZ_ARGS_LDS_BYTES / 4u; i += FZ_FILTER_THREADS)
-            reinterpret_cast<uint32_t *>(args_lds)[i] = src[i];
-    }
     if (threadIdx.x < FZ_LUT_SLOTS) {
         uint32_t t = ((threadIdx.x + 1u) & (FZ_LUT_SLOTS - 1u)) << a.lut_shift;   // free slot: a value of the next slot
         for (uint32_t g = 0; g < a.nblk; ++g)
             if (((a.H[g] >> a.lut_shift) & (FZ_LUT_SLOTS - 1u)) == threadIdx.x) t = a.H[g];
         lut[threadIdx.x] = t;
     }
+    // lane g of hvec = hash of block g: the rare path reads it back with v_readlane (no memory latency)
+    // (up to 4 blocks: the unrolled rare path names a.H[g] directly and the compiler keeps it in SGPRs)
+    uint32_t hvec = 0;
+    if (TG > 4) {
+#pragma unroll
+        for (uint32_t g = 0; g < FZ_MAX_BLOCKS_PER_LAUNCH; ++g)
+            if (fz_lane() == g) hvec = a.H[g];
+    }
     __syncthreads();
-    // The loop keeps as little state as it can (32-bit, wave-uniform -> SGPRs): whatever is live across
-    // the hot loop takes registers away from it.  Chunk numbers are 32-bit (16 TiB of sequence).
-    const uint32_t wave = fz_uniform(threadIdx.x >> 6);
+    const FzWaveLds w = fz_wave_lds(smem + FZ_LUT_BYTES + mpad, threadIdx.x >> 6, FUSED ? a.win_dwords : 0u,
+                                    FUSED ? a.band_w : 0u, a.vlanes, true);
+    const uint32_t hash_k = a.hash_k;
+    // byte address of a hash's slot = (h >> (lut_shift - 2)) & 0x7c: two VGPR-only VALU ops (a shift
+    // amount in an SGPR or an SDWA byte select would issue at half the rate, benchmarks/valu_rates.hip)
+    uint32_t slot_shift;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(slot_shift) : "s"(a.lut_shift - 2u));
+    const uint32_t mask1 = a.mask1;
     const uint32_t lane = fz_lane();
-    const uint32_t nchunks = (uint32_t)a.nchunks;
-    const bool static_split = (a.flags & 1u) != 0;    // tuning knob: chunks dealt round-robin, no tickets
-    // Every wave processes at most `budget` chunks, then flushes its queue and retires: the (latency-bound)
-    // end-of-life flushes are spread over the kernel and overlap with the streaming of the workgroups the
-    // dispatcher starts in their place.  The host sizes the grid so that the home waves of every domain
-    // can take all of its chunks (grid * 4 a multiple of FZ_NDOM, waves per domain * budget >= chunks
-    // per domain): a wave only stops early when its domain is drained.
-    uint32_t budget = a.wave_budget ? a.wave_budget : 0xffffffffu;
-    uint32_t qn = 0;                                  // queue fill
-    uint32_t qbase = 0;                               // chunk the queue codes are relative to
-
-    // chunk tickets: this wave's home domain, then up to FZ_STEALS others (spread over the XCDs)
-    const uint32_t home = fz_uniform((blockIdx.x * FZ_WAVES_PER_BLOCK + wave) % FZ_NDOM);
-    uint32_t steal = 0;
-    uint32_t dom = home;
-    // lane 0: the drawn ticket (the domain's next chunk is ticket * FZ_NDOM + dom)
-    uint32_t tk = static_split ? blockIdx.x * FZ_WAVES_PER_BLOCK + wave : fz_ticket_issue(tickets, dom);
-    uint32_t chunk = 0;
-    bool have = false;                                // `chunk` is drawn but not processed yet
-    bool slow = false;                                // `chunk` is being re-queued group by group
-    bool done = false;
+    const uint32_t lane_off = threadIdx.x * 16u;
+    uint32_t qn = 0;                                  // wave-uniform queue fill
+    uint32_t confirmed = 0;                           // wave-uniform statistics
+    uint32_t titer = 0;                               // tile iteration of this workgroup
+    uint64_t tile = blockIdx.x;
+    bool slow = false;                                // a tile is being re-scanned by enumeration
     uint32_t slow_pos = 0;
 
-    // One flush site only (the flush is large: inlined several times it pushed the hot loop into scratch).
     for (;;) {
         if (slow) {
-            // the chunk overflowed the queue: queue every one of its 1024 groups instead, 64 at a time
-            // (the flush tests them exactly)
-            if (qn == 0) qbase = chunk;
-            uint32_t *queue = fz_wave_lds(smem + FZ_LUT_BYTES + mpad + FZ_ARGS_LDS_BYTES, wave, FUSED ? a.win_dwords : 0u,
-                                          FUSED ? a.band_w : 0u, a.vlanes, true).queue;
-            while (slow_pos < FZ_FILTER_ROWS * 4u && qn + 64u <= FZ_QCAP) {
-                queue[qn + lane] = ((lane << 2) + ((slow_pos >> 2) * 256u + (slow_pos & 3u))) | ((chunk - qbase) << FZ_GROUP_BITS);
+            // enumerate (row, offset, block) candidates of tile `tile`, 64 lanes at a time
+            const uint32_t steps = FZ_FILTER_ROWS * 16u * a.nblk;
+            while (slow_pos < steps && qn + 64u <= FZ_QCAP) {
+                const uint32_t blk = slow_pos % a.nblk;
+                const uint32_t ro = slow_pos / a.nblk;
+                w.queue[qn + lane] = fz_code((ro >> 4) * FZ_ROW_BYTES + lane_off + (ro & 15u), blk, titer);
                 qn += 64u;
                 ++slow_pos;
             }
-            if (slow_pos == FZ_FILTER_ROWS * 4u) slow = false;
-        } else if (!done) {
-            if (!have) {
-                // domain d owns the chunks c with c % FZ_NDOM == d: the 256 domains advance together, so at any
-                // time the chip reads one moving window of the buffer (contiguous domains put 256 read fronts at
-                // equal offsets 4 MiB apart, i.e. onto the same memory channels)
-                const uint32_t c = static_split ? tk : fz_uniform(tk) * FZ_NDOM + dom;
-                if (c < nchunks && budget) {
-                    chunk = c;
-                    have = true;
-                    --budget;
-                } else if (static_split || steal == FZ_STEALS || !budget || a.wave_budget) {
-                    done = true;                      // own domain and the steal targets are drained
-                } else {
-                    ++steal;
-                    dom = (home + steal * 4u * 9u) % FZ_NDOM;   // 4 waves per workgroup, consecutive workgroups on consecutive XCDs
-                    tk = fz_ticket_issue(tickets, dom);
-                    continue;
-                }
-            }
-            // the queue codes are relative to qbase: a chunk outside their range waits for the flush below
-            if (have && !(qn && (chunk < qbase || chunk - qbase >= FZ_CODE_CHUNKS))) {
-                if (qn == 0) qbase = chunk;
-                // Per-chunk constants are set up here, not before the loop: kept live across the (large)
-                // flush they were the first values the register allocator pushed to scratch.
-                const uint32_t hash_k = a.hash_k;
-                const uint32_t mask1 = a.mask1;
-                // byte address of a hash's slot = (h >> (lut_shift - 2)) & 0x7c: two VGPR-only VALU ops (a shift
-                // amount in an SGPR or an SDWA byte select would issue at half the rate, benchmarks/valu_rates.hip)
-                uint32_t slot_shift;
-                asm volatile("v_mov_b32 %0, %1" : "=v"(slot_shift) : "s"(a.lut_shift - 2u));
-                uint32_t lane_code = lane << 2;        // this lane's part of a queue code: its first group in a row
-                asm volatile("" : "+v"(lane_code));
-                uint32_t queue_lds;                    // LDS byte address of this wave's queue
-                {
-                    uint8_t *qp = reinterpret_cast<uint8_t *>(
-                        fz_wave_lds(smem + FZ_LUT_BYTES + mpad + FZ_ARGS_LDS_BYTES, wave, FUSED ? a.win_dwords : 0u,
-                                    FUSED ? a.band_w : 0u, a.vlanes, true).queue);
-                    queue_lds = fz_uniform((uint32_t)(uintptr_t)((FzLdsU8 *)qp));
-                }
-                const uint8_t *src0 = buf + (uint64_t)chunk * FZ_CHUNK_BYTES + lane * 16u;
+            if (slow_pos >= steps) { slow = false; tile += gridDim.x; ++titer; }
+        } else {
+            while (tile < ntiles && qn <= FZ_QCAP / 2) {
+                const uint64_t tile_base = tile * (uint64_t)FZ_TILE_BYTES;
                 uint4 v[FZ_FILTER_ROWS];
                 uint2 h[FZ_FILTER_ROWS];
 #pragma unroll
                 for (int r = 0; r < FZ_FILTER_ROWS; ++r) {
-                    const uint8_t *src = src0 + (uint64_t)r * FZ_ROW_BYTES;
+                    const uint8_t *src = buf + tile_base + lane_off + (uint64_t)r * FZ_ROW_BYTES;
                     v[r] = *reinterpret_cast<const uint4 *>(src);
                     h[r] = *reinterpret_cast<const uint2 *>(src + 16);
                 }
-                // next ticket: its latency hides behind this chunk (none when this was the wave's last chunk:
-                // a drawn ticket must be processed)
-                if (budget) tk = static_split ? chunk + gridDim.x * FZ_WAVES_PER_BLOCK : fz_ticket_issue(tickets, dom);
-                have = false;
-                const uint32_t q_chunk = qn;
-                const uint32_t code_chunk = (chunk - qbase) << FZ_GROUP_BITS;
+                const uint32_t q_tile = qn;
 #pragma unroll
                 for (int r = 0; r < FZ_FILTER_ROWS; ++r) {
                     const uint32_t w6[6] = {v[r].x, v[r].y, v[r].z, v[r].w, h[r].x, h[r].y};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {     // 4 byte offsets per ballot
-                        uint32_t am[4];
+                        uint32_t hv[4], am[4];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const int o = 4 * j + i;
                             const uint32_t x = FZ_WIN(w6, o);
-                            uint32_t hv;
-                            if (NWIN == 1) hv = (x & mask1) * hash_k;                             // v_mul_lo_u32
-                            else hv = __umul24(FZ_WIN(w6, o + DH), hash_k) + x;                   // v_mad_u32_u24
+                            if (NWIN == 1) hv[i] = (x & mask1) * hash_k;                             // v_mul_lo_u32
+                            else hv[i] = __umul24(FZ_WIN(w6, o + DH), hash_k) + x;                   // v_mad_u32_u24
                             uint32_t slot4;
-                            asm("v_lshrrev_b32 %0, %1, %2\n\tv_and_b32 %0, 0x7c, %0" : "=v"(slot4) : "v"(slot_shift), "v"(hv));
-                            am[i] = hv ^ *reinterpret_cast<FzLdsU32 *>(slot4);   // lut sits at LDS address 0
+                            asm("v_lshrrev_b32 %0, %1, %2\n\tv_and_b32 %0, " FZ_LUT_ADDR_MASK_STR ", %0" : "=v"(slot4) : "v"(slot_shift), "v"(hv[i]));
+                            am[i] = hv[i] ^ *reinterpret_cast<FzLdsU32 *>(slot4);   // lut sits at LDS address 0
                         }
                         const uint32_t acc = min(min(am[0], am[1]), min(am[2], am[3]));
-                        const unsigned long long fired = __ballot(acc == 0);
-                        if (__builtin_expect(fired != 0, 0)) {   // wave-uniform, rare: some lane, some offset of this group
-                            const uint32_t slot = qn + fz_rank(fired);
-                            if (acc == 0 && slot < FZ_QCAP)
-                                *reinterpret_cast<__attribute__((address_space(3))) uint32_t *>(queue_lds + slot * 4u) =
-                                    (lane_code + (uint32_t)(r * 256 + j)) | code_chunk;
-                            qn += (uint32_t)__popcll(fired);
+                        if (__builtin_expect(__ballot(acc == 0) != 0, 0)) {   // wave-uniform, rare: some lane, some offset
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                if (__ballot(am[i] == 0)) {           // which offset (scalar branch)
+                                    // which block(s): equal n-grams share a slot
+                                    auto push = [&](uint32_t g) {
+                                        const uint32_t hg = TG <= 4 ? a.H[g] : (uint32_t)__builtin_amdgcn_readlane((int)hvec, (int)g);
+                                        const unsigned long long mk = __ballot(hv[i] == hg);
+                                        if (mk) {
+                                            const uint32_t slot = qn + fz_rank(mk);
+                                            // the empty asm keeps LICM from hoisting the loop-invariant
+                                            // queue codes into VGPRs
+                                            uint32_t code = threadIdx.x;           // recomputed here: a spilled copy costs a scratch round trip per firing
+                                            asm volatile("v_lshlrev_b32 %0, 4, %0" : "+v"(code));
+                                            code = fz_code(code + (uint32_t)(r * FZ_ROW_BYTES + 4 * j + i), g, titer);
+                                            if (hv[i] == hg && slot < FZ_QCAP) w.queue[slot] = code;
+                                            qn += (uint32_t)__popcll(mk);
+                                        }
+                                    };
+                                    if constexpr (TG <= 4) {          // unrolled: 6 % faster at 17 % firing groups (DNA, L = 6)
+#pragma unroll
+                                        for (int g = 0; g < TG; ++g) push((uint32_t)g);
+                                    } else {                          // rolled: 64 x 8 unrolled copies stop the row loop from unrolling
+#pragma unroll 1
+                                        for (uint32_t g = 0; g < (uint32_t)TG; ++g) push(g);
+                                    }
+                                }
+                            }
                         }
                     }
                 }
-                if (qn > FZ_QCAP) {                   // denser than the queue: drop the partial entries, re-queue by enumeration
-                    qn = q_chunk;
+                if (qn > FZ_QCAP) {                   // this tile overflowed the queue: drop its
+                    qn = q_tile;                      // partial entries and re-scan it by enumeration
                     slow = true;
                     slow_pos = 0;
+                    break;
                 }
+                tile += gridDim.x;
+                ++titer;
             }
         }
-        if (qn && (done || have || slow || qn > FZ_QCAP / 2 || qn + 64u > FZ_QCAP)) {
-            const FzWaveLds w = fz_wave_lds(smem + FZ_LUT_BYTES + mpad + FZ_ARGS_LDS_BYTES, wave, FUSED ? a.win_dwords : 0u,
-                                            FUSED ? a.band_w : 0u, a.vlanes, true);
-            // the dynamic LDS area starts at LDS address 0: offsets into smem are LDS addresses
-            const uint32_t confirmed = fz_queue_flush<FUSED>(
-                buf, FZ_LUT_BYTES + mpad, FZ_LUT_BYTES, (uint32_t)(reinterpret_cast<uint8_t *>(w.queue) - smem),
-                (uint32_t)(reinterpret_cast<uint8_t *>(w.win) - smem), (uint32_t)(reinterpret_cast<uint8_t *>(w.scores) - smem), qn,
-                qbase, hits, recs, counters);
-            if (FUSED && lane == 0 && confirmed) atomicAdd(&counters[8 + (blockIdx.x & 63u)], (unsigned long long)confirmed);
-            qn = 0;
-        }
-        if (done) break;
+        if (qn) confirmed += fz_queue_flush<FUSED>(buf, a, pat_lds, w, qn, hits, recs, counters);
+        qn = 0;
+        if (!slow && tile >= ntiles) break;
     }
-    fz_finish_launch(a, counters, tickets, lut);
+    if (FUSED && lane == 0 && confirmed) atomicAdd(&counters[8 + (blockIdx.x & 63u)], (unsigned long long)confirmed);
+    fz_finish_launch(a, counters, lut);
 }
 
 // Verification of a hit list in HBM, one lane per candidate (parameter ranges whose LDS footprint does
@@ -583,7 +495,7 @@ __global__ void fz_verify_kernel(const uint8_t *__restrict__ buf, const FzScanAr
             fz_wave_verify<FZ_REG_BAND_MAX>(buf, a, pat_lds, w, fz_lane(), hit, sg, valid, recs, counters);
         }
     }
-    fz_finish_launch(a, counters, nullptr, reinterpret_cast<uint32_t *>(smem));
+    fz_finish_launch(a, counters, reinterpret_cast<uint32_t *>(smem));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -759,7 +671,7 @@ __global__ __launch_bounds__(256) void fz_verify_wf_kernel(const uint8_t *__rest
             fz_wave_lds_sync();
         }
     }
-    fz_finish_launch(a, counters, nullptr, reinterpret_cast<uint32_t *>(smem));
+    fz_finish_launch(a, counters, reinterpret_cast<uint32_t *>(smem));
 }
 
 // ---------------------------------------------------------------------------------------------

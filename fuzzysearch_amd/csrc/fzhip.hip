@@ -1,8 +1,8 @@
 // fzhip.hip — host side of libfzhip.so: the C-ABI of include/fzhip.h over the gfx950 kernels.
 //
 // Data layout in HBM (per device shard):
-//   [FZ_PAD_FRONT zero bytes][buf_len sequence bytes][zero bytes up to a whole 4 KiB chunk + FZ_PAD_BACK]
-// so the scan can read whole chunks and 8-byte halos without bounds checks; zero padding can
+//   [FZ_PAD_FRONT zero bytes][buf_len sequence bytes][zero bytes up to a whole tile + FZ_PAD_BACK]
+// so the scan can read whole 16 KiB tiles and 8-byte halos without bounds checks; zero padding can
 // never create an accepted hit because every candidate is range-checked against the global length.
 //   d_out  : [1 KiB header: counters][records, 24 B each] in one allocation, so the usual result
 //            comes back in ONE D2H copy (header + about as many records as the previous call had)
@@ -91,8 +91,6 @@ struct DevState {
     // Large record sets of the automaton kernels (10^5 .. 10^6 records): a pinned, device-mapped host
     // buffer that grows on demand; the kernel's stores cross PCIe while it runs instead of a D2H copy
     // into pageable memory afterwards.
-    unsigned long long *d_tickets = nullptr;     // FZ_NDOM chunk-ticket counters of the scan, one per 128 bytes;
-                                                 // zero between launches (the last workgroup of a scan resets them)
     uint8_t *d_cand = nullptr;                   // HBM candidate lists of the automaton kernels (rare fallback)
     uint64_t cand_bytes = 0;
     uint8_t *h_big = nullptr, *h_big_dev = nullptr;
@@ -215,21 +213,38 @@ struct BlockPlan {
     uint64_t abs_lo = 0, abs_hi = ~0ull;   // absolute index range (exact search with start / end index)
 };
 
-using ScanKernel = void (*)(const uint8_t *, const FzScanArgs, unsigned long long *, uint64_t *, FzRec *, unsigned long long *);
+using ScanKernel = void (*)(const uint8_t *, const FzScanArgs, uint64_t, uint64_t *, FzRec *, unsigned long long *);
 
-template <bool FUSED>
-ScanKernel scan_kernel_f(int nwin, int dh) {
-    if (nwin == 1) return fz_scan_kernel<1, 0, FUSED>;
+template <int TG, bool FUSED>
+ScanKernel scan_kernel_tg(int nwin, int dh) {
+    if (nwin == 1) return fz_scan_kernel<TG, 1, 0, FUSED>;
     switch (dh) {
-        case 2: return fz_scan_kernel<2, 2, FUSED>;
-        case 3: return fz_scan_kernel<2, 3, FUSED>;
-        case 4: return fz_scan_kernel<2, 4, FUSED>;
-        default: return fz_scan_kernel<2, 5, FUSED>;
+        case 2: return fz_scan_kernel<TG, 2, 2, FUSED>;
+        case 3: return fz_scan_kernel<TG, 2, 3, FUSED>;
+        case 4: return fz_scan_kernel<TG, 2, 4, FUSED>;
+        default: return fz_scan_kernel<TG, 2, 5, FUSED>;
     }
 }
 
-ScanKernel scan_kernel(int nwin, int dh, bool fused) {
-    return fused ? scan_kernel_f<true>(nwin, dh) : scan_kernel_f<false>(nwin, dh);
+template <bool FUSED>
+ScanKernel scan_kernel_f(int tg, int nwin, int dh) {
+    switch (tg) {
+        case 1: return scan_kernel_tg<1, FUSED>(nwin, dh);
+        case 2: return scan_kernel_tg<2, FUSED>(nwin, dh);
+        case 3: return scan_kernel_tg<3, FUSED>(nwin, dh);
+        case 4: return scan_kernel_tg<4, FUSED>(nwin, dh);
+        case 6: return scan_kernel_tg<6, FUSED>(nwin, dh);
+        default: return scan_kernel_tg<8, FUSED>(nwin, dh);
+    }
+}
+
+ScanKernel scan_kernel(int tg, int nwin, int dh, bool fused) {
+    return fused ? scan_kernel_f<true>(tg, nwin, dh) : scan_kernel_f<false>(tg, nwin, dh);
+}
+
+int pick_tg(uint32_t nblk) {
+    if (nblk <= 4) return (int)nblk;
+    return nblk <= 6 ? 6 : 8;
 }
 
 // Odd multipliers tried for the window hash (24-bit ones serve v_mad_u32_u24).  One search needs a
@@ -334,23 +349,21 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
 
     const uint32_t L = q.plan.L;
     const uint32_t G = (uint32_t)q.plan.s.size();
-    const uint64_t nchunks = (sh.geom.buf_len + FZ_CHUNK_BYTES - 1) / FZ_CHUNK_BYTES;
-    // Persistent grid: as many workgroups as the chip holds at once (7 per CU at this kernel's register
-    // use; one more per CU does no harm — a workgroup that finds every ticket domain drained leaves at
-    // once).  The waves draw 4 KiB chunks from 256 ticket counters, so the grid size only has to cover
-    // the domains: 4 * grid >= min(256, chunks).
-    static const int wg_per_cu = []() { const char *e = getenv("FZ_WG_PER_CU"); int v = e ? atoi(e) : 0; return v > 0 ? v : 7; }();
-    static const int wave_budget = []() { const char *e = getenv("FZ_CHUNKS_PER_WAVE"); int v = e ? atoi(e) : -1; return v >= 0 ? v : 0; }();
-    const uint64_t resident = (uint64_t)d.n_cus * wg_per_cu;
-    uint64_t want = (nchunks + FZ_WAVES_PER_BLOCK - 1) / FZ_WAVES_PER_BLOCK;
-    if (wave_budget) {
-        // waves per domain * budget >= chunks per domain, and grid * 4 a multiple of the domain count
-        const uint64_t per_dom = (nchunks + FZ_NDOM - 1) / FZ_NDOM;
-        want = std::max<uint64_t>(1, (per_dom + wave_budget - 1) / wave_budget) * (FZ_NDOM / FZ_WAVES_PER_BLOCK);
-    } else {
-        want = std::min<uint64_t>(want, resident);
-    }
-    dim3 grid((unsigned)std::max<uint64_t>(1, want));
+    const uint64_t ntiles = (sh.geom.buf_len + FZ_TILE_BYTES - 1) / FZ_TILE_BYTES;
+    // Grid: every workgroup strides over ~16 tiles (256 KiB).  Measured on MI355X at 1 GiB: 6 / 8 /
+    // 12 / 16 / 20 / 32 / 64 workgroups per CU -> 0.302 / 0.302 / 0.276 / 0.267 / 0.265 / 0.280 /
+    // 0.333 ms: several rounds of short workgroups overlap one workgroup's end-of-life verification
+    // (latency-bound) with the others' streaming; too many pay the per-workgroup fixed cost.  At least
+    // 6 per CU (the co-resident count at this kernel's SGPR use) so small inputs still fill the chip.
+    // (Round 2 measured the alternative — a persistent grid whose waves draw 4 KiB chunks from ticket
+    // counters so that all finish together: same time without candidates, 0.04 ms slower on DNA,
+    // because every wave then runs its verification at the same moment, at the end.)
+    static const int tiles_per_wg = []() { const char *e = getenv("FZ_TILES_PER_WG"); int v = e ? atoi(e) : 0; return v > 0 ? v : 16; }();
+    const uint64_t max_grid = std::max<uint64_t>((uint64_t)d.n_cus * 6, ntiles / tiles_per_wg);
+    // the queue codes carry a bounded per-workgroup tile iteration
+    const uint64_t min_grid = (ntiles + FZ_TITER_MAX - 1) / FZ_TITER_MAX;
+    dim3 grid((unsigned)std::max<uint64_t>(std::max<uint64_t>(1, min_grid), std::min<uint64_t>(ntiles, max_grid)));
+
     FzScanArgs fa;
     fill_common_args(fa, sh, q);
     const HashGeom hgeom(L);
@@ -362,25 +375,21 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     fa.win_dwords = (q.m + 2 * q.k + 6) / 4 + 1;
     fa.hit_cap = d.hit_cap;
     fa.rec_cap = direct ? kHostRecs : d.rec_cap;
-    fa.nchunks = nchunks;
-    static const uint32_t scan_flags = []() { const char *e = getenv("FZ_SCAN_FLAGS"); return e ? (uint32_t)atoi(e) : 0u; }();
-    fa.flags = scan_flags;
-    fa.wave_budget = (uint32_t)wave_budget;
     const uint32_t mpad = (q.m + 15u) & ~15u;
     // Lanes that verify at once: all 64 while the staged windows stay small; fewer for long patterns
     // so that the scan keeps ~8 workgroups per CU resident (measured at m = 64, k = 5 on 1 GiB of text:
     // 64 lanes -> 31.6 KB LDS, 5 workgroups/CU, scan 0.540 ms; candidates are rare there anyway).
     static const uint32_t target = []() { const char *e = getenv("FZ_FUSED_TARGET_KB"); int v = e ? atoi(e) : 0; return (uint32_t)(v > 0 ? v : 18) * 1024u; }();
     fa.vlanes = 64;
-    while (fa.vlanes > 16 && mpad + FZ_LUT_BYTES + FZ_ARGS_LDS_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, fa.vlanes, true) > target)
+    while (fa.vlanes > 16 && mpad + FZ_LUT_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, fa.vlanes, true) > target)
         fa.vlanes >>= 1;
-    const uint32_t fused_lds = mpad + FZ_LUT_BYTES + FZ_ARGS_LDS_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, fa.vlanes, true);
+    const uint32_t fused_lds = mpad + FZ_LUT_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, fa.vlanes, true);
     // k > 4 (register band too wide for the scan kernel's VGPR budget) -> verify in a kernel of its own
     fa.fused = (with_verify && fused_lds <= kFusedLdsBudget && (q.mode != FZ_MODE_LEV || q.k <= 4)) ? 1u : 0u;
-    const uint32_t scan_lds = fa.fused ? fused_lds : mpad + FZ_LUT_BYTES + FZ_ARGS_LDS_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(0, 0, 64, true);
+    const uint32_t scan_lds = fa.fused ? fused_lds : mpad + FZ_LUT_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(0, 0, 64, true);
 
     uint32_t launches = 0;
-    for (uint32_t g0 = 0; g0 < G && nchunks > 0;) {
+    for (uint32_t g0 = 0; g0 < G && ntiles > 0;) {
         // Blocks [g0, g0 + nblk) of this launch and the hash multiplier: the longest run of blocks (at
         // most 8) whose distinct hashes land in distinct table slots under some multiplier.  One block
         // always fits; equal n-grams (equal hashes) share a slot.
@@ -401,10 +410,12 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
         // the final kernel of the search publishes the counters to the host (direct mode)
         const bool verify_follows = with_verify && !fa.fused;
         fa.host_hdr = (direct && !verify_follows && g0 + nblk >= G) ? reinterpret_cast<uint64_t>(d.h_stage_dev) : 0;
-        ScanKernel kern = scan_kernel(nwin, dh, fa.fused != 0);
+        const int tg = pick_tg(nblk);
+        for (int b = (int)nblk; b < tg; ++b) fa.H[b] = fa.H[0];      // compiled-in spare blocks: dropped by the range check
+        ScanKernel kern = scan_kernel(tg, nwin, dh, fa.fused != 0);
         static const uint32_t extra_lds = []() { const char *e = getenv("FZ_EXTRA_LDS_KB"); return e ? (uint32_t)atoi(e) * 1024u : 0u; }();
-        hipLaunchKernelGGL(kern, grid, dim3(FZ_FILTER_THREADS), scan_lds + extra_lds, d.stream, sh.d_buf, fa, d.d_tickets, d.d_hits,
-                           recs, counters);
+        hipLaunchKernelGGL(kern, grid, dim3(FZ_FILTER_THREADS), scan_lds + extra_lds, d.stream, sh.d_buf, fa, ntiles, d.d_hits, recs,
+                           counters);
         HIP_TRY(hipGetLastError());
         ++launches;
         g0 += nblk;
@@ -414,7 +425,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     d.scan_end_event = (copy_back && direct && !(with_verify && !fa.fused)) ? 3 : 1;
     if (d.scan_end_event == 1) HIP_TRY(hipEventRecord(d.ev[1], d.stream));
     d.verify_launched = false;
-    if (with_verify && !fa.fused && nchunks > 0 && G > 0) {
+    if (with_verify && !fa.fused && ntiles > 0 && G > 0) {
         d.verify_launched = true;
         fa.nblk = 0;
         fa.g0 = 0;
@@ -854,8 +865,6 @@ int fz_create(const int *device_ids, int n_devices, fz_ctx **out) {
             for (auto &ev : d.ev) HIP_TRY(hipEventCreate(&ev));
             HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&d.h_stage), kHeaderBytes + kHostRecs * sizeof(FzRec), hipHostMallocMapped));
             HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&d.h_stage_dev), d.h_stage, 0));
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d.d_tickets), FZ_NDOM * FZ_TICKET_STRIDE * sizeof(unsigned long long)));
-            HIP_TRY(hipMemsetAsync(d.d_tickets, 0, FZ_NDOM * FZ_TICKET_STRIDE * sizeof(unsigned long long), d.stream));
             return FZ_OK;
         };
         rc = init();
@@ -878,7 +887,6 @@ void fz_destroy(fz_ctx *ctx) {
         if (d.h_stage) (void)hipHostFree(d.h_stage);
         if (d.h_big) (void)hipHostFree(d.h_big);
         if (d.d_cand) (void)hipFree(d.d_cand);
-        if (d.d_tickets) (void)hipFree(d.d_tickets);
         for (auto &ev : d.ev) if (ev) (void)hipEventDestroy(ev);
         if (d.stream) (void)hipStreamDestroy(d.stream);
     }
@@ -888,8 +896,8 @@ void fz_destroy(fz_ctx *ctx) {
 static int upload_one(fz_ctx *ctx, int dev_index, const uint8_t *host_buf, const FzGeom &geom, Shard &sh) {
     DevState &d = ctx->devs[dev_index];
     HIP_TRY(hipSetDevice(d.device));
-    const uint64_t chunks = (geom.buf_len + FZ_CHUNK_BYTES - 1) / FZ_CHUNK_BYTES;
-    const uint64_t body = std::max<uint64_t>(1, chunks) * FZ_CHUNK_BYTES;
+    const uint64_t tiles = (geom.buf_len + FZ_TILE_BYTES - 1) / FZ_TILE_BYTES;
+    const uint64_t body = std::max<uint64_t>(1, tiles) * FZ_TILE_BYTES;
     sh.dev = dev_index;
     sh.alloc_bytes = FZ_PAD_FRONT + body + FZ_PAD_BACK;
     sh.geom = geom;
