@@ -47,11 +47,19 @@
 #define FZ_PAD_FRONT 256                                   // zero bytes before buf[0]
 #define FZ_PAD_BACK 64                                     // zero bytes the kernels may over-read
 #define FZ_QCAP 256                                        // fast-hit queue entries per wave
-#ifndef FZ_LUT_SLOTS
-#define FZ_LUT_SLOTS 32u                                   // slots of the block-hash table: one per LDS bank
+#ifndef FZ_H_SGPR
+#define FZ_H_SGPR(tg) ((tg) <= 4)                            // rare path: block hashes named as kernel arguments (SGPRs) or read from a lane vector
 #endif
+#ifndef FZ_LUT_BITS
+#define FZ_LUT_BITS 5                                      // 32 slots: one per LDS bank (6 = the round-1 table, 2-way conflicts)
+#endif
+#define FZ_LUT_SLOTS (1u << FZ_LUT_BITS)                   // slots of the block-hash table
 #define FZ_LUT_BYTES (FZ_LUT_SLOTS * 4u)
+#if FZ_LUT_BITS == 5
 #define FZ_LUT_ADDR_MASK_STR "0x7c"                        // (FZ_LUT_SLOTS - 1) * 4: byte address of a slot
+#else
+#define FZ_LUT_ADDR_MASK_STR "0xfc"
+#endif
 
 // 32-bit little-endian window starting `b` bytes into the 64-bit value hi:lo (v_alignbyte_b32).
 __device__ __forceinline__ uint32_t fz_win(uint32_t lo, uint32_t hi, int b) {
@@ -256,10 +264,12 @@ __device__ __forceinline__ uint32_t fz_code(uint32_t off, uint32_t blk, uint32_t
     return off | (blk << FZ_TILE_BITS) | (titer << (FZ_TILE_BITS + 3));
 }
 
-// Process queue entries [0, qn): range-check against every segment the position may belong to (one,
-// or two with the file API's overlapping chunks), then verify in place (FUSED) or confirm against HBM
-// and bulk-append to the global hit list.  Returns the number of confirmed n-gram hits.
-template <bool FUSED>
+// Process queue entries [0, qn): range-check, then verify in place (FUSED) or confirm against HBM and
+// bulk-append to the global hit list.  SEG: the sequence is a batch of file chunks (segments), a
+// position may belong to two of them and is range-checked / verified once per segment; compiled
+// separately because the in-memory search (one segment, the whole sequence) must not pay for it in
+// registers.  Returns the number of confirmed n-gram hits.
+template <bool FUSED, bool SEG>
 __device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ buf, const FzScanArgs &a,
                                                    const uint8_t *pat_lds, const FzWaveLds &w, uint32_t qn,
                                                    uint64_t *__restrict__ hits, FzRec *__restrict__ recs,
@@ -268,45 +278,47 @@ __device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ b
     uint32_t confirmed = 0;
     fz_wave_lds_sync();
     const uint32_t width = FUSED ? a.vlanes : 64u;          // candidates handled per pass
-    const uint32_t ncand = FUSED ? fz_segment_candidates(a.geom) : 1u;
-    // one loop over (batch, candidate segment): a single inlined copy of the verification
-    for (uint32_t it = 0; it * width < qn * ncand; ++it) {
-        const uint32_t e0 = (it / ncand) * width, c = it % ncand;
-        const uint32_t e = e0 + lane;
-        bool valid = lane < width && e < qn;
-        uint64_t hit = 0;
-        uint64_t local = 0;
-        uint32_t blk = 0;
-        FzSeg sg;
-        sg.sa = sg.se = 0; sg.j = 0; sg.ok = 0;
-        if (valid) {
-            const uint32_t code = w.queue[e];
-            blk = (code >> FZ_TILE_BITS) & 7u;
-            const uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)(code >> (FZ_TILE_BITS + 3)) * gridDim.x;
-            local = tile * (uint64_t)FZ_TILE_BYTES + (code & (FZ_TILE_BYTES - 1u));
-            const uint64_t idx = a.geom.buf_off + local;
-            if (FUSED) {
-                sg = fz_segment(a.geom, idx, c);
-                valid = fz_hit_in_range(a, blk, idx, sg);
-            } else {                                          // hit list: accepted by ANY segment (the verify kernel re-checks)
-                valid = false;
-                for (uint32_t cc = 0; cc < fz_segment_candidates(a.geom); ++cc)
-                    valid = valid || fz_hit_in_range(a, blk, idx, fz_segment(a.geom, idx, cc));
+    const uint32_t ncand = (SEG && FUSED) ? fz_segment_candidates(a.geom) : 1u;
+    for (uint32_t e0 = 0; e0 < qn; e0 += width) {
+        for (uint32_t c = 0; c < ncand; ++c) {               // one inlined copy of the verification for both segments
+            const uint32_t e = e0 + lane;
+            bool valid = lane < width && e < qn;
+            uint64_t hit = 0;
+            uint64_t local = 0;
+            uint32_t blk = 0;
+            FzSeg sg;
+            sg.sa = 0; sg.se = a.geom.n; sg.j = 0; sg.ok = 1;
+            if (valid) {
+                const uint32_t code = w.queue[e];
+                blk = (code >> FZ_TILE_BITS) & 7u;
+                const uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)(code >> (FZ_TILE_BITS + 3)) * gridDim.x;
+                local = tile * (uint64_t)FZ_TILE_BYTES + (code & (FZ_TILE_BYTES - 1u));
+                const uint64_t idx = a.geom.buf_off + local;
+                if (!SEG) {
+                    valid = fz_hit_in_range(a, blk, idx, sg);
+                } else if (FUSED) {
+                    sg = fz_segment(a.geom, idx, c);
+                    valid = fz_hit_in_range(a, blk, idx, sg);
+                } else {                                      // hit list: accepted by ANY segment (the verify kernel re-checks)
+                    valid = false;
+                    for (uint32_t cc = 0; cc < fz_segment_candidates(a.geom); ++cc)
+                        valid = valid || fz_hit_in_range(a, blk, idx, fz_segment(a.geom, idx, cc));
+                }
+                hit = fz_hit_pack(a.g0 + blk, idx);
             }
-            hit = fz_hit_pack(a.g0 + blk, idx);
-        }
-        if (FUSED) {
-            if (c && !__ballot(valid)) continue;
-            confirmed += fz_wave_verify<4>(buf, a, pat_lds, w, lane, hit, sg, valid, recs, counters);
-        } else {
-            if (valid) valid = fz_confirm(buf, a, blk, local);
-            const unsigned long long mask = __ballot(valid);
-            if (mask) {
-                unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(&counters[0], (unsigned long long)__popcll(mask));
-                base = fz_bcast64(base);
-                const unsigned long long slot = base + fz_rank(mask);
-                if (valid && slot < a.hit_cap) hits[slot] = hit;
+            if (FUSED) {
+                if (SEG && c && !__ballot(valid)) continue;
+                confirmed += fz_wave_verify<4>(buf, a, pat_lds, w, lane, hit, sg, valid, recs, counters);
+            } else {
+                if (valid) valid = fz_confirm(buf, a, blk, local);
+                const unsigned long long mask = __ballot(valid);
+                if (mask) {
+                    unsigned long long base = 0;
+                    if (lane == 0) base = atomicAdd(&counters[0], (unsigned long long)__popcll(mask));
+                    base = fz_bcast64(base);
+                    const unsigned long long slot = base + fz_rank(mask);
+                    if (valid && slot < a.hit_cap) hits[slot] = hit;
+                }
             }
         }
     }
@@ -319,6 +331,7 @@ __device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ b
 // NWIN  : 1 -> hash = (masked dword at the offset) * K               (L <= 4, v_mul_lo_u32);
 //         2 -> hash = low24(dword at offset + DH) * K + dword at offset (v_mad_u32_u24), DH = min(L, 8) - 3.
 // FUSED : verify candidates inside this kernel (records out) or emit exact hits (hit list out).
+// SEG   : the buffer is a batch of file chunks with per-chunk clamps (find_near_matches_in_file).
 // Each thread owns 16 consecutive byte offsets per row and reads 24 bytes (16 + 8 halo).
 // Block test: slot = (hash >> lut_shift) & 31; lut[slot] holds the hash of the block that lives there
 // (the host picks K and lut_shift so that different block hashes get different slots) or, for a free
@@ -332,7 +345,7 @@ __device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ b
 // by enumeration ("slow tile": correctness path for pathological inputs).
 // 7 waves per SIMD (72 VGPRs): measured 2-3 % faster than the natural 79-VGPR / 6-wave allocation;
 // 8 waves (64 VGPRs) spills 27 VGPRs in the verify path and is 50 % slower.
-template <int TG, int NWIN, int DH, bool FUSED>
+template <int TG, int NWIN, int DH, bool FUSED, bool SEG>
 __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_eu(7, 7))) void fz_scan_kernel(
     const uint8_t *__restrict__ buf, const FzScanArgs a, uint64_t ntiles,
     uint64_t *__restrict__ hits, FzRec *__restrict__ recs, unsigned long long *__restrict__ counters) {
@@ -354,7 +367,7 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
     // lane g of hvec = hash of block g: the rare path reads it back with v_readlane (no memory latency)
     // (up to 4 blocks: the unrolled rare path names a.H[g] directly and the compiler keeps it in SGPRs)
     uint32_t hvec = 0;
-    if (TG > 4) {
+    if (!FZ_H_SGPR(TG)) {
 #pragma unroll
         for (uint32_t g = 0; g < FZ_MAX_BLOCKS_PER_LAUNCH; ++g)
             if (fz_lane() == g) hvec = a.H[g];
@@ -424,7 +437,7 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                                 if (__ballot(am[i] == 0)) {           // which offset (scalar branch)
                                     // which block(s): equal n-grams share a slot
                                     auto push = [&](uint32_t g) {
-                                        const uint32_t hg = TG <= 4 ? a.H[g] : (uint32_t)__builtin_amdgcn_readlane((int)hvec, (int)g);
+                                        const uint32_t hg = FZ_H_SGPR(TG) ? a.H[g] : (uint32_t)__builtin_amdgcn_readlane((int)hvec, (int)g);
                                         const unsigned long long mk = __ballot(hv[i] == hg);
                                         if (mk) {
                                             const uint32_t slot = qn + fz_rank(mk);
@@ -459,7 +472,7 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                 ++titer;
             }
         }
-        if (qn) confirmed += fz_queue_flush<FUSED>(buf, a, pat_lds, w, qn, hits, recs, counters);
+        if (qn) confirmed += fz_queue_flush<FUSED, SEG>(buf, a, pat_lds, w, qn, hits, recs, counters);
         qn = 0;
         if (!slow && tile >= ntiles) break;
     }

@@ -215,31 +215,34 @@ struct BlockPlan {
 
 using ScanKernel = void (*)(const uint8_t *, const FzScanArgs, uint64_t, uint64_t *, FzRec *, unsigned long long *);
 
-template <int TG, bool FUSED>
+template <int TG, bool FUSED, bool SEG>
 ScanKernel scan_kernel_tg(int nwin, int dh) {
-    if (nwin == 1) return fz_scan_kernel<TG, 1, 0, FUSED>;
+    if (nwin == 1) return fz_scan_kernel<TG, 1, 0, FUSED, SEG>;
     switch (dh) {
-        case 2: return fz_scan_kernel<TG, 2, 2, FUSED>;
-        case 3: return fz_scan_kernel<TG, 2, 3, FUSED>;
-        case 4: return fz_scan_kernel<TG, 2, 4, FUSED>;
-        default: return fz_scan_kernel<TG, 2, 5, FUSED>;
+        case 2: return fz_scan_kernel<TG, 2, 2, FUSED, SEG>;
+        case 3: return fz_scan_kernel<TG, 2, 3, FUSED, SEG>;
+        case 4: return fz_scan_kernel<TG, 2, 4, FUSED, SEG>;
+        default: return fz_scan_kernel<TG, 2, 5, FUSED, SEG>;
     }
 }
 
-template <bool FUSED>
+template <bool FUSED, bool SEG>
 ScanKernel scan_kernel_f(int tg, int nwin, int dh) {
     switch (tg) {
-        case 1: return scan_kernel_tg<1, FUSED>(nwin, dh);
-        case 2: return scan_kernel_tg<2, FUSED>(nwin, dh);
-        case 3: return scan_kernel_tg<3, FUSED>(nwin, dh);
-        case 4: return scan_kernel_tg<4, FUSED>(nwin, dh);
-        case 6: return scan_kernel_tg<6, FUSED>(nwin, dh);
-        default: return scan_kernel_tg<8, FUSED>(nwin, dh);
+        case 1: return scan_kernel_tg<1, FUSED, SEG>(nwin, dh);
+        case 2: return scan_kernel_tg<2, FUSED, SEG>(nwin, dh);
+        case 3: return scan_kernel_tg<3, FUSED, SEG>(nwin, dh);
+        case 4: return scan_kernel_tg<4, FUSED, SEG>(nwin, dh);
+        case 6: return scan_kernel_tg<6, FUSED, SEG>(nwin, dh);
+        default: return scan_kernel_tg<8, FUSED, SEG>(nwin, dh);
     }
 }
 
-ScanKernel scan_kernel(int tg, int nwin, int dh, bool fused) {
-    return fused ? scan_kernel_f<true>(tg, nwin, dh) : scan_kernel_f<false>(tg, nwin, dh);
+// The segmented variants (file API) only exist where a segment changes the outcome: Levenshtein /
+// generic clamps.  Exact and substitutions-only windows fit exactly one chunk (the host assigns it).
+ScanKernel scan_kernel(int tg, int nwin, int dh, bool fused, bool seg) {
+    if (seg) return fused ? scan_kernel_f<true, true>(tg, nwin, dh) : scan_kernel_f<false, true>(tg, nwin, dh);
+    return fused ? scan_kernel_f<true, false>(tg, nwin, dh) : scan_kernel_f<false, false>(tg, nwin, dh);
 }
 
 int pick_tg(uint32_t nblk) {
@@ -285,7 +288,7 @@ uint32_t choose_launch_blocks(const uint8_t *p, const uint32_t *starts, uint32_t
         uint32_t hb[FZ_MAX_BLOCKS_PER_LAUNCH];
         uint32_t nb = 0;
         for (; nb < max_blocks && g0 + nb < G; ++nb) hb[nb] = hg.hash(p + starts[g0 + nb], L, kk);
-        for (int shift = 27; shift >= 2; shift -= 5) {
+        for (int shift = 32 - FZ_LUT_BITS; shift >= 2; shift -= FZ_LUT_BITS) {
             uint32_t slot_hash[FZ_LUT_SLOTS];
             bool used[FZ_LUT_SLOTS] = {false};
             uint32_t fit = 0;
@@ -412,7 +415,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
         fa.host_hdr = (direct && !verify_follows && g0 + nblk >= G) ? reinterpret_cast<uint64_t>(d.h_stage_dev) : 0;
         const int tg = pick_tg(nblk);
         for (int b = (int)nblk; b < tg; ++b) fa.H[b] = fa.H[0];      // compiled-in spare blocks: dropped by the range check
-        ScanKernel kern = scan_kernel(tg, nwin, dh, fa.fused != 0);
+        ScanKernel kern = scan_kernel(tg, nwin, dh, fa.fused != 0, sh.geom.seg_stride != 0);
         static const uint32_t extra_lds = []() { const char *e = getenv("FZ_EXTRA_LDS_KB"); return e ? (uint32_t)atoi(e) * 1024u : 0u; }();
         hipLaunchKernelGGL(kern, grid, dim3(FZ_FILTER_THREADS), scan_lds + extra_lds, d.stream, sh.d_buf, fa, ntiles, d.d_hits, recs,
                            counters);
