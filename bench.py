@@ -42,34 +42,140 @@ def parse():
     ap.add_argument("--mib", type=int, default=1024, help="MiB of sequence per GPU (default: 1 GiB = configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mib", type=int, default=1024)
+    ap.add_argument("--no-extras", action="store_true", help="skip the 4 GiB target and the other BASELINE configs (N = 1 extras)")
     return ap.parse_args()
 
 
-def cpu_baseline(seq, pattern, k, sample_mib):
-    """Time the reference's own native path (oracle/_ref) — or the C port — on a bounded sample."""
+def _cpu_fn():
+    """-> (callable(p, t, k) -> raw matches, kind): the reference's own natives (oracle/_ref) or the C port."""
     import oracle
-    n = min(len(seq), sample_mib << 20)
-    sample = seq[:n].tobytes()
-    p = pattern.tobytes()
-    kind = "port"
     try:
         from oracle import ref_glue, ref_loader
         if ref_loader.have_ref_natives():
-            fn = lambda: ref_glue.lev_ngrams_raw(p, sample, k)     # noqa: E731
-            fn_small = lambda: ref_glue.lev_ngrams_raw(p, sample[:1 << 20], k)   # noqa: E731
-            fn_small()
-            kind = "reference"
+            ref_glue.lev_ngrams_raw(b"ACGTACGTACGT", b"ACGTACGTACGTACGT" * 64, 1)
+            return ref_glue.lev_ngrams_raw, "reference"
     except Exception as exc:                                        # pragma: no cover
         print("cpu_baseline: reference natives unusable (%r); timing the C port instead" % (exc,), file=sys.stderr)
-        kind = "port"
-    if kind == "port":
-        fn = lambda: oracle.lev_ngrams_raw(p, sample, k)           # noqa: E731
-    t0 = time.perf_counter()
+    return oracle.lev_ngrams_raw, "port"
+
+
+_CPU_SHARD = {}
+
+
+def _cpu_worker(args):
+    lo, hi = args
+    fn, t, p, k = _CPU_SHARD["fn"], _CPU_SHARD["t"], _CPU_SHARD["p"], _CPU_SHARD["k"]
+    return [(s + lo, e + lo, d) for (s, e, d, *_r) in fn(p, t[lo:hi], k)]
+
+
+def cpu_baseline(seq, pattern, k, sample_mib, one_core_mib=256):
+    """The reference CPU path on the host cores of this box: (i) one core, as shipped
+    (the reference has no parallelism), best of 3 on a bounded sample; (ii) all cores: the sample cut into
+    os.cpu_count() contiguous shards overlapping by m - 1 + k bytes (the reference's own chunk overlap,
+    __init__.py:135-138), one process per shard (fork, before the HIP runtime exists), best of 3.
+    Must run BEFORE the GPU engine is created (fork)."""
+    import multiprocessing as mp
+    fn, kind = _cpu_fn()
+    p = pattern.tobytes()
+    n1 = min(len(seq), one_core_mib << 20)
+    t1 = seq[:n1].tobytes()
+    best1, res1 = None, None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        res1 = fn(p, t1, k)
+        dt = time.perf_counter() - t0
+        best1 = dt if best1 is None else min(best1, dt)
+    out = {"value": round(n1 / best1 / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": kind,
+           "sample": "first %d MiB of the same DNA workload, |p|=20 k=2, single thread (the reference has no "
+                     "parallelism), best of 3; %d raw matches in %.2f s" % (n1 >> 20, len(res1), best1)}
+    cores = os.cpu_count() or 1
+    n = min(len(seq), sample_mib << 20)
+    t = seq[:n].tobytes()
+    keep = len(p) - 1 + k
+    bounds = [(max(0, n * i // cores - keep), min(n, n * (i + 1) // cores)) for i in range(cores)]
+    _CPU_SHARD.update(fn=fn, t=t, p=p, k=k)
+    try:
+        ctx = mp.get_context("fork")
+        with ctx.Pool(cores) as pool:
+            pool.map(_cpu_worker, [(0, min(n, 1 << 16))] * cores)          # start the workers (untimed)
+            best, merged = None, None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                parts = pool.map(_cpu_worker, bounds, chunksize=1)
+                merged = [m for part in parts for m in part]
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+        out["all_cores"] = {"value": round(n / best / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": kind,
+                            "sample": "first %d MiB, %d processes over contiguous shards with %d-byte overlap, matches "
+                                      "merged; best of 3 (%.2f s, %d raw matches incl. overlap duplicates)"
+                                      % (n >> 20, cores, keep, best, len(merged))}
+    except Exception as exc:                                        # pragma: no cover
+        out["all_cores"] = {"error": repr(exc), "cores": cores}
+    finally:
+        _CPU_SHARD.clear()
+    return out
+
+
+def time_call(engine, fn, reps, warm_s=0.2):
+    """-> (ms per call at the C-ABI, mean scan kernel ms, mean verify kernel ms, last result)."""
+    t_end = time.perf_counter() + warm_s
     res = fn()
-    dt = time.perf_counter() - t0
-    return {"value": n / dt / 1e9, "unit": "GB/s", "cores": 1, "kind": kind,
-            "sample": "first %d MiB of the same DNA workload, |p|=20 k=2, 1 pass, single thread "
-                      "(the reference has no parallelism); %d raw matches in %.2f s" % (n >> 20, len(res), dt)}
+    while time.perf_counter() < t_end:
+        res = fn()
+    f_ms, v_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = fn()
+        f_, v_, _d = engine.kernel_ms()
+        f_ms.append(f_)
+        v_ms.append(v_)
+    dt = (time.perf_counter() - t0) / reps
+    return dt * 1e3, float(np.mean(f_ms)), float(np.mean(v_ms)), res
+
+
+def extra_blocks(engine, workloads, reps):
+    """Driver-visible numbers for the north-star target (4 GiB DNA) and the other BASELINE configs, measured
+    in the same run as the headline (N = 1 only): C-ABI GB/s, kernel ms, raw match counts."""
+    out = {}
+    pattern = workloads.dna(20, 1)
+    p = pattern.tobytes()
+    gib = 1 << 30
+    # north star: 4 GiB DNA, |p| = 20, k = 2
+    seq = np.empty(4 * gib, dtype=np.uint8)
+    for i in range(4):
+        seq[i * gib:(i + 1) * gib] = workloads.dna(gib, 20250925 + i)
+    workloads.plant_variants(seq, pattern, 4096, 7)
+    h = engine.upload(seq)
+    ms, f_ms, v_ms, res = time_call(engine, lambda: engine.lev_ngrams(h, p, 2, as_array=True), reps)
+    st = engine.stats()
+    h.release()
+    del seq
+    out["target_4gib"] = {"workload": "4 GiB iid random DNA bytes, |pattern|=20, max_l_dist=2, 4096 planted variants; resident",
+                          "ms_per_call": round(ms, 4), "GB_per_s": round(4 * gib / ms / 1e6, 1), "scan_kernel_ms": round(f_ms, 4),
+                          "roofline_frac": round(4 * gib / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          "raw_matches": int(len(res)), "ngram_hits": int(st["ngram_hits"])}
+    cfgs = {}
+    seq, pat, _ = workloads.cfg3(gib, 1024)
+    p2 = pat.tobytes()
+    h = engine.upload(seq)
+    ms, f_ms, v_ms, res = time_call(engine, lambda: engine.subs_ngrams(h, p2, 3, as_array=True), reps)
+    h.release()
+    cfgs["configs[2] ASCII m=32 subs<=3 (substitutions_only)"] = {
+        "ms_per_call": round(ms, 4), "GB_per_s": round(gib / ms / 1e6, 1), "scan_kernel_ms": round(f_ms, 4), "raw_matches": int(len(res))}
+    seq, pat, _ = workloads.cfg4(gib, 1024)
+    p3 = pat.tobytes()
+    h = engine.upload(seq)
+    ms, f_ms, v_ms, res = time_call(engine, lambda: engine.lev_ngrams(h, p3, 5, as_array=True), reps)
+    cfgs["configs[3a] UTF-8 m=64 max_l_dist=5 (levenshtein_ngram, wavefront verify)"] = {
+        "ms_per_call": round(ms, 4), "GB_per_s": round(gib / ms / 1e6, 1), "scan_kernel_ms": round(f_ms, 4),
+        "verify_kernel_ms": round(v_ms, 4), "raw_matches": int(len(res))}
+    ms, f_ms, v_ms, res = time_call(engine, lambda: engine.generic_ngrams(h, p3, 5, 2, 2, 5, as_array=True), max(20, reps // 4))
+    h.release()
+    cfgs["configs[3b] UTF-8 m=64 limits (5,2,2,5) (generic_search)"] = {
+        "ms_per_call": round(ms, 4), "GB_per_s": round(gib / ms / 1e6, 1), "scan_kernel_ms": round(f_ms, 4),
+        "automaton_kernel_ms": round(v_ms, 4), "raw_matches": int(len(res))}
+    out["configs"] = cfgs
+    return out
 
 
 def measured_traffic(shard_bytes):
@@ -127,6 +233,10 @@ def main():
         if rank > 0:
             seq[:10] = pattern[10:]
 
+    cpu = None
+    if world == 1 and not use_dist and not args.no_cpu_baseline and rank == 0:
+        cpu = cpu_baseline(seq, pattern, k, args.cpu_sample_mib)      # forks: before the HIP runtime exists
+
     engine = _native.Engine([local_rank])
     if not use_dist:
         handle = engine.upload(seq)
@@ -157,7 +267,7 @@ def main():
     first = step()
     while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
         again = step()
-        assert len(again) == len(first), "non-deterministic result"
+        assert np.array_equal(again, first), "non-deterministic result: two searches returned different streams"
     for _ in range(args.warmup):
         matches = step()
     filter_ms, verify_ms, device_ms = [], [], []
@@ -232,10 +342,11 @@ def main():
             "kernel_ms": {"filter": round(f_ms, 4), "verify": round(float(np.mean(verify_ms)), 4),
                           "device_total": round(float(np.mean(device_ms)), 4)},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(seq, pattern, k, args.cpu_sample_mib)
-        else:
-            out["cpu_baseline"] = None
+        out["cpu_baseline"] = cpu
+        if world == 1 and not use_dist and not args.no_extras:
+            handle.release()
+            del seq
+            out.update(extra_blocks(engine, workloads, max(20, args.steps // 2)))
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -1,5 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > gpurun_out/pytest1.log
-tail -4 gpurun_out/pytest1.log
-(for rep in 1 2; do for L in fuzzysearch_amd/libfzhip.so benchmarks/r1/libfzhip_r1.so; do FUZZYSEARCH_HIP_LIB=$PWD/$L timeout 300 python benchmarks/ab_scan.py 1024 300 --all; done; done) 2>&1 | tee gpurun_out/ab8.log | cut -c1-250
+timeout 2400 python -m pytest tests/test_gpu_full_size.py -m gpu -x -q 2>&1 | tail -15 > gpurun_out/pytest_full.log
+tail -6 gpurun_out/pytest_full.log
+nproc; free -g | head -2
+( time timeout 900 python bench.py ) > gpurun_out/bench_r02a.json 2> gpurun_out/bench_r02a.err; tail -3 gpurun_out/bench_r02a.err; cat gpurun_out/bench_r02a.json

@@ -1,0 +1,99 @@
+"""-m gpu: every BASELINE.json configuration at its STATED size (1 GiB per GPU), ordered raw streams
+bit-exact against the oracle on the full input, plus the 64-bit index path beyond 2^32 bytes.
+Workloads: tests/workloads.py; the oracle needs 5-10 s per configuration."""
+import numpy as np
+import pytest
+
+import oracle
+from tests import workloads
+
+pytestmark = pytest.mark.gpu
+
+GIB = 1 << 30
+
+
+def _rows(arr):
+    return [tuple(int(x) for x in r) for r in arr.tolist()]
+
+
+def test_config1_dna_1gib_levenshtein(engine):
+    """configs[1]: 1 GiB random DNA, |p| = 20, max_l_dist = 2 (the headline workload), raw stream and public API."""
+    import fuzzysearch_amd as fa
+    seq, pat, planted = workloads.cfg2(GIB, 1024)
+    p = pat.tobytes()
+    h = engine.upload(seq)
+    got = _rows(engine.lev_ngrams(h, p, 2, as_array=True))
+    st = engine.stats()
+    h.release()
+    exp = oracle.lev_ngrams_raw(p, seq.tobytes(), 2)
+    assert got == exp
+    assert len(planted) >= 1000 and len(exp) >= len(planted)
+    assert st["bytes_scanned"] == GIB and st["ngram_hits"] > 700000
+    res = fa.resident(seq)
+    api = fa.find_near_matches(p, res, max_l_dist=2)
+    res.release()
+    assert [(m.start, m.end, m.dist) for m in api] == oracle.consolidate(exp)
+    assert all(bytes(m.matched) == seq[m.start:m.end].tobytes() for m in api[:50])
+
+
+def test_config2_ascii_1gib_substitutions(engine):
+    """configs[2]: 1 GiB over 65 ASCII symbols, |p| = 32, <= 3 substitutions (bytes input)."""
+    seq, pat, planted = workloads.cfg3(GIB, 1024)
+    p = pat.tobytes()
+    h = engine.upload(seq)
+    got = _rows(engine.subs_ngrams(h, p, 3, as_array=True))
+    h.release()
+    exp = oracle.subs_ngrams_raw(p, seq.tobytes(), 3)
+    assert got == exp
+    assert len(exp) >= len(planted) >= 1000
+
+
+def test_config3_utf8_1gib_wide_band_and_generic(engine):
+    """configs[3]: 1 GiB UTF-8 text as bytes, |p| = 64: (a) max_l_dist = 5 -> Levenshtein n-grams with the
+    lane-per-cell verification, (b) limits (5, 2, 2, 5) -> generic search (SURVEY.md trap 4)."""
+    seq, pat, planted = workloads.cfg4(GIB, 1024)
+    p, t = pat.tobytes(), seq.tobytes()
+    h = engine.upload(seq)
+    got_a = _rows(engine.lev_ngrams(h, p, 5, as_array=True))
+    got_b = _rows(engine.generic_ngrams(h, p, 5, 2, 2, 5, as_array=True))
+    h.release()
+    exp_a = oracle.lev_ngrams_raw(p, t, 5)
+    assert got_a == exp_a
+    assert len(exp_a) >= len(planted) >= 1000
+    exp_b = oracle.generic_ngrams_raw(p, t, 5, 2, 2, 5)
+    assert got_b == exp_b
+    assert len(exp_b) > 100000
+
+
+def test_beyond_4gib_indices(engine):
+    """64-bit index paths: 4.5 GiB = nine copies of one 512 MiB block, variants planted beyond 2^32 and
+    across 2^32.  Size-independent property: the matches inside copy i are those of copy 0 shifted by
+    i * 512 MiB (the oracle only has to run on one block and on the planted tail)."""
+    block = 512 << 20
+    copies = 9
+    n = block * copies
+    pattern = workloads.dna(20, 1)
+    p = pattern.tobytes()
+    base = workloads.dna(block, 900)
+    seq = np.tile(base, copies)
+    tail0 = 8 * block + (block >> 1)                     # 4.25 GiB: the second half of the last copy
+    assert tail0 > (1 << 32)
+    planted = workloads.plant_variants(seq[tail0:], pattern, 256, 17)
+    seq[(1 << 32) - 10:(1 << 32) + 10] = pattern         # a match straddling 2^32 (= start of copy 8)
+    h = engine.upload(seq)
+    got = _rows(engine.lev_ngrams(h, p, 2, as_array=True))
+    h.release()
+    keys = [(g, s) for (s, e, d, g) in got]
+    assert keys == sorted(keys)                          # block-major, ascending: reference order
+    margin = 64
+    exp0 = [r for r in oracle.lev_ngrams_raw(p, base.tobytes(), 2) if margin <= r[0] and r[1] <= block - margin]
+    assert len(exp0) > 0
+    for i in range(8):                                   # copies 0..7 are untouched away from their seams
+        lo, hi = i * block, (i + 1) * block
+        inside = sorted((s - lo, e - lo, d, g) for (s, e, d, g) in got if lo + margin <= s and e <= hi - margin)
+        assert inside == sorted(exp0), i
+    exp_tail = oracle.lev_ngrams_raw(p, seq[tail0:].tobytes(), 2)
+    got_tail = [(s - tail0, e - tail0, d, g) for (s, e, d, g) in got if s >= tail0 + margin]
+    assert got_tail == [r for r in exp_tail if r[0] >= margin]
+    assert len(planted) >= 200 and len(got_tail) >= len(planted)
+    assert any(s == (1 << 32) - 10 and e == (1 << 32) + 10 and d == 0 for (s, e, d, g) in got)
