@@ -1,6 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 2400 python -m pytest tests/test_gpu_full_size.py -m gpu -x -q 2>&1 | tail -15 > gpurun_out/pytest_full.log
-tail -6 gpurun_out/pytest_full.log
-nproc; free -g | head -2
-( time timeout 900 python bench.py ) > gpurun_out/bench_r02a.json 2> gpurun_out/bench_r02a.err; tail -3 gpurun_out/bench_r02a.err; cat gpurun_out/bench_r02a.json
+timeout 2400 python -m pytest tests/test_gpu_file_api.py tests/test_gpu_golden.py tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -25 > gpurun_out/pytest_file.log
+tail -25 gpurun_out/pytest_file.log
+timeout 600 python benchmarks/file_api.py 1024 2>&1 | tee gpurun_out/file_api.log | tail -20

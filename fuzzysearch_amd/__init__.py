@@ -21,6 +21,7 @@ from .generic_search import GenericSearch
 from .levenshtein import LevenshteinSearch
 from .search_exact import ExactSearch
 from .substitutions_only import SubstitutionsOnlySearch
+from . import _file_stream
 
 __version__ = '0.1.0'
 
@@ -73,6 +74,12 @@ def find_near_matches_in_file(subsequence, sequence_file,
     Reproduces the reference's chunk geometry exactly (``_chunk_size`` windows overlapping by
     ``len(subsequence) - 1 + extra`` items, every chunk searched as an independent sequence, one
     global consolidation at the end) because the result depends on it.
+
+    Regular files, in-memory binary files and text files go through the streaming pipeline
+    (fz_stream): many chunks cross PCIe as one batch from pinned, double-buffered memory and are
+    searched by one launch with per-chunk clamps.  Everything else (unseekable streams, patterns on the
+    reference's linear-programming routes, chunks shorter than twice the overlap) is searched chunk by
+    chunk, exactly as the reference does it.
     """
     search_params = LevenshteinSearchParams(max_substitutions, max_insertions,
                                             max_deletions, max_l_dist)
@@ -81,6 +88,12 @@ def find_near_matches_in_file(subsequence, sequence_file,
         raise ValueError('subsequence must not be empty')
     binary = 'b' in getattr(sequence_file, 'mode', '') or isinstance(sequence_file, io.RawIOBase)
     keep = len(subsequence) - 1 + search_class.extra_items_for_chunked_search(subsequence, search_params)
+    plan = _file_stream.plan(search_class, subsequence, search_params, _chunk_size, keep, binary, sequence_file)
+    if plan is not None:
+        try:
+            return _file_stream.run(plan, search_class, subsequence, sequence_file)
+        except _file_stream.Unsupported:
+            pass                                   # nothing has been read yet: take the per-chunk path
     if binary:
         matches = _search_binary_file(subsequence, sequence_file, search_params, search_class, _chunk_size, keep)
     else:

@@ -20,6 +20,7 @@ EXPORTED_SYMBOLS = (
     "fz_seq_upload", "fz_seq_upload_shard", "fz_seq_len", "fz_seq_release",
     "fz_search_exact", "fz_lev_ngrams", "fz_lev_ngrams_begin", "fz_lev_ngrams_end", "fz_subs_ngrams", "fz_generic_ngrams",
     "fz_lev_lp", "fz_subs_lp", "fz_generic_lp",
+    "fz_stream_open", "fz_stream_buffer", "fz_stream_submit", "fz_stream_read_fd", "fz_stream_finish", "fz_stream_close",
     "fz_consolidate", "fz_group_best", "fz_merge_ranks", "fz_wire_pack", "fz_wire_merge", "fz_debug_launch_plan", "fz_stats", "fz_free",
 )
 
@@ -95,6 +96,18 @@ def load_library():
         L.fz_subs_lp.argtypes = [vp, vp, u8p, u32, u32, mpp, u64p]
         L.fz_generic_lp.restype = ci
         L.fz_generic_lp.argtypes = [vp, vp, u8p, u32, u32, u32, u32, u32, mpp, u64p]
+        L.fz_stream_open.restype = ci
+        L.fz_stream_open.argtypes = [vp, u32, u8p, u32, u32, u32, u32, u32, u64, u32, u32, u64, ctypes.POINTER(vp)]
+        L.fz_stream_buffer.restype = ci
+        L.fz_stream_buffer.argtypes = [vp, ctypes.POINTER(vp), u64p]
+        L.fz_stream_submit.restype = ci
+        L.fz_stream_submit.argtypes = [vp, u64, ci]
+        L.fz_stream_read_fd.restype = ci
+        L.fz_stream_read_fd.argtypes = [vp, ci, ctypes.c_int64, ci, u64p]
+        L.fz_stream_finish.restype = ci
+        L.fz_stream_finish.argtypes = [vp, mpp, ctypes.POINTER(ctypes.POINTER(u32)), u64p]
+        L.fz_stream_close.restype = None
+        L.fz_stream_close.argtypes = [vp]
         L.fz_consolidate.restype = ci
         L.fz_consolidate.argtypes = [ctypes.POINTER(FzMatch), u64, mpp, u64p]
         L.fz_group_best.restype = ci
@@ -165,11 +178,17 @@ def _mv_offset(mv, obj):
 
 
 def matches_to_array(raw):
+    """(start, end, dist[, block]) rows, or an fz_match structured array -> (address-able buffer, n)."""
+    import numpy as np
+    if isinstance(raw, np.ndarray) and raw.dtype == _match_dtype():
+        arr = np.ascontiguousarray(raw)
+        return arr, len(arr)
     n = len(raw)
-    arr = (FzMatch * max(1, n))()
-    for i, r in enumerate(raw):
-        arr[i].start, arr[i].end, arr[i].dist = r[0], r[1], r[2]
-        arr[i].block = r[3] if len(r) > 3 else -1
+    arr = np.empty(n, dtype=_match_dtype())
+    if n:
+        rows = np.asarray([tuple(r[:3]) for r in raw], dtype=np.int64).reshape(n, 3)
+        arr["start"], arr["end"], arr["dist"] = rows[:, 0], rows[:, 1], rows[:, 2]
+        arr["block"] = [r[3] if len(r) > 3 else -1 for r in raw]
     return arr, n
 
 
@@ -198,25 +217,97 @@ def _take_matches(L, ptr, n):
     return _take_matches_array(L, ptr, n).tolist()
 
 
-def consolidate(raw):
-    """consolidate_overlapping_matches (common.py:185-189) on (start, end, dist[, block]) tuples."""
+def _array_call(fn, raw):
     L = load_library()
     arr, n = matches_to_array(raw)
     ptr = ctypes.POINTER(FzMatch)()
     cnt = ctypes.c_uint64(0)
-    _check(L.fz_consolidate(arr, n, ctypes.byref(ptr), ctypes.byref(cnt)))
-    return _take_matches(L, ptr, cnt.value)
+    _check(fn(L)(ctypes.cast(arr.ctypes.data, ctypes.POINTER(FzMatch)), n, ctypes.byref(ptr), ctypes.byref(cnt)))
+    return _take_matches_array(L, ptr, cnt.value)
+
+
+def consolidate_array(raw):
+    """consolidate_overlapping_matches (common.py:185-189) on an fz_match array (or rows) -> fz_match array;
+    no per-record Python work."""
+    return _array_call(lambda L: L.fz_consolidate, raw)
+
+
+def group_best_array(raw):
+    """[get_best_match_in_group(g) for g in group_matches(ms)] in group-list order
+    (substitutions_only.py:279-282) on an fz_match array (or rows) -> fz_match array."""
+    return _array_call(lambda L: L.fz_group_best, raw)
+
+
+def consolidate(raw):
+    """consolidate_overlapping_matches on (start, end, dist[, block]) tuples -> list of tuples."""
+    return consolidate_array(raw).tolist()
 
 
 def group_best(raw):
-    """[get_best_match_in_group(g) for g in group_matches(ms)] in group-list order
-    (substitutions_only.py:279-282)."""
-    L = load_library()
-    arr, n = matches_to_array(raw)
-    ptr = ctypes.POINTER(FzMatch)()
-    cnt = ctypes.c_uint64(0)
-    _check(L.fz_group_best(arr, n, ctypes.byref(ptr), ctypes.byref(cnt)))
-    return _take_matches(L, ptr, cnt.value)
+    return group_best_array(raw).tolist()
+
+
+class FileStream(object):
+    """fz_stream: the chunks of a file searched in batches (include/fzhip.h)."""
+
+    def __init__(self, engine, mode, pattern, limits, k, seg_stride, seg_pre, seg_post, batch_bytes):
+        self.engine = engine
+        self._lib = engine._lib
+        self._h = None
+        paddr, m, keep = _buffer_address(pattern)
+        h = ctypes.c_void_p()
+        ms, mi, md = limits
+        with engine._lock:
+            _check(self._lib.fz_stream_open(engine._h, mode, paddr, m, ms, mi, md, k, seg_stride, seg_pre, seg_post,
+                                            batch_bytes, ctypes.byref(h)))
+        del keep
+        self._h = h
+
+    def buffer(self):
+        """-> writable memoryview of the free part of the current pinned staging buffer."""
+        ptr = ctypes.c_void_p()
+        cap = ctypes.c_uint64(0)
+        _check(self._lib.fz_stream_buffer(self._h, ctypes.byref(ptr), ctypes.byref(cap)))
+        if cap.value == 0:
+            return memoryview(bytearray(0))
+        return memoryview((ctypes.c_char * cap.value).from_address(ptr.value)).cast('B')
+
+    def submit(self, nbytes, last=False):
+        with self.engine._lock:
+            _check(self._lib.fz_stream_submit(self._h, nbytes, 1 if last else 0))
+
+    def read_fd(self, fd, offset, threads=0):
+        total = ctypes.c_uint64(0)
+        with self.engine._lock:
+            _check(self._lib.fz_stream_read_fd(self._h, fd, offset, threads, ctypes.byref(total)))
+        return total.value
+
+    def finish(self):
+        """-> (fz_match structured array in the reference's order, uint32 chunk number per record)."""
+        import numpy as np
+        ptr = ctypes.POINTER(FzMatch)()
+        seg = ctypes.POINTER(ctypes.c_uint32)()
+        cnt = ctypes.c_uint64(0)
+        with self.engine._lock:
+            _check(self._lib.fz_stream_finish(self._h, ctypes.byref(ptr), ctypes.byref(seg), ctypes.byref(cnt)))
+        n = cnt.value
+        segs = np.empty(n, dtype=np.uint32)
+        if n:
+            ctypes.memmove(segs.ctypes.data, seg, 4 * n)
+        self._lib.fz_free(seg)
+        return _take_matches_array(self._lib, ptr, n), segs
+
+    def close(self):
+        if self._h is not None and self.engine._h is not None:
+            with self.engine._lock:
+                self._lib.fz_stream_close(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class ResidentSequence(object):
@@ -259,7 +350,8 @@ class Engine(object):
         self._h = h
         self.devices = list(devices) if devices else [0]
         # a fz_ctx is not internally locked and ctypes drops the GIL during calls: serialise per engine
-        self._lock = threading.Lock()
+        # re-entrant: the cyclic GC may finalize a ResidentSequence (-> release()) on a thread that already holds it
+        self._lock = threading.RLock()
         self._st = FzStats()
         self._st_ref = ctypes.byref(self._st)
 

@@ -17,7 +17,7 @@ import attr
 from . import _native
 
 __all__ = [
-    'Match', 'LevenshteinSearchParams', 'FuzzySearchBase',
+    'Match', 'RawMatches', 'LevenshteinSearchParams', 'FuzzySearchBase',
     'group_matches', 'get_best_match_in_group', 'consolidate_overlapping_matches',
     'count_differences_with_maximum',
 ]
@@ -92,7 +92,53 @@ def count_differences_with_maximum(sequence1, sequence2, max_differences):
     return n_different
 
 
-def _as_tuples(matches):
+class RawMatches(object):
+    """A raw match stream as it left the C-ABI: an fz_match structured array (start, end, dist, block) plus
+    the sequence the indices refer to.  Behaves like a read-only list of Match objects, but the objects —
+    and their ``matched`` slices — are only built when somebody looks (common.py:15-32 builds one attrs
+    object per raw match; at 2e5 raw matches that costs more than the search).  Consolidation works on
+    the array and materialises the survivors only."""
+    __slots__ = ('array', 'sequence', 'offset', '_list')
+
+    def __init__(self, array, sequence, offset=0):
+        self.array = array
+        self.sequence = sequence
+        self.offset = offset                # added to start / end (file API: chunk offsets are already global -> 0)
+        self._list = None
+
+    def _make(self, rows):
+        seq, off = self.sequence, self.offset
+        return [Match(s + off, e + off, d, matched=seq[s:e]) for (s, e, d, _g) in rows]
+
+    def materialize(self):
+        if self._list is None:
+            self._list = self._make(self.array.tolist())
+        return self._list
+
+    def subset(self, array):
+        """Match objects for another fz_match array over the same sequence (e.g. the consolidated one)."""
+        return self._make(array.tolist())
+
+    def __len__(self):
+        return len(self.array)
+
+    def __iter__(self):
+        return iter(self.materialize())
+
+    def __getitem__(self, item):
+        return self.materialize()[item]
+
+    def __eq__(self, other):
+        return self.materialize() == (other.materialize() if isinstance(other, RawMatches) else other)
+
+    def __ne__(self, other):
+        return not self == other
+
+    def __repr__(self):
+        return 'RawMatches(%r)' % (self.materialize(),)
+
+
+def _rows_of(matches):
     return [(m.start, m.end, m.dist) for m in matches]
 
 
@@ -123,28 +169,33 @@ def get_best_match_in_group(group):
     return min(group, key=lambda m: (m.dist, -(m.end - m.start), m.start))
 
 
-def consolidate_overlapping_matches(matches):
-    """One best match per group of overlapping matches, sorted (common.py:185-189)."""
+def _reduce(matches, array_fn):
+    """Run a C-side reduction (consolidation / best of groups) and hand back Match objects.  A RawMatches
+    input never materialises the raw stream: only the survivors become objects."""
+    if isinstance(matches, RawMatches):
+        if len(matches) == 0:
+            return []
+        if matches.offset:
+            raise ValueError('offset streams must be rebased first')
+        return matches.subset(array_fn(matches.array))
     matches = list(matches)
     if not matches:
         return []
     by_key = {}
     for m in matches:
         by_key.setdefault((m.start, m.end, m.dist), m)
-    best = _native.consolidate(_as_tuples(matches))
+    best = array_fn(_rows_of(matches)).tolist()
     return [by_key[(s, e, d)] for (s, e, d, _b) in best]
+
+
+def consolidate_overlapping_matches(matches):
+    """One best match per group of overlapping matches, sorted (common.py:185-189)."""
+    return _reduce(matches, _native.consolidate_array)
 
 
 def best_of_groups_in_discovery_order(matches):
     """[get_best_match_in_group(g) for g in group_matches(matches)] (substitutions_only.py:279-282)."""
-    matches = list(matches)
-    if not matches:
-        return []
-    by_key = {}
-    for m in matches:
-        by_key.setdefault((m.start, m.end, m.dist), m)
-    best = _native.group_best(_as_tuples(matches))
-    return [by_key[(s, e, d)] for (s, e, d, _b) in best]
+    return _reduce(matches, _native.group_best_array)
 
 
 class FuzzySearchBase(object):
@@ -156,6 +207,8 @@ class FuzzySearchBase(object):
 
     @classmethod
     def consolidate_matches(cls, matches):
+        if isinstance(matches, RawMatches):
+            return matches.materialize()
         try:
             len(matches)
         except TypeError:

@@ -26,6 +26,8 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
+#include <unistd.h>
 #include <vector>
 
 #include "../../include/fzhip.h"
@@ -130,6 +132,7 @@ struct fz_ctx {
     uint64_t view_n = 0;
     const FzGenRec *gen_view = nullptr;          // same for the per-hit automaton's records (pinned h_big)
     uint64_t gen_view_n = 0;
+    struct fz_stream *stream_inflight = nullptr;  // a file stream whose batch is on the device (other searches are refused)
     // fz_lev_ngrams_begin .. _end: the one search that may be in flight
     struct Pending {
         bool active = false;
@@ -691,6 +694,7 @@ int alloc_out(uint64_t n, size_t elem, void **out) {
 int validate(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m) {
     if (!ctx || !seq || seq->ctx != ctx) return fail(FZ_EINVAL, "bad ctx/seq handle");
     if (ctx->pending.active) return fail(FZ_EINVAL, "a search started with fz_lev_ngrams_begin is still in flight");
+    if (ctx->stream_inflight) return fail(FZ_EINVAL, "a file stream of this context has a batch in flight (finish or close it first)");
     if (!p || m == 0) return fail(FZ_EINVAL, "subsequence must not be empty");
     if (m > FZ_MAX_M) return fail(FZ_EUNSUPPORTED, "subsequence longer than %d bytes", FZ_MAX_M);
     return FZ_OK;
@@ -1438,6 +1442,358 @@ extern "C" int fz_subs_lp(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m
     ctx->stats.raw_matches = recs.size();
     return FZ_OK;
 }
+
+// ---- (f)2 / a12: find_near_matches_in_file as a pipeline -------------------------------------------
+// The reference reads a file in chunks and searches every chunk as an independent sequence
+// (__init__.py:129-200).  Here the file crosses PCIe in large batches (many chunks each) from pinned,
+// double-buffered staging memory; the chunks of a batch are SEGMENTS of one resident buffer with their
+// own clamps (FzGeom), searched by one launch, while the host already fills the next staging buffer.
+struct fz_stream {
+    fz_ctx *ctx = nullptr;
+    uint32_t mode = 0, m = 0, k = 0, max_subs = 0, max_ins = 0, max_dels = 0;
+    std::vector<uint8_t> pat;
+    uint64_t S = 0;                      // segment stride
+    uint32_t pre = 0, post = 0;          // segment j = [j*S - pre, (j+1)*S + post) clipped to the file
+    uint64_t cap = 0;                    // bytes a staging buffer holds
+    uint8_t *h_buf[2] = {nullptr, nullptr};   // pinned staging
+    int cur = 0;                         // staging buffer being filled
+    uint64_t stage_off = 0;              // file offset of h_buf[cur][0]
+    uint64_t stage_len = 0;              // valid bytes in h_buf[cur]
+    uint64_t next_seg = 0;               // first segment not launched yet
+    bool eof = false;
+    fz_seq *seq = nullptr;               // one transient shard over the device batch buffer
+    bool inflight = false;
+    uint64_t fl_j0 = 0, fl_j1 = 0;       // segments of the batch in flight
+    Search q;
+    std::vector<fz_match> out;
+    std::vector<uint32_t> out_seg;
+    uint64_t bytes_total = 0;
+};
+
+namespace {
+
+uint64_t stream_segments_at_eof(const fz_stream *st, uint64_t F) {
+    if (F == 0) return 0;
+    if (F <= st->post) return 1;
+    return (F - st->post - 1) / st->S + 1;                 // segment j >= 1 exists iff j*S + post < F
+}
+
+// segment that owns the window [i0, i0 + m) of an exact / substitutions-only match: such windows fit
+// exactly one chunk (the overlap is m - 1 items)
+uint64_t stream_window_segment(const fz_stream *st, uint64_t i0) {
+    return st->post ? i0 / st->S : (i0 + st->m - 1) / st->S;
+}
+
+int stream_build_search(fz_stream *st) {
+    Search &q = st->q;
+    q = Search();
+    q.mode = st->mode; q.m = st->m; q.k = st->k; q.p = st->pat.data();
+    q.max_subs = st->max_subs; q.max_ins = st->max_ins; q.max_dels = st->max_dels;
+    if (st->mode == FZ_MODE_EXACT) {
+        q.plan.L = st->m;
+        q.plan.s = {0};
+        return FZ_OK;
+    }
+    const uint32_t L = st->m / (st->k + 1);
+    if (L == 0) return fail(FZ_EINVAL, "the subsequence length must be greater than the distance limit");
+    q.plan.L = L;
+    for (uint32_t s = 0; s + L <= st->m; s += L) q.plan.s.push_back(s);
+    if (q.plan.s.size() > 255) return fail(FZ_EUNSUPPORTED, "more than 255 n-gram blocks");
+    return FZ_OK;
+}
+
+int stream_collect(fz_stream *st) {
+    if (!st->inflight) return FZ_OK;
+    fz_ctx *ctx = st->ctx;
+    st->inflight = false;
+    ctx->stream_inflight = nullptr;
+    const uint32_t L = st->q.plan.L;
+    fz_match *mo = nullptr;
+    uint32_t *so = nullptr;
+    uint64_t cnt = 0;
+    int rc = FZ_OK;
+    if (st->mode == FZ_MODE_GENERIC) {
+        std::vector<FzGenRec> recs;
+        rc = run_generic(ctx, st->seq, st->q, recs);
+        if (rc) return rc;
+        rc = emit_generic(ctx, st->seq, recs, L, st->k, &mo, &cnt, &so);
+        if (rc) return rc;
+    } else {
+        std::vector<FzRec> recs;
+        std::vector<uint64_t> hits;
+        const bool with_verify = st->mode != FZ_MODE_EXACT;
+        rc = search_collect(ctx, st->seq, st->q, with_verify, recs, hits);
+        if (rc) return rc;
+        if (st->mode == FZ_MODE_LEV) {
+            const FzRec *r = ctx->view ? ctx->view : recs.data();
+            const size_t nr = ctx->view ? (size_t)ctx->view_n : recs.size();
+            rc = emit_matches_seg(r, nr, L, &mo, &cnt, &so);
+            if (rc) return rc;
+        } else {
+            // exact / substitutions-only: no clamp depends on the chunk; the chunk of a window follows from
+            // its position, and this batch keeps the windows of its own chunks
+            std::vector<fz_match> tmp;
+            if (st->mode == FZ_MODE_EXACT) {
+                std::sort(hits.begin(), hits.end());
+                tmp.resize(hits.size());
+                for (size_t i = 0; i < hits.size(); ++i) {
+                    const int64_t idx = (int64_t)fz_hit_index(hits[i]);
+                    tmp[i] = fz_match{idx, idx + (int64_t)st->m, 0, 0};
+                }
+            } else {
+                fz_match *em = nullptr;
+                uint64_t en = 0;
+                rc = emit_matches(ctx, recs, L, &em, &en);
+                if (rc) return rc;
+                tmp.assign(em, em + en);
+                free(em);
+            }
+            std::vector<std::pair<uint64_t, uint32_t>> order;      // (segment, position in tmp)
+            for (size_t i = 0; i < tmp.size(); ++i) {
+                const uint64_t j = stream_window_segment(st, (uint64_t)tmp[i].start);
+                if (j >= st->fl_j0 && j < st->fl_j1) order.emplace_back(j, (uint32_t)i);
+            }
+            std::stable_sort(order.begin(), order.end(), [](const std::pair<uint64_t, uint32_t> &x, const std::pair<uint64_t, uint32_t> &y) { return x.first < y.first; });
+            for (const auto &o : order) { st->out.push_back(tmp[o.second]); st->out_seg.push_back((uint32_t)o.first); }
+            return FZ_OK;
+        }
+    }
+    st->out.insert(st->out.end(), mo, mo + cnt);
+    st->out_seg.insert(st->out_seg.end(), so, so + cnt);
+    free(mo);
+    free(so);
+    return FZ_OK;
+}
+
+// Upload the staged bytes the segments [j0, j1) need and launch their search (asynchronous).
+int stream_launch(fz_stream *st, uint64_t j0, uint64_t j1, uint64_t data_hi) {
+    fz_ctx *ctx = st->ctx;
+    DevState &d = ctx->devs[0];
+    Shard &sh = st->seq->shards[0];
+    HIP_TRY(hipSetDevice(d.device));
+    const uint64_t len = data_hi - st->stage_off;
+    FzGeom g{};
+    g.n = data_hi;
+    g.buf_off = st->stage_off;
+    g.buf_len = len;
+    g.own_lo = 0;
+    g.own_hi = data_hi;
+    const bool segmented = st->mode == FZ_MODE_LEV || st->mode == FZ_MODE_GENERIC;
+    if (segmented) {
+        g.seg_stride = st->S; g.seg_org = 0; g.seg_pre = st->pre; g.seg_post = st->post;
+        g.seg_j0 = j0; g.seg_j1 = j1;
+    }
+    sh.geom = g;
+    st->seq->n = data_hi;
+    if (len) HIP_TRY(hipMemcpyAsync(sh.d_buf, st->h_buf[st->cur], len, hipMemcpyHostToDevice, d.stream));
+    const uint64_t tiles = (len + FZ_TILE_BYTES - 1) / FZ_TILE_BYTES;
+    const uint64_t body = std::max<uint64_t>(1, tiles) * FZ_TILE_BYTES;
+    HIP_TRY(hipMemsetAsync(sh.d_buf + len, 0, body + FZ_PAD_BACK - len, d.stream));
+    st->fl_j0 = j0;
+    st->fl_j1 = j1;
+    int rc = ensure_hits(d, std::max<uint64_t>(1u << 20, len / 64));
+    if (rc) return rc;
+    if (st->mode != FZ_MODE_GENERIC) {
+        memset(&ctx->stats, 0, sizeof ctx->stats);
+        ctx->stats.n_devices = 1;
+        rc = search_enqueue(ctx, st->seq, st->q, st->mode != FZ_MODE_EXACT);
+        if (rc) return rc;
+    }
+    st->inflight = true;
+    ctx->stream_inflight = st;
+    return FZ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fz_stream_open(fz_ctx *ctx, uint32_t mode, const uint8_t *p, uint32_t m, uint32_t max_subs, uint32_t max_ins,
+                   uint32_t max_dels, uint32_t k, uint64_t seg_stride, uint32_t seg_pre, uint32_t seg_post,
+                   uint64_t batch_bytes, fz_stream **out) {
+    if (!out) return fail(FZ_EINVAL, "null argument");
+    *out = nullptr;
+    if (!ctx || ctx->devs.empty()) return fail(FZ_EINVAL, "bad ctx handle");
+    if (ctx->devs.size() != 1) return fail(FZ_EUNSUPPORTED, "file streams run on a single-device context");
+    if (ctx->pending.active || ctx->stream_inflight) return fail(FZ_EINVAL, "another search of this context is in flight");
+    if (!p || m == 0) return fail(FZ_EINVAL, "subsequence must not be empty");
+    if (m > FZ_MAX_M) return fail(FZ_EUNSUPPORTED, "subsequence longer than %d bytes", FZ_MAX_M);
+    if (k > FZ_MAX_K) return fail(FZ_EUNSUPPORTED, "distance limit above %d is not supported", FZ_MAX_K);
+    if (mode > FZ_MODE_GENERIC) return fail(FZ_EINVAL, "bad mode");
+    if (seg_stride == 0 || (seg_pre && seg_post)) return fail(FZ_EINVAL, "bad segment geometry");
+    // a position may lie in at most two segments, and a chunk must hold a whole pattern window with its reach
+    if ((uint64_t)seg_pre + seg_post > seg_stride / 2 || (uint64_t)m + 2ull * k + 2 > seg_stride)
+        return fail(FZ_EUNSUPPORTED, "chunk too small for this pattern (use the per-chunk path)");
+    fz_stream *st = new (std::nothrow) fz_stream();
+    if (!st) return fail(FZ_ENOMEM, "out of memory");
+    st->ctx = ctx;
+    st->mode = mode; st->m = m; st->k = k;
+    st->max_subs = std::min(max_subs, 255u); st->max_ins = std::min(max_ins, 255u); st->max_dels = std::min(max_dels, 255u);
+    st->pat.assign(p, p + m);
+    st->S = seg_stride; st->pre = seg_pre; st->post = seg_post;
+    int rc = stream_build_search(st);
+    if (rc) { delete st; return rc; }
+    const uint64_t ext = (uint64_t)seg_pre + seg_post;
+    st->cap = std::max<uint64_t>(batch_bytes, 4 * (seg_stride + ext)) + seg_stride + ext;
+    DevState &d = ctx->devs[0];
+    auto init = [&]() -> int {
+        HIP_TRY(hipSetDevice(d.device));
+        for (int i = 0; i < 2; ++i) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&st->h_buf[i]), st->cap, hipHostMallocDefault));
+        st->seq = new (std::nothrow) fz_seq();
+        if (!st->seq) return fail(FZ_ENOMEM, "out of memory");
+        st->seq->ctx = ctx;
+        st->seq->shards.emplace_back();
+        Shard &sh = st->seq->shards[0];
+        sh.dev = 0;
+        sh.alloc_bytes = FZ_PAD_FRONT + ((st->cap + FZ_TILE_BYTES - 1) / FZ_TILE_BYTES + 1) * FZ_TILE_BYTES + FZ_PAD_BACK;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sh.d_alloc), sh.alloc_bytes));
+        sh.d_buf = sh.d_alloc + FZ_PAD_FRONT;
+        HIP_TRY(hipMemsetAsync(sh.d_alloc, 0, FZ_PAD_FRONT, d.stream));
+        return FZ_OK;
+    };
+    rc = init();
+    if (rc) { fz_stream_close(st); return rc; }
+    *out = st;
+    return FZ_OK;
+}
+
+int fz_stream_buffer(fz_stream *st, uint8_t **host, uint64_t *capacity) {
+    if (!st || !host || !capacity) return fail(FZ_EINVAL, "null argument");
+    *host = st->h_buf[st->cur] + st->stage_len;
+    *capacity = st->eof ? 0 : st->cap - st->stage_len;
+    return FZ_OK;
+}
+
+int fz_stream_submit(fz_stream *st, uint64_t nbytes, int last) {
+    if (!st) return fail(FZ_EINVAL, "null argument");
+    if (st->eof) return fail(FZ_EINVAL, "the stream has already seen its last bytes");
+    if (nbytes > st->cap - st->stage_len) return fail(FZ_EINVAL, "more bytes than the staging buffer holds");
+    st->stage_len += nbytes;
+    st->bytes_total += nbytes;
+    if (last) st->eof = true;
+    const uint64_t data_end = st->stage_off + st->stage_len;
+    const uint64_t ext_lo = st->pre, ext_hi = st->post;
+    for (;;) {
+        uint64_t j1;
+        if (st->eof) j1 = stream_segments_at_eof(st, data_end);
+        else j1 = data_end >= ext_hi + st->S ? (data_end - ext_hi) / st->S : 0;      // (j + 1) * S + post <= data_end
+        if (j1 <= st->next_seg) {
+            if (st->eof || st->stage_len < st->cap) break;
+            return fail(FZ_EUNSUPPORTED, "staging buffer smaller than one chunk");
+        }
+        int rc = stream_collect(st);                        // the previous batch (its staging buffer becomes free)
+        if (rc) return rc;
+        const uint64_t data_hi = st->eof ? data_end : j1 * st->S + ext_hi;
+        rc = stream_launch(st, st->next_seg, j1, data_hi);
+        if (rc) return rc;
+        st->next_seg = j1;
+        if (st->eof) break;
+        // carry the bytes the next segments need into the other staging buffer
+        const uint64_t keep_from = j1 * st->S > ext_lo ? j1 * st->S - ext_lo : 0;
+        const uint64_t from = std::max(keep_from, st->stage_off);
+        const uint64_t carry = data_end - from;
+        const int other = st->cur ^ 1;
+        memcpy(st->h_buf[other], st->h_buf[st->cur] + (from - st->stage_off), carry);
+        st->cur = other;
+        st->stage_off = from;
+        st->stage_len = carry;
+        break;
+    }
+    return FZ_OK;
+}
+
+int fz_stream_read_fd(fz_stream *st, int fd, int64_t offset, int threads, uint64_t *total) {
+    if (!st || fd < 0 || offset < 0) return fail(FZ_EINVAL, "bad argument");
+    if (threads <= 0) threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency() / 2));
+    uint64_t pos = (uint64_t)offset, sum = 0;
+    while (!st->eof) {
+        uint8_t *dst = nullptr;
+        uint64_t room = 0;
+        int rc = fz_stream_buffer(st, &dst, &room);
+        if (rc) return rc;
+        if (room == 0) return fail(FZ_EDEVICE, "internal: no staging room");
+        // `threads` readers, each a contiguous slice (page cache -> pinned memory is a memcpy: one core
+        // moves ~5-10 GB/s, the PCIe link ~55)
+        std::vector<uint64_t> got((size_t)threads, 0);
+        std::vector<int> err((size_t)threads, 0);
+        const uint64_t slice = ((room + threads - 1) / threads + 4095) & ~(uint64_t)4095;
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; ++t) {
+            const uint64_t lo = std::min<uint64_t>(room, (uint64_t)t * slice), hi = std::min<uint64_t>(room, lo + slice);
+            if (lo >= hi) break;
+            pool.emplace_back([=, &got, &err]() {
+                uint64_t done = 0;
+                while (lo + done < hi) {
+                    const ssize_t r = pread(fd, dst + lo + done, hi - lo - done, (off_t)(pos + lo + done));
+                    if (r < 0) { err[(size_t)t] = 1; break; }
+                    if (r == 0) break;
+                    done += (uint64_t)r;
+                }
+                got[(size_t)t] = done;
+            });
+        }
+        for (auto &th : pool) th.join();
+        uint64_t n = 0;
+        bool short_read = false;
+        for (size_t t = 0; t < pool.size(); ++t) {
+            if (err[t]) return fail(FZ_EDEVICE, "pread failed");
+            const uint64_t lo = std::min<uint64_t>(room, (uint64_t)t * slice), hi = std::min<uint64_t>(room, lo + slice);
+            if (!short_read) n += got[t];
+            if (got[t] < hi - lo) short_read = true;      // end of file inside this slice: later slices hold nothing valid
+        }
+        rc = fz_stream_submit(st, n, short_read ? 1 : 0);
+        if (rc) return rc;
+        pos += n;
+        sum += n;
+    }
+    if (total) *total = sum;
+    return FZ_OK;
+}
+
+int fz_stream_finish(fz_stream *st, fz_match **out, uint32_t **seg, uint64_t *n) {
+    if (!st || !out || !seg || !n) return fail(FZ_EINVAL, "null argument");
+    *out = nullptr; *seg = nullptr; *n = 0;
+    if (!st->eof) {
+        int rc = fz_stream_submit(st, 0, 1);
+        if (rc) return rc;
+    }
+    int rc = stream_collect(st);
+    if (rc) return rc;
+    void *mem = nullptr, *smem_ = nullptr;
+    rc = alloc_out(st->out.size(), sizeof(fz_match), &mem);
+    if (rc) return rc;
+    rc = alloc_out(st->out_seg.size(), sizeof(uint32_t), &smem_);
+    if (rc) { free(mem); return rc; }
+    if (!st->out.empty()) {
+        memcpy(mem, st->out.data(), st->out.size() * sizeof(fz_match));
+        memcpy(smem_, st->out_seg.data(), st->out_seg.size() * sizeof(uint32_t));
+    }
+    *out = static_cast<fz_match *>(mem);
+    *seg = static_cast<uint32_t *>(smem_);
+    *n = st->out.size();
+    st->out.clear();
+    st->out_seg.clear();
+    return FZ_OK;
+}
+
+void fz_stream_close(fz_stream *st) {
+    if (!st) return;
+    fz_ctx *ctx = st->ctx;
+    if (ctx && !ctx->devs.empty()) {
+        DevState &d = ctx->devs[0];
+        (void)hipSetDevice(d.device);
+        if (d.stream) (void)hipStreamSynchronize(d.stream);
+        if (ctx->stream_inflight == st) ctx->stream_inflight = nullptr;
+    }
+    for (int i = 0; i < 2; ++i) if (st->h_buf[i]) (void)hipHostFree(st->h_buf[i]);
+    if (st->seq) {
+        for (Shard &sh : st->seq->shards) if (sh.d_alloc) (void)hipFree(sh.d_alloc);
+        delete st->seq;
+    }
+    delete st;
+}
+
+}  // extern "C"
 
 extern "C" {
 

@@ -2,7 +2,7 @@
 
 Mirrors src/fuzzysearch/generic_search.py:25-54, :198-237, :256-273.
 """
-from .common import FuzzySearchBase, Match, consolidate_overlapping_matches
+from .common import FuzzySearchBase, Match, RawMatches, consolidate_overlapping_matches
 from .engine import prepare
 from .search_exact import search_exact
 
@@ -12,6 +12,10 @@ __all__ = ['find_near_matches_generic', 'find_near_matches_generic_ngrams',
 
 
 def find_near_matches_generic_ngrams(subsequence, sequence, search_params):
+    return raw_generic_ngrams(subsequence, sequence, search_params).materialize()
+
+
+def raw_generic_ngrams(subsequence, sequence, search_params):
     if not len(subsequence):
         raise ValueError('Given subsequence is empty!')
     max_subs, max_ins, max_dels, max_l = search_params.unpacked
@@ -19,37 +23,48 @@ def find_near_matches_generic_ngrams(subsequence, sequence, search_params):
         raise ValueError('the subsequence length must be greater than max_l_dist')
     pr = prepare(subsequence, sequence)
     try:
-        raw = pr.engine.generic_ngrams(pr.handle, pr.pattern, max_subs, max_ins, max_dels, max_l)
+        raw = pr.engine.generic_ngrams(pr.handle, pr.pattern, max_subs, max_ins, max_dels, max_l, as_array=True)
     finally:
         pr.release()
-    seq = pr.original
-    return [Match(s, e, d, matched=seq[s:e]) for (s, e, d, _g) in raw]
+    return RawMatches(raw, pr.original)
 
 
 def find_near_matches_generic(subsequence, sequence, search_params):
+    res = raw_generic(subsequence, sequence, search_params)
+    return res.materialize() if isinstance(res, RawMatches) else res
+
+
+def raw_generic(subsequence, sequence, search_params):
     if not len(subsequence):
         raise ValueError('Given subsequence is empty!')
     m = len(subsequence)
     if search_params.max_l_dist == 0:
         return [Match(i, i + m, 0, matched=sequence[i:i + m]) for i in search_exact(subsequence, sequence)]
     if m // (search_params.max_l_dist + 1) >= 3:
-        return find_near_matches_generic_ngrams(subsequence, sequence, search_params)
-    return find_near_matches_generic_linear_programming(subsequence, sequence, search_params)
+        return raw_generic_ngrams(subsequence, sequence, search_params)
+    return raw_generic_lp(subsequence, sequence, search_params)
 
 
 def find_near_matches_generic_linear_programming(subsequence, sequence, search_params):
     """generic_search.py:57-177 over the whole sequence, on the GPU tiled by start position."""
+    return raw_generic_lp(subsequence, sequence, search_params).materialize()
+
+
+def raw_generic_lp(subsequence, sequence, search_params):
     if not len(subsequence):
         raise ValueError('Given subsequence is empty!')
     unlimited = 1 << 29
     max_subs, max_ins, max_dels, max_l = (unlimited if x is None else x for x in search_params.unpacked)
     pr = prepare(subsequence, sequence)
     try:
-        raw = pr.engine.generic_lp(pr.handle, pr.pattern, max_subs, max_ins, max_dels, min(max_l, 255))
+        # max_l goes through unclamped: beyond the kernels' limit the library answers FZ_EUNSUPPORTED
+        # (NotImplementedError) instead of silently dropping matches; the three per-kind limits may be
+        # clamped, each is <= max_l anyway
+        raw = pr.engine.generic_lp(pr.handle, pr.pattern, min(max_subs, unlimited), min(max_ins, unlimited),
+                                   min(max_dels, unlimited), min(max_l, (1 << 32) - 1), as_array=True)
     finally:
         pr.release()
-    seq = pr.original
-    return [Match(s, e, d, matched=seq[s:e]) for (s, e, d, _g) in raw]
+    return RawMatches(raw, pr.original)
 
 
 def has_near_match_generic_ngrams(subsequence, sequence, search_params):
@@ -60,7 +75,7 @@ def has_near_match_generic_ngrams(subsequence, sequence, search_params):
 class GenericSearch(FuzzySearchBase):
     @classmethod
     def search(cls, subsequence, sequence, search_params):
-        return find_near_matches_generic(subsequence, sequence, search_params)
+        return raw_generic(subsequence, sequence, search_params)
 
     @classmethod
     def consolidate_matches(cls, matches):

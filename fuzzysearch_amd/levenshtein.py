@@ -1,7 +1,7 @@
 """Levenshtein search dispatcher (mirrors src/fuzzysearch/levenshtein.py:9-38, :151-164)."""
-from .common import FuzzySearchBase, Match, consolidate_overlapping_matches
+from .common import FuzzySearchBase, Match, RawMatches, consolidate_overlapping_matches
 from .engine import prepare
-from .levenshtein_ngram import find_near_matches_levenshtein_ngrams
+from .levenshtein_ngram import raw_levenshtein_ngrams
 from .search_exact import search_exact
 
 __all__ = ['find_near_matches_levenshtein', 'find_near_matches_levenshtein_linear_programming',
@@ -9,6 +9,11 @@ __all__ = ['find_near_matches_levenshtein', 'find_near_matches_levenshtein_linea
 
 
 def find_near_matches_levenshtein(subsequence, sequence, max_l_dist):
+    res = raw_levenshtein(subsequence, sequence, max_l_dist)
+    return res.materialize() if isinstance(res, RawMatches) else res
+
+
+def raw_levenshtein(subsequence, sequence, max_l_dist):
     if not len(subsequence):
         raise ValueError('Given subsequence is empty!')
     if max_l_dist < 0:
@@ -17,28 +22,31 @@ def find_near_matches_levenshtein(subsequence, sequence, max_l_dist):
     if max_l_dist == 0:
         return [Match(i, i + m, 0, sequence[i:i + m]) for i in search_exact(subsequence, sequence)]
     if m // (max_l_dist + 1) >= 3:
-        return find_near_matches_levenshtein_ngrams(subsequence, sequence, max_l_dist)
-    return find_near_matches_levenshtein_linear_programming(subsequence, sequence, max_l_dist)
+        return raw_levenshtein_ngrams(subsequence, sequence, max_l_dist)
+    return raw_levenshtein_lp(subsequence, sequence, max_l_dist)
+
+
+def raw_levenshtein_lp(subsequence, sequence, max_l_dist):
+    if not len(subsequence):
+        raise ValueError('Given subsequence is empty!')
+    pr = prepare(subsequence, sequence)
+    try:
+        raw = pr.engine.lev_lp(pr.handle, pr.pattern, max_l_dist, as_array=True)
+    finally:
+        pr.release()
+    return RawMatches(raw, pr.original)
 
 
 def find_near_matches_levenshtein_linear_programming(subsequence, sequence, max_l_dist):
     """levenshtein.py:52-148 — the candidate automaton for short patterns, run on the GPU tiled by
     start position (fz_lev_lp); same ordered list of matches as the reference yields."""
-    if not len(subsequence):
-        raise ValueError('Given subsequence is empty!')
-    pr = prepare(subsequence, sequence)
-    try:
-        raw = pr.engine.lev_lp(pr.handle, pr.pattern, max_l_dist)
-    finally:
-        pr.release()
-    seq = pr.original
-    return [Match(s, e, d, matched=seq[s:e]) for (s, e, d, _g) in raw]
+    return raw_levenshtein_lp(subsequence, sequence, max_l_dist).materialize()
 
 
 class LevenshteinSearch(FuzzySearchBase):
     @classmethod
     def search(cls, subsequence, sequence, search_params):
-        return find_near_matches_levenshtein(subsequence, sequence, search_params.max_l_dist)
+        return raw_levenshtein(subsequence, sequence, search_params.max_l_dist)
 
     @classmethod
     def consolidate_matches(cls, matches):

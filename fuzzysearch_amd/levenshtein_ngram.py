@@ -5,20 +5,24 @@ same arguments, same ValueError, same raw (un-consolidated, ordered) stream of M
 fz_lev_ngrams call replaces the reference's G passes of search_exact_byteslike plus two
 c_expand_* calls per n-gram hit.
 """
-from .common import Match
+from .common import RawMatches
 from .engine import prepare
 
 __all__ = ['find_near_matches_levenshtein_ngrams']
 
 
-def find_near_matches_levenshtein_ngrams(subsequence, sequence, max_l_dist):
+def raw_levenshtein_ngrams(subsequence, sequence, max_l_dist):
+    """-> RawMatches (the stream as an array; Match objects only on demand)."""
     m = len(subsequence)
     if m // (max_l_dist + 1) == 0:
         raise ValueError('the subsequence length must be greater than max_l_dist')
     pr = prepare(subsequence, sequence)
     try:
-        raw = pr.engine.lev_ngrams(pr.handle, pr.pattern, max_l_dist)
+        raw = pr.engine.lev_ngrams(pr.handle, pr.pattern, max_l_dist, as_array=True)
     finally:
         pr.release()
-    seq = pr.original
-    return [Match(s, e, d, matched=seq[s:e]) for (s, e, d, _g) in raw]
+    return RawMatches(raw, pr.original)
+
+
+def find_near_matches_levenshtein_ngrams(subsequence, sequence, max_l_dist):
+    return raw_levenshtein_ngrams(subsequence, sequence, max_l_dist).materialize()

@@ -5,7 +5,7 @@ group in group-creation order (C path + group_matches, :258-282); for ``str`` it
 Hamming <= k window sorted by start (pure-Python path, :160-167).  Both are reproduced from the
 same GPU raw stream (fz_subs_ngrams).
 """
-from .common import FuzzySearchBase, Match, best_of_groups_in_discovery_order
+from .common import FuzzySearchBase, Match, RawMatches, best_of_groups_in_discovery_order
 from .engine import prepare
 from .search_exact import search_exact
 
@@ -26,23 +26,30 @@ def _check_arguments(subsequence, sequence, max_substitutions):
 def find_near_matches_substitutions_ngrams(subsequence, sequence, max_substitutions):
     _check_arguments(subsequence, sequence, max_substitutions)
     m = len(subsequence)
-    if m // (max_substitutions + 1) == 0:
-        raise ValueError("The subsequence's length must be greater than max_substitutions!")
     pr = prepare(subsequence, sequence)
     try:
-        raw = pr.engine.subs_ngrams(pr.handle, pr.pattern, max_substitutions)
+        if m // (max_substitutions + 1) == 0:
+            # n-gram length 0.  The reference's C path (bytes-like input) answers every window
+            # (_substitutions_only_ngrams_template.h:76-88: `max_substitutions >= len` -> all starts), its
+            # pure-Python path (str) raises (substitutions_only.py:239-242).
+            if not pr.byteslike:
+                raise ValueError("The subsequence's length must be greater than max_substitutions!")
+            raw = pr.engine.subs_lp(pr.handle, pr.pattern, max_substitutions, as_array=True)
+        else:
+            raw = pr.engine.subs_ngrams(pr.handle, pr.pattern, max_substitutions, as_array=True)
     finally:
         pr.release()
-    seq = pr.original
-    if pr.byteslike:
-        matches = [Match(s, e, d, matched=seq[s:e]) for (s, e, d, _g) in raw]
-        return best_of_groups_in_discovery_order(matches)
-    seen, out = set(), []
-    for (s, e, d, _g) in raw:
-        if s not in seen:
-            seen.add(s)
-            out.append(Match(s, e, d, matched=seq[s:e]))
-    return sorted(out, key=lambda match: match.start)
+    return _finish_ngrams(raw, pr.original, pr.byteslike)
+
+
+def _finish_ngrams(raw, seq, byteslike):
+    """Raw stream -> what the reference's wrapper returns: bytes-like input -> best of every overlap group in
+    group-creation order (:266-282); str -> every window once, sorted by start (:160-167)."""
+    if byteslike:
+        return best_of_groups_in_discovery_order(RawMatches(raw, seq))
+    import numpy as np
+    _starts, first = np.unique(raw["start"], return_index=True)     # sorted by start, first occurrence of each
+    return RawMatches(raw[first], seq).materialize()
 
 
 def find_near_matches_substitutions(subsequence, sequence, max_substitutions):
@@ -61,11 +68,10 @@ def find_near_matches_substitutions_lp(subsequence, sequence, max_substitutions)
     _check_arguments(subsequence, sequence, max_substitutions)
     pr = prepare(subsequence, sequence)
     try:
-        raw = pr.engine.subs_lp(pr.handle, pr.pattern, max_substitutions)
+        raw = pr.engine.subs_lp(pr.handle, pr.pattern, max_substitutions, as_array=True)
     finally:
         pr.release()
-    seq = pr.original
-    return [Match(s, e, d, matched=seq[s:e]) for (s, e, d, _g) in raw]
+    return RawMatches(raw, pr.original).materialize()
 
 
 def _any_raw(call, subsequence, sequence, max_substitutions):
@@ -81,7 +87,9 @@ def has_near_match_substitutions_ngrams(subsequence, sequence, max_substitutions
     (The reference stops at the first one; the GPU scan is one pass either way.)"""
     _check_arguments(subsequence, sequence, max_substitutions)
     if len(subsequence) // (max_substitutions + 1) == 0:
-        raise ValueError("The subsequence's length must be greater than max_substitutions!")
+        if isinstance(subsequence, str):
+            raise ValueError("The subsequence's length must be greater than max_substitutions!")
+        return len(sequence) >= len(subsequence)          # template.h:76-88: every window matches
     return _any_raw(lambda eng: eng.subs_ngrams, subsequence, sequence, max_substitutions)
 
 

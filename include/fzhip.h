@@ -170,6 +170,32 @@ int fz_wire_pack(const fz_match *in, uint64_t n, uint64_t cap_rows, void *dst);
 int fz_wire_merge(const void *recv, uint32_t world, uint64_t rows_per_rank, uint64_t cap_rows,
                   fz_match *out, uint64_t out_cap, uint64_t *n_out, uint64_t *max_count);
 
+/* find_near_matches_in_file as a pipeline (replaces the chunk loops of __init__.py:129-171 and :174-200).
+ * The reference searches every chunk of the file as an INDEPENDENT sequence, so results depend on the
+ * chunk geometry; the stream reproduces it: chunk ("segment") j covers the items
+ *     [j * seg_stride - seg_pre, (j + 1) * seg_stride + seg_post)   clipped to the file,
+ * binary files: seg_stride = _chunk_size - keep, seg_pre = 0, seg_post = keep; text files: seg_stride =
+ * _chunk_size, seg_pre = keep, seg_post = 0 (keep = len(subsequence) - 1 + extra_items_for_chunked_search).
+ * Many chunks cross PCIe as one batch from pinned, double-buffered staging memory and are searched by one
+ * launch with per-chunk clamps while the caller fills the next staging buffer.
+ *   mode 0 exact (search_exact per chunk), 1 Levenshtein n-grams (k = max_l_dist), 2 substitutions-only
+ *   n-grams (k = max_substitutions), 3 generic n-grams (k = max_l_dist + the three limits).
+ * Protocol: fz_stream_buffer -> where to put the next bytes and how many fit; fz_stream_submit(n, last)
+ * after writing n of them (a launch happens whenever whole chunks are available); or fz_stream_read_fd,
+ * which drives both from a file descriptor with several pread threads until end of file.
+ * fz_stream_finish -> the raw match stream of the whole file in the reference's order (chunk by chunk,
+ * each chunk in its in-memory order, file coordinates) and the chunk number of every record.
+ * Requires seg_pre + seg_post <= seg_stride / 2 (FZ_EUNSUPPORTED otherwise: use per-chunk searches). */
+typedef struct fz_stream fz_stream;
+int  fz_stream_open(fz_ctx *ctx, uint32_t mode, const uint8_t *p, uint32_t m, uint32_t max_subs, uint32_t max_ins,
+                    uint32_t max_dels, uint32_t k, uint64_t seg_stride, uint32_t seg_pre, uint32_t seg_post,
+                    uint64_t batch_bytes, fz_stream **out);
+int  fz_stream_buffer(fz_stream *st, uint8_t **host, uint64_t *capacity);
+int  fz_stream_submit(fz_stream *st, uint64_t nbytes, int last);
+int  fz_stream_read_fd(fz_stream *st, int fd, int64_t offset, int threads, uint64_t *total);
+int  fz_stream_finish(fz_stream *st, fz_match **out, uint32_t **seg, uint64_t *n);
+void fz_stream_close(fz_stream *st);
+
 /* Test hook (no device needed): how the scan would split the n-gram blocks of pattern p (block
  * length L, blocks at 0, L, 2L, ...) into launches.  out[4i .. 4i+3] = first block, number of blocks,
  * hash multiplier, slot shift of launch i (at most `cap` launches are written); *n_launches = total. */

@@ -66,6 +66,50 @@ int64_t emul_search(int mode, const uint8_t *p, uint32_t m, const uint8_t *t, ui
     return cnt;
 }
 
+// Levenshtein n-gram search over a batch of file chunks ("segments", FzGeom): every n-gram occurrence in the
+// resident buffer [buf_off, buf_off + buf_len) is offered to each candidate segment exactly as the scan
+// kernel's flush does (fz_segment -> fz_hit_in_range -> fz_verify_lev with the segment's ends).
+struct OutRecSeg { int64_t start, end; int32_t dist, block; int64_t seg; };
+int64_t emul_search_segments(const uint8_t *p, uint32_t m, const uint8_t *t, uint64_t n, uint32_t k,
+                             uint64_t S, uint32_t pre, uint32_t post, uint64_t j0, uint64_t j1,
+                             uint64_t buf_off, uint64_t buf_len, OutRecSeg *out, int64_t cap) {
+    const uint32_t L = m / (k + 1);
+    if (L == 0) return -1;
+    HostScores sc;
+    sc.v.assign(2 * k + 4, 0);
+    std::vector<uint8_t> shard(buf_len + 64, 0xEE);
+    memcpy(shard.data(), t + buf_off, buf_len);
+    FzSeqView view{shard.data(), buf_off};
+    FzScanArgs a;
+    memset(&a, 0, sizeof a);
+    a.geom.n = n; a.geom.buf_off = buf_off; a.geom.buf_len = buf_len; a.geom.own_lo = 0; a.geom.own_hi = n;
+    a.geom.seg_stride = S; a.geom.seg_org = 0; a.geom.seg_pre = pre; a.geom.seg_post = post;
+    a.geom.seg_j0 = j0; a.geom.seg_j1 = j1;
+    a.mode = FZ_MODE_LEV; a.m = m; a.k = k; a.L = L; a.abs_lo = 0; a.abs_hi = ~0ull;
+    int64_t cnt = 0;
+    uint32_t g = 0;
+    for (uint32_t s = 0; s + L <= m; s += L, ++g) {
+        for (uint64_t idx = buf_off; idx + L <= buf_off + buf_len; ++idx) {
+            if (memcmp(shard.data() + (idx - buf_off), p + s, L) != 0) continue;
+            for (uint32_t c = 0; c < fz_segment_candidates(a.geom); ++c) {
+                const FzSeg sg = fz_segment(a.geom, idx, c);
+                if (!fz_hit_in_range_s(a, s, idx, sg)) continue;
+                FzRec rec;
+                if (!fz_verify_lev<FZ_REG_BAND_MAX>(sc, view, sg.sa, sg.se, p, m, k, L, s, idx, rec)) continue;
+                if (cnt < cap) {
+                    out[cnt].start = (int64_t)idx - (int64_t)rec.l;
+                    out[cnt].end = (int64_t)idx + L + rec.r;
+                    out[cnt].dist = (int32_t)rec.dist;
+                    out[cnt].block = (int32_t)g;
+                    out[cnt].seg = sg.j;
+                }
+                ++cnt;
+            }
+        }
+    }
+    return cnt;
+}
+
 // Generic automaton over one window, driven candidate by candidate through fz_generic_step exactly
 // as the GPU kernel does (the kernel only parallelises the candidate loop and keeps the order).
 int64_t emul_generic_lp(const uint8_t *p, uint32_t m, const uint8_t *t, uint32_t n, uint32_t max_subs,

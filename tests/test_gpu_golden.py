@@ -165,25 +165,3 @@ def test_reference_readme_examples(engine):
     sub = 'TGCACTGTAGGGATAACAAT'
     assert fa.find_near_matches(sub, seq, max_l_dist=2) == [fa.Match(3, 24, 1, 'TAGCACTGTAGGGATAACAAT')]
     assert fa.find_near_matches(sub.encode(), seq.encode(), max_l_dist=2) == [fa.Match(3, 24, 1, b'x')]
-
-
-def test_find_near_matches_in_file_on_gpu(engine, tmp_path):
-    """The reference's chunk-boundary sweep (tests/test_find_near_matches_in_file.py:73-152) on the
-    n-gram route, binary and text mode."""
-    import attr
-    needle, hay = b'PATTERNPATTERN', b'PATTERNPATERN'
-    fn = tmp_path / "hay.bin"
-    for chunk_size in (100, 1 << 10, 1 << 12):
-        for delta in sorted({-len(needle), -len(needle) + 1, -4, -2, -1, 0, 1}):
-            data = bytearray(chunk_size + 100)
-            data[chunk_size + delta:chunk_size + delta + len(hay)] = hay
-            fn.write_bytes(bytes(data))
-            exp_raw = oracle.consolidate(oracle.lev_ngrams_raw(needle, bytes(data), 2))
-            for cs in (chunk_size, chunk_size // 2):
-                with open(fn, 'rb') as f:
-                    got = fa.find_near_matches_in_file(needle, f, max_l_dist=2, _chunk_size=cs)
-                assert [(m.start, m.end, m.dist) for m in got] == exp_raw, (chunk_size, delta, cs)
-                assert all(m.matched == bytes(data[m.start:m.end]) for m in got)
-            with open(fn, 'r', encoding='latin-1') as f:
-                got = fa.find_near_matches_in_file(needle.decode(), f, max_l_dist=2, _chunk_size=chunk_size)
-            assert [(m.start, m.end, m.dist) for m in got] == exp_raw
