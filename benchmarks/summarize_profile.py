@@ -13,8 +13,16 @@ shutil.copy(stats, os.path.join(root, "profiles", tag + "_rocprof_kernel_stats.c
 # per-kernel table that is committed is rebuilt from the full --kernel-trace of the same run
 trace = newest(os.path.join(base, "stats", "*", "*_kernel_trace.csv"))
 per = collections.defaultdict(list)
+head = []                              # the headline launches: the 3-block DNA kernel over 1 GiB (4096 workgroups)
 for r in csv.DictReader(open(trace)):
-    per[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    name = r["Kernel_Name"]
+    grid = int(r.get("Grid_Size_X", r.get("Grid_Size", "0")) or 0)
+    if "fz_scan_kernel<3, 2, 3, true" in name:
+        name += " [grid %d]" % grid
+        if grid == alg // (16 * 16384) * 256:
+            head.append(dur)
+    per[name].append(dur)
 total = sum(sum(v) for v in per.values())
 with open(os.path.join(root, "profiles", tag + "_kernel_stats.csv"), "w", newline="") as f:
     wr = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)
@@ -22,10 +30,7 @@ with open(os.path.join(root, "profiles", tag + "_kernel_stats.csv"), "w", newlin
     for name, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
         vs = sorted(v)
         wr.writerow([name, len(v), sum(v), round(sum(v) / len(v), 1), round(100.0 * sum(v) / total, 2), vs[0], vs[-1], vs[len(vs) // 2]])
-avg_ns = None
-for name, v in per.items():
-    if "fz_scan" in name:
-        avg_ns, kname, calls = sum(v) / len(v), name, len(v)
+avg_ns, kname, calls = sum(head) / len(head), "void fz_scan_kernel<3, 2, 3, true, false>", len(head)
 out = {}
 for d in sorted(glob.glob(os.path.join(base, "pmc*"))):
     if not os.path.isdir(d):
@@ -33,7 +38,7 @@ for d in sorted(glob.glob(os.path.join(base, "pmc*"))):
     f = newest(os.path.join(d, "*", "*_counter_collection.csv"))
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "fz_scan" in r["Kernel_Name"]:
+        if "fz_scan_kernel<3, 2, 3, true" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         out[k] = sum(v) / len(v)

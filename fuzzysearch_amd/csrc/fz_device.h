@@ -137,6 +137,8 @@ struct FzRec {
     uint32_t aux;        // segment number (file API), else 0
 };
 
+#define FZ_REC_NONE 0xffffffffu        // FzRec.dist of a slot whose hit did not verify (slot-per-hit kernels)
+
 FZ_HD uint64_t fz_hit_pack(uint32_t g, uint64_t idx) { return ((uint64_t)g << 56) | idx; }
 FZ_HD uint32_t fz_hit_block(uint64_t h) { return (uint32_t)(h >> 56); }
 FZ_HD uint64_t fz_hit_index(uint64_t h) { return h & 0x00ffffffffffffffull; }

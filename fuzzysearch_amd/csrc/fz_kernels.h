@@ -243,11 +243,12 @@ __device__ __forceinline__ bool fz_confirm(const uint8_t *__restrict__ buf, cons
 // `flag` is one LDS dword the workgroup no longer needs (no static __shared__ here: it would move the
 // dynamic LDS base off 0 and cost the scan an address add per table lookup).
 __device__ __forceinline__ void fz_finish_launch(const FzScanArgs &a, unsigned long long *__restrict__ counters,
-                                                 volatile uint32_t *flag) {
+                                                 volatile uint32_t *flag, uint32_t participants = 0) {
     if (!a.host_hdr) return;
+    if (participants == 0) participants = gridDim.x;       // workgroups that take a ticket (all, unless the caller says fewer)
     __syncthreads();                                       // all waves' counter atomics are complete, LDS is free
     if (threadIdx.x == 0)
-        *flag = atomicAdd(&counters[FZ_HDR_TICKET], 1ull) == (unsigned long long)gridDim.x - 1ull;
+        *flag = atomicAdd(&counters[FZ_HDR_TICKET], 1ull) == (unsigned long long)participants - 1ull;
     __syncthreads();
     if (*flag) {
         unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.host_hdr);
@@ -534,10 +535,13 @@ __device__ __forceinline__ uint32_t fz_xl_shl1(uint32_t v, uint32_t fill, uint32
 template <int GW>
 __device__ __forceinline__ uint32_t fz_xl_prefix_min(uint32_t v, uint32_t gl) {
     if constexpr (GW == 16) {
-        v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xf, 0xf, false));   // row_shr:1
-        v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x112, 0xf, 0xf, false));
-        v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114, 0xf, 0xf, false));
-        v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118, 0xf, 0xf, false));
+        // v = min(v, v of the lane n below) in one instruction each: a DPP source outside the row disables
+        // the lane, and since destination and second source are the same register such a lane keeps v
+        asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+                     : "+v"(v));
     } else {
 #pragma unroll
         for (int n = 1; n < GW; n <<= 1) {
@@ -548,14 +552,15 @@ __device__ __forceinline__ uint32_t fz_xl_prefix_min(uint32_t v, uint32_t gl) {
     return v;
 }
 
-// One bounded expansion for every candidate of the wave.  All arguments but gl are uniform inside a
+// The rows of one bounded expansion for every group of the wave.  All arguments but gl are uniform inside a
 // group.  sub(i) = lds[sub_addr + i * sub_step], win(j) = lds[win_addr + j * win_step] (bytes in LDS;
 // reads one element outside either range land in this workgroup's LDS and only feed cells that are
-// forced anyway).  -> ok / dist / consumed, uniform inside the group.
+// forced anyway).  -> the lane's cell of the bottom row, D[sublen][sublen + gl - K] (garbage above `budget`
+// once every live group has run out of cells within its budget: nothing can pass then).
 template <int GW>
-__device__ __forceinline__ bool fz_wf_expand(const uint8_t *lds, uint32_t gl, uint32_t K, int sub_addr, int sub_step,
-                                             uint32_t sublen, int win_addr, int win_step, uint32_t winlen,
-                                             uint32_t budget, bool valid, uint32_t &dist, uint32_t &consumed) {
+__device__ __forceinline__ uint32_t fz_wf_rows(const uint8_t *lds, uint32_t gl, uint32_t K, int sub_addr, int sub_step,
+                                               uint32_t sublen, int win_addr, int win_step, uint32_t winlen,
+                                               uint32_t budget, bool valid) {
     constexpr uint32_t INF = 0x3fffu;
     const int d = (int)gl - (int)K;
     const bool act = valid && gl <= 2u * K;
@@ -587,8 +592,17 @@ __device__ __forceinline__ bool fz_wf_expand(const uint8_t *lds, uint32_t gl, ui
         // row minima never decrease: once no live candidate has a cell within its budget, nothing can pass
         if ((i & 3u) == 0u && !__ballot(live && cell <= budget)) break;
     }
-    const int jb = (int)sublen + d;
-    const bool validj = act && jb >= 1 && jb <= (int)winlen;
+    return cell;
+}
+
+// Bottom row -> (best, last arg-min) over the columns 1 .. winlen from the column-0 baseline
+// (pyx:33-34, :67-69); uniform inside the group.  winlen may be smaller than the one the rows ran with:
+// a cell only depends on cells of smaller or equal columns.
+template <int GW>
+__device__ __forceinline__ bool fz_wf_pick(uint32_t cell, uint32_t gl, uint32_t K, uint32_t sublen, uint32_t winlen,
+                                           uint32_t budget, bool valid, uint32_t &dist, uint32_t &consumed) {
+    const int jb = (int)sublen + (int)gl - (int)K;
+    const bool validj = valid && gl <= 2u * K && jb >= 1 && jb <= (int)winlen;
     uint32_t key = validj ? ((cell << 8) | (255u - gl)) : 0xffffffffu;     // min cell, then the LARGEST column
     key = fz_xl_prefix_min<GW>(key, gl);
     key = (uint32_t)__shfl((int)key, (int)((fz_lane() & ~((uint32_t)GW - 1u)) + (uint32_t)GW - 1u), 64);
@@ -602,14 +616,21 @@ __device__ __forceinline__ bool fz_wf_expand(const uint8_t *lds, uint32_t gl, ui
     return valid && best <= budget;
 }
 
-// Levenshtein verification of a hit list, GW lanes per hit (64 / GW hits per wave at a time).
-// Dynamic LDS: pattern + per-wave window areas (one contiguous byte window per group).
+// Levenshtein verification of a hit list, GW lanes per hit (64 / GW hits per wave at a time): right
+// expansion, then left with what the right one left of the budget (levenshtein_ngram.py:177-189).
+// (Measured and dropped: right and left expansions of a hit side by side on two lane groups — half the
+// rows per wave but twice the workgroups, 0.031 vs 0.029 ms: the rows are ~11 us of this kernel, the rest
+// is launch, two dependent load round trips and the finish tickets.)
+// Record slot = hit number (x candidate segment): no slot atomics — all waves of this kernel finish at
+// about the same time, and 1400 atomics on one counter word took longer than the DP rows.  Slots of hits
+// that did not verify carry FZ_REC_NONE; the host drops them.
+// Dynamic LDS: pattern + per-wave window areas (one contiguous byte window per hit).
 template <int GW>
-__global__ __launch_bounds__(256) void fz_verify_wf_kernel(const uint8_t *__restrict__ buf, const FzScanArgs a,
-                                                           const uint64_t *__restrict__ hits, FzRec *__restrict__ recs,
-                                                           unsigned long long *__restrict__ counters) {
+__global__ __launch_bounds__(1024) void fz_verify_wf_kernel(const uint8_t *__restrict__ buf, const FzScanArgs a,
+                                                            const uint64_t *__restrict__ hits, FzRec *__restrict__ recs,
+                                                            unsigned long long *__restrict__ counters) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    constexpr uint32_t NG = 64u / (uint32_t)GW;                         // candidates per wave
+    constexpr uint32_t NH = 64u / (uint32_t)GW;                         // hits per wave
     const uint32_t mpad = (a.m + 15u) & ~15u;
     uint8_t *pat_lds = smem + 16;                                       // 16 bytes of slack below p[0] (reversed reads)
     for (uint32_t i = threadIdx.x; i < a.m; i += blockDim.x) pat_lds[i] = a.pat[i];
@@ -617,13 +638,18 @@ __global__ __launch_bounds__(256) void fz_verify_wf_kernel(const uint8_t *__rest
     const uint32_t lane = fz_lane();
     const uint32_t grp = lane / (uint32_t)GW, gl = lane % (uint32_t)GW;
     const uint32_t wbytes = a.win_dwords * 4u;
-    uint8_t *gwin = smem + 16 + mpad + 16 + ((threadIdx.x >> 6) * NG + grp) * (wbytes + 16u);
+    uint8_t *gwin = smem + 16 + mpad + 16 + ((threadIdx.x >> 6) * NH + grp) * (wbytes + 16u);
     unsigned long long nh = counters[0];
     if (nh > a.hit_cap) nh = a.hit_cap;
     const uint64_t waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t ncand = fz_segment_candidates(a.geom);
-    for (uint64_t q0 = wave * NG; q0 < nh; q0 += waves * NG) {
+    // workgroups without a hit leave at once and take no finish ticket (a ticket is an atomic on one word)
+    const uint64_t per_wg = (uint64_t)NH * (blockDim.x >> 6);
+    uint32_t active_wgs = (uint32_t)((nh + per_wg - 1) / per_wg < gridDim.x ? (nh + per_wg - 1) / per_wg : gridDim.x);
+    if (active_wgs == 0) active_wgs = 1;
+    if (blockIdx.x >= active_wgs) return;
+    for (uint64_t q0 = wave * NH; q0 < nh; q0 += waves * NH) {
         const uint64_t q = q0 + grp;
         const bool have = q < nh;
         const uint64_t hit = have ? hits[q] : 0;
@@ -633,8 +659,10 @@ __global__ __launch_bounds__(256) void fz_verify_wf_kernel(const uint8_t *__rest
         for (uint32_t c = 0; c < ncand; ++c) {
             const FzSeg sg = fz_segment(a.geom, idx, c);
             const bool valid = have && fz_hit_in_range_s(a, s, idx, sg);
+            const unsigned long long slot = q * ncand + c;
+            if (have && !valid && gl == 0 && slot < a.rec_cap) recs[slot].dist = FZ_REC_NONE;   // not a hit of this segment
             if (!__ballot(valid)) continue;
-            // the group's window [wlo, whi), staged as plain bytes: byte g of the sequence at gwin[g - wbase]
+            // the hit's window [wlo, whi), staged as plain bytes: byte g of the sequence at gwin[g - wbase]
             uint64_t wlo = 0, whi = 0, wbase = 0;
             if (valid) {
                 const uint64_t reach = (uint64_t)s + a.k;
@@ -659,32 +687,30 @@ __global__ __launch_bounds__(256) void fz_verify_wf_kernel(const uint8_t *__rest
             if (rend > sg.se) rend = sg.se;
             if (rbeg > sg.se) rbeg = sg.se;
             if (rend < rbeg) rend = rbeg;
+            const uint32_t rwin = (uint32_t)(rend - rbeg), rlen = a.m - s - a.L;
             uint32_t dR = 0, r = 0, dL = 0, l = 0;
-            const bool ok1 = fz_wf_expand<GW>(smem, gl, a.k, (int)(pat_lds - smem) + (int)(s + a.L), 1, a.m - s - a.L,
-                                              lds_of(rbeg), 1, (uint32_t)(rend - rbeg), a.k, valid, dR, r);
+            const uint32_t cellr = fz_wf_rows<GW>(smem, gl, a.k, (int)(pat_lds - smem) + (int)(s + a.L), 1, rlen, lds_of(rbeg), 1, rwin,
+                                                  a.k, valid);
+            const bool ok1 = fz_wf_pick<GW>(cellr, gl, a.k, rlen, rwin, a.k, valid, dR, r);
             // left: reversed p[:s] vs reversed t[max(sa, idx-s-(k-dR)) : idx], budget k - dR
             const uint32_t bl = ok1 ? a.k - dR : 0u;
             const uint64_t want = (uint64_t)s + bl;
             const uint64_t lbeg = (idx - sg.sa > want) ? idx - want : sg.sa;
-            const bool ok = fz_wf_expand<GW>(smem, gl, a.k, (int)(pat_lds - smem) + (int)s - 1, -1, s,
-                                             lds_of(idx) - 1, -1, ok1 ? (uint32_t)(idx - lbeg) : 0u, bl, ok1, dL, l);
-            const bool emit = ok && gl == 0;
-            const unsigned long long mask = __ballot(emit);
-            if (mask) {
-                unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(&counters[1], (unsigned long long)__popcll(mask));
-                base = fz_bcast64(base);
-                if (emit) {
-                    FzRec rec;
-                    rec.key = hit; rec.l = l; rec.r = r; rec.dist = dL + dR; rec.aux = sg.j;
-                    const unsigned long long slot = base + fz_rank(mask);
-                    if (slot < a.rec_cap) recs[slot] = rec;
-                }
+            const uint32_t lwin = ok1 ? (uint32_t)(idx - lbeg) : 0u;
+            const uint32_t celll = fz_wf_rows<GW>(smem, gl, a.k, (int)(pat_lds - smem) + (int)s - 1, -1, s, lds_of(idx) - 1, -1, lwin,
+                                                  bl, ok1);
+            const bool ok = fz_wf_pick<GW>(celll, gl, a.k, s, lwin, bl, ok1, dL, l);
+            if (valid && gl == 0 && slot < a.rec_cap) {
+                FzRec rec;
+                rec.key = hit; rec.l = l; rec.r = r; rec.dist = ok ? dL + dR : FZ_REC_NONE; rec.aux = sg.j;
+                recs[slot] = rec;
             }
             fz_wave_lds_sync();
         }
     }
-    fz_finish_launch(a, counters, reinterpret_cast<uint32_t *>(smem));
+    // the record count the host sees = number of slots; only workgroups that had hits take a finish ticket
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters[1], nh * ncand);
+    fz_finish_launch(a, counters, reinterpret_cast<uint32_t *>(smem), active_wgs);
 }
 
 // ---------------------------------------------------------------------------------------------

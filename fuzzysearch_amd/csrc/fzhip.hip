@@ -105,6 +105,10 @@ struct DevState {
     bool header_zeroed = false;                  // the counters were already zeroed after the last D2H copy
     bool verify_launched = false;                // the last enqueue ran fz_verify_kernel (ev[2] recorded)
     int scan_end_event = 1;                      // which event marks the end of the last scan (1 or 3)
+    // staging of the last closed file stream, kept for the next one (pinning 2 x 65 MiB costs ~30 ms)
+    uint8_t *stream_h[2] = {nullptr, nullptr};
+    uint8_t *stream_d = nullptr;
+    uint64_t stream_cap = 0, stream_d_bytes = 0;
     int n_cus = 256;
 };
 
@@ -441,10 +445,11 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
             // lane-per-cell: 64 / gw candidates per wave, one contiguous byte window per candidate
             const int gw = wavefront_group(q.k);
             fa.gw = (uint32_t)gw;
-            const uint32_t per_wave = (64u / gw) * (fa.win_dwords * 4u + 16u);
-            const size_t lds = 16 + mpad + 16 + 4 * per_wave;
+            const uint32_t per_wave = (64u / gw) * (fa.win_dwords * 4u + 16u);     // one window per hit (at most 64 / gw hits per wave)
+            // 16 waves per workgroup: few workgroups = few finish tickets (every ticket is an atomic on one word)
+            const size_t lds = 16 + mpad + 16 + 16 * per_wave;
             if (lds > 64 * 1024) return fail(FZ_EUNSUPPORTED, "pattern too long for the verify kernel (m=%u, k=%u)", q.m, q.k);
-            const dim3 vgrid(d.n_cus * 4), vblock(256);
+            const dim3 vgrid(d.n_cus * 2), vblock(1024);
             if (gw == 16) hipLaunchKernelGGL(fz_verify_wf_kernel<16>, vgrid, vblock, lds, d.stream, sh.d_buf, fa, d.d_hits, recs, counters);
             else if (gw == 32) hipLaunchKernelGGL(fz_verify_wf_kernel<32>, vgrid, vblock, lds, d.stream, sh.d_buf, fa, d.d_hits, recs, counters);
             else hipLaunchKernelGGL(fz_verify_wf_kernel<64>, vgrid, vblock, lds, d.stream, sh.d_buf, fa, d.d_hits, recs, counters);
@@ -729,7 +734,20 @@ void sort_recs(std::vector<FzRec> &recs) {
 // squeezed next to the record's position into one 64-bit word and those words are sorted with 11-bit
 // LSD radix passes over the key bits only (8-byte elements instead of 24-byte records); the records
 // are then read once, in order.
+// Slot-per-hit kernels leave FZ_REC_NONE in the slots of hits that did not verify.
+bool drop_empty_slots(const FzRec *recs, size_t cnt, std::vector<FzRec> &kept) {
+    size_t empty = 0;
+    for (size_t i = 0; i < cnt; ++i) empty += recs[i].dist == FZ_REC_NONE;
+    if (!empty) return false;
+    kept.clear();
+    kept.reserve(cnt - empty);
+    for (size_t i = 0; i < cnt; ++i) if (recs[i].dist != FZ_REC_NONE) kept.push_back(recs[i]);
+    return true;
+}
+
 int emit_matches(const FzRec *recs, size_t cnt, uint32_t L, fz_match **out, uint64_t *n) {
+    std::vector<FzRec> kept;
+    if (drop_empty_slots(recs, cnt, kept)) return emit_matches(kept.data(), kept.size(), L, out, n);
     void *mem = nullptr;
     int rc = alloc_out(cnt, sizeof(fz_match), &mem);
     if (rc) return rc;
@@ -782,6 +800,8 @@ int emit_matches(const FzRec *recs, size_t cnt, uint32_t L, fz_match **out, uint
 
 // Segmented searches (file API): reference order = segment (chunk) major, then (block, index).
 int emit_matches_seg(const FzRec *recs, size_t cnt, uint32_t L, fz_match **out, uint64_t *n, uint32_t **seg_out) {
+    std::vector<FzRec> kept;
+    if (drop_empty_slots(recs, cnt, kept)) return emit_matches_seg(kept.data(), kept.size(), L, out, n, seg_out);
     void *mem = nullptr, *smem_ = nullptr;
     int rc = alloc_out(cnt, sizeof(fz_match), &mem);
     if (rc) return rc;
@@ -894,6 +914,8 @@ void fz_destroy(fz_ctx *ctx) {
         if (d.h_stage) (void)hipHostFree(d.h_stage);
         if (d.h_big) (void)hipHostFree(d.h_big);
         if (d.d_cand) (void)hipFree(d.d_cand);
+        for (int i = 0; i < 2; ++i) if (d.stream_h[i]) (void)hipHostFree(d.stream_h[i]);
+        if (d.stream_d) (void)hipFree(d.stream_d);
         for (auto &ev : d.ev) if (ev) (void)hipEventDestroy(ev);
         if (d.stream) (void)hipStreamDestroy(d.stream);
     }
@@ -1071,6 +1093,7 @@ int fz_lev_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32
     tr.mark("run_search");
     rc = emit_matches(ctx, recs, q.plan.L, out, n);
     tr.mark("sort+emit");
+    if (rc == FZ_OK) ctx->stats.raw_matches = *n;
     return rc;
 }
 
@@ -1455,6 +1478,7 @@ struct fz_stream {
     uint64_t S = 0;                      // segment stride
     uint32_t pre = 0, post = 0;          // segment j = [j*S - pre, (j+1)*S + post) clipped to the file
     uint64_t cap = 0;                    // bytes a staging buffer holds
+    uint64_t cap_alloc = 0;              // bytes the staging allocations really have (reused buffers may be larger)
     uint8_t *h_buf[2] = {nullptr, nullptr};   // pinned staging
     int cur = 0;                         // staging buffer being filled
     uint64_t stage_off = 0;              // file offset of h_buf[cur][0]
@@ -1638,15 +1662,30 @@ int fz_stream_open(fz_ctx *ctx, uint32_t mode, const uint8_t *p, uint32_t m, uin
     DevState &d = ctx->devs[0];
     auto init = [&]() -> int {
         HIP_TRY(hipSetDevice(d.device));
-        for (int i = 0; i < 2; ++i) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&st->h_buf[i]), st->cap, hipHostMallocDefault));
+        const uint64_t need_d = FZ_PAD_FRONT + ((st->cap + FZ_TILE_BYTES - 1) / FZ_TILE_BYTES + 1) * FZ_TILE_BYTES + FZ_PAD_BACK;
+        uint8_t *cached_d = nullptr;
+        if (d.stream_h[0] && d.stream_cap >= st->cap && d.stream_d_bytes >= need_d) {       // reuse the previous stream's buffers
+            st->h_buf[0] = d.stream_h[0]; st->h_buf[1] = d.stream_h[1];
+            cached_d = d.stream_d;
+            st->cap_alloc = d.stream_cap;
+            d.stream_h[0] = d.stream_h[1] = nullptr; d.stream_d = nullptr;
+        } else {
+            for (int i = 0; i < 2; ++i) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&st->h_buf[i]), st->cap, hipHostMallocDefault));
+            st->cap_alloc = st->cap;
+        }
         st->seq = new (std::nothrow) fz_seq();
         if (!st->seq) return fail(FZ_ENOMEM, "out of memory");
         st->seq->ctx = ctx;
         st->seq->shards.emplace_back();
         Shard &sh = st->seq->shards[0];
         sh.dev = 0;
-        sh.alloc_bytes = FZ_PAD_FRONT + ((st->cap + FZ_TILE_BYTES - 1) / FZ_TILE_BYTES + 1) * FZ_TILE_BYTES + FZ_PAD_BACK;
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sh.d_alloc), sh.alloc_bytes));
+        if (cached_d) {
+            sh.d_alloc = cached_d;
+            sh.alloc_bytes = d.stream_d_bytes;
+        } else {
+            sh.alloc_bytes = need_d;
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sh.d_alloc), sh.alloc_bytes));
+        }
         sh.d_buf = sh.d_alloc + FZ_PAD_FRONT;
         HIP_TRY(hipMemsetAsync(sh.d_alloc, 0, FZ_PAD_FRONT, d.stream));
         return FZ_OK;
@@ -1785,11 +1824,25 @@ void fz_stream_close(fz_stream *st) {
         if (d.stream) (void)hipStreamSynchronize(d.stream);
         if (ctx->stream_inflight == st) ctx->stream_inflight = nullptr;
     }
-    for (int i = 0; i < 2; ++i) if (st->h_buf[i]) (void)hipHostFree(st->h_buf[i]);
-    if (st->seq) {
-        for (Shard &sh : st->seq->shards) if (sh.d_alloc) (void)hipFree(sh.d_alloc);
-        delete st->seq;
+    // hand the staging to the context for the next stream (freed with the context)
+    bool kept = false;
+    if (ctx && !ctx->devs.empty() && st->h_buf[0] && st->h_buf[1] && st->seq && !st->seq->shards.empty() && st->seq->shards[0].d_alloc) {
+        DevState &d = ctx->devs[0];
+        if (!d.stream_h[0] || d.stream_cap < st->cap_alloc) {
+            for (int i = 0; i < 2; ++i) if (d.stream_h[i]) (void)hipHostFree(d.stream_h[i]);
+            if (d.stream_d) (void)hipFree(d.stream_d);
+            d.stream_h[0] = st->h_buf[0]; d.stream_h[1] = st->h_buf[1];
+            d.stream_d = st->seq->shards[0].d_alloc;
+            d.stream_cap = st->cap_alloc;
+            d.stream_d_bytes = st->seq->shards[0].alloc_bytes;
+            kept = true;
+        }
     }
+    if (!kept) {
+        for (int i = 0; i < 2; ++i) if (st->h_buf[i]) (void)hipHostFree(st->h_buf[i]);
+        if (st->seq) for (Shard &sh : st->seq->shards) if (sh.d_alloc) (void)hipFree(sh.d_alloc);
+    }
+    delete st->seq;
     delete st;
 }
 
