@@ -61,6 +61,25 @@ __global__ void NAME(uint32_t *out, unsigned long long *cyc, uint32_t s, uint32_
 #define S_PKADD(n) "v_pk_add_u16 %" #n ", %8, %" #n "\n"
 #define S_PKMUL(n) "v_pk_mul_lo_u16 %" #n ", %8, %" #n "\n"
 #define S_MED3(n) "v_med3_u32 %" #n ", %" #n ", %8, %9\n"
+#define S_AND(n) "v_and_b32 %" #n ", %8, %" #n "\n"
+#define S_ANDLIT(n) "v_and_b32 %" #n ", 0x7c, %" #n "\n"
+#define S_OR(n) "v_or_b32 %" #n ", %8, %" #n "\n"
+#define S_LSHL(n) "v_lshlrev_b32 %" #n ", %8, %" #n "\n"
+#define S_LSHRI(n) "v_lshrrev_b32 %" #n ", 25, %" #n "\n"
+#define S_ADDU16(n) "v_add_u16 %" #n ", %8, %" #n "\n"
+#define S_MAXU16(n) "v_max_u16 %" #n ", %8, %" #n "\n"
+#define S_MULLOU16(n) "v_mul_lo_u16 %" #n ", %8, %" #n "\n"
+#define S_MINF32(n) "v_min_f32 %" #n ", %8, %" #n "\n"
+#define S_MOV(n) "v_mov_b32 %" #n ", %8\n"
+#define S_BFI(n) "v_bfi_b32 %" #n ", %8, %9, %" #n "\n"
+#define S_MINI16(n) "v_min_i16 %" #n ", %8, %" #n "\n"
+#define S_ADD3(n) "v_add3_u32 %" #n ", %" #n ", %8, %9\n"
+#define S_LSHLOR(n) "v_lshl_or_b32 %" #n ", %8, 4, %" #n "\n"
+#define S_MUL24V(n) "v_mul_u32_u24 %" #n ", %8, %" #n "\n"
+#define S_MAD24V(n) "v_mad_u32_u24 %" #n ", %8, %9, %" #n "\n"
+#define S_DOT4V(n) "v_dot4_u32_u8 %" #n ", %8, %9, %" #n "\n"
+#define S_FMAC(n) "v_fmac_f32 %" #n ", %8, %9\n"
+#define S_MBCNT(n) "v_mbcnt_lo_u32_b32 %" #n ", %10, %" #n "\n"
 
 KERNEL(k_xor, S_XOR) KERNEL(k_xor_sgpr, S_XORS) KERNEL(k_min, S_MIN) KERNEL(k_min3, S_MIN3) KERNEL(k_align, S_ALIGN)
 KERNEL(k_mad24, S_MAD24) KERNEL(k_perm, S_PERM) KERNEL(k_pkmin, S_PKMIN) KERNEL(k_pksub, S_PKSUB) KERNEL(k_andor, S_ANDOR)
@@ -69,6 +88,42 @@ KERNEL(k_sadu8, S_SADU8) KERNEL(k_dot4, S_DOT4) KERNEL(k_add, S_ADD) KERNEL(k_su
 KERNEL(k_fma, S_FMA) KERNEL(k_mul24, S_PKFMA) KERNEL(k_mullo, S_MULLO) KERNEL(k_lshr, S_LSHR) KERNEL(k_max3, S_MAX3) KERNEL(k_med3, S_MED3)
 KERNEL(k_pkmad, S_PKMAD) KERNEL(k_madu16, S_MADU16) KERNEL(k_xor64, S_XOR64) KERNEL(k_xorsdwa, S_XORSDWA) KERNEL(k_minu16, S_MINU16)
 KERNEL(k_xorlit, S_XORLIT) KERNEL(k_pkadd, S_PKADD) KERNEL(k_pkmul, S_PKMUL)
+KERNEL(k_and, S_AND) KERNEL(k_andlit, S_ANDLIT) KERNEL(k_or, S_OR) KERNEL(k_lshl, S_LSHL) KERNEL(k_lshri, S_LSHRI) KERNEL(k_addu16, S_ADDU16)
+KERNEL(k_maxu16, S_MAXU16) KERNEL(k_mullou16, S_MULLOU16) KERNEL(k_minf32, S_MINF32) KERNEL(k_mov, S_MOV) KERNEL(k_bfi, S_BFI)
+KERNEL(k_mini16, S_MINI16) KERNEL(k_add3, S_ADD3) KERNEL(k_lshlor, S_LSHLOR) KERNEL(k_mad24v, S_MAD24V) KERNEL(k_fmac, S_FMAC) KERNEL(k_mbcnt, S_MBCNT)
+
+// ds_read_b32 at aligned / unaligned byte addresses inside a 160-byte table: correctness of the unaligned
+// form (does the hardware return bytes a .. a+3?) and its issue cost.
+template <int UNALIGNED>
+__global__ void k_ldsread(uint32_t *out, unsigned long long *cyc, uint32_t s, uint32_t t) {
+    __shared__ uint8_t tab[256];
+    tab[threadIdx.x & 255u] = (uint8_t)((threadIdx.x * 7u + 3u) & 255u);
+    __syncthreads();
+    uint32_t a0 = (threadIdx.x * 13u + s) & 127u, acc = 0, bad = 0;
+    if (!UNALIGNED) a0 &= ~3u;
+    // correctness: every address 0..131
+    for (uint32_t a = threadIdx.x & 63u; a < 132u; a += 64u) {
+        uint32_t got;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(got) : "v"(a));
+        uint32_t exp = 0;
+        for (int b = 0; b < 4; ++b) exp |= (uint32_t)(uint8_t)(((a + b) * 7u + 3u) & 255u) << (8 * b);
+        if (UNALIGNED || (a & 3u) == 0) bad += got != exp;
+    }
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < ITERS; ++i) {
+        uint32_t r0, r1, r2, r3, r4, r5, r6, r7;
+        asm volatile("ds_read_b32 %0, %8\n\tds_read_b32 %1, %8 offset:4\n\tds_read_b32 %2, %8 offset:8\n\tds_read_b32 %3, %8 offset:12\n\t"
+                     "ds_read_b32 %4, %8 offset:16\n\tds_read_b32 %5, %8 offset:20\n\tds_read_b32 %6, %8 offset:24\n\tds_read_b32 %7, %8 offset:28\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3), "=v"(r4), "=v"(r5), "=v"(r6), "=v"(r7) : "v"(a0));
+        acc ^= r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7;
+        a0 = (a0 + (UNALIGNED ? 5u : 4u)) & 127u;
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc + (bad << 24);
+    if (bad) atomicAdd(&cyc[1], (unsigned long long)bad);
+    if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
+}
 
 // the filter's per-offset mix: 3 xor + min3 + min (+ mad + alignbyte), all independent chains
 __global__ void k_mix(uint32_t *out, unsigned long long *cyc, uint32_t s, uint32_t t) {
@@ -124,7 +179,7 @@ __global__ void k_cmp_sgpr(uint32_t *out, unsigned long long *cyc, uint32_t s, u
 
 int main() {
     uint32_t *out; unsigned long long *cyc;
-    CHECK(hipMalloc((void **)&out, 256 * 1024 * 4)); CHECK(hipMalloc((void **)&cyc, 8));
+    CHECK(hipMalloc((void **)&out, 256 * 1024 * 4)); CHECK(hipMalloc((void **)&cyc, 16));
 #define RUN(K, WAVES) { hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); \
     hipLaunchKernelGGL(K, dim3(256), dim3(64 * (WAVES)), 0, 0, out, cyc, 12345u, 678u); \
     hipEventRecord(e0); hipLaunchKernelGGL(K, dim3(256), dim3(64 * (WAVES)), 0, 0, out, cyc, 12345u, 678u); hipEventRecord(e1); \
@@ -166,6 +221,14 @@ int main() {
     RUN(k_xorlit, 16)
     RUN(k_pkadd, 16)
     RUN(k_pkmul, 16)
+    RUN(k_and, 16) RUN(k_andlit, 16) RUN(k_or, 16) RUN(k_lshl, 16) RUN(k_lshri, 16) RUN(k_addu16, 16) RUN(k_maxu16, 16) RUN(k_mullou16, 16)
+    RUN(k_minf32, 16) RUN(k_mov, 16) RUN(k_bfi, 16) RUN(k_mini16, 16) RUN(k_add3, 16) RUN(k_lshlor, 16) RUN(k_mad24v, 16) RUN(k_fmac, 16) RUN(k_mbcnt, 16)
+    CHECK(hipMemset(cyc, 0, 16));
+    RUN(k_ldsread<0>, 16)
+    { unsigned long long b; CHECK(hipMemcpy(&b, cyc + 1, 8, hipMemcpyDeviceToHost)); printf("aligned ds_read_b32: %llu wrong values\n", b); }
+    CHECK(hipMemset(cyc, 0, 16));
+    RUN(k_ldsread<1>, 16)
+    { unsigned long long b; CHECK(hipMemcpy(&b, cyc + 1, 8, hipMemcpyDeviceToHost)); printf("UNALIGNED ds_read_b32: %llu wrong values\n", b); }
     RUN(k_mix, 16)
     RUN(k_mixpk, 16)
     RUN(k_xor, 8) RUN(k_xor, 4) RUN(k_add, 8) RUN(k_min, 8) RUN(k_mix, 8)

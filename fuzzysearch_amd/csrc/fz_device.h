@@ -113,6 +113,8 @@ struct FzScanArgs {
     uint32_t hash_k;                            // odd multiplier of the window hash (24 bits when L > 4)
     uint32_t lut_shift;                         // table slot of a hash h = (h >> lut_shift) & 31
     uint32_t gw;                                // wavefront verification: lanes per candidate (16, 32 or 64)
+    uint32_t qcap;                              // fused in-memory scan: queue entries (= prefetched windows) per wave
+    uint32_t win_pieces;                        // ... and 16-byte pieces per window (LDS-DMA granule)
     uint32_t flags;                             // tuning knobs (0 in production)
     uint32_t H[FZ_MAX_BLOCKS_PER_LAUNCH];       // fast-path hash of each block's n-gram
     uint32_t A[FZ_MAX_BLOCKS_PER_LAUNCH];       // 1st window value per block (little endian)

@@ -35,6 +35,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstddef>
+#include <type_traits>
 #include "fz_device.h"
 
 #define FZ_FILTER_THREADS 256
@@ -45,7 +46,7 @@
 #define FZ_TILE_BITS 14                                    // log2(FZ_TILE_BYTES)
 #define FZ_TITER_MAX ((1u << (32 - FZ_TILE_BITS - 3)) - 1) // tile iterations a queue code can carry
 #define FZ_PAD_FRONT 256                                   // zero bytes before buf[0]
-#define FZ_PAD_BACK 64                                     // zero bytes the kernels may over-read
+#define FZ_PAD_BACK 256                                    // zero bytes the kernels may over-read (halo loads, whole 16-byte window pieces)
 #define FZ_QCAP 256                                        // fast-hit queue entries per wave
 #ifndef FZ_H_SGPR
 #define FZ_H_SGPR(tg) ((tg) <= 4)                            // rare path: block hashes named as kernel arguments (SGPRs) or read from a lane vector
@@ -92,11 +93,20 @@ __device__ __forceinline__ uint32_t fz_load_win(const uint8_t *__restrict__ buf,
     return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(local & 3));
 }
 
-// Per-wave LDS areas, carved from dynamic LDS by fz_wave_lds().
+#ifdef FZ_LAB_TIMING
+static __device__ unsigned long long fz_lab_t[64];
+#define FZ_LAB_STAMP(i) do { if ((blockIdx.x & 1023u) == 512u && threadIdx.x == 0) fz_lab_t[(blockIdx.x >> 10) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define FZ_LAB_STAMP(i) do { } while (0)
+#endif
+
+// Per-wave LDS areas, carved from dynamic LDS by fz_wave_lds() / fz_wave_lds_pref().
 struct FzWaveLds {
-    uint32_t *queue;      // [FZ_QCAP]  fast hits: tile-local offset | block << 14 | tile iteration << 17
-    uint32_t *win;        // [win_dwords * 64]  sequence window of each lane's hit (dword d of lane l at d*64+l)
-    uint16_t *scores;     // [band_w * 64]      ring of DP score slots (slot s of lane l at s*64+l)
+    uint32_t *queue;      // [qcap]  fast hits: tile-local offset | block << 14 | tile iteration << 17
+    uint32_t *win;        // staged layout:     [win_dwords * vlanes]  dword d of the hit in slot l at d*vlanes+l
+                          // prefetched layout: [win_pieces][qcap][16 bytes]  piece c of queue entry e at (c*qcap+e)*16
+    uint16_t *scores;     // [band_w * vlanes]  ring of DP score slots (slot s of lane l at s*vlanes+l); none when prefetched
+    uint32_t win_lds;     // LDS byte address of `win` (the LDS-DMA destination base; wave-uniform)
 };
 
 __host__ __device__ inline uint32_t fz_wave_lds_bytes(uint32_t win_dwords, uint32_t band_w, uint32_t vlanes,
@@ -116,6 +126,25 @@ __device__ __forceinline__ FzWaveLds fz_wave_lds(uint8_t *base, uint32_t wave, u
     if (with_queue) { w.queue = reinterpret_cast<uint32_t *>(p); p += FZ_QCAP * 4; }
     w.win = reinterpret_cast<uint32_t *>(p); p += win_dwords * vlanes * 4;
     w.scores = reinterpret_cast<uint16_t *>(p);
+    w.win_lds = 0;
+    return w;
+}
+
+// Fused in-memory scan: every queue entry owns win_pieces 16-byte pieces of its sequence window, filled by
+// LDS-DMA while the scan goes on (fz_prefetch_windows).
+__host__ __device__ inline uint32_t fz_wave_lds_pref_bytes(uint32_t qcap, uint32_t win_pieces) {
+    return qcap * 4u + win_pieces * qcap * 16u;
+}
+
+// `base_lds` = LDS byte address of `base` (the scan kernel's dynamic LDS starts at address 0).
+__device__ __forceinline__ FzWaveLds fz_wave_lds_pref(uint8_t *base, uint32_t base_lds, uint32_t wave, uint32_t qcap,
+                                                      uint32_t win_pieces) {
+    const uint32_t off = wave * fz_wave_lds_pref_bytes(qcap, win_pieces);
+    FzWaveLds w;
+    w.queue = reinterpret_cast<uint32_t *>(base + off);
+    w.win = reinterpret_cast<uint32_t *>(base + off + qcap * 4u);
+    w.scores = nullptr;
+    w.win_lds = base_lds + off + qcap * 4u;
     return w;
 }
 
@@ -136,21 +165,61 @@ struct FzLdsWindow {
     }
 };
 
+// A window that LDS-DMA laid down: 16-byte piece c of the entry at base + c * rstride.
+struct FzDmaWindow {
+    const uint8_t *base;                                   // piece 0 of this entry
+    uint64_t wbase;                                        // global index of byte 0 of the window
+    uint32_t rstride;                                      // = qcap * 16
+    __device__ __forceinline__ uint8_t at(uint64_t gidx) const {
+        const uint32_t off = (uint32_t)(gidx - wbase);
+        return base[(off >> 4) * rstride + (off & 15u)];
+    }
+};
+
+// Start of the staged window of the hit (block starting at s, index idx) inside the segment that starts at sa:
+// the dword-aligned buffer position at or below max(sa, idx - s - k).
+__device__ __forceinline__ uint64_t fz_window_lo(const FzScanArgs &a, uint64_t idx, uint32_t s, uint64_t sa) {
+    const uint64_t reach = (uint64_t)s + a.k;
+    uint64_t wlo = idx - sa > reach ? idx - reach : sa;
+    if (wlo < a.geom.buf_off) wlo = a.geom.buf_off;
+    return wlo;
+}
+__device__ __forceinline__ uint64_t fz_window_base(const FzScanArgs &a, uint64_t wlo) {
+    return a.geom.buf_off + ((wlo - a.geom.buf_off) & ~(uint64_t)3);
+}
+
+// Asynchronous 16-byte copy global -> LDS (global_load_lds_dwordx4): every active lane l copies 16 bytes from
+// ITS address gsrc to LDS byte address lds_dst + 16 * l (lds_dst wave-uniform, goes through M0).  No VGPR is
+// written; completion is tracked by vmcnt like any load.  hipcc does not count this statement in its own
+// s_waitcnt bookkeeping: its vmcnt(N) waits then cover MORE than it intended (vmcnt(N) = "at most N still
+// in flight", and loads retire in order), never less; the consumer of the LDS bytes waits vmcnt(0) itself.
+__device__ __forceinline__ void fz_glds16(const uint8_t *gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
 __device__ __forceinline__ unsigned long long fz_bcast64(unsigned long long v) {
-    return ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) |
-           __builtin_amdgcn_readfirstlane((uint32_t)v);
+    // (the builtin returns int: widen through uint32_t, or a low word with bit 31 set sign-extends into the high word)
+    return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
+           (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
 }
 
 // ---------------------------------------------------------------------------------------------
-// Wave-level verification of up to a.vlanes candidates: each valid lane owns one (hit = block | idx),
-// the segment it is verified in and the slot vl < a.vlanes of the staging areas.
-//  1. every lane fetches the <= m + 2k window bytes around its candidate into LDS with independent
-//     aligned dword loads (one HBM/L2 round trip instead of one per byte),
-//  2. confirms the n-gram exactly (the filter only compared its first min(L, 8) bytes), then runs the
-//     reference's per-hit logic (fz_verify_lev / fz_verify_subs) out of LDS,
+// Wave-level verification of up to 64 candidates: each valid lane owns one (hit = block | idx), the segment it
+// is verified in and a slot vl of the window area.
+//  1. staged form (PREF = false): every lane fetches the <= m + 2k window bytes around its candidate into LDS
+//     with independent aligned dword loads (slot vl < a.vlanes);
+//     prefetched form (PREF = true, the fused in-memory scan): the window of queue entry vl is already in LDS —
+//     fz_prefetch_windows requested it by LDS-DMA right after the tile that produced the hit, while its cache
+//     lines were still in L2, and the scan went on meanwhile.  (Measured, round 2: the fetch at flush time, one
+//     exposed HBM round trip per wave at the end of its life, cost 0.019 of the 0.226 ms of the headline scan;
+//     the DP itself cost nothing measurable.)
+//  2. the n-gram is confirmed exactly (the filter only compared a hash of its first min(L, 8) bytes), then the
+//     reference's per-hit logic (fz_verify_lev / fz_verify_subs) runs out of LDS,
 //  3. the wave appends its records with ONE global atomic.
 // Returns the number of exactly-confirmed n-gram hits (wave-uniform, statistics).
-template <int MAXK>
+template <int MAXK, bool PREF>
 __device__ __forceinline__ uint32_t fz_wave_verify(const uint8_t *__restrict__ buf, const FzScanArgs &a,
                                                    const uint8_t *pat_lds, const FzWaveLds &w, uint32_t vl,
                                                    uint64_t hit, const FzSeg &sg, bool valid,
@@ -160,49 +229,56 @@ __device__ __forceinline__ uint32_t fz_wave_verify(const uint8_t *__restrict__ b
     const uint64_t idx = fz_hit_index(hit);
     const uint32_t s = g * a.L;
     // window [wlo, whi) in global coordinates; every byte the verification touches lies inside it
-    uint64_t wlo = 0, whi = 0, wbase = 0;
-    if (valid) {
-        const uint64_t reach = (uint64_t)s + a.k;
-        wlo = idx - sg.sa > reach ? idx - reach : sg.sa;
-        if (wlo < a.geom.buf_off) wlo = a.geom.buf_off;
-        whi = idx - s + a.m + a.k;
+    const uint64_t wlo = fz_window_lo(a, idx, s, sg.sa);
+    const uint64_t wbase = fz_window_base(a, wlo);
+    if constexpr (!PREF) {
+        uint64_t whi = idx - s + a.m + a.k;
         const uint64_t lim = a.geom.buf_off + a.geom.buf_len;
         if (whi > lim) whi = lim;
         if (whi > sg.se) whi = sg.se;
-        wbase = a.geom.buf_off + ((wlo - a.geom.buf_off) & ~(uint64_t)3);   // dword-aligned in the buffer
-    }
-    const uint32_t nd = valid ? (uint32_t)((whi - wbase + 3) >> 2) : 0u;
-    const int64_t lbase = (int64_t)(wbase - a.geom.buf_off);
-    // eight loads in flight per lane, then eight LDS stores (a load-store loop would pay the HBM/L2
-    // round trip once per dword: 8 - 21 serial round trips per flush)
-    for (uint32_t d0 = 0; d0 < a.win_dwords; d0 += 8) {
-        uint32_t v[8];
+        const uint32_t nd = valid ? (uint32_t)((whi - wbase + 3) >> 2) : 0u;
+        const int64_t lbase = (int64_t)(wbase - a.geom.buf_off);
+        // eight loads in flight per lane, then eight LDS stores (a load-store loop would pay the HBM/L2
+        // round trip once per dword: 8 - 21 serial round trips per flush)
+        for (uint32_t d0 = 0; d0 < a.win_dwords; d0 += 8) {
+            uint32_t v[8];
 #pragma unroll
-        for (uint32_t j = 0; j < 8; ++j)
-            v[j] = (d0 + j < nd) ? *reinterpret_cast<const uint32_t *>(buf + lbase + (int64_t)(d0 + j) * 4) : 0u;
+            for (uint32_t j = 0; j < 8; ++j)
+                v[j] = (d0 + j < nd) ? *reinterpret_cast<const uint32_t *>(buf + lbase + (int64_t)(d0 + j) * 4) : 0u;
 #pragma unroll
-        for (uint32_t j = 0; j < 8; ++j)
-            if (d0 + j < nd) w.win[(d0 + j) * a.vlanes + vl] = v[j];
+            for (uint32_t j = 0; j < 8; ++j)
+                if (d0 + j < nd) w.win[(d0 + j) * a.vlanes + vl] = v[j];
+        }
+        fz_wave_lds_sync();
     }
-    fz_wave_lds_sync();
     FzRec rec;
     bool ok = false;
-    FzLdsWindow t{reinterpret_cast<const uint8_t *>(w.win + vl), wbase, a.vlanes * 4u};
-    if (valid) {
-        const uint8_t *ng = pat_lds + s;
-        for (uint32_t b = 0; b < a.L; ++b)
-            if (ng[b] != t.at(idx + b)) { valid = false; break; }
-    }
-    const uint32_t confirmed = (uint32_t)__popcll(__ballot(valid));
-    if (valid) {
-        if (a.mode == FZ_MODE_LEV) {
-            FzLdsScores sc{w.scores + vl, a.vlanes};
-            ok = fz_verify_lev<MAXK>(sc, t, sg.sa, sg.se, pat_lds, a.m, a.k, a.L, s, idx, rec);
-        } else {
-            ok = fz_verify_subs(t, pat_lds, a.m, a.k, a.L, s, idx, rec);
+    auto run = [&](const auto &t) {
+        if (valid) {
+            const uint8_t *ng = pat_lds + s;
+            for (uint32_t b = 0; b < a.L; ++b)
+                if (ng[b] != t.at(idx + b)) { valid = false; break; }
         }
+        const uint32_t confirmed = (uint32_t)__popcll(__ballot(valid));
+        FZ_LAB_STAMP(5);
+        if (valid) {
+            if (a.mode == FZ_MODE_LEV) {
+                FzLdsScores sc{w.scores + (PREF ? 0u : vl), a.vlanes};
+                ok = fz_verify_lev<MAXK>(sc, t, sg.sa, sg.se, pat_lds, a.m, a.k, a.L, s, idx, rec);
+            } else {
+                ok = fz_verify_subs(t, pat_lds, a.m, a.k, a.L, s, idx, rec);
+            }
+        }
+        return confirmed;
+    };
+    uint32_t confirmed;
+    if constexpr (PREF) {
+        confirmed = run(FzDmaWindow{reinterpret_cast<const uint8_t *>(w.win) + vl * 16u, wbase, a.qcap * 16u});
+    } else {
+        confirmed = run(FzLdsWindow{reinterpret_cast<const uint8_t *>(w.win + vl), wbase, a.vlanes * 4u});
     }
     const unsigned long long mask = __ballot(ok);
+    FZ_LAB_STAMP(6);
     if (mask) {
         unsigned long long base = 0;
         if (lane == 0) base = atomicAdd(&counters[1], (unsigned long long)__popcll(mask));
@@ -265,20 +341,58 @@ __device__ __forceinline__ uint32_t fz_code(uint32_t off, uint32_t blk, uint32_t
     return off | (blk << FZ_TILE_BITS) | (titer << (FZ_TILE_BITS + 3));
 }
 
+// Queue entry -> (block of this launch, local byte position in the buffer).
+__device__ __forceinline__ uint64_t fz_code_local(uint32_t code, uint32_t &blk) {
+    blk = (code >> FZ_TILE_BITS) & 7u;
+    const uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)(code >> (FZ_TILE_BITS + 3)) * gridDim.x;
+    return tile * (uint64_t)FZ_TILE_BYTES + (code & (FZ_TILE_BYTES - 1u));
+}
+
+// Fused in-memory scan: request the sequence windows of the queue entries [qf, qn) — a.win_pieces LDS-DMA
+// copies of 16 bytes per entry, lane = entry, destination = the entry's slot of the window area.  Called
+// after every tile that queued something, i.e. while the lines are still in L2 (the re-fetch at flush time
+// used to be 10 % extra HBM traffic, profiles/r01_pmc_summary.json), and nothing waits for the data before
+// the flush.  Entries that the range check will drop are fetched as well (their address is inside the
+// buffer; cheaper than testing here).
+__device__ __forceinline__ void fz_prefetch_windows(const uint8_t *__restrict__ buf, const FzScanArgs &a,
+                                                    const FzWaveLds &w, uint32_t qf, uint32_t qn) {
+    const uint32_t lane = fz_lane();
+    // The queue entries were stored by this wave: a wave's LDS operations are performed in issue order, so the
+    // reads below see them; only the compiler must not reorder.  (fz_wave_lds_sync() would be wrong here: its
+    // workgroup-scope release is an s_waitcnt vmcnt(0), i.e. a wait for the rows just requested for the next tile.)
+    asm volatile("" ::: "memory");
+    for (uint32_t e0 = qf; e0 < qn; e0 += 64u) {
+        const uint32_t e = e0 + lane;
+        if (e < qn) {
+            uint32_t blk;
+            const uint64_t idx = a.geom.buf_off + fz_code_local(w.queue[e], blk);
+            const uint64_t wbase = fz_window_base(a, fz_window_lo(a, idx, (a.g0 + blk) * a.L, 0));
+            const uint8_t *src = buf + (wbase - a.geom.buf_off);
+            for (uint32_t c = 0; c < a.win_pieces; ++c)
+                fz_glds16(src + 16u * c, (uint32_t)__builtin_amdgcn_readfirstlane((int)(w.win_lds + (c * a.qcap + e0) * 16u)));
+        }
+    }
+}
+
 // Process queue entries [0, qn): range-check, then verify in place (FUSED) or confirm against HBM and
 // bulk-append to the global hit list.  SEG: the sequence is a batch of file chunks (segments), a
 // position may belong to two of them and is range-checked / verified once per segment; compiled
 // separately because the in-memory search (one segment, the whole sequence) must not pay for it in
-// registers.  Returns the number of confirmed n-gram hits.
+// registers.  FUSED && !SEG: the windows were prefetched (entry e -> slot e).  Returns the number of
+// confirmed n-gram hits.
 template <bool FUSED, bool SEG>
 __device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ buf, const FzScanArgs &a,
                                                    const uint8_t *pat_lds, const FzWaveLds &w, uint32_t qn,
                                                    uint64_t *__restrict__ hits, FzRec *__restrict__ recs,
                                                    unsigned long long *__restrict__ counters) {
+    constexpr bool PREF = FUSED && !SEG;
     const uint32_t lane = fz_lane();
     uint32_t confirmed = 0;
+    FZ_LAB_STAMP(1);
+    if (PREF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every prefetched window has landed in LDS
     fz_wave_lds_sync();
-    const uint32_t width = FUSED ? a.vlanes : 64u;          // candidates handled per pass
+    FZ_LAB_STAMP(2);
+    const uint32_t width = (FUSED && !PREF) ? a.vlanes : 64u;  // candidates handled per pass
     const uint32_t ncand = (SEG && FUSED) ? fz_segment_candidates(a.geom) : 1u;
     for (uint32_t e0 = 0; e0 < qn; e0 += width) {
         for (uint32_t c = 0; c < ncand; ++c) {               // one inlined copy of the verification for both segments
@@ -290,10 +404,7 @@ __device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ b
             FzSeg sg;
             sg.sa = 0; sg.se = a.geom.n; sg.j = 0; sg.ok = 1;
             if (valid) {
-                const uint32_t code = w.queue[e];
-                blk = (code >> FZ_TILE_BITS) & 7u;
-                const uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)(code >> (FZ_TILE_BITS + 3)) * gridDim.x;
-                local = tile * (uint64_t)FZ_TILE_BYTES + (code & (FZ_TILE_BYTES - 1u));
+                local = fz_code_local(w.queue[e], blk);
                 const uint64_t idx = a.geom.buf_off + local;
                 if (!SEG) {
                     valid = fz_hit_in_range(a, blk, idx, sg);
@@ -309,7 +420,11 @@ __device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ b
             }
             if (FUSED) {
                 if (SEG && c && !__ballot(valid)) continue;
-                confirmed += fz_wave_verify<4>(buf, a, pat_lds, w, lane, hit, sg, valid, recs, counters);
+#ifdef FZ_LAB_NOVERIFY
+                confirmed += (uint32_t)__popcll(__ballot(valid));
+#else
+                confirmed += fz_wave_verify<4, PREF>(buf, a, pat_lds, w, PREF ? e : lane, hit, sg, valid, recs, counters);
+#endif
             } else {
                 if (valid) valid = fz_confirm(buf, a, blk, local);
                 const unsigned long long mask = __ballot(valid);
@@ -324,6 +439,7 @@ __device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ b
         }
     }
     fz_wave_lds_sync();
+    FZ_LAB_STAMP(3);
     return confirmed;
 }
 
@@ -344,12 +460,23 @@ __device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ b
 // Fast hits are queued per wave ACROSS tiles and processed 64 at a time (full lanes, one latency
 // chain per ~100 candidates instead of one per tile).  A tile denser than the queue is re-scanned
 // by enumeration ("slow tile": correctness path for pathological inputs).
+// Half-tile software pipeline: rows 0-1 of the NEXT tile are requested before rows 2-3 of this one are
+// tested, so a wave always has two rows (3 KiB) of loads in flight while it computes, on the same 24 data
+// VGPRs as "load a tile, test a tile" (measured: 0.236 -> 0.227 ms on the headline workload).
+// What round 2 measured about this kernel (benchmarks/lab_*.sh, 1 GiB DNA, |p| = 20, k = 2):
+//   * one VALU op less per offset (slot address by v_and only): no change -> the hot loop is not bound by
+//     VALU issue; the scan without candidates takes 0.200 ms at 7, 6, 5 and 4 workgroups per CU alike;
+//   * without verification 0.206 ms, with the window fetch but no DP 0.225 ms, complete 0.226 ms: what
+//     candidates cost was the exposed fetch of their windows at the end of every wave's life -> prefetched
+//     by LDS-DMA now (fz_prefetch_windows).
 // 7 waves per SIMD (72 VGPRs): measured 2-3 % faster than the natural 79-VGPR / 6-wave allocation;
 // 8 waves (64 VGPRs) spills 27 VGPRs in the verify path and is 50 % slower.
 template <int TG, int NWIN, int DH, bool FUSED, bool SEG>
 __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_eu(7, 7))) void fz_scan_kernel(
     const uint8_t *__restrict__ buf, const FzScanArgs a, uint64_t ntiles,
     uint64_t *__restrict__ hits, FzRec *__restrict__ recs, unsigned long long *__restrict__ counters) {
+    constexpr bool PREF = FUSED && !SEG;              // candidate windows are prefetched by LDS-DMA
+    FZ_LAB_STAMP(0);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t mpad = (a.m + 15u) & ~15u;
     // [32] hash living in the slot.  The kernel has no static LDS, so the dynamic area, and with it this
@@ -374,8 +501,11 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
             if (fz_lane() == g) hvec = a.H[g];
     }
     __syncthreads();
-    const FzWaveLds w = fz_wave_lds(smem + FZ_LUT_BYTES + mpad, threadIdx.x >> 6, FUSED ? a.win_dwords : 0u,
-                                    FUSED ? a.band_w : 0u, a.vlanes, true);
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t qcap = PREF ? a.qcap : (uint32_t)FZ_QCAP;   // queue entries per wave
+    const FzWaveLds w = PREF ? fz_wave_lds_pref(smem + FZ_LUT_BYTES + mpad, FZ_LUT_BYTES + mpad, wave, qcap, a.win_pieces)
+                             : fz_wave_lds(smem + FZ_LUT_BYTES + mpad, wave, FUSED ? a.win_dwords : 0u,
+                                           FUSED ? a.band_w : 0u, a.vlanes, true);
     const uint32_t hash_k = a.hash_k;
     // byte address of a hash's slot = (h >> (lut_shift - 2)) & 0x7c: two VGPR-only VALU ops (a shift
     // amount in an SGPR or an SDWA byte select would issue at half the rate, benchmarks/valu_rates.hip)
@@ -385,17 +515,68 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
     const uint32_t lane = fz_lane();
     const uint32_t lane_off = threadIdx.x * 16u;
     uint32_t qn = 0;                                  // wave-uniform queue fill
+    uint32_t qf = 0;                                  // PREF: entries [0, qf) have their windows requested
     uint32_t confirmed = 0;                           // wave-uniform statistics
     uint32_t titer = 0;                               // tile iteration of this workgroup
     uint64_t tile = blockIdx.x;
     bool slow = false;                                // a tile is being re-scanned by enumeration
     uint32_t slow_pos = 0;
 
+    // the filter over one row (row R of the tile)
+    auto test_row = [&](const uint4 &v, const uint2 &h, auto Rc) {
+        constexpr int r = decltype(Rc)::value;
+        const uint32_t w6[6] = {v.x, v.y, v.z, v.w, h.x, h.y};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                 // 4 byte offsets per ballot
+            uint32_t hv[4], am[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int o = 4 * j + i;
+                const uint32_t x = FZ_WIN(w6, o);
+                if (NWIN == 1) hv[i] = (x & mask1) * hash_k;                             // v_mul_lo_u32
+                else hv[i] = __umul24(FZ_WIN(w6, o + DH), hash_k) + x;                   // v_mad_u32_u24
+                uint32_t slot4;
+                asm("v_lshrrev_b32 %0, %1, %2\n\tv_and_b32 %0, " FZ_LUT_ADDR_MASK_STR ", %0" : "=v"(slot4) : "v"(slot_shift), "v"(hv[i]));
+                am[i] = hv[i] ^ *reinterpret_cast<FzLdsU32 *>(slot4);   // lut sits at LDS address 0
+            }
+            const uint32_t acc = min(min(am[0], am[1]), min(am[2], am[3]));
+            if (__builtin_expect(__ballot(acc == 0) != 0, 0)) {   // wave-uniform, rare: some lane, some offset
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (__ballot(am[i] == 0)) {           // which offset (scalar branch)
+                        // which block(s): equal n-grams share a slot
+                        auto push = [&](uint32_t g) {
+                            const uint32_t hg = FZ_H_SGPR(TG) ? a.H[g] : (uint32_t)__builtin_amdgcn_readlane((int)hvec, (int)g);
+                            const unsigned long long mk = __ballot(hv[i] == hg);
+                            if (mk) {
+                                const uint32_t slot = qn + fz_rank(mk);
+                                // recomputed here: a copy kept in a VGPR (LICM hoists the loop-invariant codes) costs
+                                // a scratch round trip per firing once it is spilled
+                                uint32_t code = threadIdx.x;
+                                asm volatile("v_lshlrev_b32 %0, 4, %0" : "+v"(code));
+                                code = fz_code(code + (uint32_t)(r * FZ_ROW_BYTES + 4 * j + i), g, titer);
+                                if (hv[i] == hg && slot < qcap) w.queue[slot] = code;
+                                qn += (uint32_t)__popcll(mk);
+                            }
+                        };
+                        if constexpr (TG <= 4) {          // unrolled: 6 % faster at 17 % firing groups (DNA, L = 6)
+#pragma unroll
+                            for (int g = 0; g < TG; ++g) push((uint32_t)g);
+                        } else {                          // rolled: 64 x 8 unrolled copies stop the row loop from unrolling
+#pragma unroll 1
+                            for (uint32_t g = 0; g < (uint32_t)TG; ++g) push(g);
+                        }
+                    }
+                }
+            }
+        }
+    };
+
     for (;;) {
         if (slow) {
             // enumerate (row, offset, block) candidates of tile `tile`, 64 lanes at a time
             const uint32_t steps = FZ_FILTER_ROWS * 16u * a.nblk;
-            while (slow_pos < steps && qn + 64u <= FZ_QCAP) {
+            while (slow_pos < steps && qn + 64u <= qcap) {
                 const uint32_t blk = slow_pos % a.nblk;
                 const uint32_t ro = slow_pos / a.nblk;
                 w.queue[qn + lane] = fz_code((ro >> 4) * FZ_ROW_BYTES + lane_off + (ro & 15u), blk, titer);
@@ -403,81 +584,71 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                 ++slow_pos;
             }
             if (slow_pos >= steps) { slow = false; tile += gridDim.x; ++titer; }
-        } else {
-            while (tile < ntiles && qn <= FZ_QCAP / 2) {
-                const uint64_t tile_base = tile * (uint64_t)FZ_TILE_BYTES;
-                uint4 v[FZ_FILTER_ROWS];
-                uint2 h[FZ_FILTER_ROWS];
+        } else if (tile < ntiles && qn <= qcap / 2) {
+            uint4 va[2], vb[2];
+            uint2 ha[2], hb[2];
+            bool pre;                                 // va / ha hold rows 0-1 of the next tile
+            {
+                const uint8_t *tsrc = buf + fz_bcast64(tile * (uint64_t)FZ_TILE_BYTES);
 #pragma unroll
-                for (int r = 0; r < FZ_FILTER_ROWS; ++r) {
-                    const uint8_t *src = buf + tile_base + lane_off + (uint64_t)r * FZ_ROW_BYTES;
-                    v[r] = *reinterpret_cast<const uint4 *>(src);
-                    h[r] = *reinterpret_cast<const uint2 *>(src + 16);
+                for (int r = 0; r < 2; ++r) {
+                    va[r] = *reinterpret_cast<const uint4 *>(tsrc + r * FZ_ROW_BYTES + lane_off);
+                    ha[r] = *reinterpret_cast<const uint2 *>(tsrc + r * FZ_ROW_BYTES + lane_off + 16);
                 }
+            }
+            do {
+                const uint8_t *tsrc = buf + fz_bcast64(tile * (uint64_t)FZ_TILE_BYTES);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    vb[r] = *reinterpret_cast<const uint4 *>(tsrc + (r + 2) * FZ_ROW_BYTES + lane_off);
+                    hb[r] = *reinterpret_cast<const uint2 *>(tsrc + (r + 2) * FZ_ROW_BYTES + lane_off + 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);    // all loads are issued before the first use
                 const uint32_t q_tile = qn;
+                test_row(va[0], ha[0], std::integral_constant<int, 0>{});
+                test_row(va[1], ha[1], std::integral_constant<int, 1>{});
+                const uint64_t next = tile + gridDim.x;
+                pre = next < ntiles && qn <= qcap / 2;
+                {   // unconditional (a branch here would make the compiler wait for the prefetch at the join):
+                    // without a next tile the loads re-read this one (L2 hits, results unused)
+                    const uint8_t *nsrc = buf + fz_bcast64((pre ? next : tile) * (uint64_t)FZ_TILE_BYTES);
 #pragma unroll
-                for (int r = 0; r < FZ_FILTER_ROWS; ++r) {
-                    const uint32_t w6[6] = {v[r].x, v[r].y, v[r].z, v[r].w, h[r].x, h[r].y};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {     // 4 byte offsets per ballot
-                        uint32_t hv[4], am[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int o = 4 * j + i;
-                            const uint32_t x = FZ_WIN(w6, o);
-                            if (NWIN == 1) hv[i] = (x & mask1) * hash_k;                             // v_mul_lo_u32
-                            else hv[i] = __umul24(FZ_WIN(w6, o + DH), hash_k) + x;                   // v_mad_u32_u24
-                            uint32_t slot4;
-                            asm("v_lshrrev_b32 %0, %1, %2\n\tv_and_b32 %0, " FZ_LUT_ADDR_MASK_STR ", %0" : "=v"(slot4) : "v"(slot_shift), "v"(hv[i]));
-                            am[i] = hv[i] ^ *reinterpret_cast<FzLdsU32 *>(slot4);   // lut sits at LDS address 0
-                        }
-                        const uint32_t acc = min(min(am[0], am[1]), min(am[2], am[3]));
-                        if (__builtin_expect(__ballot(acc == 0) != 0, 0)) {   // wave-uniform, rare: some lane, some offset
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                if (__ballot(am[i] == 0)) {           // which offset (scalar branch)
-                                    // which block(s): equal n-grams share a slot
-                                    auto push = [&](uint32_t g) {
-                                        const uint32_t hg = FZ_H_SGPR(TG) ? a.H[g] : (uint32_t)__builtin_amdgcn_readlane((int)hvec, (int)g);
-                                        const unsigned long long mk = __ballot(hv[i] == hg);
-                                        if (mk) {
-                                            const uint32_t slot = qn + fz_rank(mk);
-                                            // the empty asm keeps LICM from hoisting the loop-invariant
-                                            // queue codes into VGPRs
-                                            uint32_t code = threadIdx.x;           // recomputed here: a spilled copy costs a scratch round trip per firing
-                                            asm volatile("v_lshlrev_b32 %0, 4, %0" : "+v"(code));
-                                            code = fz_code(code + (uint32_t)(r * FZ_ROW_BYTES + 4 * j + i), g, titer);
-                                            if (hv[i] == hg && slot < FZ_QCAP) w.queue[slot] = code;
-                                            qn += (uint32_t)__popcll(mk);
-                                        }
-                                    };
-                                    if constexpr (TG <= 4) {          // unrolled: 6 % faster at 17 % firing groups (DNA, L = 6)
-#pragma unroll
-                                        for (int g = 0; g < TG; ++g) push((uint32_t)g);
-                                    } else {                          // rolled: 64 x 8 unrolled copies stop the row loop from unrolling
-#pragma unroll 1
-                                        for (uint32_t g = 0; g < (uint32_t)TG; ++g) push(g);
-                                    }
-                                }
-                            }
-                        }
+                    for (int r = 0; r < 2; ++r) {
+                        va[r] = *reinterpret_cast<const uint4 *>(nsrc + r * FZ_ROW_BYTES + lane_off);
+                        ha[r] = *reinterpret_cast<const uint2 *>(nsrc + r * FZ_ROW_BYTES + lane_off + 16);
                     }
                 }
-                if (qn > FZ_QCAP) {                   // this tile overflowed the queue: drop its
+                __builtin_amdgcn_sched_barrier(0);
+                test_row(vb[0], hb[0], std::integral_constant<int, 2>{});
+                test_row(vb[1], hb[1], std::integral_constant<int, 3>{});
+                if (qn > qcap) {                      // this tile overflowed the queue: drop its
                     qn = q_tile;                      // partial entries and re-scan it by enumeration
                     slow = true;
                     slow_pos = 0;
                     break;
                 }
-                tile += gridDim.x;
+                if (PREF && qn > qf) { fz_prefetch_windows(buf, a, w, qf, qn); qf = qn; }
+                tile = next;
                 ++titer;
-            }
+            } while (pre);                            // else: the end of the sequence, or a flush is due
         }
-        if (qn) confirmed += fz_queue_flush<FUSED, SEG>(buf, a, pat_lds, w, qn, hits, recs, counters);
+        if (qn) {
+            if (PREF && qn > qf) fz_prefetch_windows(buf, a, w, qf, qn);
+            confirmed += fz_queue_flush<FUSED, SEG>(buf, a, pat_lds, w, qn, hits, recs, counters);
+        }
         qn = 0;
+        qf = 0;
         if (!slow && tile >= ntiles) break;
     }
     if (FUSED && lane == 0 && confirmed) atomicAdd(&counters[8 + (blockIdx.x & 63u)], (unsigned long long)confirmed);
+#ifdef FZ_LAB_TIMING
+    FZ_LAB_STAMP(4);
+    if ((blockIdx.x & 1023u) == 512u && threadIdx.x == 0) {
+        const unsigned long long *t = fz_lab_t + (blockIdx.x >> 10) * 8;
+        printf("wg %u: life %llu cyc; scan %llu, wait-dma %llu, decode+range+exact %llu, dp %llu, append %llu, tail %llu; confirmed %u\n", blockIdx.x,
+               t[4] - t[0], t[1] - t[0], t[2] - t[1], t[5] - t[2], t[6] - t[5], t[3] - t[6], t[4] - t[3], confirmed);
+    }
+#endif
     fz_finish_launch(a, counters, lut);
 }
 
@@ -506,7 +677,7 @@ __global__ void fz_verify_kernel(const uint8_t *__restrict__ buf, const FzScanAr
             const FzSeg sg = fz_segment(a.geom, fz_hit_index(hit), c);
             const bool valid = have && fz_hit_in_range_s(a, fz_hit_block(hit) * a.L, fz_hit_index(hit), sg);
             if (!__ballot(valid)) continue;
-            fz_wave_verify<FZ_REG_BAND_MAX>(buf, a, pat_lds, w, fz_lane(), hit, sg, valid, recs, counters);
+            fz_wave_verify<FZ_REG_BAND_MAX, false>(buf, a, pat_lds, w, fz_lane(), hit, sg, valid, recs, counters);
         }
     }
     fz_finish_launch(a, counters, reinterpret_cast<uint32_t *>(smem));

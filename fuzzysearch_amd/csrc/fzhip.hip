@@ -248,8 +248,14 @@ ScanKernel scan_kernel_f(int tg, int nwin, int dh) {
 // The segmented variants (file API) only exist where a segment changes the outcome: Levenshtein /
 // generic clamps.  Exact and substitutions-only windows fit exactly one chunk (the host assigns it).
 ScanKernel scan_kernel(int tg, int nwin, int dh, bool fused, bool seg) {
+#ifdef FZ_LAB_ONLY      // lab builds (benchmarks/lab_build.sh): only the instances of the headline and exact-search workloads
+    if (tg == 3 && nwin == 2 && dh == 3 && fused && !seg) return fz_scan_kernel<3, 2, 3, true, false>;
+    if (tg == 1 && nwin == 2 && dh == 5 && !fused && !seg) return fz_scan_kernel<1, 2, 5, false, false>;
+    return nullptr;
+#else
     if (seg) return fused ? scan_kernel_f<true, true>(tg, nwin, dh) : scan_kernel_f<false, true>(tg, nwin, dh);
     return fused ? scan_kernel_f<true, false>(tg, nwin, dh) : scan_kernel_f<false, false>(tg, nwin, dh);
+#endif
 }
 
 int pick_tg(uint32_t nblk) {
@@ -295,7 +301,11 @@ uint32_t choose_launch_blocks(const uint8_t *p, const uint32_t *starts, uint32_t
         uint32_t hb[FZ_MAX_BLOCKS_PER_LAUNCH];
         uint32_t nb = 0;
         for (; nb < max_blocks && g0 + nb < G; ++nb) hb[nb] = hg.hash(p + starts[g0 + nb], L, kk);
+#ifdef FZ_SLOT_AND_ONLY
+        for (int shift = 2; shift >= 2; shift -= FZ_LUT_BITS) {
+#else
         for (int shift = 32 - FZ_LUT_BITS; shift >= 2; shift -= FZ_LUT_BITS) {
+#endif
             uint32_t slot_hash[FZ_LUT_SLOTS];
             bool used[FZ_LUT_SLOTS] = {false};
             uint32_t fit = 0;
@@ -391,9 +401,22 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     // 64 lanes -> 31.6 KB LDS, 5 workgroups/CU, scan 0.540 ms; candidates are rare there anyway).
     static const uint32_t target = []() { const char *e = getenv("FZ_FUSED_TARGET_KB"); int v = e ? atoi(e) : 0; return (uint32_t)(v > 0 ? v : 18) * 1024u; }();
     fa.vlanes = 64;
-    while (fa.vlanes > 16 && mpad + FZ_LUT_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, fa.vlanes, true) > target)
-        fa.vlanes >>= 1;
-    const uint32_t fused_lds = mpad + FZ_LUT_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, fa.vlanes, true);
+    uint32_t fused_lds;
+    if (sh.geom.seg_stride == 0) {
+        // in-memory search: the windows of queued candidates are prefetched by LDS-DMA, 16-byte pieces, one slot
+        // per queue entry (fz_prefetch_windows); the queue shrinks for long patterns (a tile that outgrows it is
+        // re-scanned by enumeration, 64 entries at a time: 64 is the floor)
+        fa.win_pieces = (q.m + 2 * q.k + 3 + 15) / 16;           // window <= m + 2k bytes + 3 of dword alignment
+        fa.qcap = 128;
+        while (fa.qcap > 64 && mpad + FZ_LUT_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_pref_bytes(fa.qcap, fa.win_pieces) > target + 4096)
+            fa.qcap >>= 1;
+        fused_lds = mpad + FZ_LUT_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_pref_bytes(fa.qcap, fa.win_pieces);
+        if (fa.win_pieces * 16u + 16u > FZ_PAD_BACK) fused_lds = ~0u;   // the last pieces may lie past the sequence: inside the padding only
+    } else {
+        while (fa.vlanes > 16 && mpad + FZ_LUT_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, fa.vlanes, true) > target)
+            fa.vlanes >>= 1;
+        fused_lds = mpad + FZ_LUT_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, fa.vlanes, true);
+    }
     // k > 4 (register band too wide for the scan kernel's VGPR budget) -> verify in a kernel of its own
     fa.fused = (with_verify && fused_lds <= kFusedLdsBudget && (q.mode != FZ_MODE_LEV || q.k <= 4)) ? 1u : 0u;
     const uint32_t scan_lds = fa.fused ? fused_lds : mpad + FZ_LUT_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(0, 0, 64, true);
@@ -423,6 +446,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
         const int tg = pick_tg(nblk);
         for (int b = (int)nblk; b < tg; ++b) fa.H[b] = fa.H[0];      // compiled-in spare blocks: dropped by the range check
         ScanKernel kern = scan_kernel(tg, nwin, dh, fa.fused != 0, sh.geom.seg_stride != 0);
+        if (!kern) return fail(FZ_EUNSUPPORTED, "this (lab) build carries no scan kernel for tg=%d nwin=%d dh=%d", tg, nwin, dh);
         static const uint32_t extra_lds = []() { const char *e = getenv("FZ_EXTRA_LDS_KB"); return e ? (uint32_t)atoi(e) * 1024u : 0u; }();
         hipLaunchKernelGGL(kern, grid, dim3(FZ_FILTER_THREADS), scan_lds + extra_lds, d.stream, sh.d_buf, fa, ntiles, d.d_hits, recs,
                            counters);
