@@ -272,6 +272,17 @@ FZ_HD bool fz_expand_band(SubF sub, uint32_t sublen, WinF win, uint32_t winlen, 
     return false;
 }
 
+// A byte string held in N registers: byte q of the string = byte (q & 3) of r[q >> 2].
+// (Round 2 also measured the whole band DP on such registers — four rows per loop trip, every character a static
+// byte of a register, dwords streamed a trip ahead: the rows of a flush took 6 300 instead of 11 500 cycles of
+// latency but twice the wave instructions, and the fused scan is bound by VALU issue: 0.231 -> 0.235 ms.  Not kept;
+// commit a3442c1^..HEAD~ has it with its host test.)
+template <int N>
+struct FzBytes {
+    uint32_t r[N];
+    FZ_HD uint32_t at(int q) const { return (r[q >> 2] >> (8 * (q & 3))) & 0xffu; }
+};
+
 // Budget-dispatched expansion: register band for k <= MAXK (<= FZ_REG_BAND_MAX), LDS ring otherwise.
 // MAXK is a compile-time cap so that a kernel only pays (in VGPRs) for the band widths it may run:
 // the fused scan kernel uses 4 (keeps it at <= 64 VGPRs), the stand-alone verify kernel 8.

@@ -47,6 +47,9 @@
 #define FZ_TITER_MAX ((1u << (32 - FZ_TILE_BITS - 3)) - 1) // tile iterations a queue code can carry
 #define FZ_PAD_FRONT 256                                   // zero bytes before buf[0]
 #define FZ_PAD_BACK 256                                    // zero bytes the kernels may over-read (halo loads, whole 16-byte window pieces)
+#ifndef FZ_GROUP
+#define FZ_GROUP 4                                         // byte offsets tested per wave-uniform branch (4 or 8)
+#endif
 #define FZ_QCAP 256                                        // fast-hit queue entries per wave
 #ifndef FZ_H_SGPR
 #define FZ_H_SGPR(tg) ((tg) <= 4)                            // rare path: block hashes named as kernel arguments (SGPRs) or read from a lane vector
@@ -174,7 +177,26 @@ struct FzDmaWindow {
         const uint32_t off = (uint32_t)(gidx - wbase);
         return base[(off >> 4) * rstride + (off & 15u)];
     }
+    // aligned dword at window byte offset o (o % 4 == 0); offsets past the staged pieces read other LDS
+    // bytes (or 0 beyond the allocation): callers only use the bytes they know to be staged
+    __device__ __forceinline__ uint32_t dword(uint32_t o) const {
+        return *reinterpret_cast<const uint32_t *>(base + (o >> 4) * rstride + (o & 15u));
+    }
 };
+
+// N dwords of the byte string that starts at byte offset `off` of a dword-readable source: rd(o) = the aligned
+// dword at byte offset o.  One v_alignbyte per dword brings the string to byte 0 of the result.
+template <int N, class Rd>
+__device__ __forceinline__ FzBytes<N> fz_load_bytes(Rd rd, uint32_t off) {
+    const uint32_t a0 = off & ~3u, sh = off & 3u;
+    uint32_t raw[N + 1];
+#pragma unroll
+    for (int q = 0; q <= N; ++q) raw[q] = rd(a0 + 4u * (uint32_t)q);
+    FzBytes<N> b;
+#pragma unroll
+    for (int q = 0; q < N; ++q) b.r[q] = __builtin_amdgcn_alignbyte(raw[q + 1], raw[q], sh);
+    return b;
+}
 
 // Start of the staged window of the hit (block starting at s, index idx) inside the segment that starts at sa:
 // the dword-aligned buffer position at or below max(sa, idx - s - k).
@@ -254,20 +276,35 @@ __device__ __forceinline__ uint32_t fz_wave_verify(const uint8_t *__restrict__ b
     FzRec rec;
     bool ok = false;
     auto run = [&](const auto &t) {
-        if (valid) {
-            const uint8_t *ng = pat_lds + s;
-            for (uint32_t b = 0; b < a.L; ++b)
-                if (ng[b] != t.at(idx + b)) { valid = false; break; }
+        auto prd = [&](uint32_t o) -> uint32_t { return *reinterpret_cast<const uint32_t *>(pat_lds + o); };
+        if constexpr (PREF) {
+            // exact n-gram test on registers: 8 bytes of text and pattern, masked to min(L, 8) (uniform), the
+            // rest (L > 8) byte by byte
+            const uint32_t off = (uint32_t)(idx - wbase);
+            const FzBytes<2> tn = fz_load_bytes<2>([&](uint32_t o) { return t.dword(o); }, off);
+            const FzBytes<2> pn = fz_load_bytes<2>(prd, s);
+            const uint32_t m0 = a.L >= 4 ? 0xffffffffu : (1u << (8u * a.L)) - 1u;
+            const uint32_t m1 = a.L >= 8 ? 0xffffffffu : a.L > 4 ? (1u << (8u * (a.L - 4u))) - 1u : 0u;
+            if ((((tn.r[0] ^ pn.r[0]) & m0) | ((tn.r[1] ^ pn.r[1]) & m1)) != 0) valid = false;
+            if (a.L > 8 && valid) {
+                const uint8_t *ng = pat_lds + s;
+                for (uint32_t b = 8; b < a.L; ++b)
+                    if (ng[b] != t.at(idx + b)) { valid = false; break; }
+            }
+        } else {
+            if (valid) {
+                const uint8_t *ng = pat_lds + s;
+                for (uint32_t b = 0; b < a.L; ++b)
+                    if (ng[b] != t.at(idx + b)) { valid = false; break; }
+            }
         }
         const uint32_t confirmed = (uint32_t)__popcll(__ballot(valid));
         FZ_LAB_STAMP(5);
-        if (valid) {
-            if (a.mode == FZ_MODE_LEV) {
-                FzLdsScores sc{w.scores + (PREF ? 0u : vl), a.vlanes};
-                ok = fz_verify_lev<MAXK>(sc, t, sg.sa, sg.se, pat_lds, a.m, a.k, a.L, s, idx, rec);
-            } else {
-                ok = fz_verify_subs(t, pat_lds, a.m, a.k, a.L, s, idx, rec);
-            }
+        if (a.mode == FZ_MODE_LEV) {
+            FzLdsScores sc{w.scores + (PREF ? 0u : vl), a.vlanes};
+            if (valid) ok = fz_verify_lev<MAXK>(sc, t, sg.sa, sg.se, pat_lds, a.m, a.k, a.L, s, idx, rec);
+        } else if (valid) {
+            ok = fz_verify_subs(t, pat_lds, a.m, a.k, a.L, s, idx, rec);
         }
         return confirmed;
     };
@@ -449,6 +486,11 @@ __device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ b
 //         2 -> hash = low24(dword at offset + DH) * K + dword at offset (v_mad_u32_u24), DH = min(L, 8) - 3.
 // FUSED : verify candidates inside this kernel (records out) or emit exact hits (hit list out).
 // SEG   : the buffer is a batch of file chunks with per-chunk clamps (find_near_matches_in_file).
+// SA    : the table slot comes from hash bits 2..6 as they are (one v_and per offset instead of v_lshrrev + v_and;
+//         measured -7 % on the headline workload: the fused scan is bound by VALU issue, +/- one full-rate VALU op
+//         per offset = +10 / -7 %).  Those bits only depend on window bytes 0 and DH, so the host can use this form
+//         when the blocks of a launch differ there (fzhip.hip: choose_launch_blocks); the general form takes any
+//         five hash bits.
 // Each thread owns 16 consecutive byte offsets per row and reads 24 bytes (16 + 8 halo).
 // Block test: slot = (hash >> lut_shift) & 31; lut[slot] holds the hash of the block that lives there
 // (the host picks K and lut_shift so that different block hashes get different slots) or, for a free
@@ -471,7 +513,7 @@ __device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ b
 //     by LDS-DMA now (fz_prefetch_windows).
 // 7 waves per SIMD (72 VGPRs): measured 2-3 % faster than the natural 79-VGPR / 6-wave allocation;
 // 8 waves (64 VGPRs) spills 27 VGPRs in the verify path and is 50 % slower.
-template <int TG, int NWIN, int DH, bool FUSED, bool SEG>
+template <int TG, int NWIN, int DH, bool FUSED, bool SEG, bool SA>
 __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_eu(7, 7))) void fz_scan_kernel(
     const uint8_t *__restrict__ buf, const FzScanArgs a, uint64_t ntiles,
     uint64_t *__restrict__ hits, FzRec *__restrict__ recs, unsigned long long *__restrict__ counters) {
@@ -527,22 +569,27 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
         constexpr int r = decltype(Rc)::value;
         const uint32_t w6[6] = {v.x, v.y, v.z, v.w, h.x, h.y};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {                 // 4 byte offsets per ballot
-            uint32_t hv[4], am[4];
+        for (int j = 0; j < 16 / FZ_GROUP; ++j) {     // FZ_GROUP byte offsets per ballot
+            uint32_t hv[FZ_GROUP], am[FZ_GROUP];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int o = 4 * j + i;
+            for (int i = 0; i < FZ_GROUP; ++i) {
+                const int o = FZ_GROUP * j + i;
                 const uint32_t x = FZ_WIN(w6, o);
                 if (NWIN == 1) hv[i] = (x & mask1) * hash_k;                             // v_mul_lo_u32
                 else hv[i] = __umul24(FZ_WIN(w6, o + DH), hash_k) + x;                   // v_mad_u32_u24
                 uint32_t slot4;
-                asm("v_lshrrev_b32 %0, %1, %2\n\tv_and_b32 %0, " FZ_LUT_ADDR_MASK_STR ", %0" : "=v"(slot4) : "v"(slot_shift), "v"(hv[i]));
+                if constexpr (SA) asm("v_and_b32 %0, " FZ_LUT_ADDR_MASK_STR ", %1" : "=v"(slot4) : "v"(hv[i]));
+                else asm("v_lshrrev_b32 %0, %1, %2\n\tv_and_b32 %0, " FZ_LUT_ADDR_MASK_STR ", %0" : "=v"(slot4) : "v"(slot_shift), "v"(hv[i]));
                 am[i] = hv[i] ^ *reinterpret_cast<FzLdsU32 *>(slot4);   // lut sits at LDS address 0
             }
+#if FZ_GROUP == 8
+            const uint32_t acc = min(min(min(am[0], am[1]), min(am[2], am[3])), min(min(am[4], am[5]), min(am[6], am[7])));
+#else
             const uint32_t acc = min(min(am[0], am[1]), min(am[2], am[3]));
+#endif
             if (__builtin_expect(__ballot(acc == 0) != 0, 0)) {   // wave-uniform, rare: some lane, some offset
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < FZ_GROUP; ++i) {
                     if (__ballot(am[i] == 0)) {           // which offset (scalar branch)
                         // which block(s): equal n-grams share a slot
                         auto push = [&](uint32_t g) {
@@ -554,7 +601,7 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                                 // a scratch round trip per firing once it is spilled
                                 uint32_t code = threadIdx.x;
                                 asm volatile("v_lshlrev_b32 %0, 4, %0" : "+v"(code));
-                                code = fz_code(code + (uint32_t)(r * FZ_ROW_BYTES + 4 * j + i), g, titer);
+                                code = fz_code(code + (uint32_t)(r * FZ_ROW_BYTES + FZ_GROUP * j + i), g, titer);
                                 if (hv[i] == hg && slot < qcap) w.queue[slot] = code;
                                 qn += (uint32_t)__popcll(mk);
                             }
@@ -627,13 +674,17 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                     slow_pos = 0;
                     break;
                 }
+#ifndef FZ_LAB_NOPREFETCH
                 if (PREF && qn > qf) { fz_prefetch_windows(buf, a, w, qf, qn); qf = qn; }
+#endif
                 tile = next;
                 ++titer;
             } while (pre);                            // else: the end of the sequence, or a flush is due
         }
         if (qn) {
+#ifndef FZ_LAB_NOPREFETCH
             if (PREF && qn > qf) fz_prefetch_windows(buf, a, w, qf, qn);
+#endif
             confirmed += fz_queue_flush<FUSED, SEG>(buf, a, pat_lds, w, qn, hits, recs, counters);
         }
         qn = 0;

@@ -222,46 +222,47 @@ struct BlockPlan {
 
 using ScanKernel = void (*)(const uint8_t *, const FzScanArgs, uint64_t, uint64_t *, FzRec *, unsigned long long *);
 
-template <int TG, bool FUSED, bool SEG>
+template <int TG, bool FUSED, bool SEG, bool SA>
 ScanKernel scan_kernel_tg(int nwin, int dh) {
-    if (nwin == 1) return fz_scan_kernel<TG, 1, 0, FUSED, SEG>;
+    if (nwin == 1) return fz_scan_kernel<TG, 1, 0, FUSED, SEG, SA>;
     switch (dh) {
-        case 2: return fz_scan_kernel<TG, 2, 2, FUSED, SEG>;
-        case 3: return fz_scan_kernel<TG, 2, 3, FUSED, SEG>;
-        case 4: return fz_scan_kernel<TG, 2, 4, FUSED, SEG>;
-        default: return fz_scan_kernel<TG, 2, 5, FUSED, SEG>;
+        case 2: return fz_scan_kernel<TG, 2, 2, FUSED, SEG, SA>;
+        case 3: return fz_scan_kernel<TG, 2, 3, FUSED, SEG, SA>;
+        case 4: return fz_scan_kernel<TG, 2, 4, FUSED, SEG, SA>;
+        default: return fz_scan_kernel<TG, 2, 5, FUSED, SEG, SA>;
+    }
+}
+
+template <bool FUSED, bool SEG, bool SA>
+ScanKernel scan_kernel_f(int tg, int nwin, int dh) {
+    switch (tg) {
+        case 2: return scan_kernel_tg<2, FUSED, SEG, SA>(nwin, dh);
+        case 4: return scan_kernel_tg<4, FUSED, SEG, SA>(nwin, dh);
+        default: return scan_kernel_tg<8, FUSED, SEG, SA>(nwin, dh);
     }
 }
 
 template <bool FUSED, bool SEG>
-ScanKernel scan_kernel_f(int tg, int nwin, int dh) {
-    switch (tg) {
-        case 1: return scan_kernel_tg<1, FUSED, SEG>(nwin, dh);
-        case 2: return scan_kernel_tg<2, FUSED, SEG>(nwin, dh);
-        case 3: return scan_kernel_tg<3, FUSED, SEG>(nwin, dh);
-        case 4: return scan_kernel_tg<4, FUSED, SEG>(nwin, dh);
-        case 6: return scan_kernel_tg<6, FUSED, SEG>(nwin, dh);
-        default: return scan_kernel_tg<8, FUSED, SEG>(nwin, dh);
-    }
+ScanKernel scan_kernel_s(int tg, int nwin, int dh, bool sa) {
+    return sa ? scan_kernel_f<FUSED, SEG, true>(tg, nwin, dh) : scan_kernel_f<FUSED, SEG, false>(tg, nwin, dh);
 }
 
 // The segmented variants (file API) only exist where a segment changes the outcome: Levenshtein /
 // generic clamps.  Exact and substitutions-only windows fit exactly one chunk (the host assigns it).
-ScanKernel scan_kernel(int tg, int nwin, int dh, bool fused, bool seg) {
+// sa: the launch's blocks are told apart by hash bits 2..6 (slot address = one v_and).
+ScanKernel scan_kernel(int tg, int nwin, int dh, bool fused, bool seg, bool sa) {
 #ifdef FZ_LAB_ONLY      // lab builds (benchmarks/lab_build.sh): only the instances of the headline and exact-search workloads
-    if (tg == 3 && nwin == 2 && dh == 3 && fused && !seg) return fz_scan_kernel<3, 2, 3, true, false>;
-    if (tg == 1 && nwin == 2 && dh == 5 && !fused && !seg) return fz_scan_kernel<1, 2, 5, false, false>;
+    if (tg == 4 && nwin == 2 && dh == 3 && fused && !seg) return sa ? fz_scan_kernel<4, 2, 3, true, false, true> : fz_scan_kernel<4, 2, 3, true, false, false>;
+    if (tg == 2 && nwin == 2 && dh == 5 && !fused && !seg) return sa ? fz_scan_kernel<2, 2, 5, false, false, true> : fz_scan_kernel<2, 2, 5, false, false, false>;
     return nullptr;
 #else
-    if (seg) return fused ? scan_kernel_f<true, true>(tg, nwin, dh) : scan_kernel_f<false, true>(tg, nwin, dh);
-    return fused ? scan_kernel_f<true, false>(tg, nwin, dh) : scan_kernel_f<false, false>(tg, nwin, dh);
+    if (seg) return fused ? scan_kernel_s<true, true>(tg, nwin, dh, sa) : scan_kernel_s<false, true>(tg, nwin, dh, sa);
+    return fused ? scan_kernel_s<true, false>(tg, nwin, dh, sa) : scan_kernel_s<false, false>(tg, nwin, dh, sa);
 #endif
 }
 
-int pick_tg(uint32_t nblk) {
-    if (nblk <= 4) return (int)nblk;
-    return nblk <= 6 ? 6 : 8;
-}
+// Compiled-in blocks of the rare path: 2, 4 or 8 (spare ones carry a hash no window can be queued with).
+int pick_tg(uint32_t nblk) { return nblk <= 2 ? 2 : nblk <= 4 ? 4 : 8; }
 
 // Odd multipliers tried for the window hash (24-bit ones serve v_mad_u32_u24).  One search needs a
 // multiplier under which its (at most 8 per launch) distinct block hashes fall into distinct slots of
@@ -295,29 +296,33 @@ uint32_t choose_launch_blocks(const uint8_t *p, const uint32_t *starts, uint32_t
     const char *cap_env = getenv("FZ_MAX_BLOCKS");
     const uint32_t max_blocks = cap_env && atoi(cap_env) > 0 ? std::min<uint32_t>((uint32_t)atoi(cap_env), FZ_MAX_BLOCKS_PER_LAUNCH)
                                                              : FZ_MAX_BLOCKS_PER_LAUNCH;
+    static const bool no_sa = getenv("FZ_NO_SLOT_AND") != nullptr;     // test knob: never use the low-bits form
+    const uint32_t want = std::min<uint32_t>(max_blocks, G - g0);
     uint32_t nblk = 0;
-    for (uint32_t cand : kHashMultipliers) {
-        const uint32_t kk = hg.nwin == 2 ? cand : (cand * 0x9E3779B1u) | 1u;
-        uint32_t hb[FZ_MAX_BLOCKS_PER_LAUNCH];
-        uint32_t nb = 0;
-        for (; nb < max_blocks && g0 + nb < G; ++nb) hb[nb] = hg.hash(p + starts[g0 + nb], L, kk);
-#ifdef FZ_SLOT_AND_ONLY
-        for (int shift = 2; shift >= 2; shift -= FZ_LUT_BITS) {
-#else
-        for (int shift = 32 - FZ_LUT_BITS; shift >= 2; shift -= FZ_LUT_BITS) {
-#endif
-            uint32_t slot_hash[FZ_LUT_SLOTS];
-            bool used[FZ_LUT_SLOTS] = {false};
-            uint32_t fit = 0;
-            for (; fit < nb; ++fit) {
-                const uint32_t slot = (hb[fit] >> shift) & (FZ_LUT_SLOTS - 1u);
-                if (used[slot] && slot_hash[slot] != hb[fit]) break;
-                used[slot] = true;
-                slot_hash[slot] = hb[fit];
+    // Pass 0: hash bits 2..6 as they are (lut_shift == 2: the kernel forms the slot address with one v_and; those
+    // bits only see window bytes 0 and DH) — taken only if it fits every block this launch could carry.
+    // Pass 1: any aligned group of five hash bits.
+    for (int pass = no_sa ? 1 : 0; pass < 2; ++pass) {
+        for (uint32_t cand : kHashMultipliers) {
+            const uint32_t kk = hg.nwin == 2 ? cand : (cand * 0x9E3779B1u) | 1u;
+            uint32_t hb[FZ_MAX_BLOCKS_PER_LAUNCH];
+            uint32_t nb = 0;
+            for (; nb < want; ++nb) hb[nb] = hg.hash(p + starts[g0 + nb], L, kk);
+            for (int shift = pass == 0 ? 2 : 32 - FZ_LUT_BITS; shift >= 2; shift -= FZ_LUT_BITS) {
+                uint32_t slot_hash[FZ_LUT_SLOTS];
+                bool used[FZ_LUT_SLOTS] = {false};
+                uint32_t fit = 0;
+                for (; fit < nb; ++fit) {
+                    const uint32_t slot = (hb[fit] >> shift) & (FZ_LUT_SLOTS - 1u);
+                    if (used[slot] && slot_hash[slot] != hb[fit]) break;
+                    used[slot] = true;
+                    slot_hash[slot] = hb[fit];
+                }
+                if (fit > nblk && (pass == 1 || fit == want)) { nblk = fit; hash_k = kk; lut_shift = (uint32_t)shift; }
             }
-            if (fit > nblk) { nblk = fit; hash_k = kk; lut_shift = (uint32_t)shift; }
+            if (nblk == want) break;
         }
-        if (nblk == max_blocks || g0 + nblk == G) break;
+        if (nblk == want) break;
     }
     return nblk;
 }
@@ -444,8 +449,15 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
         const bool verify_follows = with_verify && !fa.fused;
         fa.host_hdr = (direct && !verify_follows && g0 + nblk >= G) ? reinterpret_cast<uint64_t>(d.h_stage_dev) : 0;
         const int tg = pick_tg(nblk);
-        for (int b = (int)nblk; b < tg; ++b) fa.H[b] = fa.H[0];      // compiled-in spare blocks: dropped by the range check
-        ScanKernel kern = scan_kernel(tg, nwin, dh, fa.fused != 0, sh.geom.seg_stride != 0);
+        for (int b = (int)nblk; b < tg; ++b) {                        // compiled-in spare blocks: a hash that no queued window has
+            uint32_t v = fa.H[0] + 1u;                               // (a window is queued when its hash IS a real block's)
+            for (bool again = true; again;) {
+                again = false;
+                for (uint32_t r = 0; r < nblk; ++r) if (fa.H[r] == v) { ++v; again = true; }
+            }
+            fa.H[b] = v;
+        }
+        ScanKernel kern = scan_kernel(tg, nwin, dh, fa.fused != 0, sh.geom.seg_stride != 0, fa.lut_shift == 2);
         if (!kern) return fail(FZ_EUNSUPPORTED, "this (lab) build carries no scan kernel for tg=%d nwin=%d dh=%d", tg, nwin, dh);
         static const uint32_t extra_lds = []() { const char *e = getenv("FZ_EXTRA_LDS_KB"); return e ? (uint32_t)atoi(e) * 1024u : 0u; }();
         hipLaunchKernelGGL(kern, grid, dim3(FZ_FILTER_THREADS), scan_lds + extra_lds, d.stream, sh.d_buf, fa, ntiles, d.d_hits, recs,
