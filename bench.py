@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mib", type=int, default=1024)
     ap.add_argument("--no-extras", action="store_true", help="skip the 4 GiB target and the other BASELINE configs (N = 1 extras)")
+    ap.add_argument("--sync", action="store_true", help="time synchronous fz_lev_ngrams calls (one search in flight) instead of the two-deep pipeline")
     return ap.parse_args()
 
 
@@ -273,7 +274,13 @@ def main():
     filter_ms, verify_ms, device_ms = [], [], []
     sync()
     t0 = time.perf_counter()
-    if not use_dist:
+    # Two-deep pipeline through the C-ABI (fz_lev_ngrams_begin / _end, two pinned result slots per device):
+    # the scan of step i + 1 is on the GPU while the host orders and consumes the records of step i (and,
+    # for N > 1, while RCCL all-gathers them: the scan runs on the engine's own HIP stream, the collective
+    # and its staging copies on torch's).  Every step still ends with its complete, ordered match list
+    # on this rank's host, and exactly K searches (and K all-gathers) start and complete inside the timed
+    # region.  args.sync times plain synchronous fz_lev_ngrams calls instead.
+    if args.sync and not use_dist:
         for _ in range(args.steps):
             matches = step()
             f_, v_, d_ = engine.kernel_ms()                # hipEvent spans of this step's kernels
@@ -281,20 +288,16 @@ def main():
             verify_ms.append(v_)
             device_ms.append(d_)
     else:
-        # N > 1: the collective of step i overlaps the scan of step i + 1 (fz_lev_ngrams_begin / _end;
-        # the scan runs on the engine's own HIP stream, RCCL and its staging copies on torch's).  Every
-        # step still ends with its merged, ordered match list on this rank's host, and all K searches
-        # and K all-gathers complete inside the timed region.
         engine.lev_ngrams_begin(handle, p, k)
         for i in range(args.steps):
+            if i + 1 < args.steps:
+                engine.lev_ngrams_begin(handle, p, k)
             raw = engine.lev_ngrams_end(as_array=True)
             f_, v_, d_ = engine.kernel_ms()
             filter_ms.append(f_)
             verify_ms.append(v_)
             device_ms.append(d_)
-            if i + 1 < args.steps:
-                engine.lev_ngrams_begin(handle, p, k)
-            matches = fzd.allgather_matches(raw, as_array=True)
+            matches = fzd.allgather_matches(raw, as_array=True) if use_dist else raw
     sync()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -303,6 +306,13 @@ def main():
         elapsed = float(tmax.item())
 
     st = engine.stats()
+    sync_ms = None
+    if not use_dist and not args.sync:
+        # latency of one synchronous call (one search in flight), outside the timed region
+        t1 = time.perf_counter()
+        for _ in range(50):
+            assert np.array_equal(step(), matches), "pipelined and synchronous searches returned different streams"
+        sync_ms = (time.perf_counter() - t1) / 50 * 1e3
     if rank == 0:
         import fuzzysearch_amd as fa
         matches = [tuple(int(x) for x in r) for r in matches.tolist()]
@@ -328,6 +338,7 @@ def main():
             "config": {"workload": "%d MiB iid random DNA bytes per GPU, |pattern|=20, max_l_dist=2, "
                                    "1024 planted variants per GiB (BASELINE configs[1]); resident in HBM" % args.mib,
                        "bytes_per_gpu": shard_bytes, "pattern_len": m, "max_l_dist": k,
+                       "calls_in_flight": 1 if (args.sync and not use_dist) else 2,
                        "sharding": "none" if not use_dist else "contiguous shards, (m+k)-byte halo, RCCL all_gather of "
                                    "matches; the all_gather of step i overlaps the scan of step i+1"},
             "matches_per_s": round(len(matches) * args.steps / elapsed, 1),
@@ -341,6 +352,7 @@ def main():
                          "algorithmic_bytes_per_launch": shard_bytes},
             "kernel_ms": {"filter": round(f_ms, 4), "verify": round(float(np.mean(verify_ms)), 4),
                           "device_total": round(float(np.mean(device_ms)), 4)},
+            "sync_ms_per_call": None if sync_ms is None else round(sync_ms, 4),
         }
         out["cpu_baseline"] = cpu
         if world == 1 and not use_dist and not args.no_extras:

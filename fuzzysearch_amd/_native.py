@@ -417,8 +417,10 @@ class Engine(object):
         return self._match_call(self._lib.fz_lev_ngrams, seq, pattern, k, as_array=as_array)
 
     def lev_ngrams_begin(self, seq, pattern, k):
-        """Launch lev_ngrams and return; lev_ngrams_end() delivers the result.  One search in flight per
-        engine; the host and other streams (a collective, a copy) can work meanwhile."""
+        """Launch lev_ngrams and return; lev_ngrams_end() delivers the result of the OLDEST search in flight.
+        Up to two searches may be in flight per engine (the scan of search i + 1 runs while the host orders
+        and consumes the records of search i); the host and other streams (a collective, a copy) can work
+        meanwhile."""
         if type(pattern) is bytes:
             paddr, m, keep = pattern, len(pattern), None
         else:

@@ -110,6 +110,30 @@ struct DevState {
     uint8_t *stream_d = nullptr;
     uint64_t stream_cap = 0, stream_d_bytes = 0;
     int n_cus = 256;
+    // what the search being collected ran with (an overflow is judged against these, not against buffers
+    // that a search collected in between may have grown)
+    uint64_t hit_cap_used = 0, rec_cap_used = 0;
+    bool fused_used = false;
+    // The second result slot: fz_lev_ngrams_begin with one search already in flight launches into it, so
+    // that the host orders the records of search i while search i + 1 scans (two-deep pipeline).
+    struct Slot {
+        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+        uint8_t *h_stage = nullptr, *h_stage_dev = nullptr;
+        bool last_direct = false, verify_launched = false, fused_used = false;
+        int scan_end_event = 1;
+        uint64_t hit_cap_used = 0, rec_cap_used = 0;
+    } other;
+    void swap_slot() {
+        for (int i = 0; i < 4; ++i) std::swap(ev[i], other.ev[i]);
+        std::swap(h_stage, other.h_stage);
+        std::swap(h_stage_dev, other.h_stage_dev);
+        std::swap(last_direct, other.last_direct);
+        std::swap(verify_launched, other.verify_launched);
+        std::swap(fused_used, other.fused_used);
+        std::swap(scan_end_event, other.scan_end_event);
+        std::swap(hit_cap_used, other.hit_cap_used);
+        std::swap(rec_cap_used, other.rec_cap_used);
+    }
 };
 
 struct Shard {
@@ -137,13 +161,15 @@ struct fz_ctx {
     const FzGenRec *gen_view = nullptr;          // same for the per-hit automaton's records (pinned h_big)
     uint64_t gen_view_n = 0;
     struct fz_stream *stream_inflight = nullptr;  // a file stream whose batch is on the device (other searches are refused)
-    // fz_lev_ngrams_begin .. _end: the one search that may be in flight
+    // fz_lev_ngrams_begin .. _end: up to two searches in flight, collected in launch order (pend[0] is the
+    // oldest and owns the devices' current result slot, pend[1] their second slot)
     struct Pending {
-        bool active = false;
         fz_seq *seq = nullptr;
         std::vector<uint8_t> pattern;
         uint32_t m = 0, k = 0;
-    } pending;
+        bool launched = false;                       // false: deferred until the older search has been collected
+    } pend[2];
+    int npend = 0;
 };
 
 struct fz_seq {
@@ -519,6 +545,9 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     }
     ctx->stats.filter_launches += launches;
     ctx->last_fused = fa.fused != 0;
+    d.fused_used = fa.fused != 0;
+    d.hit_cap_used = d.hit_cap;
+    d.rec_cap_used = d.rec_cap;
     return FZ_OK;
 }
 
@@ -534,16 +563,18 @@ int collect_shard(fz_ctx *ctx, const Shard &sh, bool with_verify, bool view_ok, 
     const unsigned long long *cnt = reinterpret_cast<const unsigned long long *>(d.h_stage);
     uint64_t nh = cnt[0];
     const uint64_t nr = cnt[1];
-    const bool fused = with_verify && ctx->last_fused;
+    const bool fused = with_verify && d.fused_used;
     if (fused) { nh = 0; for (int i = 0; i < 64; ++i) nh += cnt[8 + i]; }
     rerun = false;
-    if (nh > d.hit_cap && !fused) {
+    if (nh > d.hit_cap_used && !fused) {
+        HIP_TRY(hipStreamSynchronize(d.stream));          // a second search in flight still uses the old buffers
         int rc = ensure_hits(d, nh + nh / 8 + 1024);
         if (rc) return rc;
         rerun = true;
     }
     if (d.last_direct && with_verify && nr > kHostRecs) d.direct = false;   // too many for the staging buffer
-    if (nr > (d.last_direct ? kHostRecs : d.rec_cap)) {
+    if (nr > (d.last_direct ? kHostRecs : d.rec_cap_used)) {
+        HIP_TRY(hipStreamSynchronize(d.stream));
         int rc = ensure_recs(d, nr + nr / 8 + 1024);
         if (rc) return rc;
         rerun = true;
@@ -614,6 +645,9 @@ int search_collect(fz_ctx *ctx, fz_seq *seq, const Search &q, bool with_verify, 
     for (int attempt = 0; attempt < 4; ++attempt) {
         recs.clear();
         hits.clear();
+        // the statistics describe the search being collected (a younger one may have been launched meanwhile)
+        ctx->stats.bytes_scanned = ctx->stats.ngram_hits = ctx->stats.raw_matches = 0;
+        ctx->stats.filter_ms = ctx->stats.verify_ms = ctx->stats.device_ms = 0;
         Trace tr;
         bool any_rerun = false;
         for (const Shard &sh : seq->shards) {
@@ -632,7 +666,7 @@ int search_collect(fz_ctx *ctx, fz_seq *seq, const Search &q, bool with_verify, 
 
 int run_search(fz_ctx *ctx, fz_seq *seq, const Search &q, bool with_verify, std::vector<FzRec> &recs,
                std::vector<uint64_t> &hits) {
-    if (ctx->pending.active) return fail(FZ_EINVAL, "a search started with fz_lev_ngrams_begin is still in flight");
+    if (ctx->npend) return fail(FZ_EINVAL, "a search started with fz_lev_ngrams_begin is still in flight");
     memset(&ctx->stats, 0, sizeof ctx->stats);
     ctx->stats.n_devices = (uint32_t)ctx->devs.size();
     Trace tr;
@@ -732,9 +766,9 @@ int alloc_out(uint64_t n, size_t elem, void **out) {
     return FZ_OK;
 }
 
-int validate(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m) {
+int validate(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, bool in_pipeline = false) {
     if (!ctx || !seq || seq->ctx != ctx) return fail(FZ_EINVAL, "bad ctx/seq handle");
-    if (ctx->pending.active) return fail(FZ_EINVAL, "a search started with fz_lev_ngrams_begin is still in flight");
+    if (ctx->npend && !in_pipeline) return fail(FZ_EINVAL, "a search started with fz_lev_ngrams_begin is still in flight");
     if (ctx->stream_inflight) return fail(FZ_EINVAL, "a file stream of this context has a batch in flight (finish or close it first)");
     if (!p || m == 0) return fail(FZ_EINVAL, "subsequence must not be empty");
     if (m > FZ_MAX_M) return fail(FZ_EUNSUPPORTED, "subsequence longer than %d bytes", FZ_MAX_M);
@@ -928,6 +962,9 @@ int fz_create(const int *device_ids, int n_devices, fz_ctx **out) {
             for (auto &ev : d.ev) HIP_TRY(hipEventCreate(&ev));
             HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&d.h_stage), kHeaderBytes + kHostRecs * sizeof(FzRec), hipHostMallocMapped));
             HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&d.h_stage_dev), d.h_stage, 0));
+            for (auto &ev : d.other.ev) HIP_TRY(hipEventCreate(&ev));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&d.other.h_stage), kHeaderBytes + kHostRecs * sizeof(FzRec), hipHostMallocMapped));
+            HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&d.other.h_stage_dev), d.other.h_stage, 0));
             return FZ_OK;
         };
         rc = init();
@@ -948,6 +985,8 @@ void fz_destroy(fz_ctx *ctx) {
         if (d.d_out) (void)hipFree(d.d_out);
         if (d.spare_alloc) (void)hipFree(d.spare_alloc);
         if (d.h_stage) (void)hipHostFree(d.h_stage);
+        if (d.other.h_stage) (void)hipHostFree(d.other.h_stage);
+        for (auto &ev : d.other.ev) if (ev) (void)hipEventDestroy(ev);
         if (d.h_big) (void)hipHostFree(d.h_big);
         if (d.d_cand) (void)hipFree(d.d_cand);
         for (int i = 0; i < 2; ++i) if (d.stream_h[i]) (void)hipHostFree(d.stream_h[i]);
@@ -1100,8 +1139,8 @@ int fz_search_exact(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint
 }
 
 // Argument checks and the block plan of find_near_matches_levenshtein_ngrams (levenshtein_ngram.py:159-176).
-static int lev_plan(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, Search &q) {
-    int rc = validate(ctx, seq, p, m);
+static int lev_plan(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, Search &q, bool in_pipeline = false) {
+    int rc = validate(ctx, seq, p, m, in_pipeline);
     if (rc) return rc;
     const uint32_t L = m / (k + 1);
     if (L == 0) return fail(FZ_EINVAL, "the subsequence length must be greater than max_l_dist");
@@ -1134,36 +1173,59 @@ int fz_lev_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32
 }
 
 int fz_lev_ngrams_begin(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k) {
-    if (ctx && ctx->pending.active) return fail(FZ_EINVAL, "a search is already in flight on this context");
+    if (ctx && ctx->npend >= 2) return fail(FZ_EINVAL, "two searches are already in flight on this context");
     Search q;
-    int rc = lev_plan(ctx, seq, p, m, k, q);
+    int rc = lev_plan(ctx, seq, p, m, k, q, true);
     if (rc) return rc;
-    ctx->pending.pattern.assign(p, p + m);                   // the caller's buffer is only borrowed for this call
-    ctx->pending.seq = seq;
-    ctx->pending.m = m;
-    ctx->pending.k = k;
-    q.p = ctx->pending.pattern.data();
+    fz_ctx::Pending &pd = ctx->pend[ctx->npend];
+    pd.pattern.assign(p, p + m);                             // the caller's buffer is only borrowed for this call
+    pd.seq = seq;
+    pd.m = m;
+    pd.k = k;
+    q.p = pd.pattern.data();
     memset(&ctx->stats, 0, sizeof ctx->stats);
     ctx->stats.n_devices = (uint32_t)ctx->devs.size();
-    rc = search_enqueue(ctx, seq, q, true);
-    if (rc) return rc;
-    ctx->pending.active = true;
+    // with a search in flight this one goes to the devices' second result slot — unless a device is out of
+    // direct mode (large record sets are fetched from the shared device buffer after the kernel: a second
+    // search would overwrite it), then the launch waits for fz_lev_ngrams_end of the older search
+    const bool second = ctx->npend == 1;
+    pd.launched = true;
+    if (second) for (const DevState &d : ctx->devs) if (!d.direct) pd.launched = false;
+    if (pd.launched) {
+        if (second) for (DevState &d : ctx->devs) d.swap_slot();
+        rc = search_enqueue(ctx, seq, q, true);
+        if (second) for (DevState &d : ctx->devs) d.swap_slot();
+        if (rc) return rc;
+    }
+    ++ctx->npend;
     return FZ_OK;
 }
 
 int fz_lev_ngrams_end(fz_ctx *ctx, fz_match **out, uint64_t *n) {
     if (!ctx || !out || !n) return fail(FZ_EINVAL, "null argument");
     *out = nullptr; *n = 0;
-    if (!ctx->pending.active) return fail(FZ_EINVAL, "no search in flight");
-    ctx->pending.active = false;
+    if (!ctx->npend) return fail(FZ_EINVAL, "no search in flight");
+    fz_ctx::Pending &pd = ctx->pend[0];
     Search q;
-    int rc = lev_plan(ctx, ctx->pending.seq, ctx->pending.pattern.data(), ctx->pending.m, ctx->pending.k, q);
-    if (rc) return rc;
+    int rc = lev_plan(ctx, pd.seq, pd.pattern.data(), pd.m, pd.k, q, true);
     std::vector<FzRec> recs;
     std::vector<uint64_t> hits;
-    rc = search_collect(ctx, ctx->pending.seq, q, true, recs, hits);
-    if (rc) return rc;
-    return emit_matches(ctx, recs, q.plan.L, out, n);
+    if (rc == FZ_OK) rc = search_collect(ctx, pd.seq, q, true, recs, hits);
+    if (rc == FZ_OK) rc = emit_matches(ctx, recs, q.plan.L, out, n);
+    // the younger search (if any) becomes the oldest: its slot becomes the current one
+    if (--ctx->npend == 1) {
+        std::swap(ctx->pend[0], ctx->pend[1]);
+        if (ctx->pend[0].launched) {
+            for (DevState &d : ctx->devs) d.swap_slot();
+        } else {                                             // deferred: launch it now, into the slot that just became free
+            Search q2;
+            int rc2 = lev_plan(ctx, ctx->pend[0].seq, ctx->pend[0].pattern.data(), ctx->pend[0].m, ctx->pend[0].k, q2, true);
+            if (rc2 == FZ_OK) rc2 = search_enqueue(ctx, ctx->pend[0].seq, q2, true);
+            if (rc2 != FZ_OK) { ctx->npend = 0; if (rc == FZ_OK) rc = rc2; }
+            ctx->pend[0].launched = true;
+        }
+    }
+    return rc;
 }
 
 int fz_subs_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, fz_match **out, uint64_t *n) {
@@ -1675,7 +1737,7 @@ int fz_stream_open(fz_ctx *ctx, uint32_t mode, const uint8_t *p, uint32_t m, uin
     *out = nullptr;
     if (!ctx || ctx->devs.empty()) return fail(FZ_EINVAL, "bad ctx handle");
     if (ctx->devs.size() != 1) return fail(FZ_EUNSUPPORTED, "file streams run on a single-device context");
-    if (ctx->pending.active || ctx->stream_inflight) return fail(FZ_EINVAL, "another search of this context is in flight");
+    if (ctx->npend || ctx->stream_inflight) return fail(FZ_EINVAL, "another search of this context is in flight");
     if (!p || m == 0) return fail(FZ_EINVAL, "subsequence must not be empty");
     if (m > FZ_MAX_M) return fail(FZ_EUNSUPPORTED, "subsequence longer than %d bytes", FZ_MAX_M);
     if (k > FZ_MAX_K) return fail(FZ_EUNSUPPORTED, "distance limit above %d is not supported", FZ_MAX_K);

@@ -111,8 +111,10 @@ int fz_lev_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32
 
 /* The same search split in two so that the host (and other streams: a collective, a copy) can work
  * while the scan runs: _begin launches it and returns, _end waits and delivers exactly what
- * fz_lev_ngrams would.  One search in flight per ctx; `p` is copied, `seq` must stay alive; every
- * other search call on the ctx fails with FZ_EINVAL until _end has been called. */
+ * fz_lev_ngrams would.  Up to TWO searches may be in flight per ctx (a two-deep pipeline: the scan
+ * of search i + 1 runs while the host orders and consumes the records of search i; every device has
+ * two pinned result slots); _end always delivers the OLDEST one.  `p` is copied, `seq` must stay
+ * alive; every other search call on the ctx fails with FZ_EINVAL until every _begin has had its _end. */
 int fz_lev_ngrams_begin(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k);
 int fz_lev_ngrams_end(fz_ctx *ctx, fz_match **out, uint64_t *n);
 

@@ -213,26 +213,45 @@ def test_blocks_split_over_several_launches(engine, monkeypatch):
 
 
 def test_begin_end_split_equals_the_synchronous_call(engine):
-    """fz_lev_ngrams_begin / _end: same stream as fz_lev_ngrams, also across a result-buffer overflow;
-    other searches are refused while one is in flight."""
-    from fuzzysearch_amd import _native
+    """fz_lev_ngrams_begin / _end: same stream as fz_lev_ngrams, also across a result-buffer overflow; up to two
+    searches in flight, delivered oldest first; other searches are refused meanwhile."""
     t = workloads.dna(1 << 20, 31).tobytes()
-    p = t[5000:5020]
+    p, p2 = t[5000:5020], t[70000:70024]
     dense = b'ACGT' * 30000
     h, hd = engine.upload(t), engine.upload(dense)
-    want = oracle.lev_ngrams_raw(p, t, 2)
+    want, want2 = oracle.lev_ngrams_raw(p, t, 2), oracle.lev_ngrams_raw(p2, t, 3)
     for _ in range(3):
         engine.lev_ngrams_begin(h, p, 2)
         with pytest.raises(ValueError):
             engine.lev_ngrams(h, p, 2)
+        engine.lev_ngrams_begin(h, p2, 3)                      # second search in flight: the other result slot
         with pytest.raises(ValueError):
-            engine.lev_ngrams_begin(h, p, 2)
+            engine.lev_ngrams_begin(h, p, 2)                   # a third one is refused
+        assert engine.lev_ngrams_end() == want                 # oldest first
+        engine.lev_ngrams_begin(h, p, 2)                       # ... and its slot is free again
+        assert engine.lev_ngrams_end() == want2
         assert engine.lev_ngrams_end() == want
     with pytest.raises(ValueError):
         engine.lev_ngrams_end()
+    # a steady two-deep pipeline, as bench.py drives it
+    engine.lev_ngrams_begin(h, p, 2)
+    for i in range(6):
+        engine.lev_ngrams_begin(h, p2 if i % 2 == 0 else p, 3 if i % 2 == 0 else 2)
+        assert engine.lev_ngrams_end() == (want if i % 2 == 0 else want2)
+    assert engine.lev_ngrams_end() == want
+    # result-buffer overflows (the dense search leaves direct mode, grows the device buffers and re-runs) with a
+    # second search in flight, before and behind it
     pd = b'ACGTACGTACGTAC'
+    want_d = oracle.lev_ngrams_raw(pd, dense, 2)
+    assert len(want_d) > 20000
     engine.lev_ngrams_begin(hd, bytearray(pd), 2)              # the pattern buffer is copied by _begin
-    assert engine.lev_ngrams_end() == oracle.lev_ngrams_raw(pd, dense, 2)
+    engine.lev_ngrams_begin(h, p, 2)
+    assert engine.lev_ngrams_end() == want_d
+    engine.lev_ngrams_begin(hd, pd, 2)                         # launched (or deferred) while not in direct mode
+    assert engine.lev_ngrams_end() == want
+    engine.lev_ngrams_begin(h, p2, 3)
+    assert engine.lev_ngrams_end() == want_d
+    assert engine.lev_ngrams_end() == want2
     assert engine.lev_ngrams(h, p, 2) == want
     h.release(); hd.release()
 
