@@ -8,11 +8,12 @@ region.  One "step" = one fz_lev_ngrams() call through the C-ABI over the reside
 kernel (filter + fused verification, records and counters written to pinned host memory) + host
 ordering of the raw match stream.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling — every rank owns one
-1 GiB shard of an N GiB global sequence, holds (m + k)-byte halos of its neighbours' bytes, scans
-its shard with no data-path collective and the ranks' match lists are all-gathered over RCCL
-(SURVEY.md §8(e)); the all-gather of step i runs while the scan of step i + 1 is on the GPU
-(fz_lev_ngrams_begin / _end, separate HIP streams); value = N GiB / max-over-ranks time.
+N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling, BASELINE configs[4] — every
+rank owns one 4 GiB shard of a 4N GiB global sequence (32 GiB at N = 8; copies of the pattern planted
+around every shard boundary), holds (m + k)-byte halos of its neighbours' bytes, scans its shard with
+no data-path collective and the ranks' match lists are all-gathered over RCCL; the
+all-gather of step i runs while the scan of step i + 1 is on the GPU (fz_lev_ngrams_begin / _end, two
+searches in flight, separate HIP streams); value = 4N GiB / max-over-ranks time.
 
 Prints ONE JSON line on rank 0.
 """
@@ -39,7 +40,8 @@ def parse():
                     help="untimed device settle phase before the warmup steps (a step is only ~0.35 ms, far "
                          "shorter than the GPU's DVFS ramp: 23 back-to-back steps run the kernel 12%% slower "
                          "than 250; the timed region is unaffected: exactly --steps steps)")
-    ap.add_argument("--mib", type=int, default=1024, help="MiB of sequence per GPU (default: 1 GiB = configs[1])")
+    ap.add_argument("--mib", type=int, default=0, help="MiB of sequence per GPU (default: 1024 = BASELINE configs[1] at N = 1, "
+                    "4096 = configs[4] — 32 GiB over 8 GPUs — at N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mib", type=int, default=1024)
     ap.add_argument("--no-extras", action="store_true", help="skip the 4 GiB target and the other BASELINE configs (N = 1 extras)")
@@ -216,6 +218,8 @@ def main():
     from tests import workloads
 
     k = 2
+    if args.mib <= 0:
+        args.mib = 1024 if world == 1 else 4096
     shard_bytes = args.mib << 20
     pattern = workloads.dna(20, 1)
     m = len(pattern)
@@ -227,12 +231,16 @@ def main():
     if world == 1:
         seq, _, _ = workloads.cfg2(shard_bytes, 1024)
     else:
-        seq = workloads.dna(shard_bytes, 20250925 + rank)
-        workloads.plant_variants(seq, pattern, 1024, 7 + rank)
-        # variants straddling the boundary with the next shard: first half lives in our tail
-        seq[-10:] = pattern[:10]
-        if rank > 0:
-            seq[:10] = pattern[10:]
+        # BASELINE configs[4]: every rank generates its own shard (seed + rank, 1 GiB pieces), 1024 planted
+        # variants per GiB, plus exact copies around every shard boundary at deltas {-m-k ... +1}
+        # (tests/workloads.py::boundary_plants; every rank writes the bytes that fall into its shard)
+        seq = np.empty(shard_bytes, dtype=np.uint8)
+        piece = 1 << 30
+        for i, lo in enumerate(range(0, shard_bytes, piece)):
+            seq[lo:lo + piece] = workloads.dna(min(piece, shard_bytes - lo), 20250925 + 64 * rank + i)
+        workloads.plant_variants(seq, pattern, 1024 * max(1, args.mib // 1024), 7 + rank)
+        edge_plants = workloads.boundary_plants(m, k, shard_bytes, world)
+        workloads.apply_plants(seq, rank * shard_bytes, edge_plants, pattern)
 
     cpu = None
     if world == 1 and not use_dist and not args.no_cpu_baseline and rank == 0:
@@ -316,6 +324,11 @@ def main():
     if rank == 0:
         import fuzzysearch_amd as fa
         matches = [tuple(int(x) for x in r) for r in matches.tolist()]
+        if world > 1:
+            # every copy planted around a shard boundary is in the merged stream, at its exact position
+            found = {(s_, e_, d_) for (s_, e_, d_, _g) in matches}
+            missing = [q for q in edge_plants if (q, q + m, 0) not in found]
+            assert not missing, "matches across shard boundaries are missing: %r" % (missing[:8],)
         consolidated = fa.common._native.consolidate(matches)
         ms_per_step = elapsed / args.steps * 1e3
         value = global_n * args.steps / elapsed / 1e9
@@ -336,7 +349,9 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": "%d MiB iid random DNA bytes per GPU, |pattern|=20, max_l_dist=2, "
-                                   "1024 planted variants per GiB (BASELINE configs[1]); resident in HBM" % args.mib,
+                                   "1024 planted variants per GiB (BASELINE %s); resident in HBM"
+                                   % (args.mib, "configs[1]" if world == 1 else "configs[4]: %d GiB over %d GPUs, copies of the pattern "
+                                      "around every shard boundary" % (args.mib * world >> 10, world)),
                        "bytes_per_gpu": shard_bytes, "pattern_len": m, "max_l_dist": k,
                        "calls_in_flight": 1 if (args.sync and not use_dist) else 2,
                        "sharding": "none" if not use_dist else "contiguous shards, (m+k)-byte halo, RCCL all_gather of "

@@ -48,7 +48,7 @@
 #define FZ_PAD_FRONT 256                                   // zero bytes before buf[0]
 #define FZ_PAD_BACK 256                                    // zero bytes the kernels may over-read (halo loads, whole 16-byte window pieces)
 #ifndef FZ_GROUP
-#define FZ_GROUP 4                                         // byte offsets tested per wave-uniform branch (4 or 8)
+#define FZ_GROUP 0                                         // lab knob: force 4 or 8 byte offsets per wave-uniform branch (0: by n-gram length)
 #endif
 #define FZ_QCAP 256                                        // fast-hit queue entries per wave
 #ifndef FZ_H_SGPR
@@ -567,13 +567,19 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
     // the filter over one row (row R of the tile)
     auto test_row = [&](const uint4 &v, const uint2 &h, auto Rc) {
         constexpr int r = decltype(Rc)::value;
+        // byte offsets tested per wave-uniform branch: 8 in the hit-emitting form when the n-grams have 8 bytes or
+        // more (DH == 5) — such n-grams are rare in any data, the branch is hardly ever taken and one compare serves
+        // twice the offsets (exact search of a 20-byte pattern: 0.199 -> 0.194 ms per GiB); 4 otherwise (on DNA with
+        // 6-byte n-grams 17 % of the 4-offset groups fire: with 8 the rare path's compares double, 0.223 -> 0.246 ms;
+        // the fused form has no registers to spare for 8 hashes: 26 VGPRs spilled)
+        constexpr int GRP = FZ_GROUP ? FZ_GROUP : (NWIN == 2 && DH == 5 && !FUSED ? 8 : 4);
         const uint32_t w6[6] = {v.x, v.y, v.z, v.w, h.x, h.y};
 #pragma unroll
-        for (int j = 0; j < 16 / FZ_GROUP; ++j) {     // FZ_GROUP byte offsets per ballot
-            uint32_t hv[FZ_GROUP], am[FZ_GROUP];
+        for (int j = 0; j < 16 / GRP; ++j) {     // GRP byte offsets per ballot
+            uint32_t hv[GRP], am[GRP];
 #pragma unroll
-            for (int i = 0; i < FZ_GROUP; ++i) {
-                const int o = FZ_GROUP * j + i;
+            for (int i = 0; i < GRP; ++i) {
+                const int o = GRP * j + i;
                 const uint32_t x = FZ_WIN(w6, o);
                 if (NWIN == 1) hv[i] = (x & mask1) * hash_k;                             // v_mul_lo_u32
                 else hv[i] = __umul24(FZ_WIN(w6, o + DH), hash_k) + x;                   // v_mad_u32_u24
@@ -582,14 +588,11 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                 else asm("v_lshrrev_b32 %0, %1, %2\n\tv_and_b32 %0, " FZ_LUT_ADDR_MASK_STR ", %0" : "=v"(slot4) : "v"(slot_shift), "v"(hv[i]));
                 am[i] = hv[i] ^ *reinterpret_cast<FzLdsU32 *>(slot4);   // lut sits at LDS address 0
             }
-#if FZ_GROUP == 8
-            const uint32_t acc = min(min(min(am[0], am[1]), min(am[2], am[3])), min(min(am[4], am[5]), min(am[6], am[7])));
-#else
-            const uint32_t acc = min(min(am[0], am[1]), min(am[2], am[3]));
-#endif
+            uint32_t acc = min(min(am[0], am[1]), min(am[2], am[3]));
+            if constexpr (GRP == 8) acc = min(acc, min(min(am[4], am[5]), min(am[6], am[7])));
             if (__builtin_expect(__ballot(acc == 0) != 0, 0)) {   // wave-uniform, rare: some lane, some offset
 #pragma unroll
-                for (int i = 0; i < FZ_GROUP; ++i) {
+                for (int i = 0; i < GRP; ++i) {
                     if (__ballot(am[i] == 0)) {           // which offset (scalar branch)
                         // which block(s): equal n-grams share a slot
                         auto push = [&](uint32_t g) {
@@ -601,7 +604,7 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                                 // a scratch round trip per firing once it is spilled
                                 uint32_t code = threadIdx.x;
                                 asm volatile("v_lshlrev_b32 %0, 4, %0" : "+v"(code));
-                                code = fz_code(code + (uint32_t)(r * FZ_ROW_BYTES + FZ_GROUP * j + i), g, titer);
+                                code = fz_code(code + (uint32_t)(r * FZ_ROW_BYTES + GRP * j + i), g, titer);
                                 if (hv[i] == hg && slot < qcap) w.queue[slot] = code;
                                 qn += (uint32_t)__popcll(mk);
                             }

@@ -41,6 +41,9 @@ def main():
             cut = fzd.shard_bounds(n, world, b)[0]
             if m // 2 <= cut <= n - m:
                 seq[cut - m // 2:cut - m // 2 + m] = pattern
+        if case == 0:                                  # ... and the bench's plants at deltas {-m-k ... +1} (equal shards)
+            plants = workloads.boundary_plants(m, k, n // world, world)
+            workloads.apply_plants(seq, 0, plants, pattern)
         p, halo = pattern.tobytes(), m + k
         shard = seq[lo:hi].copy()                      # all this rank keeps of the sequence
         left, right = fzd.exchange_halos(shard, halo)
@@ -57,6 +60,9 @@ def main():
         mine = [(out[i].start, out[i].end, out[i].dist, out[i].block) for i in range(c)]
         merged = fzd.allgather_matches(mine)
         exp = oracle.lev_ngrams_raw(p, seq.tobytes(), k)
+        if case == 0 and n % world == 0:
+            found = {(int(a), int(b), int(c)) for (a, b, c, _g) in merged}
+            assert all((q, q + m, 0) in found for q in plants), "boundary plants missing"
         if [tuple(int(x) for x in r) for r in merged] != exp:
             ok = False
             print("rank %d case %d MISMATCH: %d vs %d" % (rank, case, len(merged), len(exp)), flush=True)

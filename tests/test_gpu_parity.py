@@ -86,6 +86,47 @@ def test_lev_ngrams_wide_budgets_random(engine):
     assert all(v > 50 for v in n_cases.values()), n_cases
 
 
+def test_lev_ngrams_budgets_5_to_8_long_ngrams(engine):
+    """Budgets 5 .. 8 with n-grams of 8 bytes or more (the shape of BASELINE configs[3]: long pattern, wide band,
+    few n-gram hits) against the oracle: planted edited copies, ragged ends, small alphabets.  (Round 2 measured
+    verifying these inside the scan kernel with a register band up to 8: 0.283 instead of 0.206 + 0.031 ms at
+    m = 64, k = 5 on 1 GiB of text — a lone candidate's 64-row DP at the end of a wave's life costs more than
+    the lane-per-cell kernel needs for all of them; not kept.)"""
+    rnd = random.Random(23)
+    cases = []
+    for it in range(260):
+        alpha = bytes(rnd.sample(range(33, 127), rnd.choice([2, 3, 4, 20])))
+        k = rnd.choice([5, 6, 7, 8])
+        m = rnd.randint(8 * (k + 1), 8 * (k + 1) + 40)
+        n = rnd.randint(0, 1500)
+        t = bytearray(rnd.choice(alpha) for _ in range(n))
+        p = bytes(rnd.choice(alpha) for _ in range(m))
+        for _rep in range(3):
+            if n > m + 10 and rnd.random() < 0.8:
+                v = bytearray(p)
+                for _ in range(rnd.randint(0, k)):
+                    q = rnd.randrange(len(v))
+                    op = rnd.random()
+                    if op < 0.4:
+                        v[q] = rnd.choice(alpha)
+                    elif op < 0.7 and len(v) > 2:
+                        del v[q]
+                    else:
+                        v.insert(q, rnd.choice(alpha))
+                st = rnd.choice([0, 1, n - len(v) - 1, n - len(v), rnd.randint(0, max(0, n - len(v)))])
+                st = max(0, min(st, n - len(v)))
+                t[st:st + len(v)] = v
+        cases.append((p, bytes(t), k))
+    hits = 0
+    for p, t, k in cases:
+        seq = engine.upload(t)
+        got = engine.lev_ngrams(seq, p, k)
+        seq.release()
+        assert got == oracle.lev_ngrams_raw(p, t, k), (p, t, k)
+        hits += len(got)
+    assert hits > 200
+
+
 def test_subs_ngrams_raw_random(engine):
     rnd = random.Random(12)
     for _ in range(1000):

@@ -61,7 +61,7 @@ def test_levenshtein_ngrams_raw_stream():
 
 def test_find_near_matches_levenshtein_dispatch():
     """find_near_matches_levenshtein (levenshtein.py:9-38): k == 0 -> exact; n-gram route when
-    len // (k+1) >= 3; the LP route is outside the hot path (not restated)."""
+    len // (k+1) >= 3, else the linear-programming route (oracle.lev_lp_raw, SURVEY.md §8(f)3)."""
     n = 0
     for rec in _records("find_near_matches_levenshtein"):
         sub, seq, k = (list(rec["args"]) + [rec["kwargs"].get("max_l_dist")])[:3]

@@ -102,6 +102,36 @@ def test_generic_raw(ref):
                 [r[:3] for r in oracle.generic_ngrams_raw(p, t, *a)], (p, t, a)
 
 
+def test_linear_programming_fallbacks_raw(ref):
+    """(f)3: the oracle's restatement of the linear-programming fallbacks against the reference's own functions
+    (levenshtein.py:52-148, substitutions_only.py:82-136) — ordered emission lists, short and long patterns,
+    budgets up to and beyond the pattern length."""
+    from fuzzysearch.levenshtein import find_near_matches_levenshtein_linear_programming as ref_lev_lp
+    from fuzzysearch.substitutions_only import find_near_matches_substitutions_lp as ref_subs_lp
+    rnd = random.Random(9)
+    n_lev = n_subs = 0
+    for _ in range(4000):
+        alpha = bytes(rnd.sample(range(65, 91), rnd.choice([2, 2, 3, 4])))
+        t = bytes(rnd.choice(alpha) for _ in range(rnd.randint(0, 50)))
+        m = rnd.randint(1, 10)
+        if rnd.random() < 0.5 and len(t) >= m:
+            st = rnd.randint(0, len(t) - m)
+            p = bytearray(t[st:st + m])
+            if rnd.random() < 0.5:
+                p[rnd.randrange(m)] = rnd.choice(alpha)
+            p = bytes(p)
+        else:
+            p = bytes(rnd.choice(alpha) for _ in range(m))
+        k = rnd.randint(0, 4)
+        exp = [(x.start, x.end, x.dist) for x in ref_lev_lp(p, t, k)]
+        assert [r[:3] for r in oracle.lev_lp_raw(p, t, k)] == exp, (p, t, k)
+        n_lev += bool(exp)
+        exp = [(x.start, x.end, x.dist) for x in ref_subs_lp(p, t, k)]
+        assert [r[:3] for r in oracle.subs_lp_raw(p, t, k)] == exp, (p, t, k)
+        n_subs += bool(exp)
+    assert n_lev > 1500 and n_subs > 1000
+
+
 def test_api_consolidated_tie_aware(ref):
     """find_near_matches(max_l_dist=k) == consolidate(raw) up to hash-seed dependent ties."""
     from tests import golden_io

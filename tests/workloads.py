@@ -75,3 +75,29 @@ def cfg2(n=2 ** 30, n_plant=1024):
     pattern = dna(20, 1)
     planted = plant_variants(seq, pattern, n_plant, 7)
     return seq, pattern, planted
+
+
+def boundary_plants(m, k, shard_bytes, world):
+    """BASELINE config 5: exact copies of the pattern around every shard boundary b, at
+    deltas from {-m-k, ..., +1}.  Odd boundaries: a copy straddling b (a different split per boundary) with a copy
+    k bytes before and one k bytes after it; even boundaries: a copy that ends k bytes before b (delta -m-k: its
+    right window reaches into the next shard) and one that starts at b + 1 (its left window reaches back).
+    Non-overlapping.  -> sorted global start positions."""
+    out = []
+    for r in range(1, world):
+        b = r * shard_bytes
+        if r % 2:
+            left = 1 + (5 * r) % (m - 1)                     # bytes of the straddling copy left of the boundary
+            out += [b - left - k - m, b - left, b - left + m + k]
+        else:
+            out += [b - m - k, b + 1]
+    return sorted(out)
+
+
+def apply_plants(shard, shard_lo, positions, pattern):
+    """Write the part of every planted copy (global start positions) that falls inside shard [shard_lo, +len)."""
+    m, n = len(pattern), len(shard)
+    for q in positions:
+        lo, hi = max(q, shard_lo), min(q + m, shard_lo + n)
+        if lo < hi:
+            shard[lo - shard_lo:hi - shard_lo] = pattern[lo - q:hi - q]
