@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # kernel trace over the whole default bench (headline + 4 GiB target + the other configs); counters over the headline only
-BENCH="python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras"
+BENCH="python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras"   # (two searches in flight, as the default bench)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $OUT/stats.log 2>&1
 echo "stats rc=$?"
 i=0

@@ -51,9 +51,10 @@
 #define FZ_GROUP 0                                         // lab knob: force 4 or 8 byte offsets per wave-uniform branch (0: by n-gram length)
 #endif
 #define FZ_QCAP 256                                        // fast-hit queue entries per wave
-#ifndef FZ_H_SGPR
-#define FZ_H_SGPR(tg) ((tg) <= 4)                            // rare path: block hashes named as kernel arguments (SGPRs) or read from a lane vector
-#endif
+// rare path: the block hashes are read back from a lane vector with v_readlane.  (Naming them as kernel arguments
+// instead made the compiler re-load them from the argument block at every use once the SGPRs ran out — 260 s_load
+// + s_waitcnt pairs in the rare path of the 4-block kernel, 1.3 % of the headline scan.)
+#define FZ_H_SGPR(tg) 0
 #ifndef FZ_LUT_BITS
 #define FZ_LUT_BITS 5                                      // 32 slots: one per LDS bank (6 = the round-1 table, 2-way conflicts)
 #endif
@@ -648,12 +649,18 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
             }
             do {
                 const uint8_t *tsrc = buf + fz_bcast64(tile * (uint64_t)FZ_TILE_BYTES);
+#ifdef FZ_LAB_SETPRIO
+                __builtin_amdgcn_s_setprio(FZ_LAB_SETPRIO);
+#endif
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     vb[r] = *reinterpret_cast<const uint4 *>(tsrc + (r + 2) * FZ_ROW_BYTES + lane_off);
                     hb[r] = *reinterpret_cast<const uint2 *>(tsrc + (r + 2) * FZ_ROW_BYTES + lane_off + 16);
                 }
                 __builtin_amdgcn_sched_barrier(0);    // all loads are issued before the first use
+#ifdef FZ_LAB_SETPRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
                 const uint32_t q_tile = qn;
                 test_row(va[0], ha[0], std::integral_constant<int, 0>{});
                 test_row(va[1], ha[1], std::integral_constant<int, 1>{});
@@ -662,6 +669,9 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                 {   // unconditional (a branch here would make the compiler wait for the prefetch at the join):
                     // without a next tile the loads re-read this one (L2 hits, results unused)
                     const uint8_t *nsrc = buf + fz_bcast64((pre ? next : tile) * (uint64_t)FZ_TILE_BYTES);
+#ifdef FZ_LAB_SETPRIO
+                    __builtin_amdgcn_s_setprio(FZ_LAB_SETPRIO);
+#endif
 #pragma unroll
                     for (int r = 0; r < 2; ++r) {
                         va[r] = *reinterpret_cast<const uint4 *>(nsrc + r * FZ_ROW_BYTES + lane_off);
@@ -669,6 +679,9 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#ifdef FZ_LAB_SETPRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
                 test_row(vb[0], hb[0], std::integral_constant<int, 2>{});
                 test_row(vb[1], hb[1], std::integral_constant<int, 3>{});
                 if (qn > qcap) {                      // this tile overflowed the queue: drop its

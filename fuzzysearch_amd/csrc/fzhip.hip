@@ -409,7 +409,10 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     // (Round 2 measured the alternative — a persistent grid whose waves draw 4 KiB chunks from ticket
     // counters so that all finish together: same time without candidates, 0.04 ms slower on DNA,
     // because every wave then runs its verification at the same moment, at the end.)
-    static const int tiles_per_wg = []() { const char *e = getenv("FZ_TILES_PER_WG"); int v = e ? atoi(e) : 0; return v > 0 ? v : 16; }();
+    // (re-measured with the software-pipelined loop of round 2, 1 GiB: 8 / 10 / 12 / 14 / 16 / 20 / 24 / 32 tiles ->
+    //  DNA k = 2: 0.232 / 0.223 / 0.222 / 0.222 / 0.224 / 0.240 / 0.244 / 0.260 ms; exact search: 0.191 / 0.182 /
+    //  0.187 / 0.193 / 0.199 / 0.201 / 0.196 / 0.205 ms)
+    static const int tiles_per_wg = []() { const char *e = getenv("FZ_TILES_PER_WG"); int v = e ? atoi(e) : 0; return v > 0 ? v : 12; }();
     const uint64_t max_grid = std::max<uint64_t>((uint64_t)d.n_cus * 6, ntiles / tiles_per_wg);
     // the queue codes carry a bounded per-workgroup tile iteration
     const uint64_t min_grid = (ntiles + FZ_TITER_MAX - 1) / FZ_TITER_MAX;
