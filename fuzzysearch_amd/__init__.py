@@ -17,6 +17,7 @@ import attr
 
 from .common import Match, LevenshteinSearchParams
 from .engine import DeviceSequence, resident
+from ._native import UnsupportedSearch
 from .generic_search import GenericSearch
 from .levenshtein import LevenshteinSearch
 from .search_exact import ExactSearch
@@ -30,6 +31,7 @@ __all__ = [
     'find_near_matches_in_file',
     'Match',
     'resident',
+    'UnsupportedSearch',
 ]
 
 
@@ -55,6 +57,13 @@ def find_near_matches(subsequence, sequence,
 
     Limits (relative to the subsequence): maximum substitutions, insertions, deletions and their
     total (the Levenshtein distance).  ``sequence`` may also be a ``resident()`` handle.
+
+    Every route runs on the GPU; there is no CPU fallback.  What the engine does not support raises
+    ``UnsupportedSearch`` (a ``NotImplementedError``) before anything is searched: a subsequence of more
+    than 1024 items, a budget (``max_l_dist`` / ``max_substitutions``) above 255, more than 255 n-gram
+    blocks, more than 255 distinct symbols in a subsequence that is neither bytes nor latin-1 text, and
+    generic searches whose candidate sets outgrow 2**18 entries.  The reference accepts all of these:
+    catch the exception to route such a call there.
     """
     search_params = LevenshteinSearchParams(max_substitutions, max_insertions,
                                             max_deletions, max_l_dist)

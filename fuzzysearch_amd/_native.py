@@ -130,6 +130,13 @@ def load_library():
         return L
 
 
+class UnsupportedSearch(NotImplementedError):
+    """The search is outside what the GPU engine supports (subsequence longer than 1024 items, a budget above
+    255, more than 255 n-gram blocks, more than 255 distinct symbols in a non-bytes subsequence, automaton
+    candidate sets beyond 2^18 entries).  Nothing was searched and there is no CPU fallback: a caller that needs
+    such a search catches this and routes it to the reference implementation."""
+
+
 def _raise(rc):
     msg = (load_library().fz_last_error() or b"").decode("utf-8", "replace")
     if rc == FZ_EINVAL:
@@ -137,7 +144,7 @@ def _raise(rc):
     if rc == FZ_ENOMEM:
         raise MemoryError(msg)
     if rc == FZ_EUNSUPPORTED:
-        raise NotImplementedError(msg)
+        raise UnsupportedSearch(msg)
     raise HipEngineError("libfzhip error %d: %s" % (rc, msg))
 
 

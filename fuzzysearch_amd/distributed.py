@@ -160,11 +160,15 @@ def allgather_matches(raw, group=None, as_array=False):
     key = id(group) if group is not None else 0
     while True:
         st = _gather_state.get(key)
+        # the state holds the group object (so its id cannot be handed to another group while the entry exists)
+        # and is rebuilt if world size or device differ from what it was built for
+        if st is not None and (st.get("group") is not group or st.get("dev", dev) != dev):
+            st = None
         if st is None or st["world"] != world:
             cap = st["cap"] if st else 4096
             pin = dev.type == "cuda"
             rows = WIRE_HEADER_ROWS + cap
-            st = {"cap": cap, "world": world, "rows": rows,
+            st = {"cap": cap, "world": world, "rows": rows, "group": group, "dev": dev,
                   "h_send": torch.zeros((rows, 2), dtype=torch.int64, pin_memory=pin),
                   "h_recv": torch.zeros((world, rows, 2), dtype=torch.int64, pin_memory=pin)}
             st["send_ptr"], st["recv_ptr"] = st["h_send"].data_ptr(), st["h_recv"].data_ptr()
@@ -192,7 +196,7 @@ def allgather_matches(raw, group=None, as_array=False):
             # every rank resizes identically): the collective and the D2H copy move `cap` rows per rank
             want = max(256, -(-(top.value + top.value // 8) // 128) * 128)
             if want * 4 <= cap * 3:
-                _gather_state[key] = {"cap": want, "world": -1}
+                _gather_state[key] = {"cap": want, "world": -1, "group": group, "dev": dev}
             if as_array:
                 return merged
             out = np.empty((len(merged), 4), dtype=np.int64)
@@ -201,4 +205,4 @@ def allgather_matches(raw, group=None, as_array=False):
         new_cap = cap
         while new_cap < top.value:
             new_cap *= 2
-        _gather_state[key] = {"cap": new_cap, "world": -1}               # rebuild buffers at the new capacity
+        _gather_state[key] = {"cap": new_cap, "world": -1, "group": group, "dev": dev}   # rebuild buffers at the new capacity

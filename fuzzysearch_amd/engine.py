@@ -16,6 +16,7 @@
 import numpy as np
 
 from . import _native
+from ._native import UnsupportedSearch
 
 __all__ = ['DeviceSequence', 'resident', 'encode_pair', 'is_byteslike']
 
@@ -37,7 +38,7 @@ def _remap_str(subsequence, sequence):
     t = np.frombuffer(sequence.encode('utf-32-le'), dtype=np.uint32)
     symbols = np.unique(p)
     if len(symbols) > 255:
-        raise NotImplementedError('subsequences with more than 255 distinct symbols are not supported')
+        raise UnsupportedSearch('subsequences with more than 255 distinct symbols are not supported')
 
     def code(a):
         if len(a) == 0:
@@ -52,7 +53,7 @@ def _remap_items(subsequence, sequence):
     for item in subsequence:
         if item not in table:
             if len(table) == 255:
-                raise NotImplementedError('subsequences with more than 255 distinct symbols are not supported')
+                raise UnsupportedSearch('subsequences with more than 255 distinct symbols are not supported')
             table[item] = len(table) + 1
     get = table.get
     return bytes(table[item] for item in subsequence), bytes(bytearray(get(item, 0) for item in sequence))
