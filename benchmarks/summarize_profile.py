@@ -6,8 +6,8 @@ tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 base = os.path.join(root, "gpurun_out", "prof_" + tag)
 alg = int(sys.argv[2]) if len(sys.argv) > 2 else 2 ** 30
-# the headline instance: 3 blocks -> rare path compiled for 4, hash windows (2, DH = 3), fused, in-memory, low-bits slot
-HEAD_KERNEL = "fz_scan_kernel<4, 2, 3, true, false, true"
+# the headline instance: hash windows (NWIN = 2, DH = 3), fused, in-memory, low-bits slot
+HEAD_KERNEL = "fz_scan_kernel<2, 3, true, false, true"
 TILES_PER_WG = 12
 newest = lambda pattern: max(glob.glob(pattern), key=os.path.getmtime)   # gpurun merges runs: take the last one
 stats = newest(os.path.join(base, "stats", "*", "*_kernel_stats.csv"))

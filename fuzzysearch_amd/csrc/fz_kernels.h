@@ -51,15 +51,13 @@
 #define FZ_GROUP 0                                         // lab knob: force 4 or 8 byte offsets per wave-uniform branch (0: by n-gram length)
 #endif
 #define FZ_QCAP 256                                        // fast-hit queue entries per wave
-// rare path: the block hashes are read back from a lane vector with v_readlane.  (Naming them as kernel arguments
-// instead made the compiler re-load them from the argument block at every use once the SGPRs ran out — 260 s_load
-// + s_waitcnt pairs in the rare path of the 4-block kernel, 1.3 % of the headline scan.)
-#define FZ_H_SGPR(tg) 0
 #ifndef FZ_LUT_BITS
 #define FZ_LUT_BITS 5                                      // 32 slots: one per LDS bank (6 = the round-1 table, 2-way conflicts)
 #endif
 #define FZ_LUT_SLOTS (1u << FZ_LUT_BITS)                   // slots of the block-hash table
 #define FZ_LUT_BYTES (FZ_LUT_SLOTS * 4u)
+#define FZ_TABLE_BYTES (FZ_LUT_BYTES + FZ_LUT_SLOTS)       // the hash table + one byte per slot: the block that lives there
+#define FZ_FLAG_DUP_HASHES 1u                              // FzScanArgs.flags: two blocks of the launch have the same hash
 #if FZ_LUT_BITS == 5
 #define FZ_LUT_ADDR_MASK_STR "0x7c"                        // (FZ_LUT_SLOTS - 1) * 4: byte address of a slot
 #else
@@ -481,8 +479,6 @@ __device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ b
     return confirmed;
 }
 
-// TG    : blocks the rare path tells apart (unrolled compares); nblk <= TG are real, the rest repeat block 0
-//         and are dropped by the range check.  The hot path does not depend on it.
 // NWIN  : 1 -> hash = (masked dword at the offset) * K               (L <= 4, v_mul_lo_u32);
 //         2 -> hash = low24(dword at offset + DH) * K + dword at offset (v_mad_u32_u24), DH = min(L, 8) - 3.
 // FUSED : verify candidates inside this kernel (records out) or emit exact hits (hit list out).
@@ -514,7 +510,7 @@ __device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ b
 //     by LDS-DMA now (fz_prefetch_windows).
 // 7 waves per SIMD (72 VGPRs): measured 2-3 % faster than the natural 79-VGPR / 6-wave allocation;
 // 8 waves (64 VGPRs) spills 27 VGPRs in the verify path and is 50 % slower.
-template <int TG, int NWIN, int DH, bool FUSED, bool SEG, bool SA>
+template <int NWIN, int DH, bool FUSED, bool SEG, bool SA>
 __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_eu(7, 7))) void fz_scan_kernel(
     const uint8_t *__restrict__ buf, const FzScanArgs a, uint64_t ntiles,
     uint64_t *__restrict__ hits, FzRec *__restrict__ recs, unsigned long long *__restrict__ counters) {
@@ -527,27 +523,27 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
     // lookup); trap if a toolchain ever lays LDS out differently.
     uint32_t *lut = reinterpret_cast<uint32_t *>(smem);
     if (reinterpret_cast<uintptr_t>((FzLdsU8 *)smem) != 0) __builtin_trap();
-    uint8_t *pat_lds = smem + FZ_LUT_BYTES;
+    uint8_t *pat_lds = smem + FZ_TABLE_BYTES;
     for (uint32_t i = threadIdx.x; i < a.m; i += FZ_FILTER_THREADS) pat_lds[i] = a.pat[i];
     if (threadIdx.x < FZ_LUT_SLOTS) {
         uint32_t t = ((threadIdx.x + 1u) & (FZ_LUT_SLOTS - 1u)) << a.lut_shift;   // free slot: a value of the next slot
-        for (uint32_t g = 0; g < a.nblk; ++g)
-            if (((a.H[g] >> a.lut_shift) & (FZ_LUT_SLOTS - 1u)) == threadIdx.x) t = a.H[g];
+        uint32_t who = 0xffu;                                                     // ... and the block that lives in the slot
+        for (uint32_t g = a.nblk; g-- > 0;)
+            if (((a.H[g] >> a.lut_shift) & (FZ_LUT_SLOTS - 1u)) == threadIdx.x) { t = a.H[g]; who = g; }
         lut[threadIdx.x] = t;
+        smem[FZ_LUT_BYTES + threadIdx.x] = (uint8_t)who;
     }
-    // lane g of hvec = hash of block g: the rare path reads it back with v_readlane (no memory latency)
-    // (up to 4 blocks: the unrolled rare path names a.H[g] directly and the compiler keeps it in SGPRs)
+    // lane g of hvec = hash of block g (only launches whose blocks share hashes — equal n-grams — use it)
     uint32_t hvec = 0;
-    if (!FZ_H_SGPR(TG)) {
 #pragma unroll
-        for (uint32_t g = 0; g < FZ_MAX_BLOCKS_PER_LAUNCH; ++g)
-            if (fz_lane() == g) hvec = a.H[g];
-    }
+    for (uint32_t g = 0; g < FZ_MAX_BLOCKS_PER_LAUNCH; ++g)
+        if (fz_lane() == g) hvec = a.H[g];
+    const bool dup_hashes = (a.flags & FZ_FLAG_DUP_HASHES) != 0;
     __syncthreads();
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t qcap = PREF ? a.qcap : (uint32_t)FZ_QCAP;   // queue entries per wave
-    const FzWaveLds w = PREF ? fz_wave_lds_pref(smem + FZ_LUT_BYTES + mpad, FZ_LUT_BYTES + mpad, wave, qcap, a.win_pieces)
-                             : fz_wave_lds(smem + FZ_LUT_BYTES + mpad, wave, FUSED ? a.win_dwords : 0u,
+    const FzWaveLds w = PREF ? fz_wave_lds_pref(smem + FZ_TABLE_BYTES + mpad, FZ_TABLE_BYTES + mpad, wave, qcap, a.win_pieces)
+                             : fz_wave_lds(smem + FZ_TABLE_BYTES + mpad, wave, FUSED ? a.win_dwords : 0u,
                                            FUSED ? a.band_w : 0u, a.vlanes, true);
     const uint32_t hash_k = a.hash_k;
     // byte address of a hash's slot = (h >> (lut_shift - 2)) & 0x7c: two VGPR-only VALU ops (a shift
@@ -594,28 +590,35 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
             if (__builtin_expect(__ballot(acc == 0) != 0, 0)) {   // wave-uniform, rare: some lane, some offset
 #pragma unroll
                 for (int i = 0; i < GRP; ++i) {
-                    if (__ballot(am[i] == 0)) {           // which offset (scalar branch)
-                        // which block(s): equal n-grams share a slot
-                        auto push = [&](uint32_t g) {
-                            const uint32_t hg = FZ_H_SGPR(TG) ? a.H[g] : (uint32_t)__builtin_amdgcn_readlane((int)hvec, (int)g);
-                            const unsigned long long mk = __ballot(hv[i] == hg);
-                            if (mk) {
-                                const uint32_t slot = qn + fz_rank(mk);
-                                // recomputed here: a copy kept in a VGPR (LICM hoists the loop-invariant codes) costs
-                                // a scratch round trip per firing once it is spilled
-                                uint32_t code = threadIdx.x;
-                                asm volatile("v_lshlrev_b32 %0, 4, %0" : "+v"(code));
-                                code = fz_code(code + (uint32_t)(r * FZ_ROW_BYTES + GRP * j + i), g, titer);
-                                if (hv[i] == hg && slot < qcap) w.queue[slot] = code;
-                                qn += (uint32_t)__popcll(mk);
-                            }
-                        };
-                        if constexpr (TG <= 4) {          // unrolled: 6 % faster at 17 % firing groups (DNA, L = 6)
-#pragma unroll
-                            for (int g = 0; g < TG; ++g) push((uint32_t)g);
-                        } else {                          // rolled: 64 x 8 unrolled copies stop the row loop from unrolling
+                    const unsigned long long mi = __ballot(am[i] == 0);      // which offset (scalar branch)
+                    if (mi) {
+                        // the queue code is recomputed here: a copy kept in a VGPR (LICM hoists the loop-invariant
+                        // codes) costs a scratch round trip per firing once it is spilled
+                        uint32_t pos = threadIdx.x;
+                        asm volatile("v_lshlrev_b32 %0, 4, %0" : "+v"(pos));
+                        pos += (uint32_t)(r * FZ_ROW_BYTES + GRP * j + i);
+                        if (__builtin_expect(!dup_hashes, 1)) {
+                            // which block: the window's hash equals the one in its slot, and one byte per slot says
+                            // whose that is (one LDS read instead of a compare per block)
+                            uint32_t slot4;
+                            if constexpr (SA) asm("v_and_b32 %0, " FZ_LUT_ADDR_MASK_STR ", %1" : "=v"(slot4) : "v"(hv[i]));
+                            else asm("v_lshrrev_b32 %0, %1, %2\n\tv_and_b32 %0, " FZ_LUT_ADDR_MASK_STR ", %0" : "=v"(slot4) : "v"(slot_shift), "v"(hv[i]));
+                            const uint32_t g = smem[FZ_LUT_BYTES + (slot4 >> 2)];
+                            const uint32_t slot = qn + fz_rank(mi);
+                            if (am[i] == 0 && slot < qcap) w.queue[slot] = fz_code(pos, g, titer);
+                            qn += (uint32_t)__popcll(mi);
+                        } else {
+                            // equal n-grams share a slot: compare with every block of the launch
 #pragma unroll 1
-                            for (uint32_t g = 0; g < (uint32_t)TG; ++g) push(g);
+                            for (uint32_t g = 0; g < a.nblk; ++g) {
+                                const uint32_t hg = (uint32_t)__builtin_amdgcn_readlane((int)hvec, (int)g);
+                                const unsigned long long mk = __ballot(hv[i] == hg);
+                                if (mk) {
+                                    const uint32_t slot = qn + fz_rank(mk);
+                                    if (hv[i] == hg && slot < qcap) w.queue[slot] = fz_code(pos, g, titer);
+                                    qn += (uint32_t)__popcll(mk);
+                                }
+                            }
                         }
                     }
                 }

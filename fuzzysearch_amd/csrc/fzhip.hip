@@ -248,47 +248,35 @@ struct BlockPlan {
 
 using ScanKernel = void (*)(const uint8_t *, const FzScanArgs, uint64_t, uint64_t *, FzRec *, unsigned long long *);
 
-template <int TG, bool FUSED, bool SEG, bool SA>
-ScanKernel scan_kernel_tg(int nwin, int dh) {
-    if (nwin == 1) return fz_scan_kernel<TG, 1, 0, FUSED, SEG, SA>;
-    switch (dh) {
-        case 2: return fz_scan_kernel<TG, 2, 2, FUSED, SEG, SA>;
-        case 3: return fz_scan_kernel<TG, 2, 3, FUSED, SEG, SA>;
-        case 4: return fz_scan_kernel<TG, 2, 4, FUSED, SEG, SA>;
-        default: return fz_scan_kernel<TG, 2, 5, FUSED, SEG, SA>;
-    }
-}
-
 template <bool FUSED, bool SEG, bool SA>
-ScanKernel scan_kernel_f(int tg, int nwin, int dh) {
-    switch (tg) {
-        case 2: return scan_kernel_tg<2, FUSED, SEG, SA>(nwin, dh);
-        case 4: return scan_kernel_tg<4, FUSED, SEG, SA>(nwin, dh);
-        default: return scan_kernel_tg<8, FUSED, SEG, SA>(nwin, dh);
+ScanKernel scan_kernel_f(int nwin, int dh) {
+    if (nwin == 1) return fz_scan_kernel<1, 0, FUSED, SEG, SA>;
+    switch (dh) {
+        case 2: return fz_scan_kernel<2, 2, FUSED, SEG, SA>;
+        case 3: return fz_scan_kernel<2, 3, FUSED, SEG, SA>;
+        case 4: return fz_scan_kernel<2, 4, FUSED, SEG, SA>;
+        default: return fz_scan_kernel<2, 5, FUSED, SEG, SA>;
     }
 }
 
 template <bool FUSED, bool SEG>
-ScanKernel scan_kernel_s(int tg, int nwin, int dh, bool sa) {
-    return sa ? scan_kernel_f<FUSED, SEG, true>(tg, nwin, dh) : scan_kernel_f<FUSED, SEG, false>(tg, nwin, dh);
+ScanKernel scan_kernel_s(int nwin, int dh, bool sa) {
+    return sa ? scan_kernel_f<FUSED, SEG, true>(nwin, dh) : scan_kernel_f<FUSED, SEG, false>(nwin, dh);
 }
 
 // The segmented variants (file API) only exist where a segment changes the outcome: Levenshtein /
 // generic clamps.  Exact and substitutions-only windows fit exactly one chunk (the host assigns it).
 // sa: the launch's blocks are told apart by hash bits 2..6 (slot address = one v_and).
-ScanKernel scan_kernel(int tg, int nwin, int dh, bool fused, bool seg, bool sa) {
+ScanKernel scan_kernel(int nwin, int dh, bool fused, bool seg, bool sa) {
 #ifdef FZ_LAB_ONLY      // lab builds (benchmarks/lab_build.sh): only the instances of the headline and exact-search workloads
-    if (tg == 4 && nwin == 2 && dh == 3 && fused && !seg) return sa ? fz_scan_kernel<4, 2, 3, true, false, true> : fz_scan_kernel<4, 2, 3, true, false, false>;
-    if (tg == 2 && nwin == 2 && dh == 5 && !fused && !seg) return sa ? fz_scan_kernel<2, 2, 5, false, false, true> : fz_scan_kernel<2, 2, 5, false, false, false>;
+    if (nwin == 2 && dh == 3 && fused && !seg) return sa ? fz_scan_kernel<2, 3, true, false, true> : fz_scan_kernel<2, 3, true, false, false>;
+    if (nwin == 2 && dh == 5 && !fused && !seg) return sa ? fz_scan_kernel<2, 5, false, false, true> : fz_scan_kernel<2, 5, false, false, false>;
     return nullptr;
 #else
-    if (seg) return fused ? scan_kernel_s<true, true>(tg, nwin, dh, sa) : scan_kernel_s<false, true>(tg, nwin, dh, sa);
-    return fused ? scan_kernel_s<true, false>(tg, nwin, dh, sa) : scan_kernel_s<false, false>(tg, nwin, dh, sa);
+    if (seg) return fused ? scan_kernel_s<true, true>(nwin, dh, sa) : scan_kernel_s<false, true>(nwin, dh, sa);
+    return fused ? scan_kernel_s<true, false>(nwin, dh, sa) : scan_kernel_s<false, false>(nwin, dh, sa);
 #endif
 }
-
-// Compiled-in blocks of the rare path: 2, 4 or 8 (spare ones carry a hash no window can be queued with).
-int pick_tg(uint32_t nblk) { return nblk <= 2 ? 2 : nblk <= 4 ? 4 : 8; }
 
 // Odd multipliers tried for the window hash (24-bit ones serve v_mad_u32_u24).  One search needs a
 // multiplier under which its (at most 8 per launch) distinct block hashes fall into distinct slots of
@@ -442,18 +430,18 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
         // re-scanned by enumeration, 64 entries at a time: 64 is the floor)
         fa.win_pieces = (q.m + 2 * q.k + 3 + 15) / 16;           // window <= m + 2k bytes + 3 of dword alignment
         fa.qcap = 128;
-        while (fa.qcap > 64 && mpad + FZ_LUT_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_pref_bytes(fa.qcap, fa.win_pieces) > target + 4096)
+        while (fa.qcap > 64 && mpad + FZ_TABLE_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_pref_bytes(fa.qcap, fa.win_pieces) > target + 4096)
             fa.qcap >>= 1;
-        fused_lds = mpad + FZ_LUT_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_pref_bytes(fa.qcap, fa.win_pieces);
+        fused_lds = mpad + FZ_TABLE_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_pref_bytes(fa.qcap, fa.win_pieces);
         if (fa.win_pieces * 16u + 16u > FZ_PAD_BACK) fused_lds = ~0u;   // the last pieces may lie past the sequence: inside the padding only
     } else {
-        while (fa.vlanes > 16 && mpad + FZ_LUT_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, fa.vlanes, true) > target)
+        while (fa.vlanes > 16 && mpad + FZ_TABLE_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, fa.vlanes, true) > target)
             fa.vlanes >>= 1;
-        fused_lds = mpad + FZ_LUT_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, fa.vlanes, true);
+        fused_lds = mpad + FZ_TABLE_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, fa.vlanes, true);
     }
     // k > 4 (register band too wide for the scan kernel's VGPR budget) -> verify in a kernel of its own
     fa.fused = (with_verify && fused_lds <= kFusedLdsBudget && (q.mode != FZ_MODE_LEV || q.k <= 4)) ? 1u : 0u;
-    const uint32_t scan_lds = fa.fused ? fused_lds : mpad + FZ_LUT_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(0, 0, 64, true);
+    const uint32_t scan_lds = fa.fused ? fused_lds : mpad + FZ_TABLE_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(0, 0, 64, true);
 
     uint32_t launches = 0;
     for (uint32_t g0 = 0; g0 < G && ntiles > 0;) {
@@ -477,17 +465,13 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
         // the final kernel of the search publishes the counters to the host (direct mode)
         const bool verify_follows = with_verify && !fa.fused;
         fa.host_hdr = (direct && !verify_follows && g0 + nblk >= G) ? reinterpret_cast<uint64_t>(d.h_stage_dev) : 0;
-        const int tg = pick_tg(nblk);
-        for (int b = (int)nblk; b < tg; ++b) {                        // compiled-in spare blocks: a hash that no queued window has
-            uint32_t v = fa.H[0] + 1u;                               // (a window is queued when its hash IS a real block's)
-            for (bool again = true; again;) {
-                again = false;
-                for (uint32_t r = 0; r < nblk; ++r) if (fa.H[r] == v) { ++v; again = true; }
-            }
-            fa.H[b] = v;
-        }
-        ScanKernel kern = scan_kernel(tg, nwin, dh, fa.fused != 0, sh.geom.seg_stride != 0, fa.lut_shift == 2);
-        if (!kern) return fail(FZ_EUNSUPPORTED, "this (lab) build carries no scan kernel for tg=%d nwin=%d dh=%d", tg, nwin, dh);
+        // equal n-grams (equal hashes) share a table slot: the rare path then compares with every block
+        fa.flags = 0;
+        for (uint32_t b = 1; b < nblk; ++b)
+            for (uint32_t c = 0; c < b; ++c)
+                if (fa.H[b] == fa.H[c]) fa.flags |= FZ_FLAG_DUP_HASHES;
+        ScanKernel kern = scan_kernel(nwin, dh, fa.fused != 0, sh.geom.seg_stride != 0, fa.lut_shift == 2);
+        if (!kern) return fail(FZ_EUNSUPPORTED, "this (lab) build carries no scan kernel for nwin=%d dh=%d", nwin, dh);
         static const uint32_t extra_lds = []() { const char *e = getenv("FZ_EXTRA_LDS_KB"); return e ? (uint32_t)atoi(e) * 1024u : 0u; }();
         hipLaunchKernelGGL(kern, grid, dim3(FZ_FILTER_THREADS), scan_lds + extra_lds, d.stream, sh.d_buf, fa, ntiles, d.d_hits, recs,
                            counters);
