@@ -56,7 +56,9 @@
 #endif
 #define FZ_LUT_SLOTS (1u << FZ_LUT_BITS)                   // slots of the block-hash table
 #define FZ_LUT_BYTES (FZ_LUT_SLOTS * 4u)
-#define FZ_TABLE_BYTES (FZ_LUT_BYTES + FZ_LUT_SLOTS)       // the hash table + one byte per slot: the block that lives there
+#define FZ_TABLE_BYTES (2u * FZ_LUT_BYTES + 16u)           // the hash table + one dword per slot: the block that lives there
+                                                           // + the four waves' final queue fills (pooled last flush)
+                                                           // (same byte offset as the hash: no address arithmetic in the rare path)
 #define FZ_FLAG_DUP_HASHES 1u                              // FzScanArgs.flags: two blocks of the launch have the same hash
 #if FZ_LUT_BITS == 5
 #define FZ_LUT_ADDR_MASK_STR "0x7c"                        // (FZ_LUT_SLOTS - 1) * 4: byte address of a slot
@@ -244,7 +246,8 @@ template <int MAXK, bool PREF>
 __device__ __forceinline__ uint32_t fz_wave_verify(const uint8_t *__restrict__ buf, const FzScanArgs &a,
                                                    const uint8_t *pat_lds, const FzWaveLds &w, uint32_t vl,
                                                    uint64_t hit, const FzSeg &sg, bool valid,
-                                                   FzRec *__restrict__ recs, unsigned long long *__restrict__ counters) {
+                                                   FzRec *__restrict__ recs, unsigned long long *__restrict__ counters,
+                                                   const uint8_t *pref_win = nullptr) {
     const uint32_t lane = fz_lane();
     const uint32_t g = fz_hit_block(hit);
     const uint64_t idx = fz_hit_index(hit);
@@ -276,6 +279,9 @@ __device__ __forceinline__ uint32_t fz_wave_verify(const uint8_t *__restrict__ b
     bool ok = false;
     auto run = [&](const auto &t) {
         auto prd = [&](uint32_t o) -> uint32_t { return *reinterpret_cast<const uint32_t *>(pat_lds + o); };
+#ifdef FZ_LAB_NOEXACT
+        valid = valid && a.m > 100000u;                       // lab: neither exact test nor expansion
+#endif
         if constexpr (PREF) {
             // exact n-gram test on registers: 8 bytes of text and pattern, masked to min(L, 8) (uniform), the
             // rest (L > 8) byte by byte
@@ -299,6 +305,9 @@ __device__ __forceinline__ uint32_t fz_wave_verify(const uint8_t *__restrict__ b
         }
         const uint32_t confirmed = (uint32_t)__popcll(__ballot(valid));
         FZ_LAB_STAMP(5);
+#ifdef FZ_LAB_NODP
+        valid = valid && a.m > 100000u;                       // lab: confirm but do not expand
+#endif
         if (a.mode == FZ_MODE_LEV) {
             FzLdsScores sc{w.scores + (PREF ? 0u : vl), a.vlanes};
             if (valid) ok = fz_verify_lev<MAXK>(sc, t, sg.sa, sg.se, pat_lds, a.m, a.k, a.L, s, idx, rec);
@@ -309,7 +318,7 @@ __device__ __forceinline__ uint32_t fz_wave_verify(const uint8_t *__restrict__ b
     };
     uint32_t confirmed;
     if constexpr (PREF) {
-        confirmed = run(FzDmaWindow{reinterpret_cast<const uint8_t *>(w.win) + vl * 16u, wbase, a.qcap * 16u});
+        confirmed = run(FzDmaWindow{pref_win, wbase, a.qcap * 16u});      // piece 0 of the lane's queue entry
     } else {
         confirmed = run(FzLdsWindow{reinterpret_cast<const uint8_t *>(w.win + vl), wbase, a.vlanes * 4u});
     }
@@ -371,6 +380,11 @@ __device__ __forceinline__ void fz_finish_launch(const FzScanArgs &a, unsigned l
         }
     }
 }
+
+// A wave-uniform value the compiler does not recognise as such (it then keeps it in a VGPR and updates it with
+// VALU ops): reading it through v_readfirstlane pins it to an SGPR; on values it already knows to be uniform the
+// call folds away.
+__device__ __forceinline__ uint32_t fz_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 // Candidate code of the queue: tile-local byte offset (14 bits) | block (3 bits) | tile iteration.
 __device__ __forceinline__ uint32_t fz_code(uint32_t off, uint32_t blk, uint32_t titer) {
@@ -459,7 +473,8 @@ __device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ b
 #ifdef FZ_LAB_NOVERIFY
                 confirmed += (uint32_t)__popcll(__ballot(valid));
 #else
-                confirmed += fz_wave_verify<4, PREF>(buf, a, pat_lds, w, PREF ? e : lane, hit, sg, valid, recs, counters);
+                confirmed += fz_wave_verify<4, PREF>(buf, a, pat_lds, w, lane, hit, sg, valid, recs, counters,
+                                                     PREF ? reinterpret_cast<const uint8_t *>(w.win) + e * 16u : nullptr);
 #endif
             } else {
                 if (valid) valid = fz_confirm(buf, a, blk, local);
@@ -476,6 +491,50 @@ __device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ b
     }
     fz_wave_lds_sync();
     FZ_LAB_STAMP(3);
+    return confirmed;
+}
+
+// The LAST flush of a workgroup of the fused in-memory scan, pooled: when all tiles are done every wave holds a
+// partly filled queue (on the headline workload ~32 entries: verifying them per wave keeps half the lanes idle,
+// and the scan is short of VALU issue slots, not of latency).  The four waves publish their fills, meet at one
+// barrier and verify the concatenation of the four queues 64 entries at a time, pass p on wave p mod 4: a lane
+// finds the wave that owns its entry by three compares and reads code and prefetched window out of that wave's
+// area.  `area` = first wave's queue, `per_wave` = bytes per wave area, `fills` = four LDS dwords.
+template <int MAXK>
+__device__ __forceinline__ uint32_t fz_pooled_flush(const uint8_t *__restrict__ buf, const FzScanArgs &a,
+                                                    const uint8_t *pat_lds, const uint8_t *area, uint32_t per_wave,
+                                                    volatile uint32_t *fills, uint32_t wave, uint32_t qn,
+                                                    FzRec *__restrict__ recs, unsigned long long *__restrict__ counters) {
+    const uint32_t lane = fz_lane();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's prefetched windows have landed in LDS
+    if (lane == 0) fills[wave] = qn;
+    __syncthreads();
+    const uint32_t n0 = fills[0], n1 = fills[1], n2 = fills[2], n3 = fills[3];
+    const uint32_t total = n0 + n1 + n2 + n3;
+    FzWaveLds none;
+    none.queue = nullptr; none.win = nullptr; none.scores = nullptr; none.win_lds = 0;
+    uint32_t confirmed = 0;
+    for (uint32_t e0 = wave * 64u; e0 < total; e0 += FZ_WAVES_PER_BLOCK * 64u) {
+        uint32_t li = e0 + lane, ow = 0;
+        bool valid = li < total;
+        if (li >= n0) { li -= n0; ow = 1; if (li >= n1) { li -= n1; ow = 2; if (li >= n2) { li -= n2; ow = 3; } } }
+        const uint8_t *mine = area + ow * per_wave;
+        uint64_t hit = 0;
+        FzSeg sg;
+        sg.sa = 0; sg.se = a.geom.n; sg.j = 0; sg.ok = 1;
+        if (valid) {
+            uint32_t blk;
+            const uint64_t idx = a.geom.buf_off + fz_code_local(reinterpret_cast<const uint32_t *>(mine)[li], blk);
+            valid = fz_hit_in_range(a, blk, idx, sg);
+            hit = fz_hit_pack(a.g0 + blk, idx);
+        }
+#ifdef FZ_LAB_NOVERIFY
+        confirmed += (uint32_t)__popcll(__ballot(valid));
+#else
+        confirmed += fz_wave_verify<MAXK, true>(buf, a, pat_lds, none, lane, hit, sg, valid, recs, counters,
+                                                mine + a.qcap * 4u + li * 16u);
+#endif
+    }
     return confirmed;
 }
 
@@ -531,7 +590,7 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
         for (uint32_t g = a.nblk; g-- > 0;)
             if (((a.H[g] >> a.lut_shift) & (FZ_LUT_SLOTS - 1u)) == threadIdx.x) { t = a.H[g]; who = g; }
         lut[threadIdx.x] = t;
-        smem[FZ_LUT_BYTES + threadIdx.x] = (uint8_t)who;
+        lut[FZ_LUT_SLOTS + threadIdx.x] = who;
     }
     // lane g of hvec = hash of block g (only launches whose blocks share hashes — equal n-grams — use it)
     uint32_t hvec = 0;
@@ -588,36 +647,45 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
             uint32_t acc = min(min(am[0], am[1]), min(am[2], am[3]));
             if constexpr (GRP == 8) acc = min(acc, min(min(am[4], am[5]), min(am[6], am[7])));
             if (__builtin_expect(__ballot(acc == 0) != 0, 0)) {   // wave-uniform, rare: some lane, some offset
+                if (__builtin_expect(!dup_hashes, 1)) {
 #pragma unroll
-                for (int i = 0; i < GRP; ++i) {
-                    const unsigned long long mi = __ballot(am[i] == 0);      // which offset (scalar branch)
-                    if (mi) {
-                        // the queue code is recomputed here: a copy kept in a VGPR (LICM hoists the loop-invariant
-                        // codes) costs a scratch round trip per firing once it is spilled
-                        uint32_t pos = threadIdx.x;
-                        asm volatile("v_lshlrev_b32 %0, 4, %0" : "+v"(pos));
-                        pos += (uint32_t)(r * FZ_ROW_BYTES + GRP * j + i);
-                        if (__builtin_expect(!dup_hashes, 1)) {
-                            // which block: the window's hash equals the one in its slot, and one byte per slot says
-                            // whose that is (one LDS read instead of a compare per block)
+                    for (int i = 0; i < GRP; ++i) {
+                        const unsigned long long mi = __ballot(am[i] == 0);      // which offset (scalar branch)
+                        if (mi) {
+                            // which block: the window's hash equals the one in its slot, and the dword behind the hash
+                            // table says whose that is (one LDS read instead of a compare per block)
                             uint32_t slot4;
                             if constexpr (SA) asm("v_and_b32 %0, " FZ_LUT_ADDR_MASK_STR ", %1" : "=v"(slot4) : "v"(hv[i]));
                             else asm("v_lshrrev_b32 %0, %1, %2\n\tv_and_b32 %0, " FZ_LUT_ADDR_MASK_STR ", %0" : "=v"(slot4) : "v"(slot_shift), "v"(hv[i]));
-                            const uint32_t g = smem[FZ_LUT_BYTES + (slot4 >> 2)];
+                            const uint32_t g = *reinterpret_cast<FzLdsU32 *>(slot4 + FZ_LUT_BYTES);
                             const uint32_t slot = qn + fz_rank(mi);
-                            if (am[i] == 0 && slot < qcap) w.queue[slot] = fz_code(pos, g, titer);
+                            // the queue code is recomputed here: a (tid << 4 | titer << 17) kept in a VGPR across the tile
+                            // saves three ops per firing but is the register that spills (measured: 0.218 -> 0.221 ms)
+                            uint32_t pos = threadIdx.x;
+                            asm volatile("v_lshlrev_b32 %0, 4, %0" : "+v"(pos));
+                            if (am[i] == 0 && slot < qcap)
+                                w.queue[slot] = fz_code(pos + (uint32_t)(r * FZ_ROW_BYTES + GRP * j + i), g, titer);
                             qn += (uint32_t)__popcll(mi);
-                        } else {
-                            // equal n-grams share a slot: compare with every block of the launch
+                        }
+                    }
+                } else {
+                    // equal n-grams share a slot: compare with every block of the launch
 #pragma unroll 1
-                            for (uint32_t g = 0; g < a.nblk; ++g) {
-                                const uint32_t hg = (uint32_t)__builtin_amdgcn_readlane((int)hvec, (int)g);
-                                const unsigned long long mk = __ballot(hv[i] == hg);
-                                if (mk) {
-                                    const uint32_t slot = qn + fz_rank(mk);
-                                    if (hv[i] == hg && slot < qcap) w.queue[slot] = fz_code(pos, g, titer);
-                                    qn += (uint32_t)__popcll(mk);
-                                }
+                    for (int i = 0; i < GRP; ++i) {
+                        uint32_t hvi = hv[0], ofs = 0;
+#pragma unroll
+                        for (int q = 1; q < GRP; ++q) if (i == q) { hvi = hv[q]; ofs = (uint32_t)q; }
+                        uint32_t pos = threadIdx.x;
+                        asm volatile("v_lshlrev_b32 %0, 4, %0" : "+v"(pos));
+                        pos += (uint32_t)(r * FZ_ROW_BYTES + GRP * j) + ofs;
+#pragma unroll 1
+                        for (uint32_t g = 0; g < a.nblk; ++g) {
+                            const uint32_t hg = (uint32_t)__builtin_amdgcn_readlane((int)hvec, (int)g);
+                            const unsigned long long mk = __ballot(hvi == hg);
+                            if (mk) {
+                                const uint32_t slot = qn + fz_rank(mk);
+                                if (hvi == hg && slot < qcap) w.queue[slot] = fz_code(pos, g, titer);
+                                qn += (uint32_t)__popcll(mk);
                             }
                         }
                     }
@@ -700,6 +768,10 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                 ++titer;
             } while (pre);                            // else: the end of the sequence, or a flush is due
         }
+        const bool done = !slow && tile >= ntiles;
+#ifndef FZ_LAB_NOPOOL
+        if (PREF && done) break;                      // what is queued now is verified by the pooled flush below
+#endif
         if (qn) {
 #ifndef FZ_LAB_NOPREFETCH
             if (PREF && qn > qf) fz_prefetch_windows(buf, a, w, qf, qn);
@@ -708,9 +780,16 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
         }
         qn = 0;
         qf = 0;
-        if (!slow && tile >= ntiles) break;
+        if (done) break;
     }
-    if (FUSED && lane == 0 && confirmed) atomicAdd(&counters[8 + (blockIdx.x & 63u)], (unsigned long long)confirmed);
+#ifndef FZ_LAB_NOPOOL
+    if constexpr (PREF) {
+        if (qn > qf) fz_prefetch_windows(buf, a, w, qf, qn);
+        confirmed += fz_pooled_flush<4>(buf, a, pat_lds, smem + FZ_TABLE_BYTES + mpad, fz_wave_lds_pref_bytes(qcap, a.win_pieces),
+                                        reinterpret_cast<volatile uint32_t *>(smem + 2u * FZ_LUT_BYTES), wave, qn, recs, counters);
+    }
+#endif
+
 #ifdef FZ_LAB_TIMING
     FZ_LAB_STAMP(4);
     if ((blockIdx.x & 1023u) == 512u && threadIdx.x == 0) {
@@ -719,6 +798,9 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                t[4] - t[0], t[1] - t[0], t[2] - t[1], t[5] - t[2], t[6] - t[5], t[3] - t[6], t[4] - t[3], confirmed);
     }
 #endif
+    // (measured and not kept: one no-return atomic per workgroup — ticket and tallies in one word — with the last-indexed
+    // workgroup polling for the others instead of every workgroup waiting for its ticket: 0.2172 vs 0.2183 ms, within noise)
+    if (FUSED && lane == 0 && confirmed) atomicAdd(&counters[8 + (blockIdx.x & 63u)], (unsigned long long)confirmed);
     fz_finish_launch(a, counters, lut);
 }
 
