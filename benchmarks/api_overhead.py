@@ -1,0 +1,33 @@
+"""Public API against the C-ABI at large result counts: BASELINE configs[3b] — 1 GiB of UTF-8
+text, m = 64, limits (5, 2, 2, 5), 2.1e5 raw matches — and configs[1].  find_near_matches() on a resident()
+sequence = C-ABI search + consolidation on the array in C++ + Match objects for the survivors only."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fuzzysearch_amd as fa
+from fuzzysearch_amd import _native
+from tests import workloads
+
+mib = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+n = mib << 20
+
+
+def best(fn, reps=5):
+    fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); r = fn(); ts.append(time.perf_counter() - t0)
+    return min(ts) * 1e3, r
+
+
+seq, pat, _ = workloads.cfg4(n, 1024 * mib // 1024 or 64)
+p = pat.tobytes()
+res = fa.resident(seq)
+eng = _native.default_engine()
+ms_abi, raw = best(lambda: eng.generic_ngrams(res.handle if hasattr(res, "handle") else res._handle, p, 5, 2, 2, 5, as_array=True))
+ms_api, out = best(lambda: fa.find_near_matches(p, res, max_substitutions=5, max_insertions=2, max_deletions=2, max_l_dist=5))
+print(json.dumps({"case": "configs[3b] generic (5,2,2,5)", "MiB": mib, "raw_matches": int(len(raw)), "result_matches": len(out),
+                  "c_abi_ms": round(ms_abi, 3), "find_near_matches_ms": round(ms_api, 3), "ratio": round(ms_api / ms_abi, 2)}), flush=True)
+ms_abi, raw = best(lambda: eng.lev_ngrams(res.handle if hasattr(res, "handle") else res._handle, p, 5, as_array=True))
+ms_api, out = best(lambda: fa.find_near_matches(p, res, max_l_dist=5))
+print(json.dumps({"case": "configs[3a] levenshtein k=5", "MiB": mib, "raw_matches": int(len(raw)), "result_matches": len(out),
+                  "c_abi_ms": round(ms_abi, 3), "find_near_matches_ms": round(ms_api, 3), "ratio": round(ms_api / ms_abi, 2)}), flush=True)

@@ -39,7 +39,7 @@ try:
         print(json.dumps(rows[-1]), flush=True)
     # feeding threads: the library's pread pool (page cache -> pinned memory)
     eng = _native.default_engine()
-    for threads in (1, 2, 4, 8, 16, 32):
+    for threads in (8, 16, 32, 48, 64, 96):
         st = _native.FileStream(eng, _file_stream.MODE_LEV, p, (0, 0, 0), 2, (1 << 20) - 21, 0, 21, _file_stream.BATCH_BYTES)
         fd = os.open(name, os.O_RDONLY)
         t0 = time.perf_counter()
