@@ -389,9 +389,12 @@ class Engine(object):
         self._st_ref = ctypes.byref(self._st)
 
     def close(self):
+        """Destroy the context.  Sequences that are still resident are freed with it (fz_destroy); their
+        ResidentSequence handles become inert (release() checks the engine)."""
         if self._h is not None:
-            self._lib.fz_destroy(self._h)
-            self._h = None
+            with self._lock:
+                self._lib.fz_destroy(self._h)
+                self._h = None
 
     def __del__(self):
         try:

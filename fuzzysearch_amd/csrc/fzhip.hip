@@ -171,6 +171,8 @@ struct fz_ctx {
         bool launched = false;                       // false: deferred until the older search has been collected
     } pend[2];
     int npend = 0;
+    // sequences still resident (fz_destroy frees what the caller did not release)
+    std::vector<fz_seq *> live;
 };
 
 struct fz_seq {
@@ -1001,6 +1003,11 @@ int fz_create(const int *device_ids, int n_devices, fz_ctx **out) {
 
 void fz_destroy(fz_ctx *ctx) {
     if (!ctx) return;
+    // sequences the caller never released: their device memory goes with the context (their handles die with it)
+    while (!ctx->live.empty()) {
+        for (DevState &d : ctx->devs) { (void)hipSetDevice(d.device); if (d.stream) (void)hipStreamSynchronize(d.stream); }
+        fz_seq_release(ctx->live.back());
+    }
     for (DevState &d : ctx->devs) {
         (void)hipSetDevice(d.device);
         if (d.stream) (void)hipStreamSynchronize(d.stream);
@@ -1075,6 +1082,7 @@ int fz_seq_upload(fz_ctx *ctx, const uint8_t *host, uint64_t n, fz_seq **out) {
         hipError_t e = hipStreamSynchronize(ctx->devs[sh.dev].stream);
         if (e != hipSuccess) { fz_seq_release(seq); return fail(FZ_EDEVICE, "upload failed: %s", hipGetErrorString(e)); }
     }
+    ctx->live.push_back(seq);
     *out = seq;
     return FZ_OK;
 }
@@ -1105,6 +1113,7 @@ int fz_seq_upload_shard(fz_ctx *ctx, const uint8_t *host_buf, uint64_t buf_len, 
         if (e != hipSuccess) rc = fail(FZ_EDEVICE, "upload failed: %s", hipGetErrorString(e));
     }
     if (rc) { fz_seq_release(seq); return rc; }
+    ctx->live.push_back(seq);
     *out = seq;
     return FZ_OK;
 }
@@ -1113,6 +1122,10 @@ uint64_t fz_seq_len(const fz_seq *seq) { return seq ? seq->n : 0; }
 
 void fz_seq_release(fz_seq *seq) {
     if (!seq) return;
+    if (seq->ctx) {
+        auto &live = seq->ctx->live;
+        live.erase(std::remove(live.begin(), live.end(), seq), live.end());
+    }
     for (Shard &sh : seq->shards) {
         if (sh.d_alloc) {
             DevState &d = seq->ctx->devs[sh.dev];

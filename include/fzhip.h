@@ -79,7 +79,8 @@ int         fz_abi_version(void);
 const char *fz_last_error(void);
 int         fz_device_count(int *n);
 
-/* device_ids == NULL / n_devices == 0 -> device 0 only.  Requires gfx950. */
+/* device_ids == NULL / n_devices == 0 -> device 0 only.  Requires gfx950.
+ * fz_destroy also frees the sequences of the ctx that were not released (their handles die with it). */
 int  fz_create(const int *device_ids, int n_devices, fz_ctx **out);
 void fz_destroy(fz_ctx *ctx);
 
