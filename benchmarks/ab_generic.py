@@ -1,0 +1,21 @@
+"""configs[3b] only (UTF-8 text, m = 64, limits (5,2,2,5)): C-ABI ms per call, scan and automaton kernel times."""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fuzzysearch_amd import _native
+from tests import workloads
+eng = _native.Engine([0])
+seq, pat, _ = workloads.cfg4(1 << 30, 1024)
+p = pat.tobytes()
+h = eng.upload(seq)
+t_end = time.perf_counter() + 0.3
+while time.perf_counter() < t_end:
+    r = eng.generic_ngrams(h, p, 5, 2, 2, 5, as_array=True)
+f, v = [], []
+t0 = time.perf_counter()
+for _ in range(60):
+    r = eng.generic_ngrams(h, p, 5, 2, 2, 5, as_array=True)
+    a, b, _d = eng.kernel_ms(); f.append(a); v.append(b)
+dt = (time.perf_counter() - t0) / 60
+print(json.dumps({"lib": os.path.basename(_native.LIB_PATH), "grid_per_cu": os.environ.get("FZ_LP_GRID_PER_CU", "16"), "ms_per_call": round(dt * 1e3, 4),
+                  "scan_ms": round(float(np.mean(f)), 4), "automaton_ms": round(float(np.mean(v)), 4), "raw": len(r)}), flush=True)

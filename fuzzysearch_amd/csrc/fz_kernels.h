@@ -97,6 +97,10 @@ __device__ __forceinline__ uint32_t fz_load_win(const uint8_t *__restrict__ buf,
     return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(local & 3));
 }
 
+// Lab knobs (benchmarks/lab_build.sh -D...; never defined in the product build): FZ_LAB_TIMING device timestamps of
+// a few workgroups' phases (printf), FZ_LAB_NOVERIFY / FZ_LAB_NODP / FZ_LAB_NOEXACT / FZ_LAB_NOPREFETCH /
+// FZ_LAB_NOPOOL leave a part of the candidate handling out (DESIGN.md §4 quotes the A/B runs), FZ_GROUP forces the
+// number of offsets per branch.
 #ifdef FZ_LAB_TIMING
 static __device__ unsigned long long fz_lab_t[64];
 #define FZ_LAB_STAMP(i) do { if ((blockIdx.x & 1023u) == 512u && threadIdx.x == 0) fz_lab_t[(blockIdx.x >> 10) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
@@ -726,18 +730,12 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
             }
             do {
                 const uint8_t *tsrc = buf + fz_bcast64(tile * (uint64_t)FZ_TILE_BYTES);
-#ifdef FZ_LAB_SETPRIO
-                __builtin_amdgcn_s_setprio(FZ_LAB_SETPRIO);
-#endif
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     vb[r] = *reinterpret_cast<const uint4 *>(tsrc + (r + 2) * FZ_ROW_BYTES + lane_off);
                     hb[r] = *reinterpret_cast<const uint2 *>(tsrc + (r + 2) * FZ_ROW_BYTES + lane_off + 16);
                 }
                 __builtin_amdgcn_sched_barrier(0);    // all loads are issued before the first use
-#ifdef FZ_LAB_SETPRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
                 const uint32_t q_tile = qn;
                 test_row(va[0], ha[0], std::integral_constant<int, 0>{});
                 test_row(va[1], ha[1], std::integral_constant<int, 1>{});
@@ -746,9 +744,6 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                 {   // unconditional (a branch here would make the compiler wait for the prefetch at the join):
                     // without a next tile the loads re-read this one (L2 hits, results unused)
                     const uint8_t *nsrc = buf + fz_bcast64((pre ? next : tile) * (uint64_t)FZ_TILE_BYTES);
-#ifdef FZ_LAB_SETPRIO
-                    __builtin_amdgcn_s_setprio(FZ_LAB_SETPRIO);
-#endif
 #pragma unroll
                     for (int r = 0; r < 2; ++r) {
                         va[r] = *reinterpret_cast<const uint4 *>(nsrc + r * FZ_ROW_BYTES + lane_off);
@@ -756,9 +751,6 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-#ifdef FZ_LAB_SETPRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
                 test_row(vb[0], hb[0], std::integral_constant<int, 2>{});
                 test_row(vb[1], hb[1], std::integral_constant<int, 3>{});
                 if (qn > qcap) {                      // this tile overflowed the queue: drop its

@@ -699,12 +699,22 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             rc = ensure_big(d, 1u << 16);
             if (rc) return rc;
             fa.hit_cap = d.hit_cap;
-            fa.rec_cap = d.big_cap;
+            // Records of the automaton: into the device buffer, fetched with ONE copy once the count is known.
+            // (Round 1 let the kernel store them straight into pinned host memory: 2.1e5 scattered 24-byte stores
+            // cross PCIe at ~10 GB/s and the kernel cannot finish before they have drained — 0.49 ms for a kernel
+            // whose work takes a fraction of that; FZ_GEN_DIRECT=1 restores that path.)
+            static const bool gen_direct = getenv("FZ_GEN_DIRECT") != nullptr;
+            fa.rec_cap = gen_direct ? d.big_cap : d.rec_cap;
             unsigned long long *counters = reinterpret_cast<unsigned long long *>(d.d_out);
-            FzGenRec *recs = reinterpret_cast<FzGenRec *>(d.h_big_dev);      // records go straight to pinned host memory
+            FzGenRec *recs = gen_direct ? reinterpret_cast<FzGenRec *>(d.h_big_dev)
+                                        : reinterpret_cast<FzGenRec *>(d.d_out + kHeaderBytes);
+            static_assert(sizeof(FzGenRec) == sizeof(FzRec), "the generic records share the record buffer");
             if (lds > 64 * 1024)
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fz_lp_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            // (measured, round 2: more waves per workgroup, smaller match buffers or a larger grid do not move this
+            //  kernel — 0.41 ms is the latency of ONE hit with a few hundred live candidates: 75 window characters x
+            //  up to 4 slices of 64 candidates, each slice ~2 500 cycles of dependent LDS / shuffle work)
             hipLaunchKernelGGL(fz_lp_kernel, dim3(scratch ? kCandScratchGrid : d.n_cus * 16), dim3(64), lds, d.stream, sh.d_buf,
                                fa, d.d_hits, (uint64_t)0, recs, counters);
             HIP_TRY(hipGetLastError());
@@ -719,8 +729,12 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             HIP_TRY(hipStreamSynchronize(d.stream));
             const unsigned long long *cnt = reinterpret_cast<const unsigned long long *>(d.h_stage);
             const uint64_t nh = cnt[0], nr = cnt[1], novf = cnt[2];
+            static const bool gen_direct2 = getenv("FZ_GEN_DIRECT") != nullptr;
             if (nh > d.hit_cap) { int rc = ensure_hits(d, nh + nh / 8 + 1024); if (rc) return rc; rerun = true; }
-            if (nr > d.big_cap) { int rc = ensure_big(d, nr + nr / 8 + 1024); if (rc) return rc; rerun = true; }
+            if (nr > d.big_cap) { int rc = ensure_big(d, nr + nr / 8 + 1024); if (rc) return rc; if (gen_direct2) rerun = true; }
+            if (!gen_direct2 && nr > d.rec_cap) { int rc = ensure_recs(d, nr + nr / 8 + 1024); if (rc) return rc; rerun = true; }
+            if (!gen_direct2 && !rerun && !novf && nr)
+                HIP_TRY(hipMemcpy(d.h_big, d.d_out + kHeaderBytes, nr * sizeof(FzGenRec), hipMemcpyDeviceToHost));
             if (novf) { lists_overflowed = true; rerun = true; }
             if (rerun) continue;
             float f = 0, v = 0, t = 0;
