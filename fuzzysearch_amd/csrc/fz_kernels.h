@@ -1077,7 +1077,11 @@ __global__ __launch_bounds__(1024) void fz_verify_wf_kernel(const uint8_t *__res
 // character loop is inherently sequential; parallelism comes from hits x candidates.
 #define FZ_GEN_MCAP 512                                    // match-buffer entries per wave
 
+// Inclusive prefix sum over the 64 lanes on DPP: four row shifts scan the 16-lane rows, row_bcast:15 / :31 carry
+// the row totals across (6 VALU adds; the ds_bpermute form — six __shfl_up — paid six LDS round trips per call,
+// and the automaton calls it once per 64 candidates per window character).
 __device__ __forceinline__ uint32_t fz_wave_incl_scan(uint32_t v) {
+#ifdef FZ_LAB_SHFL_SCAN
     const uint32_t lane = fz_lane();
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -1085,6 +1089,16 @@ __device__ __forceinline__ uint32_t fz_wave_incl_scan(uint32_t v) {
         if (lane >= (uint32_t)d) v += o;
     }
     return v;
+#else
+    // update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl): lanes without a source keep `old` (0 here)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2 and 3
+    return v;
+#endif
 }
 
 __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ buf, const FzScanArgs a,
