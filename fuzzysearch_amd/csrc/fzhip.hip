@@ -2009,71 +2009,90 @@ int fz_consolidate(const fz_match *in, uint64_t n, fz_match **out, uint64_t *n_o
         if (a.end != b.end) return a.end < b.end;
         return a.dist < b.dist;
     };
-    // Order by (start, end, dist).  A comparison sort of 2e5 24-byte rows (configs[3b]) costs ~6 ms; the three
-    // fields, taken relative to their minima, and the row number normally fit one 64-bit word, which is sorted with
-    // 11-bit LSD radix passes over the key bits (like emit_matches): ~0.6 ms.
-    // scratch kept per thread between calls: fresh 3 - 5 MB vectors are page-faulted in on every call otherwise
-    static thread_local std::vector<fz_match> v;
-    static thread_local std::vector<uint64_t> a, b;
-    bool ordered = false;
-    if (n >= 2048) {
-        int64_t smin = in[0].start, smax = smin, lmin = in[0].end - in[0].start, lmax = lmin;
-        int32_t dmin = in[0].dist, dmax = dmin;
-        for (uint64_t i = 1; i < n; ++i) {
-            smin = std::min(smin, in[i].start); smax = std::max(smax, in[i].start);
-            const int64_t len = in[i].end - in[i].start;
-            lmin = std::min(lmin, len); lmax = std::max(lmax, len);
-            dmin = std::min(dmin, in[i].dist); dmax = std::max(dmax, in[i].dist);
-        }
-        auto bits_of = [](uint64_t range) { int b = 0; while (b < 64 && (range >> b)) ++b; return b; };
-        const int sb = bits_of((uint64_t)(smax - smin)), lb = bits_of((uint64_t)(lmax - lmin)), db = bits_of((uint64_t)((int64_t)dmax - dmin)),
-                  ib = bits_of(n - 1);
-        if (sb + lb + db + ib <= 64) {
-            if (a.size() < n) { a.resize(n); b.resize(n); }
-            for (uint64_t i = 0; i < n; ++i) {
-                const uint64_t key = ((((uint64_t)(in[i].start - smin) << lb) | (uint64_t)(in[i].end - in[i].start - lmin)) << db) |
-                                     (uint64_t)((int64_t)in[i].dist - dmin);
-                a[i] = (key << ib) | i;
+    // Two stages.  (1) One pass in input order folds every row that overlaps the running hull of the rows right
+    // before it into that hull (the reference's own group test, common.py:150-159, applied to consecutive rows;
+    // the partition is order independent).  The records of one n-gram hit are emitted back to back and nearly all
+    // overlap, so the 2.1e5 rows of configs[3b] leave ~6e3 (hull, best row) pairs; streams without such runs pass
+    // through unchanged.  (2) The pairs are ordered by (hull start, zero-length first) — 11-bit LSD radix passes on
+    // one 64-bit word per pair when there are many, a comparison sort otherwise (2e5 24-byte rows: ~6 ms) — and a
+    // sweep merges overlapping hulls.  Zero-length matches (start == end) never overlap anything under
+    // `not (end <= g.start or start >= g.end)` unless strictly inside a group, so both stages use that predicate
+    // against the running hull instead of assuming sorted-interval merging.
+    auto better = [](const fz_match &x, const fz_match &y) {
+        const int64_t lx = x.end - x.start, ly = y.end - y.start;
+        return x.dist < y.dist || (x.dist == y.dist && (lx > ly || (lx == ly && x.start < y.start)));
+    };
+    struct Hull { int64_t h0, h1; fz_match best; };
+    static thread_local std::vector<Hull> hulls;                // scratch kept per thread between calls
+    hulls.clear();
+    for (uint64_t i = 0; i < n; ++i) {
+        const fz_match &mt = in[i];
+        if (!hulls.empty()) {
+            Hull &h = hulls.back();
+            if (!(mt.end <= h.h0 || mt.start >= h.h1)) {
+                h.h0 = std::min(h.h0, mt.start);
+                h.h1 = std::max(h.h1, mt.end);
+                if (better(mt, h.best)) h.best = mt;
+                continue;
             }
-            uint64_t *src = a.data(), *dst = b.data();
-            for (int shift = ib; shift < ib + sb + lb + db; shift += 11) {
-                uint32_t count[2049] = {0};
-                for (uint64_t i = 0; i < n; ++i) ++count[((src[i] >> shift) & 0x7ff) + 1];
-                for (int d = 0; d < 2048; ++d) count[d + 1] += count[d];
-                for (uint64_t i = 0; i < n; ++i) dst[count[(src[i] >> shift) & 0x7ff]++] = src[i];
+        }
+        hulls.push_back(Hull{mt.start, mt.end, mt});
+    }
+    const uint64_t nh = hulls.size();
+    static thread_local std::vector<uint64_t> wa, wb;
+    std::vector<uint32_t> order;                                // hull numbers in sweep order
+    bool ordered = false;
+    if (nh >= 2048 && nh <= 0xffffffffull) {
+        int64_t smin = hulls[0].h0, smax = smin;
+        for (const Hull &h : hulls) { smin = std::min(smin, h.h0); smax = std::max(smax, h.h0); }
+        auto bits_of = [](uint64_t range) { int b = 0; while (b < 64 && (range >> b)) ++b; return b; };
+        const int kb = bits_of((uint64_t)(smax - smin)) + 1, ib = bits_of(nh - 1), npass = (kb + 10) / 11;
+        if (kb + ib <= 64 && npass <= 4) {
+            if (wa.size() < nh) { wa.resize(nh); wb.resize(nh); }
+            uint32_t hist[4][2048];
+            memset(hist, 0, sizeof hist);
+            uint64_t *src = wa.data(), *dst = wb.data();
+            for (uint64_t i = 0; i < nh; ++i) {
+                const uint64_t key = ((uint64_t)(hulls[i].h0 - smin) << 1) | (hulls[i].h1 != hulls[i].h0);
+                src[i] = (key << ib) | i;
+                for (int p = 0; p < npass; ++p) ++hist[p][(key >> (11 * p)) & 0x7ff];
+            }
+            for (int p = 0; p < npass; ++p) {
+                uint32_t run = 0;
+                for (int d = 0; d < 2048; ++d) { const uint32_t c = hist[p][d]; hist[p][d] = run; run += c; }
+                const int shift = ib + 11 * p;
+                for (uint64_t i = 0; i < nh; ++i) dst[hist[p][(src[i] >> shift) & 0x7ff]++] = src[i];
                 std::swap(src, dst);
             }
             const uint64_t imask = ib ? ((1ull << ib) - 1) : 0;
-            if (v.size() < n) v.resize(n);
-            for (uint64_t i = 0; i < n; ++i) v[i] = in[src[i] & imask];
+            order.resize(nh);
+            for (uint64_t i = 0; i < nh; ++i) order[i] = (uint32_t)(src[i] & imask);
             ordered = true;
         }
     }
     if (!ordered) {
-        if (v.size() < n) v.resize(n);
-        std::copy(in, in + n, v.begin());
-        std::sort(v.begin(), v.begin() + n, by_start_end_dist);
+        if (nh > 0xffffffffull) return fail(FZ_EUNSUPPORTED, "more than 2^32 disjoint runs of matches");
+        order.resize(nh);
+        for (uint64_t i = 0; i < nh; ++i) order[i] = (uint32_t)i;
+        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+            const Hull &a = hulls[x], &b = hulls[y];
+            if (a.h0 != b.h0) return a.h0 < b.h0;
+            if ((a.h1 != a.h0) != (b.h1 != b.h0)) return a.h1 == a.h0;
+            return x < y;
+        });
     }
-    // Zero-length matches (start == end) never overlap anything under
-    // `not (end <= g.start or start >= g.end)` unless strictly inside a group, so the sweep uses the
-    // same predicate against the running hull instead of assuming sorted-interval merging.
     std::vector<fz_match> best;
-    std::vector<std::pair<int64_t, int64_t>> hull;
-    for (uint64_t vi = 0; vi < n; ++vi) {
-        const fz_match &mt = v[vi];
-        bool placed = false;
-        if (!hull.empty()) {
-            auto &h = hull.back();
-            if (!(mt.end <= h.first || mt.start >= h.second)) {
-                h.first = std::min(h.first, mt.start);
-                h.second = std::max(h.second, mt.end);
-                fz_match &b = best.back();
-                const int64_t lm = mt.end - mt.start, lb = b.end - b.start;
-                if (mt.dist < b.dist || (mt.dist == b.dist && (lm > lb || (lm == lb && mt.start < b.start)))) b = mt;
-                placed = true;
-            }
+    int64_t h0 = 0, h1 = 0;
+    for (uint64_t vi = 0; vi < nh; ++vi) {
+        const Hull &h = hulls[order[vi]];
+        if (!best.empty() && !(h.h1 <= h0 || h.h0 >= h1)) {
+            h0 = std::min(h0, h.h0);
+            h1 = std::max(h1, h.h1);
+            if (better(h.best, best.back())) best.back() = h.best;
+        } else {
+            h0 = h.h0; h1 = h.h1;
+            best.push_back(h.best);
         }
-        if (!placed) { hull.emplace_back(mt.start, mt.end); best.push_back(mt); }
     }
     if (!std::is_sorted(best.begin(), best.end(), by_start_end_dist)) std::sort(best.begin(), best.end(), by_start_end_dist);
     void *mem = nullptr;

@@ -124,6 +124,19 @@ def test_fz_consolidate_and_group_best_against_oracle_and_golden():
         raw = golden_io.triples(list(rec["args"][0]))
         got = [b[:3] for b in _native.consolidate(raw)]
         assert golden_io.equal_modulo_ties(got, golden_io.triples(rec["result"]), raw)
+    # Large streams: the run-folding pass followed by the radix order of the hulls (>= 2048 of them), with
+    # zero-length rows at hull edges, rows in block-major runs like the generic search emits, and shuffled.
+    for n, span, run in [(3000, 60000, 1), (2600, 2000000, 1), (4000, 30000, 1), (60000, 4000000, 20), (30000, 90000, 7)]:
+        raw = []
+        while len(raw) < n:
+            s0 = rnd.randint(0, span)
+            for _ in range(run):
+                s = s0 + (rnd.randint(-4, 4) if run > 1 else 0)
+                raw.append((s, s + rnd.choice([0, 0, 1, 2, 5, 9, 30]), rnd.randint(0, 3), rnd.randint(0, 2)))
+        want = oracle.consolidate(raw)
+        assert [b[:3] for b in _native.consolidate(raw)] == want, (n, span, run)
+        rnd.shuffle(raw)
+        assert [b[:3] for b in _native.consolidate(raw)] == want, (n, span, run, "shuffled")
 
 
 def test_python_level_consolidation_helpers():
