@@ -125,6 +125,8 @@ struct FzScanArgs {
     uint64_t abs_lo, abs_hi;                    // absolute index range (exact search with start / end index)
     uint64_t hit_cap;                           // capacity of the hit list
     uint64_t rec_cap;                           // capacity of the record list
+    uint64_t gen_order;                         // generic search, one shard, no segments: device address of the ordering
+                                                // area (FZ_GEN_ORDER_MAX x {u64 first row, u32 row count}); 0: the host orders
     uint64_t host_hdr;                          // device-visible address of the host copy of the counters
                                                 // (0: none); the last workgroup of the launch fills it
     uint8_t  pat[FZ_MAX_M];                     // whole pattern
@@ -504,8 +506,31 @@ struct FzGenRec {
     uint32_t seq;        // emission number within the work item (hit window / tile)
     uint32_t se;         // window-relative start | end << 16
     uint32_t dist;
-    uint32_t win;        // tiled modes: window (tile) number
+    uint32_t win;        // tiled modes: window (tile) number; per-hit mode: segment number, or (no segments) the
+                         // hit's slot in the hit list
 };
+
+// The generic search's records are ordered on the device when one shard without segments produced at most this
+// many n-gram hits (fz_gen_order_kernel is quadratic in the hit count: 6e3 hits = 10 us); the host orders the rest.
+#define FZ_GEN_ORDER_MAX 16384u
+
+// One raw match as the C-ABI returns it (fz_match of include/fzhip.h; fzhip.hip asserts the layout).
+struct FzOutRow { int64_t start, end; int32_t dist, block; };
+
+// generic_search.py:229-237: the match `se` (window-relative start | end << 16) of the automaton run on the window
+// of n-gram hit `key`, in sequence coordinates.  `sa` = start of the hit's segment (0 without segments).
+FZ_HD FzOutRow fz_gen_row(uint64_t key, uint32_t L, uint32_t k, uint64_t sa, uint32_t se, uint32_t dist) {
+    const uint64_t idx = fz_hit_index(key);
+    const uint32_t blk = fz_hit_block(key);
+    const uint64_t reach = (uint64_t)blk * L + k;
+    const uint64_t w0 = idx - sa > reach ? idx - reach : sa;
+    FzOutRow r;
+    r.start = (int64_t)(w0 + (se & 0xffffu));
+    r.end = (int64_t)(w0 + (se >> 16));
+    r.dist = (int32_t)dist;
+    r.block = (int32_t)blk;
+    return r;
+}
 
 // Plain byte accessor over a resident buffer in GLOBAL coordinates (host emulation / tests).
 struct FzSeqView {

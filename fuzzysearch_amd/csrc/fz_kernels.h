@@ -1128,6 +1128,10 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
     unsigned long long nitems = n_items;
     if (per_hit) { nitems = counters[0]; if (nitems > a.hit_cap) nitems = a.hit_cap; }
     const uint32_t ncand = per_hit ? fz_segment_candidates(a.geom) : 1u;
+    // device-side ordering (fz_gen_order_kernel / fz_gen_scatter_kernel below): every hit leaves its row count
+    const bool order = per_hit && a.gen_order != 0;
+    unsigned long long *order_first = reinterpret_cast<unsigned long long *>(a.gen_order);
+    uint32_t *order_count = reinterpret_cast<uint32_t *>(order_first + FZ_GEN_ORDER_MAX);
     for (uint64_t qc = blockIdx.x; qc < nitems * ncand; qc += gridDim.x) {
         const uint64_t q = qc / ncand;
         uint64_t key_base, w0, w1;
@@ -1138,7 +1142,10 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
             const uint32_t s = fz_hit_block(hit) * a.L;
             const uint64_t idx = fz_hit_index(hit);
             const FzSeg sg = fz_segment(a.geom, idx, (uint32_t)(qc % ncand));
-            if (!fz_hit_in_range_s(a, s, idx, sg)) continue;           // wave-uniform: one hit per wave
+            if (!fz_hit_in_range_s(a, s, idx, sg)) {                   // wave-uniform: one hit per wave
+                if (order && q < FZ_GEN_ORDER_MAX && lane == 0) { order_first[q] = 0; order_count[q] = 0; }
+                continue;
+            }
             const uint64_t reach = (uint64_t)s + a.k;
             w0 = idx - sg.sa > reach ? idx - reach : sg.sa;            // generic_search.py:231
             w1 = idx - s + a.m + a.k;
@@ -1174,7 +1181,7 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
                     const uint64_t v = mbuf[e];
                     FzGenRec r;
                     r.key = per_hit ? key_base : key_base + (v >> 48);
-                    r.seq = mseq + e; r.se = (uint32_t)v; r.dist = (uint32_t)(v >> 32) & 0xffffu; r.win = per_hit ? seg_j : (uint32_t)q;
+                    r.seq = mseq + e; r.se = (uint32_t)v; r.dist = (uint32_t)(v >> 32) & 0xffffu; r.win = per_hit ? (order ? (uint32_t)q : seg_j) : (uint32_t)q;
                     recs[base + e] = r;
                 }
             }
@@ -1255,7 +1262,50 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
         } else {
             flush_matches();
         }
+        if (order && q < FZ_GEN_ORDER_MAX && lane == 0) { order_first[q] = 0; order_count[q] = overflow ? 0u : mseq; }
         fz_wave_lds_sync();
+    }
+}
+
+// Reference order of the generic search's rows (generic_search.py:221-237: blocks in order, the hits of a block by
+// index, the matches of a hit in emission order) restored on the device.  A hit's first row = the rows of all hits
+// with a smaller key (block << 56 | index).  Quadratic, tiled 256 x 256 over (hit, other hit) pairs with partial
+// sums added atomically: 6e3 hits = 576 tiles, ~10 us; the host orders searches with more than FZ_GEN_ORDER_MAX hits.
+__global__ __launch_bounds__(256) void fz_gen_order_kernel(const uint64_t *__restrict__ hits, const FzScanArgs a,
+                                                           const unsigned long long *__restrict__ counters) {
+    __shared__ uint64_t skey[256];
+    __shared__ uint32_t scnt[256];
+    const unsigned long long n = counters[0];
+    if (n > a.hit_cap || n > FZ_GEN_ORDER_MAX || counters[2]) return;
+    unsigned long long *first = reinterpret_cast<unsigned long long *>(a.gen_order);
+    const uint32_t *count = reinterpret_cast<const uint32_t *>(first + FZ_GEN_ORDER_MAX);
+    const uint32_t nt = ((uint32_t)n + 255u) / 256u;
+    for (uint32_t p = blockIdx.x; p < nt * nt; p += gridDim.x) {
+        const uint32_t i = (p / nt) * 256u + threadIdx.x, j = (p % nt) * 256u + threadIdx.x;
+        __syncthreads();
+        skey[threadIdx.x] = j < n ? hits[j] : ~0ull;
+        scnt[threadIdx.x] = j < n ? count[j] : 0u;
+        __syncthreads();
+        if (i < n) {
+            const uint64_t me = hits[i];
+            unsigned long long sum = 0;
+#pragma unroll 8
+            for (uint32_t t = 0; t < 256u; ++t) sum += skey[t] < me ? scnt[t] : 0u;
+            if (sum) atomicAdd(&first[i], sum);
+        }
+    }
+}
+
+// ... and every record goes to row (first row of its hit + emission number) as a finished fz_match.
+__global__ __launch_bounds__(256) void fz_gen_scatter_kernel(const uint64_t *__restrict__ hits, const FzScanArgs a,
+                                                             const FzGenRec *__restrict__ recs, FzOutRow *__restrict__ rows,
+                                                             const unsigned long long *__restrict__ counters) {
+    const unsigned long long n = counters[0], nr = counters[1];
+    if (n > a.hit_cap || n > FZ_GEN_ORDER_MAX || counters[2] || nr > a.rec_cap) return;
+    const unsigned long long *first = reinterpret_cast<const unsigned long long *>(a.gen_order);
+    for (unsigned long long r = (unsigned long long)blockIdx.x * 256u + threadIdx.x; r < nr; r += (unsigned long long)gridDim.x * 256u) {
+        const FzGenRec rec = recs[r];
+        rows[first[rec.win] + rec.seq] = fz_gen_row(hits[rec.win], a.L, a.k, 0, rec.se, rec.dist);
     }
 }
 

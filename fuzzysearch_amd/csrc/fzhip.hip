@@ -96,6 +96,10 @@ struct DevState {
     // into pageable memory afterwards.
     uint8_t *d_cand = nullptr;                   // HBM candidate lists of the automaton kernels (rare fallback)
     uint64_t cand_bytes = 0;
+    // generic search ordered on the device: per-hit {first row, row count} and the finished fz_match rows
+    uint8_t *d_gen_order = nullptr;
+    uint8_t *d_gen_rows = nullptr;
+    uint64_t gen_rows_cap = 0;                   // rows
     uint8_t *h_big = nullptr, *h_big_dev = nullptr;
     uint64_t big_cap = 0;                        // records
     // one recycled sequence allocation (chunked file reads upload / release 1 MiB buffers in a loop;
@@ -161,6 +165,9 @@ struct fz_ctx {
     uint64_t view_n = 0;
     const FzGenRec *gen_view = nullptr;          // same for the per-hit automaton's records (pinned h_big)
     uint64_t gen_view_n = 0;
+    const uint8_t *gen_rows_dev = nullptr;       // ... or the finished rows, ordered on the device (DevState::d_gen_rows)
+    uint64_t gen_rows_n = 0;
+    int gen_rows_device = 0;
     struct fz_stream *stream_inflight = nullptr;  // a file stream whose batch is on the device (other searches are refused)
     // fz_lev_ngrams_begin .. _end: up to two searches in flight, collected in launch order (pend[0] is the
     // oldest and owns the devices' current result slot, pend[1] their second slot)
@@ -223,6 +230,17 @@ int ensure_big(DevState &d, uint64_t cap) {
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&d.h_big), cap * sizeof(FzRec), hipHostMallocMapped));
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&d.h_big_dev), d.h_big, 0));
     d.big_cap = cap;
+    return FZ_OK;
+}
+
+// Ordering area and row buffer of the device-ordered generic search (rows follow the record capacity).
+int ensure_gen_rows(DevState &d) {
+    HIP_TRY(hipSetDevice(d.device));
+    if (!d.d_gen_order) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d.d_gen_order), (size_t)FZ_GEN_ORDER_MAX * 12));
+    if (d.gen_rows_cap >= d.rec_cap) return FZ_OK;
+    if (d.d_gen_rows) { HIP_TRY(hipFree(d.d_gen_rows)); d.d_gen_rows = nullptr; d.gen_rows_cap = 0; }
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d.d_gen_rows), d.rec_cap * sizeof(FzOutRow)));
+    d.gen_rows_cap = d.rec_cap;
     return FZ_OK;
 }
 
@@ -677,6 +695,8 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
         recs_out.clear();
         ctx->gen_view = nullptr;
         ctx->gen_view_n = 0;
+        ctx->gen_rows_dev = nullptr;
+        ctx->gen_rows_n = 0;
         bool rerun = false;
         ctx->stats.filter_launches = 0;
         ctx->stats.bytes_scanned = ctx->stats.ngram_hits = ctx->stats.raw_matches = 0;
@@ -704,6 +724,17 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             // cross PCIe at ~10 GB/s and the kernel cannot finish before they have drained — 0.49 ms for a kernel
             // whose work takes a fraction of that; FZ_GEN_DIRECT=1 restores that path.)
             static const bool gen_direct = getenv("FZ_GEN_DIRECT") != nullptr;
+            // One shard, no segments: the rows are ordered and finished on the device (fz_gen_order_kernel,
+            // fz_gen_scatter_kernel) and cross PCIe once, straight into the caller's buffer; FZ_GEN_HOST_ORDER=1
+            // keeps the host's run ordering (emit_generic), which also serves searches with more than
+            // FZ_GEN_ORDER_MAX hits, several shards and the file API's segments.
+            static const bool host_order = getenv("FZ_GEN_HOST_ORDER") != nullptr;
+            const bool dev_order = !gen_direct && !host_order && seq->shards.size() == 1 && sh.geom.seg_stride == 0;
+            if (dev_order) {
+                rc = ensure_gen_rows(d);
+                if (rc) return rc;
+                fa.gen_order = reinterpret_cast<uint64_t>(d.d_gen_order);
+            }
             fa.rec_cap = gen_direct ? d.big_cap : d.rec_cap;
             unsigned long long *counters = reinterpret_cast<unsigned long long *>(d.d_out);
             FzGenRec *recs = gen_direct ? reinterpret_cast<FzGenRec *>(d.h_big_dev)
@@ -719,6 +750,12 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
                                fa, d.d_hits, (uint64_t)0, recs, counters);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(d.ev[2], d.stream));
+            if (dev_order) {
+                hipLaunchKernelGGL(fz_gen_order_kernel, dim3(d.n_cus * 4), dim3(256), 0, d.stream, d.d_hits, fa, counters);
+                hipLaunchKernelGGL(fz_gen_scatter_kernel, dim3(d.n_cus * 8), dim3(256), 0, d.stream, d.d_hits, fa, recs,
+                                   reinterpret_cast<FzOutRow *>(d.d_gen_rows), counters);
+                HIP_TRY(hipGetLastError());
+            }
             HIP_TRY(hipMemcpyAsync(d.h_stage, d.d_out, kHeaderBytes, hipMemcpyDeviceToHost, d.stream));
             HIP_TRY(hipEventRecord(d.ev[3], d.stream));
         }
@@ -733,7 +770,10 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             if (nh > d.hit_cap) { int rc = ensure_hits(d, nh + nh / 8 + 1024); if (rc) return rc; rerun = true; }
             if (nr > d.big_cap) { int rc = ensure_big(d, nr + nr / 8 + 1024); if (rc) return rc; if (gen_direct2) rerun = true; }
             if (!gen_direct2 && nr > d.rec_cap) { int rc = ensure_recs(d, nr + nr / 8 + 1024); if (rc) return rc; rerun = true; }
-            if (!gen_direct2 && !rerun && !novf && nr)
+            static const bool host_order2 = getenv("FZ_GEN_HOST_ORDER") != nullptr;
+            const bool rows_ready = !gen_direct2 && !host_order2 && seq->shards.size() == 1 && sh.geom.seg_stride == 0 &&
+                                    nh <= FZ_GEN_ORDER_MAX && nr <= d.gen_rows_cap;
+            if (!gen_direct2 && !rerun && !novf && nr && !rows_ready)
                 HIP_TRY(hipMemcpy(d.h_big, d.d_out + kHeaderBytes, nr * sizeof(FzGenRec), hipMemcpyDeviceToHost));
             if (novf) { lists_overflowed = true; rerun = true; }
             if (rerun) continue;
@@ -746,7 +786,11 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             ctx->stats.device_ms = std::max<double>(ctx->stats.device_ms, t);
             ctx->stats.bytes_scanned += sh.geom.buf_len;
             ctx->stats.ngram_hits += nh;
-            if (seq->shards.size() == 1) {                    // read in place (valid until the next search)
+            if (rows_ready) {                                 // finished rows, fetched by emit_generic
+                ctx->gen_rows_dev = d.d_gen_rows;
+                ctx->gen_rows_n = nr;
+                ctx->gen_rows_device = d.device;
+            } else if (seq->shards.size() == 1) {             // read in place (valid until the next search)
                 ctx->gen_view = reinterpret_cast<const FzGenRec *>(d.h_big);
                 ctx->gen_view_n = nr;
             } else {
@@ -1033,6 +1077,8 @@ void fz_destroy(fz_ctx *ctx) {
         for (auto &ev : d.other.ev) if (ev) (void)hipEventDestroy(ev);
         if (d.h_big) (void)hipHostFree(d.h_big);
         if (d.d_cand) (void)hipFree(d.d_cand);
+        if (d.d_gen_order) (void)hipFree(d.d_gen_order);
+        if (d.d_gen_rows) (void)hipFree(d.d_gen_rows);
         for (int i = 0; i < 2; ++i) if (d.stream_h[i]) (void)hipHostFree(d.stream_h[i]);
         if (d.stream_d) (void)hipFree(d.stream_d);
         for (auto &ev : d.ev) if (ev) (void)hipEventDestroy(ev);
@@ -1335,14 +1381,32 @@ namespace {
 // and the 24-byte records are read once: 2.1e5 records order in ~0.4 ms instead of ~2 ms.
 int emit_generic(fz_ctx *ctx, fz_seq *seq, const std::vector<FzGenRec> &recs_vec, uint32_t L, uint32_t k, fz_match **out,
                  uint64_t *n, uint32_t **seg_out) {
+    if (ctx->gen_rows_dev) {                                   // ordered and finished on the device: one copy
+        static_assert(sizeof(FzOutRow) == sizeof(fz_match) && offsetof(FzOutRow, dist) == offsetof(fz_match, dist) &&
+                      offsetof(FzOutRow, block) == offsetof(fz_match, block), "FzOutRow is fz_match");
+        const uint64_t nrows = ctx->gen_rows_n;
+        HIP_TRY(hipSetDevice(ctx->gen_rows_device));
+        void *mem = nullptr;
+        int rc = alloc_out(nrows, sizeof(fz_match), &mem);
+        if (rc) return rc;
+        hipError_t e = hipMemcpy(mem, ctx->gen_rows_dev, nrows * sizeof(fz_match), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { release_out(mem); return fail(FZ_EDEVICE, "hipMemcpy of the ordered rows: %s", hipGetErrorString(e)); }
+        if (seg_out) *seg_out = nullptr;
+        *out = static_cast<fz_match *>(mem);
+        *n = nrows;
+        ctx->stats.raw_matches = nrows;
+        return FZ_OK;
+    }
     struct Run { uint64_t key; uint32_t seg; uint32_t seq0; uint32_t len; size_t first; };
     std::vector<Run> runs;
+    const FzGeom &geom = seq->shards.empty() ? FzGeom{} : seq->shards[0].geom;
+    const bool segs = geom.seg_stride != 0;                    // without segments `win` is the hit's slot, not a segment
     const FzGenRec *recs = ctx->gen_view ? ctx->gen_view : recs_vec.data();
     const size_t nrecs = ctx->gen_view ? (size_t)ctx->gen_view_n : recs_vec.size();
     for (size_t i = 0; i < nrecs;) {
         size_t j = i + 1;
         while (j < nrecs && recs[j].key == recs[i].key && recs[j].win == recs[i].win && recs[j].seq == recs[j - 1].seq + 1) ++j;
-        runs.push_back(Run{recs[i].key, recs[i].win, recs[i].seq, (uint32_t)(j - i), i});
+        runs.push_back(Run{recs[i].key, segs ? recs[i].win : 0u, recs[i].seq, (uint32_t)(j - i), i});
         i = j;
     }
     std::sort(runs.begin(), runs.end(), [](const Run &x, const Run &y) {
@@ -1360,23 +1424,16 @@ int emit_generic(fz_ctx *ctx, fz_seq *seq, const std::vector<FzGenRec> &recs_vec
         if (rc) { release_out(mem); return rc; }
         so = static_cast<uint32_t *>(smem_);
     }
-    const FzGeom &geom = seq->shards.empty() ? FzGeom{} : seq->shards[0].geom;
     size_t o = 0;
     for (const Run &run : runs) {
-        const uint64_t idx = fz_hit_index(run.key);
-        const uint32_t blk = fz_hit_block(run.key);
-        const uint64_t reach = (uint64_t)blk * L + k;
         uint64_t sa = 0;
         if (geom.seg_stride) {                                 // start of segment run.seg (fz_segment)
             const uint64_t core = geom.seg_org + (uint64_t)run.seg * geom.seg_stride;
             sa = core - geom.seg_org >= geom.seg_pre ? core - geom.seg_pre : geom.seg_org;
         }
-        const uint64_t w0 = idx - sa > reach ? idx - reach : sa;
         for (size_t i = run.first; i < run.first + run.len; ++i, ++o) {
-            mo[o].start = (int64_t)(w0 + (recs[i].se & 0xffffu));
-            mo[o].end = (int64_t)(w0 + (recs[i].se >> 16));
-            mo[o].dist = (int32_t)recs[i].dist;
-            mo[o].block = (int32_t)blk;
+            const FzOutRow row = fz_gen_row(run.key, L, k, sa, recs[i].se, recs[i].dist);
+            mo[o].start = row.start; mo[o].end = row.end; mo[o].dist = row.dist; mo[o].block = row.block;
             if (so) so[o] = run.seg;
         }
     }
