@@ -460,6 +460,76 @@ FZ_HD void fz_generic_step(const FzGCand &c, uint8_t ch, uint32_t index, uint32_
     }
 }
 
+// The same step on the candidate as it lies in memory — dword 0 = start | j << 16, dword 1 = l | ns << 8 | ni << 16 |
+// nd << 24 (FzGCand, little endian) — with the outputs in fixed slots: successor A (advance, or skip a sequence
+// character), B (substitution, or insertion + deletion), C (skip pattern characters), match 1 (at index + 1) and
+// match 2 (at index), which is the reference's order.  Field updates are additions on the packed words, there are no
+// arrays to select into: the kernel's hot form (the struct form above costs ~3x the instructions on the GPU and
+// stays as the host-tested statement of the reference; tests/test_device_logic_host.py holds the two together).
+struct FzGStep {
+    uint32_t a0, a1, b0, b1, c0, c1;
+    uint32_t fa, fb, fc;               // 0 / 1: successor present
+    uint32_t m1, d1, f1, m2, d2, f2;   // matches: start | end << 16, distance, present
+};
+
+FZ_HD void fz_gstep_clear(FzGStep &o) {
+    o.a0 = o.a1 = o.b0 = o.b1 = o.c0 = o.c1 = 0; o.fa = o.fb = o.fc = 0;
+    o.m1 = o.d1 = o.f1 = o.m2 = o.d2 = o.f2 = 0;
+}
+
+template <class PatF>
+FZ_HD void fz_generic_step_packed(uint32_t w0, uint32_t w1, uint8_t ch, uint32_t index, uint32_t m, PatF pat,
+                                  uint32_t max_subs, uint32_t max_ins, uint32_t max_dels, uint32_t max_l, FzGStep &o) {
+    const uint32_t start = w0 & 0xffffu, j = w0 >> 16;
+    const uint32_t l = w1 & 0xffu, ns = (w1 >> 8) & 0xffu, ni = (w1 >> 16) & 0xffu, nd = w1 >> 24;
+    const bool adv = pat(j) == ch;                                     // py:85-94
+    const bool at_end = j + 1u == m;
+    const bool live = !adv && l != max_l;                              // py:101-102
+    const bool can_ins = ni < max_ins, can_sub = ns < max_subs;
+    const bool second = live && (can_sub || (nd < max_dels && can_ins));
+    o.fa = ((adv && !at_end) || (live && can_ins)) ? 1u : 0u;          // py:104-109
+    o.a0 = adv ? w0 + 0x10000u : w0;
+    o.a1 = adv ? w1 : w1 + 0x00010001u;                                // ni++, l++
+    o.fb = (second && !at_end) ? 1u : 0u;                              // py:111-128
+    o.b0 = w0 + 0x10000u;
+    o.b1 = w1 + (can_sub ? 0x00000101u : 0x01010001u);                 // ns++, l++  |  ni++, nd++, l++
+    o.f1 = ((adv || second) && at_end) ? 1u : 0u;                      // py:86-88, py:129-138
+    o.m1 = start | ((index + 1u) << 16);
+    o.d1 = adv ? l : l + 1u;
+    o.fc = 0; o.c0 = 0; o.c1 = 0;
+    o.f2 = 0; o.m2 = start | (index << 16); o.d2 = 0;
+    uint32_t lim = 0;                                                  // py:141-165: skip pattern chars
+    if (live) { lim = max_dels - nd; if (max_l - l < lim) lim = max_l - l; }
+    for (uint32_t sk = 1; sk <= lim; ++sk) {
+        const bool ends = j + sk == m;
+        if (ends || pat(j + sk) == ch) {
+            if (ends || j + sk + 1u == m) { o.f2 = 1; o.d2 = l + sk; }
+            else { o.fc = 1; o.c0 = w0 + ((1u + sk) << 16); o.c1 = w1 + ((sk << 24) | sk); }
+            break;
+        }
+    }
+}
+
+FZ_HD void fz_gcand_words(const FzGCand &c, uint32_t &w0, uint32_t &w1) {
+    w0 = (uint32_t)c.start | ((uint32_t)c.j << 16);
+    w1 = (uint32_t)c.l | ((uint32_t)c.ns << 8) | ((uint32_t)c.ni << 16) | ((uint32_t)c.nd << 24);
+}
+FZ_HD FzGCand fz_gcand_of(uint32_t w0, uint32_t w1) {
+    FzGCand c;
+    c.start = (uint16_t)w0; c.j = (uint16_t)(w0 >> 16);
+    c.l = (uint8_t)w1; c.ns = (uint8_t)(w1 >> 8); c.ni = (uint8_t)(w1 >> 16); c.nd = (uint8_t)(w1 >> 24);
+    return c;
+}
+// struct form -> slot form (the tiled Levenshtein automaton and the end-of-window flush: not hot)
+FZ_HD void fz_gstep_from_out(const FzGOut &g, FzGStep &o) {
+    fz_gstep_clear(o);
+    if (g.nsucc > 0) { o.fa = 1; fz_gcand_words(g.succ[0], o.a0, o.a1); }
+    if (g.nsucc > 1) { o.fb = 1; fz_gcand_words(g.succ[1], o.b0, o.b1); }
+    if (g.nsucc > 2) { o.fc = 1; fz_gcand_words(g.succ[2], o.c0, o.c1); }
+    if (g.nmatch > 0) { o.f1 = 1; o.m1 = g.mstart[0] | (g.mend[0] << 16); o.d1 = g.mdist[0]; }
+    if (g.nmatch > 1) { o.f2 = 1; o.m2 = g.mstart[1] | (g.mend[1] << 16); o.d2 = g.mdist[1]; }
+}
+
 // find_near_matches_levenshtein_linear_programming (levenshtein.py:52-148): one candidate, one
 // sequence character.  `more_seq` is the reference's `index + 1 < len(sequence)` (global).
 template <class PatF>

@@ -1101,6 +1101,9 @@ __device__ __forceinline__ uint32_t fz_wave_incl_scan(uint32_t v) {
 #endif
 }
 
+// KIND (FzLpKind) and HBM_LISTS are compile-time: the per-hit instance carries none of the tiled Levenshtein
+// automaton's code, and with the lists in LDS their accesses are ds_ instructions instead of flat ones.
+template <int KIND, bool HBM_LISTS>
 __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ buf, const FzScanArgs a,
                                                    const uint64_t *__restrict__ hits, uint64_t n_items,
                                                    FzGenRec *__restrict__ recs,
@@ -1115,15 +1118,15 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
     // Candidate lists: LDS normally; for inputs whose candidate sets outgrow it (two-letter alphabets with
     // large budgets) per-workgroup lists in HBM.  One wave per workgroup, so the workgroup-scope fences
     // of fz_wave_lds_sync order its global accesses just as they order the LDS ones.
-    FzGCand *cur = a.cand_scratch ? reinterpret_cast<FzGCand *>(a.cand_scratch) + (size_t)blockIdx.x * 2u * a.cand_cap
-                                  : reinterpret_cast<FzGCand *>(smem + mpad + wpad);
+    FzGCand *cur = HBM_LISTS ? reinterpret_cast<FzGCand *>(a.cand_scratch) + (size_t)blockIdx.x * 2u * a.cand_cap
+                             : reinterpret_cast<FzGCand *>(smem + mpad + wpad);
     FzGCand *nxt = cur + a.cand_cap;
-    uint64_t *mbuf = reinterpret_cast<uint64_t *>(smem + mpad + wpad + (a.cand_scratch ? 0u : 2u * a.cand_cap * (uint32_t)sizeof(FzGCand)));
+    uint64_t *mbuf = reinterpret_cast<uint64_t *>(smem + mpad + wpad + (HBM_LISTS ? 0u : 2u * a.cand_cap * (uint32_t)sizeof(FzGCand)));
     for (uint32_t i = lane; i < a.m; i += 64u) pat[i] = a.pat[i];
     fz_wave_lds_sync();
     auto patf = [&](uint32_t i) -> uint8_t { return pat[i]; };
-    const bool per_hit = a.lp_kind == FZ_LP_GENERIC_HIT;
-    const bool lev = a.lp_kind == FZ_LP_LEV_SEQ;
+    constexpr bool per_hit = KIND == FZ_LP_GENERIC_HIT;
+    constexpr bool lev = KIND == FZ_LP_LEV_SEQ;
 
     unsigned long long nitems = n_items;
     if (per_hit) { nitems = counters[0]; if (nitems > a.hit_cap) nitems = a.hit_cap; }
@@ -1222,34 +1225,41 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
             const bool more_seq = w0 + index + 1 < a.geom.n;   // tiled Levenshtein mode only
             for (uint32_t c0 = 0; c0 < ncur; c0 += 64u) {
                 const bool valid = c0 + lane < ncur;
-                FzGOut o;
-                o.nsucc = 0; o.nmatch = 0;
+                FzGStep st;
+                fz_gstep_clear(st);
                 if (valid) {
-                    const FzGCand c = cur[c0 + lane];
-                    if (!last) {
-                        if (lev) fz_levlp_step(c, ch, index, more_seq, a.m, patf, a.k, o);
-                        else fz_generic_step(c, ch, index, a.m, patf, a.max_subs, a.max_ins, a.max_dels, a.k, o);
+                    const uint2 cw = reinterpret_cast<const uint2 *>(cur)[c0 + lane];
+                    if (!last && !lev) {
+                        fz_generic_step_packed(cw.x, cw.y, ch, index, a.m, patf, a.max_subs, a.max_ins, a.max_dels, a.k, st);
                     } else {
-                        uint32_t d;
-                        const bool hit_end = lev ? fz_levlp_final(c, a.m, a.k, d) : fz_generic_final(c, a.m, a.max_dels, a.k, d);
-                        if (hit_end) { o.mstart[0] = c.start; o.mend[0] = wlen; o.mdist[0] = d; o.nmatch = 1; }
+                        const FzGCand c = fz_gcand_of(cw.x, cw.y);
+                        FzGOut o;
+                        o.nsucc = 0; o.nmatch = 0;
+                        if (!last) {
+                            fz_levlp_step(c, ch, index, more_seq, a.m, patf, a.k, o);
+                        } else {
+                            uint32_t d;
+                            const bool hit_end = lev ? fz_levlp_final(c, a.m, a.k, d) : fz_generic_final(c, a.m, a.max_dels, a.k, d);
+                            if (hit_end) { o.mstart[0] = c.start; o.mend[0] = wlen; o.mdist[0] = d; o.nmatch = 1; }
+                        }
+                        fz_gstep_from_out(o, st);
                     }
                 }
-                const uint32_t packed = o.nsucc | (o.nmatch << 16);
+                const uint32_t packed = (st.fa + st.fb + st.fc) | ((st.f1 + st.f2) << 16);
                 const uint32_t incl = fz_wave_incl_scan(packed);
                 const uint32_t tot = __builtin_amdgcn_readlane(incl, 63);
                 const uint32_t excl = incl - packed;
                 const uint32_t tot_s = tot & 0xffffu, tot_m = tot >> 16;
                 if (nnext + tot_s > a.cand_cap) { overflow = true; break; }
                 if (mb + tot_m > FZ_GEN_MCAP) flush_matches();
-#pragma unroll
-                for (uint32_t i = 0; i < 3; ++i)
-                    if (i < o.nsucc) nxt[nnext + (excl & 0xffffu) + i] = o.succ[i];
-#pragma unroll
-                for (uint32_t i = 0; i < 2; ++i)
-                    if (i < o.nmatch)
-                        mbuf[mb + (excl >> 16) + i] = (uint64_t)(o.mstart[i] | (o.mend[i] << 16)) | ((uint64_t)o.mdist[i] << 32) |
-                                                      ((uint64_t)index << 48);
+                uint2 *nx = reinterpret_cast<uint2 *>(nxt) + nnext + (excl & 0xffffu);
+                if (st.fa) nx[0] = make_uint2(st.a0, st.a1);
+                if (st.fb) nx[st.fa] = make_uint2(st.b0, st.b1);
+                if (st.fc) nx[st.fa + st.fb] = make_uint2(st.c0, st.c1);
+                uint64_t *mp = mbuf + mb + (excl >> 16);
+                const uint64_t stamp = (uint64_t)index << 48;
+                if (st.f1) mp[0] = (uint64_t)st.m1 | ((uint64_t)st.d1 << 32) | stamp;
+                if (st.f2) mp[st.f1] = (uint64_t)st.m2 | ((uint64_t)st.d2 << 32) | stamp;
                 nnext += tot_s;
                 mb += tot_m;
             }

@@ -267,6 +267,16 @@ struct BlockPlan {
     uint64_t abs_lo = 0, abs_hi = ~0ull;   // absolute index range (exact search with start / end index)
 };
 
+using LpKernel = void (*)(const uint8_t *, const FzScanArgs, const uint64_t *, uint64_t, FzGenRec *, unsigned long long *);
+
+LpKernel lp_kernel(uint32_t kind, bool hbm_lists) {
+    switch (kind) {
+    case FZ_LP_GENERIC_HIT: return hbm_lists ? fz_lp_kernel<FZ_LP_GENERIC_HIT, true> : fz_lp_kernel<FZ_LP_GENERIC_HIT, false>;
+    case FZ_LP_GENERIC_SEQ: return hbm_lists ? fz_lp_kernel<FZ_LP_GENERIC_SEQ, true> : fz_lp_kernel<FZ_LP_GENERIC_SEQ, false>;
+    default: return hbm_lists ? fz_lp_kernel<FZ_LP_LEV_SEQ, true> : fz_lp_kernel<FZ_LP_LEV_SEQ, false>;
+    }
+}
+
 using ScanKernel = void (*)(const uint8_t *, const FzScanArgs, uint64_t, uint64_t *, FzRec *, unsigned long long *);
 
 template <bool FUSED, bool SEG, bool SA>
@@ -741,13 +751,13 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
                                         : reinterpret_cast<FzGenRec *>(d.d_out + kHeaderBytes);
             static_assert(sizeof(FzGenRec) == sizeof(FzRec), "the generic records share the record buffer");
             if (lds > 64 * 1024)
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fz_lp_kernel),
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(lp_kernel(FZ_LP_GENERIC_HIT, scratch != 0)),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             // (measured, round 2: more waves per workgroup, smaller match buffers or a larger grid do not move this
             //  kernel — 0.41 ms is the latency of ONE hit with a few hundred live candidates: 75 window characters x
             //  up to 4 slices of 64 candidates, each slice ~2 500 cycles of dependent LDS / shuffle work)
-            hipLaunchKernelGGL(fz_lp_kernel, dim3(scratch ? kCandScratchGrid : d.n_cus * 16), dim3(64), lds, d.stream, sh.d_buf,
-                               fa, d.d_hits, (uint64_t)0, recs, counters);
+            hipLaunchKernelGGL(lp_kernel(FZ_LP_GENERIC_HIT, scratch != 0), dim3(scratch ? kCandScratchGrid : d.n_cus * 16), dim3(64),
+                               lds, d.stream, sh.d_buf, fa, d.d_hits, (uint64_t)0, recs, counters);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(d.ev[2], d.stream));
             if (dev_order) {
@@ -1491,12 +1501,12 @@ int run_lp(fz_ctx *ctx, fz_seq *seq, const Search &q, uint32_t lp_kind, std::vec
             const uint64_t own = sh.geom.own_hi - sh.geom.own_lo;
             const uint64_t nwin = (own + kLpStarts - 1) / kLpStarts;
             if (lds > 64 * 1024)
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fz_lp_kernel),
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(lp_kernel(lp_kind, scratch != 0)),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             if (nwin) {
                 const unsigned grid = (unsigned)std::min<uint64_t>(nwin, scratch ? kCandScratchGrid : (uint64_t)d.n_cus * 64);
-                hipLaunchKernelGGL(fz_lp_kernel, dim3(grid), dim3(64), lds, d.stream, sh.d_buf, fa, d.d_hits, nwin, recs,
-                                   counters);
+                hipLaunchKernelGGL(lp_kernel(lp_kind, scratch != 0), dim3(grid), dim3(64), lds, d.stream, sh.d_buf, fa, d.d_hits,
+                                   nwin, recs, counters);
                 HIP_TRY(hipGetLastError());
             }
             HIP_TRY(hipEventRecord(d.ev[1], d.stream));

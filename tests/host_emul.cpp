@@ -140,6 +140,58 @@ int64_t emul_generic_lp(const uint8_t *p, uint32_t m, const uint8_t *t, uint32_t
     return cnt;
 }
 
+// The same automaton through the packed step the kernel runs (fz_generic_step_packed): candidates as two words,
+// outputs in fixed slots.  Also checks, candidate by candidate, that both forms of the step agree (-> -1 if not).
+int64_t emul_generic_lp_packed(const uint8_t *p, uint32_t m, const uint8_t *t, uint32_t n, uint32_t max_subs,
+                               uint32_t max_ins, uint32_t max_dels, uint32_t max_l, OutRec *out, int64_t cap) {
+    std::vector<uint64_t> cur, nxt;
+    int64_t cnt = 0;
+    bool agree = true;
+    auto pat = [&](uint32_t i) -> uint8_t { return p[i]; };
+    auto emit = [&](uint32_t se, uint32_t d) {
+        if (cnt < cap) { out[cnt].start = se & 0xffffu; out[cnt].end = se >> 16; out[cnt].dist = (int32_t)d; out[cnt].block = -1; }
+        ++cnt;
+    };
+    for (uint32_t index = 0; index < n; ++index) {
+        cur.push_back((uint64_t)index);                                // fresh candidate: start = index, everything else 0
+        nxt.clear();
+        for (uint64_t cw : cur) {
+            const uint32_t w0 = (uint32_t)cw, w1 = (uint32_t)(cw >> 32);
+            FzGStep st;
+            fz_generic_step_packed(w0, w1, t[index], index, m, pat, max_subs, max_ins, max_dels, max_l, st);
+            FzGOut o;
+            fz_generic_step(fz_gcand_of(w0, w1), t[index], index, m, pat, max_subs, max_ins, max_dels, max_l, o);
+            FzGStep ref;
+            fz_gstep_from_out(o, ref);
+            agree &= st.f1 + st.f2 == ref.f1 + ref.f2;
+            if (st.f1 && st.f2) agree &= st.m1 == ref.m1 && st.d1 == ref.d1 && st.m2 == ref.m2 && st.d2 == ref.d2;
+            else if (st.f1) agree &= st.m1 == ref.m1 && st.d1 == ref.d1;
+            else if (st.f2) agree &= st.m2 == ref.m1 && st.d2 == ref.d1;
+            // the struct form fills its slots densely, the packed form by kind: compare the sequences
+            uint64_t got[3], want[3];
+            uint32_t ng = 0, nw = 0;
+            if (st.fa) got[ng++] = st.a0 | ((uint64_t)st.a1 << 32);
+            if (st.fb) got[ng++] = st.b0 | ((uint64_t)st.b1 << 32);
+            if (st.fc) got[ng++] = st.c0 | ((uint64_t)st.c1 << 32);
+            if (ref.fa) want[nw++] = ref.a0 | ((uint64_t)ref.a1 << 32);
+            if (ref.fb) want[nw++] = ref.b0 | ((uint64_t)ref.b1 << 32);
+            if (ref.fc) want[nw++] = ref.c0 | ((uint64_t)ref.c1 << 32);
+            agree &= ng == nw;
+            for (uint32_t i = 0; i < ng && i < nw; ++i) agree &= got[i] == want[i];
+            for (uint32_t i = 0; i < ng; ++i) nxt.push_back(got[i]);
+            if (st.f1) emit(st.m1, st.d1);
+            if (st.f2) emit(st.m2, st.d2);
+        }
+        cur.swap(nxt);
+    }
+    for (uint64_t cw : cur) {
+        uint32_t d;
+        const FzGCand c = fz_gcand_of((uint32_t)cw, (uint32_t)(cw >> 32));
+        if (fz_generic_final(c, m, max_dels, max_l, d)) emit(c.start | (n << 16), d);
+    }
+    return agree ? cnt : -1;
+}
+
 int emul_expand(const uint8_t *sub, uint32_t sublen, const uint8_t *win, uint32_t winlen, uint32_t budget,
                 uint32_t *dist, uint32_t *consumed) {
     HostScores sc;

@@ -119,3 +119,30 @@ def test_shard_geometry_with_poisoned_halo(emul):
         b = _search(emul, 1, p, t, k, lo, n - lo, cut, n)
         merged = sorted(a + b, key=lambda r: r[3])       # stable: block-major, shards keep idx order
         assert merged == oracle.lev_ngrams_raw(p, t, k), (p, t, k, cut)
+
+
+def test_generic_automaton_struct_and_packed_steps_equal_oracle(emul):
+    """fz_generic_step (the host-tested statement of generic_search.py:57-177) and fz_generic_step_packed (what
+    fz_lp_kernel runs per candidate) driven over whole sequences: both emit the oracle's list, and the two forms
+    agree candidate by candidate."""
+    sig = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+           ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(OutRec), ctypes.c_int64]
+    for fn in (emul.emul_generic_lp, emul.emul_generic_lp_packed):
+        fn.restype = ctypes.c_int64
+        fn.argtypes = sig
+    rnd = random.Random(11)
+    cap = 1 << 16
+    out = (OutRec * cap)()
+    done = 0
+    while done < 2500:
+        p, t, k = _case(rnd, max_n=60, max_m=16, max_k=4)
+        limits = (rnd.randint(0, k), rnd.randint(0, k), rnd.randint(0, k))
+        max_l = min(k, sum(limits))
+        if len(p) > 60000 or max_l >= len(p):
+            continue
+        want = [r[:3] for r in oracle.generic_lp_raw(p, t, limits[0], limits[1], limits[2], max_l)]
+        for fn in (emul.emul_generic_lp, emul.emul_generic_lp_packed):
+            c = fn(p, len(p), t, len(t), limits[0], limits[1], limits[2], max_l, out, cap)
+            assert 0 <= c <= cap, (fn, p, t, limits, max_l)
+            assert [(out[i].start, out[i].end, out[i].dist) for i in range(c)] == want, (p, t, limits, max_l)
+        done += 1
