@@ -19,7 +19,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -27,6 +29,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <mutex>
 #include <vector>
@@ -1707,6 +1710,7 @@ struct fz_stream {
     std::vector<fz_match> out;
     std::vector<uint32_t> out_seg;
     uint64_t bytes_total = 0;
+    double t_fill = 0, t_collect = 0, t_launch = 0, t_carry = 0;   // FZ_STREAM_TRACE=1: where the host's time went (ms)
 };
 
 namespace {
@@ -1935,11 +1939,20 @@ int fz_stream_submit(fz_stream *st, uint64_t nbytes, int last) {
             if (st->eof || st->stage_len < st->cap) break;
             return fail(FZ_EUNSUPPORTED, "staging buffer smaller than one chunk");
         }
+        auto now = []() { return std::chrono::steady_clock::now(); };
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return std::chrono::duration<double, std::milli>(b - a).count();
+        };
+        const auto t0 = now();
         int rc = stream_collect(st);                        // the previous batch (its staging buffer becomes free)
         if (rc) return rc;
+        const auto t1 = now();
         const uint64_t data_hi = st->eof ? data_end : j1 * st->S + ext_hi;
         rc = stream_launch(st, st->next_seg, j1, data_hi);
         if (rc) return rc;
+        const auto t2 = now();
+        st->t_collect += ms(t0, t1);
+        st->t_launch += ms(t1, t2);
         st->next_seg = j1;
         if (st->eof) break;
         // carry the bytes the next segments need into the other staging buffer
@@ -1948,6 +1961,7 @@ int fz_stream_submit(fz_stream *st, uint64_t nbytes, int last) {
         const uint64_t carry = data_end - from;
         const int other = st->cur ^ 1;
         memcpy(st->h_buf[other], st->h_buf[st->cur] + (from - st->stage_off), carry);
+        st->t_carry += ms(t2, now());
         st->cur = other;
         st->stage_off = from;
         st->stage_len = carry;
@@ -1956,45 +1970,112 @@ int fz_stream_submit(fz_stream *st, uint64_t nbytes, int last) {
     return FZ_OK;
 }
 
+namespace {
+
+// Readers of fz_stream_read_fd: page cache -> pinned staging is a memcpy (one core moves ~5-10 GB/s, the PCIe link
+// ~55).  The threads live for the whole file and take 1 MiB pieces of the current batch from a shared counter;
+// starting and joining 16-48 threads for every 64 MiB batch cost ~0.5 ms of the batch's ~1.7 ms.
+struct ReadPool {
+    static constexpr uint64_t kPiece = 1u << 20;
+    std::mutex mu;
+    std::condition_variable go, done;
+    uint64_t generation = 0;
+    int busy = 0;
+    bool stop = false;
+    int fd = -1;
+    uint8_t *dst = nullptr;
+    uint64_t room = 0, pos = 0, npieces = 0;
+    std::atomic<uint64_t> next{0};
+    std::vector<uint64_t> got;           // bytes read per piece
+    std::atomic<int> err{0};
+    std::vector<std::thread> workers;
+
+    explicit ReadPool(int n) {
+        for (int t = 0; t < n; ++t) workers.emplace_back([this]() { run(); });
+    }
+    ~ReadPool() {
+        { std::lock_guard<std::mutex> g(mu); stop = true; }
+        go.notify_all();
+        for (auto &w : workers) w.join();
+    }
+    void run() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                go.wait(lk, [&]() { return stop || generation != seen; });
+                if (stop) return;
+                seen = generation;
+            }
+            for (;;) {
+                const uint64_t i = next.fetch_add(1, std::memory_order_relaxed);
+                if (i >= npieces) break;
+                const uint64_t lo = i * kPiece, hi = std::min(room, lo + kPiece);
+                uint64_t n = 0;
+                while (lo + n < hi) {
+                    const ssize_t r = pread(fd, dst + lo + n, hi - lo - n, (off_t)(pos + lo + n));
+                    if (r < 0) { err.store(1); break; }
+                    if (r == 0) break;
+                    n += (uint64_t)r;
+                }
+                got[i] = n;
+            }
+            std::lock_guard<std::mutex> g(mu);
+            if (--busy == 0) done.notify_one();
+        }
+    }
+    // fill dst[0, room) from the file at `pos`; -> bytes valid from the front (short at the end of the file)
+    int fill(int fd_, uint8_t *dst_, uint64_t room_, uint64_t pos_, uint64_t &n, bool &short_read) {
+        fd = fd_; dst = dst_; room = room_; pos = pos_;
+        npieces = (room + kPiece - 1) / kPiece;
+        got.assign(npieces, 0);
+        next.store(0);
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            busy = (int)workers.size();
+            ++generation;
+            go.notify_all();
+            done.wait(lk, [&]() { return busy == 0; });
+        }
+        if (err.load()) return fail(FZ_EDEVICE, "pread failed");
+        n = 0;
+        short_read = false;
+        for (uint64_t i = 0; i < npieces && !short_read; ++i) {
+            n += got[i];
+            if (got[i] < std::min(room, (i + 1) * kPiece) - i * kPiece) short_read = true;   // end of file inside this piece
+        }
+        return FZ_OK;
+    }
+};
+
+}  // namespace
+
 int fz_stream_read_fd(fz_stream *st, int fd, int64_t offset, int threads, uint64_t *total) {
     if (!st || fd < 0 || offset < 0) return fail(FZ_EINVAL, "bad argument");
-    if (threads <= 0) threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency() / 2));
+    if (threads <= 0) threads = (int)std::min<unsigned>(32u, std::max(1u, std::thread::hardware_concurrency() / 2));
     uint64_t pos = (uint64_t)offset, sum = 0;
+    ReadPool pool(threads);
     while (!st->eof) {
         uint8_t *dst = nullptr;
         uint64_t room = 0;
         int rc = fz_stream_buffer(st, &dst, &room);
         if (rc) return rc;
         if (room == 0) return fail(FZ_EDEVICE, "internal: no staging room");
-        // `threads` readers, each a contiguous slice (page cache -> pinned memory is a memcpy: one core
-        // moves ~5-10 GB/s, the PCIe link ~55)
-        std::vector<uint64_t> got((size_t)threads, 0);
-        std::vector<int> err((size_t)threads, 0);
-        const uint64_t slice = ((room + threads - 1) / threads + 4095) & ~(uint64_t)4095;
-        std::vector<std::thread> pool;
-        for (int t = 0; t < threads; ++t) {
-            const uint64_t lo = std::min<uint64_t>(room, (uint64_t)t * slice), hi = std::min<uint64_t>(room, lo + slice);
-            if (lo >= hi) break;
-            pool.emplace_back([=, &got, &err]() {
-                uint64_t done = 0;
-                while (lo + done < hi) {
-                    const ssize_t r = pread(fd, dst + lo + done, hi - lo - done, (off_t)(pos + lo + done));
-                    if (r < 0) { err[(size_t)t] = 1; break; }
-                    if (r == 0) break;
-                    done += (uint64_t)r;
-                }
-                got[(size_t)t] = done;
-            });
-        }
-        for (auto &th : pool) th.join();
         uint64_t n = 0;
         bool short_read = false;
-        for (size_t t = 0; t < pool.size(); ++t) {
-            if (err[t]) return fail(FZ_EDEVICE, "pread failed");
-            const uint64_t lo = std::min<uint64_t>(room, (uint64_t)t * slice), hi = std::min<uint64_t>(room, lo + slice);
-            if (!short_read) n += got[t];
-            if (got[t] < hi - lo) short_read = true;      // end of file inside this slice: later slices hold nothing valid
+        const auto tf = std::chrono::steady_clock::now();
+        static const bool nofill = getenv("FZ_STREAM_NOFILL") != nullptr;     // lab: the H2D + scan pipeline alone
+        if (nofill) {
+            struct stat sb;
+            if (fstat(fd, &sb) != 0) return fail(FZ_EDEVICE, "fstat failed");
+            const uint64_t left = (uint64_t)sb.st_size > pos ? (uint64_t)sb.st_size - pos : 0;
+            n = std::min(room, left);
+            short_read = n < room;
+        } else {
+            rc = pool.fill(fd, dst, room, pos, n, short_read);
         }
+        if (rc) return rc;
+        st->t_fill += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tf).count();
         rc = fz_stream_submit(st, n, short_read ? 1 : 0);
         if (rc) return rc;
         pos += n;
@@ -2013,6 +2094,9 @@ int fz_stream_finish(fz_stream *st, fz_match **out, uint32_t **seg, uint64_t *n)
     }
     int rc = stream_collect(st);
     if (rc) return rc;
+    if (getenv("FZ_STREAM_TRACE"))
+        fprintf(stderr, "[fz_stream] %.1f MiB: fill %.2f ms, collect %.2f ms, launch %.2f ms, carry %.2f ms\n",
+                st->bytes_total / 1048576.0, st->t_fill, st->t_collect, st->t_launch, st->t_carry);
     void *mem = nullptr, *smem_ = nullptr;
     rc = alloc_out(st->out.size(), sizeof(fz_match), &mem);
     if (rc) return rc;
