@@ -1075,7 +1075,10 @@ __global__ __launch_bounds__(1024) void fz_verify_wf_kernel(const uint8_t *__res
 // lanes; successor candidates and matches are written through wave prefix sums, so both lists keep
 // exactly the reference's order (its emitted *list*, not just the set, is reproduced).  The
 // character loop is inherently sequential; parallelism comes from hits x candidates.
-#define FZ_GEN_MCAP 512                                    // match-buffer entries per wave
+#ifndef FZ_GEN_MCAP
+#define FZ_GEN_MCAP 128                                    // match-buffer entries per wave (1 KB: with 256-entry candidate lists
+                                                           // 24 waves per CU are resident, every hit of configs[3b] at once)
+#endif
 
 // Inclusive prefix sum over the 64 lanes on DPP: four row shifts scan the 16-lane rows, row_bcast:15 / :31 carry
 // the row totals across (6 VALU adds; the ds_bpermute form — six __shfl_up — paid six LDS round trips per call,

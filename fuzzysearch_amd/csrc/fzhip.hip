@@ -756,10 +756,11 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             if (lds > 64 * 1024)
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(lp_kernel(FZ_LP_GENERIC_HIT, scratch != 0)),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            // (measured, round 2: more waves per workgroup, smaller match buffers or a larger grid do not move this
-            //  kernel — 0.41 ms is the latency of ONE hit with a few hundred live candidates: 75 window characters x
-            //  up to 4 slices of 64 candidates, each slice ~2 500 cycles of dependent LDS / shuffle work)
-            hipLaunchKernelGGL(lp_kernel(FZ_LP_GENERIC_HIT, scratch != 0), dim3(scratch ? kCandScratchGrid : d.n_cus * 16), dim3(64),
+            static const unsigned grid_per_cu = getenv("FZ_LP_GRID_PER_CU") ? (unsigned)atoi(getenv("FZ_LP_GRID_PER_CU")) : 24u;   // lab knob
+            // (measured on configs[3b], 6144 hits: 16 / 24 / 32 workgroups per CU with 512-entry match buffers 0.325 /
+            //  0.310 / 0.310 ms, with 128-entry ones 0.325 / 0.303 / 0.304 ms — once every hit is resident the kernel
+            //  takes as long as its slowest hit)
+            hipLaunchKernelGGL(lp_kernel(FZ_LP_GENERIC_HIT, scratch != 0), dim3(scratch ? kCandScratchGrid : d.n_cus * grid_per_cu), dim3(64),
                                lds, d.stream, sh.d_buf, fa, d.d_hits, (uint64_t)0, recs, counters);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(d.ev[2], d.stream));
