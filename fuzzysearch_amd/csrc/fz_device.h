@@ -18,6 +18,14 @@
 #define FZ_HD inline
 #endif
 
+// "does any lane of the wave want this?" — wave-uniform on the device (a scalar branch), the caller's own flag
+// in host code (tests/host_emul.cpp drives one candidate at a time)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FZ_WAVE_ANY(x) (__ballot((x) != 0) != 0ull)
+#else
+#define FZ_WAVE_ANY(x) ((x) != 0)
+#endif
+
 #define FZ_MAX_BLOCKS_PER_LAUNCH 8     // n-gram blocks tested by one filter launch
 #define FZ_MAX_M 1024                  // pattern bytes carried in the kernel argument block
 #define FZ_MAX_K 255                   // largest edit budget the verify kernels support
@@ -477,37 +485,49 @@ FZ_HD void fz_gstep_clear(FzGStep &o) {
     o.m1 = o.d1 = o.f1 = o.m2 = o.d2 = o.f2 = 0;
 }
 
+// Written without lane-divergent control flow: flags are 0 / 1 words combined with & | ^, the pattern-skip loop
+// runs a wave-uniform number of rounds (the profile of the branchy form showed the automaton's waves neither
+// executing vector instructions nor waiting for memory for two thirds of their time: exec-mask bookkeeping
+// and ~100 branches per 64 candidates).
 template <class PatF>
 FZ_HD void fz_generic_step_packed(uint32_t w0, uint32_t w1, uint8_t ch, uint32_t index, uint32_t m, PatF pat,
                                   uint32_t max_subs, uint32_t max_ins, uint32_t max_dels, uint32_t max_l, FzGStep &o) {
     const uint32_t start = w0 & 0xffffu, j = w0 >> 16;
     const uint32_t l = w1 & 0xffu, ns = (w1 >> 8) & 0xffu, ni = (w1 >> 16) & 0xffu, nd = w1 >> 24;
-    const bool adv = pat(j) == ch;                                     // py:85-94
-    const bool at_end = j + 1u == m;
-    const bool live = !adv && l != max_l;                              // py:101-102
-    const bool can_ins = ni < max_ins, can_sub = ns < max_subs;
-    const bool second = live && (can_sub || (nd < max_dels && can_ins));
-    o.fa = ((adv && !at_end) || (live && can_ins)) ? 1u : 0u;          // py:104-109
-    o.a0 = adv ? w0 + 0x10000u : w0;
+    const uint32_t adv = pat(j) == ch ? 1u : 0u;                       // py:85-94
+    const uint32_t at_end = j + 1u == m ? 1u : 0u;
+    const uint32_t live = (adv ^ 1u) & (l != max_l ? 1u : 0u);         // py:101-102
+    const uint32_t can_ins = ni < max_ins ? 1u : 0u, can_sub = ns < max_subs ? 1u : 0u;
+    const uint32_t second = live & (can_sub | ((nd < max_dels ? 1u : 0u) & can_ins));
+    o.fa = (adv & (at_end ^ 1u)) | (live & can_ins);                   // py:104-109
+    o.a0 = w0 + (adv << 16);
     o.a1 = adv ? w1 : w1 + 0x00010001u;                                // ni++, l++
-    o.fb = (second && !at_end) ? 1u : 0u;                              // py:111-128
+    o.fb = second & (at_end ^ 1u);                                     // py:111-128
     o.b0 = w0 + 0x10000u;
     o.b1 = w1 + (can_sub ? 0x00000101u : 0x01010001u);                 // ns++, l++  |  ni++, nd++, l++
-    o.f1 = ((adv || second) && at_end) ? 1u : 0u;                      // py:86-88, py:129-138
+    o.f1 = (adv | second) & at_end;                                    // py:86-88, py:129-138
     o.m1 = start | ((index + 1u) << 16);
-    o.d1 = adv ? l : l + 1u;
-    o.fc = 0; o.c0 = 0; o.c1 = 0;
-    o.f2 = 0; o.m2 = start | (index << 16); o.d2 = 0;
-    uint32_t lim = 0;                                                  // py:141-165: skip pattern chars
-    if (live) { lim = max_dels - nd; if (max_l - l < lim) lim = max_l - l; }
-    for (uint32_t sk = 1; sk <= lim; ++sk) {
-        const bool ends = j + sk == m;
-        if (ends || pat(j + sk) == ch) {
-            if (ends || j + sk + 1u == m) { o.f2 = 1; o.d2 = l + sk; }
-            else { o.fc = 1; o.c0 = w0 + ((1u + sk) << 16); o.c1 = w1 + ((sk << 24) | sk); }
-            break;
-        }
+    o.d1 = l + (adv ^ 1u);
+    // py:141-165: the first sk in 1..lim with j + sk == m or pattern[j + sk] == ch
+    uint32_t lim = max_dels - nd;
+    lim = max_l - l < lim ? max_l - l : lim;
+    lim = live ? lim : 0u;
+    uint32_t fsk = 0;
+    for (uint32_t sk = 1; sk <= max_dels; ++sk) {
+        const uint32_t open = (sk <= lim ? 1u : 0u) & (fsk == 0u ? 1u : 0u);
+        if (!FZ_WAVE_ANY(open)) break;
+        const uint32_t pos = j + sk;
+        const uint32_t hit = (pos >= m ? 1u : 0u) | (pat(pos < m ? pos : m - 1u) == ch ? 1u : 0u);
+        fsk = (open & hit) ? sk : fsk;
     }
+    const uint32_t found = fsk != 0u ? 1u : 0u;
+    const uint32_t to_end = j + fsk + 1u >= m ? 1u : 0u;              // ran off the pattern, or matched its last char
+    o.f2 = found & to_end;
+    o.m2 = start | (index << 16);
+    o.d2 = l + fsk;
+    o.fc = found & (to_end ^ 1u);
+    o.c0 = w0 + ((1u + fsk) << 16);
+    o.c1 = w1 + ((fsk << 24) | fsk);
 }
 
 FZ_HD void fz_gcand_words(const FzGCand &c, uint32_t &w0, uint32_t &w1) {

@@ -1200,14 +1200,16 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
             if (last && !flush_end) break;
             uint8_t ch = 0;
             uint32_t nnext = 0;
+            uint32_t fresh_at = 0xffffffffu;                           // list position of this character's fresh candidate
             if (!last) {
                 ch = win[index];
                 if (index < spawn_len) {
                     if (!lev) {                                        // generic: fresh candidate appended (py:80)
                         if (ncur >= a.cand_cap) { overflow = true; break; }
-                        if (lane == 0) { FzGCand f; f.start = (uint16_t)index; f.j = 0; f.l = f.ns = f.ni = f.nd = 0; cur[ncur] = f; }
+                        // (start = index, everything else 0) never goes through the list: the lane that owns
+                        // position ncur takes it from registers — no LDS store + wait per character
+                        fresh_at = ncur;
                         ++ncur;
-                        fz_wave_lds_sync();
                     } else {                                           // Levenshtein: levenshtein.py:75-80
                         uint32_t f = 0xffffffffu;
                         const uint32_t lim = a.k + 1 < a.m ? a.k + 1 : a.m;
@@ -1229,12 +1231,20 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
             for (uint32_t c0 = 0; c0 < ncur; c0 += 64u) {
                 const bool valid = c0 + lane < ncur;
                 FzGStep st;
-                fz_gstep_clear(st);
-                if (valid) {
-                    const uint2 cw = reinterpret_cast<const uint2 *>(cur)[c0 + lane];
-                    if (!last && !lev) {
-                        fz_generic_step_packed(cw.x, cw.y, ch, index, a.m, patf, a.max_subs, a.max_ins, a.max_dels, a.k, st);
-                    } else {
+                if (!last && !lev) {
+                    // every lane steps (positions below cand_cap are readable; lanes past the list step an all-zero
+                    // candidate) and the five output flags of the lanes past the list are cleared: no divergence
+                    uint2 cw = reinterpret_cast<const uint2 *>(cur)[c0 + lane];
+                    const bool fresh = c0 + lane == fresh_at;
+                    cw.x = valid ? (fresh ? index : cw.x) : 0u;
+                    cw.y = valid && !fresh ? cw.y : 0u;
+                    fz_generic_step_packed(cw.x, cw.y, ch, index, a.m, patf, a.max_subs, a.max_ins, a.max_dels, a.k, st);
+                    const uint32_t vm = valid ? 1u : 0u;
+                    st.fa &= vm; st.fb &= vm; st.fc &= vm; st.f1 &= vm; st.f2 &= vm;
+                } else {
+                    fz_gstep_clear(st);
+                    if (valid) {
+                        const uint2 cw = reinterpret_cast<const uint2 *>(cur)[c0 + lane];
                         const FzGCand c = fz_gcand_of(cw.x, cw.y);
                         FzGOut o;
                         o.nsucc = 0; o.nmatch = 0;
@@ -1266,7 +1276,9 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
                 nnext += tot_s;
                 mb += tot_m;
             }
-            fz_wave_lds_sync();
+            // the next character reads what this one stored: a wave's LDS operations are performed in issue order,
+            // only the compiler must not reorder; lists in HBM need the real thing
+            if (HBM_LISTS) fz_wave_lds_sync(); else asm volatile("" ::: "memory");
             FzGCand *tmp = cur; cur = nxt; nxt = tmp;
             ncur = nnext;
         }
