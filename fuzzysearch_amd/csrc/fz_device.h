@@ -492,40 +492,42 @@ FZ_HD void fz_gstep_clear(FzGStep &o) {
 template <class PatF>
 FZ_HD void fz_generic_step_packed(uint32_t w0, uint32_t w1, uint8_t ch, uint32_t index, uint32_t m, PatF pat,
                                   uint32_t max_subs, uint32_t max_ins, uint32_t max_dels, uint32_t max_l, FzGStep &o) {
+    // conditions as bools combined with & | ! (never && ||): lane masks in scalar registers on the GPU, where the
+    // vector ALU is this kernel's busiest unit
     const uint32_t start = w0 & 0xffffu, j = w0 >> 16;
     const uint32_t l = w1 & 0xffu, ns = (w1 >> 8) & 0xffu, ni = (w1 >> 16) & 0xffu, nd = w1 >> 24;
-    const uint32_t adv = pat(j) == ch ? 1u : 0u;                       // py:85-94
-    const uint32_t at_end = j + 1u == m ? 1u : 0u;
-    const uint32_t live = (adv ^ 1u) & (l != max_l ? 1u : 0u);         // py:101-102
-    const uint32_t can_ins = ni < max_ins ? 1u : 0u, can_sub = ns < max_subs ? 1u : 0u;
-    const uint32_t second = live & (can_sub | ((nd < max_dels ? 1u : 0u) & can_ins));
-    o.fa = (adv & (at_end ^ 1u)) | (live & can_ins);                   // py:104-109
-    o.a0 = w0 + (adv << 16);
+    const bool adv = pat(j) == ch;                                     // py:85-94
+    const bool at_end = j + 1u == m;
+    const bool live = !adv & (l != max_l);                             // py:101-102
+    const bool can_ins = ni < max_ins, can_sub = ns < max_subs;
+    const bool second = live & (can_sub | ((nd < max_dels) & can_ins));
+    o.fa = ((adv & !at_end) | (live & can_ins)) ? 1u : 0u;             // py:104-109
+    o.a0 = adv ? w0 + 0x10000u : w0;
     o.a1 = adv ? w1 : w1 + 0x00010001u;                                // ni++, l++
-    o.fb = second & (at_end ^ 1u);                                     // py:111-128
+    o.fb = (second & !at_end) ? 1u : 0u;                               // py:111-128
     o.b0 = w0 + 0x10000u;
     o.b1 = w1 + (can_sub ? 0x00000101u : 0x01010001u);                 // ns++, l++  |  ni++, nd++, l++
-    o.f1 = (adv | second) & at_end;                                    // py:86-88, py:129-138
+    o.f1 = ((adv | second) & at_end) ? 1u : 0u;                        // py:86-88, py:129-138
     o.m1 = start | ((index + 1u) << 16);
-    o.d1 = l + (adv ^ 1u);
+    o.d1 = adv ? l : l + 1u;
     // py:141-165: the first sk in 1..lim with j + sk == m or pattern[j + sk] == ch
     uint32_t lim = max_dels - nd;
     lim = max_l - l < lim ? max_l - l : lim;
     lim = live ? lim : 0u;
     uint32_t fsk = 0;
     for (uint32_t sk = 1; sk <= max_dels; ++sk) {
-        const uint32_t open = (sk <= lim ? 1u : 0u) & (fsk == 0u ? 1u : 0u);
-        if (!FZ_WAVE_ANY(open)) break;
+        const bool open = (sk <= lim) & (fsk == 0u);
+        if (!FZ_WAVE_ANY(open ? 1u : 0u)) break;
         const uint32_t pos = j + sk;
-        const uint32_t hit = (pos >= m ? 1u : 0u) | (pat(pos < m ? pos : m - 1u) == ch ? 1u : 0u);
+        const bool hit = (pos >= m) | (pat(pos < m ? pos : m - 1u) == ch);
         fsk = (open & hit) ? sk : fsk;
     }
-    const uint32_t found = fsk != 0u ? 1u : 0u;
-    const uint32_t to_end = j + fsk + 1u >= m ? 1u : 0u;              // ran off the pattern, or matched its last char
-    o.f2 = found & to_end;
+    const bool found = fsk != 0u;
+    const bool to_end = j + fsk + 1u >= m;                             // ran off the pattern, or matched its last char
+    o.f2 = (found & to_end) ? 1u : 0u;
     o.m2 = start | (index << 16);
     o.d2 = l + fsk;
-    o.fc = found & (to_end ^ 1u);
+    o.fc = (found & !to_end) ? 1u : 0u;
     o.c0 = w0 + ((1u + fsk) << 16);
     o.c1 = w1 + ((fsk << 24) | fsk);
 }

@@ -1228,22 +1228,48 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
                 }
             }
             const bool more_seq = w0 + index + 1 < a.geom.n;   // tiled Levenshtein mode only
-            for (uint32_t c0 = 0; c0 < ncur; c0 += 64u) {
-                const bool valid = c0 + lane < ncur;
-                FzGStep st;
-                if (!last && !lev) {
-                    // every lane steps (positions below cand_cap are readable; lanes past the list step an all-zero
-                    // candidate) and the five output flags of the lanes past the list are cleared: no divergence
+            // the outputs of one slice of 64 candidates go to the lists through wave prefix sums, in list order
+            auto emit = [&](const FzGStep &st) -> bool {
+                const uint32_t packed = (st.fa + st.fb + st.fc) | ((st.f1 + st.f2) << 16);
+                const uint32_t incl = fz_wave_incl_scan(packed);
+                const uint32_t tot = __builtin_amdgcn_readlane(incl, 63);
+                const uint32_t excl = incl - packed;
+                const uint32_t tot_s = tot & 0xffffu, tot_m = tot >> 16;
+                if (nnext + tot_s > a.cand_cap) return false;
+                if (mb + tot_m > FZ_GEN_MCAP) flush_matches();
+                uint2 *nx = reinterpret_cast<uint2 *>(nxt) + nnext + (excl & 0xffffu);
+                if (st.fa) nx[0] = make_uint2(st.a0, st.a1);
+                if (st.fb) nx[st.fa] = make_uint2(st.b0, st.b1);
+                if (st.fc) nx[st.fa + st.fb] = make_uint2(st.c0, st.c1);
+                uint64_t *mp = mbuf + mb + (excl >> 16);
+                const uint64_t stamp = (uint64_t)index << 48;
+                if (st.f1) mp[0] = (uint64_t)st.m1 | ((uint64_t)st.d1 << 32) | stamp;
+                if (st.f2) mp[st.f1] = (uint64_t)st.m2 | ((uint64_t)st.d2 << 32) | stamp;
+                nnext += tot_s;
+                mb += tot_m;
+                return true;
+            };
+            if (!last && !lev) {
+                // the hot loop (its own copy of `emit`: no register shuffling where the two forms would join).  Every
+                // lane steps — positions below cand_cap are readable, lanes past the list step an all-zero candidate
+                // and have their five output flags cleared: no divergence
+                for (uint32_t c0 = 0; c0 < ncur; c0 += 64u) {
+                    const bool valid = c0 + lane < ncur;
                     uint2 cw = reinterpret_cast<const uint2 *>(cur)[c0 + lane];
                     const bool fresh = c0 + lane == fresh_at;
                     cw.x = valid ? (fresh ? index : cw.x) : 0u;
                     cw.y = valid && !fresh ? cw.y : 0u;
+                    FzGStep st;
                     fz_generic_step_packed(cw.x, cw.y, ch, index, a.m, patf, a.max_subs, a.max_ins, a.max_dels, a.k, st);
                     const uint32_t vm = valid ? 1u : 0u;
                     st.fa &= vm; st.fb &= vm; st.fc &= vm; st.f1 &= vm; st.f2 &= vm;
-                } else {
+                    if (!emit(st)) { overflow = true; break; }
+                }
+            } else {
+                for (uint32_t c0 = 0; c0 < ncur; c0 += 64u) {
+                    FzGStep st;
                     fz_gstep_clear(st);
-                    if (valid) {
+                    if (c0 + lane < ncur) {
                         const uint2 cw = reinterpret_cast<const uint2 *>(cur)[c0 + lane];
                         const FzGCand c = fz_gcand_of(cw.x, cw.y);
                         FzGOut o;
@@ -1257,24 +1283,8 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
                         }
                         fz_gstep_from_out(o, st);
                     }
+                    if (!emit(st)) { overflow = true; break; }
                 }
-                const uint32_t packed = (st.fa + st.fb + st.fc) | ((st.f1 + st.f2) << 16);
-                const uint32_t incl = fz_wave_incl_scan(packed);
-                const uint32_t tot = __builtin_amdgcn_readlane(incl, 63);
-                const uint32_t excl = incl - packed;
-                const uint32_t tot_s = tot & 0xffffu, tot_m = tot >> 16;
-                if (nnext + tot_s > a.cand_cap) { overflow = true; break; }
-                if (mb + tot_m > FZ_GEN_MCAP) flush_matches();
-                uint2 *nx = reinterpret_cast<uint2 *>(nxt) + nnext + (excl & 0xffffu);
-                if (st.fa) nx[0] = make_uint2(st.a0, st.a1);
-                if (st.fb) nx[st.fa] = make_uint2(st.b0, st.b1);
-                if (st.fc) nx[st.fa + st.fb] = make_uint2(st.c0, st.c1);
-                uint64_t *mp = mbuf + mb + (excl >> 16);
-                const uint64_t stamp = (uint64_t)index << 48;
-                if (st.f1) mp[0] = (uint64_t)st.m1 | ((uint64_t)st.d1 << 32) | stamp;
-                if (st.f2) mp[st.f1] = (uint64_t)st.m2 | ((uint64_t)st.d2 << 32) | stamp;
-                nnext += tot_s;
-                mb += tot_m;
             }
             // the next character reads what this one stored: a wave's LDS operations are performed in issue order,
             // only the compiler must not reorder; lists in HBM need the real thing
