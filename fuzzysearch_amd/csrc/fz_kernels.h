@@ -1304,29 +1304,32 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
 
 // Reference order of the generic search's rows (generic_search.py:221-237: blocks in order, the hits of a block by
 // index, the matches of a hit in emission order) restored on the device.  A hit's first row = the rows of all hits
-// with a smaller key (block << 56 | index).  Quadratic, tiled 256 x 256 over (hit, other hit) pairs with partial
-// sums added atomically: 6e3 hits = 576 tiles, ~10 us; the host orders searches with more than FZ_GEN_ORDER_MAX hits.
+// with a smaller key (block << 56 | index).  Quadratic, tiled 256 x 64 over (hit, other hit) pairs with partial
+// sums added atomically (6e3 hits = 2304 tiles); the host orders searches with more than FZ_GEN_ORDER_MAX hits.
 __global__ __launch_bounds__(256) void fz_gen_order_kernel(const uint64_t *__restrict__ hits, const FzScanArgs a,
                                                            const unsigned long long *__restrict__ counters) {
-    __shared__ uint64_t skey[256];
-    __shared__ uint32_t scnt[256];
+    constexpr uint32_t TJ = 64;                                 // other hits per tile: the length of a thread's serial chain
+    __shared__ uint64_t skey[TJ];
+    __shared__ uint32_t scnt[TJ];
     const unsigned long long n = counters[0];
     if (n > a.hit_cap || n > FZ_GEN_ORDER_MAX || counters[2]) return;
     unsigned long long *first = reinterpret_cast<unsigned long long *>(a.gen_order);
     const uint32_t *count = reinterpret_cast<const uint32_t *>(first + FZ_GEN_ORDER_MAX);
-    const uint32_t nt = ((uint32_t)n + 255u) / 256u;
-    for (uint32_t p = blockIdx.x; p < nt * nt; p += gridDim.x) {
-        const uint32_t i = (p / nt) * 256u + threadIdx.x, j = (p % nt) * 256u + threadIdx.x;
+    const uint32_t nti = ((uint32_t)n + 255u) / 256u, ntj = ((uint32_t)n + TJ - 1u) / TJ;
+    for (uint32_t p = blockIdx.x; p < nti * ntj; p += gridDim.x) {
+        const uint32_t i = (p / ntj) * 256u + threadIdx.x, j = (p % ntj) * TJ + threadIdx.x;
         __syncthreads();
-        skey[threadIdx.x] = j < n ? hits[j] : ~0ull;
-        scnt[threadIdx.x] = j < n ? count[j] : 0u;
+        if (threadIdx.x < TJ) {
+            skey[threadIdx.x] = j < n ? hits[j] : ~0ull;
+            scnt[threadIdx.x] = j < n ? count[j] : 0u;
+        }
         __syncthreads();
         if (i < n) {
             const uint64_t me = hits[i];
-            unsigned long long sum = 0;
-#pragma unroll 8
-            for (uint32_t t = 0; t < 256u; ++t) sum += skey[t] < me ? scnt[t] : 0u;
-            if (sum) atomicAdd(&first[i], sum);
+            uint32_t sum = 0;                                   // <= TJ * rows of one hit
+#pragma unroll 16
+            for (uint32_t t = 0; t < TJ; ++t) sum += skey[t] < me ? scnt[t] : 0u;
+            if (sum) atomicAdd(&first[i], (unsigned long long)sum);
         }
     }
 }

@@ -765,7 +765,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(d.ev[2], d.stream));
             if (dev_order) {
-                hipLaunchKernelGGL(fz_gen_order_kernel, dim3(d.n_cus * 4), dim3(256), 0, d.stream, d.d_hits, fa, counters);
+                hipLaunchKernelGGL(fz_gen_order_kernel, dim3(d.n_cus * 8), dim3(256), 0, d.stream, d.d_hits, fa, counters);
                 hipLaunchKernelGGL(fz_gen_scatter_kernel, dim3(d.n_cus * 8), dim3(256), 0, d.stream, d.d_hits, fa, recs,
                                    reinterpret_cast<FzOutRow *>(d.d_gen_rows), counters);
                 HIP_TRY(hipGetLastError());
@@ -774,10 +774,13 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             HIP_TRY(hipEventRecord(d.ev[3], d.stream));
         }
         bool lists_overflowed = false;
+        Trace trg;
+        trg.mark(" generic enqueue");
         for (const Shard &sh : seq->shards) {
             DevState &d = ctx->devs[sh.dev];
             HIP_TRY(hipSetDevice(d.device));
             HIP_TRY(hipStreamSynchronize(d.stream));
+            trg.mark(" generic sync");
             const unsigned long long *cnt = reinterpret_cast<const unsigned long long *>(d.h_stage);
             const uint64_t nh = cnt[0], nr = cnt[1], novf = cnt[2];
             static const bool gen_direct2 = getenv("FZ_GEN_DIRECT") != nullptr;
@@ -1380,9 +1383,13 @@ int fz_generic_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, ui
     for (uint32_t s = 0; s + L <= m; s += L) q.plan.s.push_back(s);   // generic_search.py:221-228 (ranges: fz_block_range)
     if (q.plan.s.size() > 255) return fail(FZ_EUNSUPPORTED, "more than 255 n-gram blocks");
     std::vector<FzGenRec> recs_vec;
+    Trace tr;
     rc = run_generic(ctx, seq, q, recs_vec);
     if (rc) return rc;
-    return emit_generic(ctx, seq, recs_vec, L, k, out, n, nullptr);
+    tr.mark("generic: kernels");
+    rc = emit_generic(ctx, seq, recs_vec, L, k, out, n, nullptr);
+    tr.mark("generic: rows");
+    return rc;
 }
 
 }  // extern "C"
