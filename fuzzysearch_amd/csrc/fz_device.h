@@ -496,7 +496,13 @@ FZ_HD void fz_generic_step_packed(uint32_t w0, uint32_t w1, uint8_t ch, uint32_t
     // vector ALU is this kernel's busiest unit
     const uint32_t start = w0 & 0xffffu, j = w0 >> 16;
     const uint32_t l = w1 & 0xffu, ns = (w1 >> 8) & 0xffu, ni = (w1 >> 16) & 0xffu, nd = w1 >> 24;
-    const bool adv = pat(j) == ch;                                     // py:85-94
+    // the pattern characters of the first two skip rounds are requested together with pattern[j]: three
+    // independent reads instead of a chain of dependent ones (the kernel takes as long as its slowest hit, and a
+    // hit's time is this chain, character after character)
+    const uint32_t j1 = j + 1u < m ? j + 1u : m - 1u, j2 = j + 2u < m ? j + 2u : m - 1u;
+    const uint8_t pj = pat(j);
+    const uint8_t p1 = max_dels >= 1u ? pat(j1) : (uint8_t)0, p2 = max_dels >= 2u ? pat(j2) : (uint8_t)0;
+    const bool adv = pj == ch;                                         // py:85-94
     const bool at_end = j + 1u == m;
     const bool live = !adv & (l != max_l);                             // py:101-102
     const bool can_ins = ni < max_ins, can_sub = ns < max_subs;
@@ -515,7 +521,9 @@ FZ_HD void fz_generic_step_packed(uint32_t w0, uint32_t w1, uint8_t ch, uint32_t
     lim = max_l - l < lim ? max_l - l : lim;
     lim = live ? lim : 0u;
     uint32_t fsk = 0;
-    for (uint32_t sk = 1; sk <= max_dels; ++sk) {
+    if (max_dels >= 1u) fsk = ((1u <= lim) & ((j + 1u >= m) | (p1 == ch))) ? 1u : 0u;
+    if (max_dels >= 2u) fsk = ((2u <= lim) & (fsk == 0u) & ((j + 2u >= m) | (p2 == ch))) ? 2u : fsk;
+    for (uint32_t sk = 3; sk <= max_dels; ++sk) {
         const bool open = (sk <= lim) & (fsk == 0u);
         if (!FZ_WAVE_ANY(open ? 1u : 0u)) break;
         const uint32_t pos = j + sk;
