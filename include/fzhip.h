@@ -125,7 +125,9 @@ int fz_subs_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint3
                    fz_match **out, uint64_t *n);
 
 /* Raw stream of find_near_matches_generic_ngrams (the greedy candidate-set automaton run on the
- * window around every n-gram hit), reference emission order. */
+ * window around every n-gram hit), reference emission order: blocks in order, the hits of a block by index,
+ * the matches of a hit as the automaton emits them, duplicates included.  The rows are ordered on the
+ * device (one shard, at most 16 384 hits) or by the host; the bytes returned are the same either way. */
 int fz_generic_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m,
                       uint32_t max_subs, uint32_t max_ins, uint32_t max_dels, uint32_t max_l,
                       fz_match **out, uint64_t *n);
@@ -185,7 +187,8 @@ int fz_wire_merge(const void *recv, uint32_t world, uint64_t rows_per_rank, uint
  *   n-grams (k = max_substitutions), 3 generic n-grams (k = max_l_dist + the three limits).
  * Protocol: fz_stream_buffer -> where to put the next bytes and how many fit; fz_stream_submit(n, last)
  * after writing n of them (a launch happens whenever whole chunks are available); or fz_stream_read_fd,
- * which drives both from a file descriptor with several pread threads until end of file.
+ * which drives both from a file descriptor until end of file: `threads` readers (0: half the cores, at most 32)
+ * live for the whole call and take 1 MiB pieces of the current batch from a shared counter.
  * fz_stream_finish -> the raw match stream of the whole file in the reference's order (chunk by chunk,
  * each chunk in its in-memory order, file coordinates) and the chunk number of every record.
  * Requires seg_pre + seg_post <= seg_stride / 2 (FZ_EUNSUPPORTED otherwise: use per-chunk searches). */
