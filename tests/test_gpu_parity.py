@@ -411,6 +411,20 @@ def test_generic_ngrams_medium(engine, m, limits):
     assert len(exp) > 50
 
 
+def test_generic_more_hits_than_the_device_orders(engine):
+    """3.7e4 n-gram hits (4-letter text, 4-byte n-grams): above FZ_GEN_ORDER_MAX = 16384 the rows are ordered by the
+    host from records whose `win` field holds the hit slot; below it (the other generic tests) on the device."""
+    seq = workloads.dna(3 << 20, 5)
+    t = seq.tobytes()
+    p = t[1000:1012]
+    h = engine.upload(seq)
+    for limits in ((1, 1, 1, 2), (2, 0, 1, 2)):
+        got = engine.generic_ngrams(h, p, *limits)
+        assert engine.stats()["ngram_hits"] > 16384
+        assert got == oracle.generic_ngrams_raw(p, t, *limits), limits
+    h.release()
+
+
 def test_generic_public_api(engine):
     import fuzzysearch_amd as fa
     rnd = random.Random(43)
