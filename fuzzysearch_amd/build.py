@@ -44,5 +44,27 @@ def build(force=False, report=False):
     return LIB
 
 
+def match_ext_path():
+    import sysconfig
+    return os.path.join(HERE, "_fzmatch" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+
+
+def build_match_ext(force=False):
+    """The CPython extension that fills Match objects from fz_match rows (csrc/_fzmatch.c; host code, gcc).
+    Optional: common.py materialises in Python when it is absent."""
+    import sysconfig
+    out, src = match_ext_path(), os.path.join(CSRC, "_fzmatch.c")
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(src):
+        return out
+    cc = os.environ.get("CC") or shutil.which("gcc") or shutil.which("cc")
+    if not cc:
+        raise RuntimeError("no C compiler for _fzmatch")
+    cmd = [cc, "-O2", "-fPIC", "-shared", "-Wall", "-I" + sysconfig.get_paths()["include"], src, "-o", out + ".tmp"]
+    subprocess.check_call(cmd)
+    os.replace(out + ".tmp", out)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, report="--report" in sys.argv))
+    print(build_match_ext(force="--force" in sys.argv))

@@ -46,6 +46,10 @@ class Match(object):
 
 _SET_START, _SET_END, _SET_DIST, _SET_MATCHED = (Match.start.__set__, Match.end.__set__, Match.dist.__set__,
                                                  Match.matched.__set__)
+try:                                        # csrc/_fzmatch.c, built by fuzzysearch_amd.build: the same fill in C
+    from . import _fzmatch
+except ImportError:                         # not built: the Python loop below does the same, ~3x slower
+    _fzmatch = None
 
 
 def _is_limit(x):
@@ -126,14 +130,20 @@ class RawMatches(object):
             out.append(m)
         return out
 
+    def _make_from_array(self, array):
+        if _fzmatch is not None and array.flags.c_contiguous:
+            return _fzmatch.make_matches(Match, array, self.sequence, self.offset, Match.start, Match.end, Match.dist,
+                                         Match.matched)
+        return self._make(array.tolist())
+
     def materialize(self):
         if self._list is None:
-            self._list = self._make(self.array.tolist())
+            self._list = self._make_from_array(self.array)
         return self._list
 
     def subset(self, array):
         """Match objects for another fz_match array over the same sequence (e.g. the consolidated one)."""
-        return self._make(array.tolist())
+        return self._make_from_array(array)
 
     def __len__(self):
         return len(self.array)

@@ -139,6 +139,61 @@ def test_fz_consolidate_and_group_best_against_oracle_and_golden():
         assert [b[:3] for b in _native.consolidate(raw)] == want, (n, span, run, "shuffled")
 
 
+def test_match_objects_from_rows_c_extension_equals_python_fill():
+    """csrc/_fzmatch.c (built by fuzzysearch_amd.build) against the Python fill of RawMatches._make and against
+    Match's own constructor: same objects for bytes / str / list sequences, offsets, empty arrays; bad rows raise."""
+    import gc
+    import sys
+    import numpy as np
+    from fuzzysearch_amd import build as fzbuild
+    fzbuild.build_match_ext()
+    from fuzzysearch_amd import _fzmatch
+    assert common._fzmatch is not None, "extension present but not picked up"
+    rnd = random.Random(21)
+    for seq in (bytes(rnd.randrange(256) for _ in range(500)), "".join(chr(rnd.randrange(32, 1000)) for _ in range(500)),
+                [rnd.randrange(10) for _ in range(500)], tuple(range(500)), bytearray(500)):
+        for n in (0, 1, 7, 300):
+            arr = np.zeros(n, dtype=_native._match_dtype())
+            for i in range(n):
+                s0 = rnd.randrange(0, 480)
+                arr[i] = (s0, s0 + rnd.randrange(0, 20), rnd.randrange(0, 9), rnd.randrange(0, 4))
+            for off in (0, 12345678901):
+                raw = common.RawMatches(arr, seq, off)
+                got = raw._make_from_array(arr)
+                want = [Match(int(r['start']) + off, int(r['end']) + off, int(r['dist']), matched=seq[int(r['start']):int(r['end'])])
+                        for r in arr]
+                assert got == want and raw._make(arr.tolist()) == want
+                assert all(type(g) is Match and g.matched == w.matched and type(g.matched) is type(w.matched) and hash(g) == hash(w)
+                           for g, w in zip(got, want))
+                assert all(type(g.start) is int and type(g.dist) is int for g in got)
+    # frozen like any Match, collectable, no reference leaked on the sequence
+    seq = bytes(1000)
+    arr = np.zeros(50, dtype=_native._match_dtype())
+    arr['end'] = 10
+    before = sys.getrefcount(seq)
+    for _ in range(200):
+        ms = _fzmatch.make_matches(Match, arr, seq, 0, Match.start, Match.end, Match.dist, Match.matched)
+    with pytest.raises(attr.exceptions.FrozenInstanceError):
+        ms[0].start = 3
+    del ms
+    gc.collect()
+    assert sys.getrefcount(seq) == before
+    bad = np.zeros(3, dtype=_native._match_dtype())
+    bad['start'][1] = -1
+    with pytest.raises(ValueError):
+        _fzmatch.make_matches(Match, bad, seq, 0, Match.start, Match.end, Match.dist, Match.matched)
+    with pytest.raises(ValueError):
+        _fzmatch.make_matches(Match, b"12345", seq, 0, Match.start, Match.end, Match.dist, Match.matched)
+    with pytest.raises(TypeError):
+        _fzmatch.make_matches(Match, arr, seq, 0, Match.start, Match.end, Match.dist, LevenshteinSearchParams.max_l_dist)
+    with pytest.raises(TypeError):                              # a sequence that cannot be sliced: the error surfaces
+        _fzmatch.make_matches(Match, arr, 5, 0, Match.start, Match.end, Match.dist, Match.matched)
+    # non-contiguous views go through the Python fill
+    wide = np.zeros(20, dtype=_native._match_dtype())
+    wide['end'] = 4
+    assert common.RawMatches(wide[::2], seq)._make_from_array(wide[::2]) == [Match(0, 4, 0, seq[0:4])] * 10
+
+
 def test_python_level_consolidation_helpers():
     ms = [Match(22, 34, 0, "a"), Match(2, 14, 1, "b"), Match(3, 15, 2, "c"), Match(40, 41, 0, "d")]
     assert common.consolidate_overlapping_matches(ms) == [Match(2, 14, 1, "b"), Match(22, 34, 0, "a"), Match(40, 41, 0, "d")]
