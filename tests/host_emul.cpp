@@ -192,6 +192,89 @@ int64_t emul_generic_lp_packed(const uint8_t *p, uint32_t m, const uint8_t *t, u
     return agree ? cnt : -1;
 }
 
+// The generic n-gram search as the GPU runs it when the rows are ordered on the device (fz_lp_kernel<0> +
+// fz_gen_order_kernel + fz_gen_scatter_kernel): n-gram hits arrive in an arbitrary order (here: scrambled with
+// `scramble`), every hit runs the packed automaton on its window (window and flush exactly as the kernel
+// computes them: fz_segment / fz_hit_in_range_s) and leaves records (hit slot, emission number, se, dist) plus a
+// row count; a hit's first row is the sum of the counts of all hits with a smaller key; every record lands at
+// first row + emission number as fz_gen_row makes it.  -> rows, or -1 if packed and struct steps ever disagreed.
+int64_t emul_generic_ngrams_ordered(const uint8_t *p, uint32_t m, const uint8_t *t, uint64_t n, uint32_t max_subs,
+                                    uint32_t max_ins, uint32_t max_dels, uint32_t max_l, uint32_t scramble,
+                                    OutRec *out, int64_t cap) {
+    const uint32_t k = max_l, L = m / (k + 1);
+    if (L == 0) return -2;
+    FzScanArgs a;
+    memset(&a, 0, sizeof a);
+    a.geom.n = n; a.geom.buf_off = 0; a.geom.buf_len = n; a.geom.own_lo = 0; a.geom.own_hi = n;
+    a.mode = FZ_MODE_GENERIC; a.m = m; a.k = k; a.L = L; a.abs_lo = 0; a.abs_hi = ~0ull;
+    std::vector<uint64_t> hits;
+    uint32_t g = 0;
+    for (uint32_t s = 0; s + L <= m; s += L, ++g)
+        for (uint64_t idx = 0; idx + L <= n; ++idx)
+            if (memcmp(t + idx, p + s, L) == 0) hits.push_back(((uint64_t)g << 56) | idx);
+    // the scan kernel appends hits with atomics: any order
+    uint64_t x = 0x9E3779B97F4A7C15ull * (scramble + 1);
+    for (size_t i = hits.size(); i > 1; --i) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        std::swap(hits[i - 1], hits[x % i]);
+    }
+    struct Rec { uint32_t slot, seq, se, dist; };
+    std::vector<Rec> recs;
+    std::vector<uint32_t> count(hits.size(), 0);
+    auto pat = [&](uint32_t i) -> uint8_t { return p[i]; };
+    for (size_t q = 0; q < hits.size(); ++q) {
+        const uint64_t hit = hits[q];
+        const uint32_t s = fz_hit_block(hit) * L;
+        const uint64_t idx = fz_hit_index(hit);
+        const FzSeg sg = fz_segment(a.geom, idx, 0);
+        if (!fz_hit_in_range_s(a, s, idx, sg)) continue;
+        const uint64_t reach = (uint64_t)s + k;
+        const uint64_t w0 = idx - sg.sa > reach ? idx - reach : sg.sa;
+        uint64_t w1 = idx - s + m + k;
+        if (w1 > sg.se) w1 = sg.se;
+        const uint32_t wlen = (uint32_t)(w1 - w0);
+        std::vector<uint64_t> cur, nxt;
+        uint32_t mseq = 0;
+        for (uint32_t index = 0; index < wlen; ++index) {
+            cur.push_back((uint64_t)index);
+            nxt.clear();
+            for (uint64_t cw : cur) {
+                FzGStep st;
+                fz_generic_step_packed((uint32_t)cw, (uint32_t)(cw >> 32), t[w0 + index], index, m, pat, max_subs, max_ins, max_dels,
+                                       max_l, st);
+                if (st.fa) nxt.push_back(st.a0 | ((uint64_t)st.a1 << 32));
+                if (st.fb) nxt.push_back(st.b0 | ((uint64_t)st.b1 << 32));
+                if (st.fc) nxt.push_back(st.c0 | ((uint64_t)st.c1 << 32));
+                if (st.f1) recs.push_back(Rec{(uint32_t)q, mseq++, st.m1, st.d1});
+                if (st.f2) recs.push_back(Rec{(uint32_t)q, mseq++, st.m2, st.d2});
+            }
+            cur.swap(nxt);
+        }
+        for (uint64_t cw : cur) {                                // end-of-window flush
+            uint32_t d;
+            const FzGCand c = fz_gcand_of((uint32_t)cw, (uint32_t)(cw >> 32));
+            if (fz_generic_final(c, m, max_dels, max_l, d)) recs.push_back(Rec{(uint32_t)q, mseq++, (uint32_t)c.start | (wlen << 16), d});
+        }
+        count[q] = mseq;
+    }
+    std::vector<uint64_t> first(hits.size(), 0);                 // fz_gen_order_kernel
+    for (size_t i = 0; i < hits.size(); ++i)
+        for (size_t j = 0; j < hits.size(); ++j)
+            if (hits[j] < hits[i]) first[i] += count[j];
+    std::vector<FzOutRow> rows(recs.size());                     // fz_gen_scatter_kernel
+    std::vector<uint8_t> written(recs.size(), 0);
+    for (const Rec &r : recs) {
+        const uint64_t pos = first[r.slot] + r.seq;
+        if (pos >= rows.size() || written[pos]) return -3;
+        written[pos] = 1;
+        rows[pos] = fz_gen_row(hits[r.slot], L, k, 0, r.se, r.dist);
+    }
+    for (size_t i = 0; i < rows.size() && (int64_t)i < cap; ++i) {
+        out[i].start = rows[i].start; out[i].end = rows[i].end; out[i].dist = rows[i].dist; out[i].block = rows[i].block;
+    }
+    return (int64_t)rows.size();
+}
+
 int emul_expand(const uint8_t *sub, uint32_t sublen, const uint8_t *win, uint32_t winlen, uint32_t budget,
                 uint32_t *dist, uint32_t *consumed) {
     HostScores sc;

@@ -146,3 +146,31 @@ def test_generic_automaton_struct_and_packed_steps_equal_oracle(emul):
             assert 0 <= c <= cap, (fn, p, t, limits, max_l)
             assert [(out[i].start, out[i].end, out[i].dist) for i in range(c)] == want, (p, t, limits, max_l)
         done += 1
+
+
+def test_generic_ngram_search_as_ordered_on_the_device_equals_oracle(emul):
+    """The whole generic n-gram pipeline in the form the GPU runs it with device-side ordering — hits in a scrambled
+    order, packed automaton per hit window, row counts, first rows by key, scatter through fz_gen_row — emits the
+    oracle's list (blocks in order, hits by index, matches in emission order, duplicates included)."""
+    fn = emul.emul_generic_ngrams_ordered
+    fn.restype = ctypes.c_int64
+    fn.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
+                   ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(OutRec), ctypes.c_int64]
+    rnd = random.Random(12)
+    cap = 1 << 17
+    out = (OutRec * cap)()
+    done = total = 0
+    while done < 1500:
+        p, t, k = _case(rnd, max_n=120, max_m=24, max_k=4)
+        limits = (rnd.randint(0, k), rnd.randint(0, k), rnd.randint(0, k))
+        max_l = min(k, sum(limits))
+        if max_l == 0 or len(p) // (max_l + 1) == 0:
+            continue
+        want = oracle.generic_ngrams_raw(p, t, limits[0], limits[1], limits[2], max_l)
+        c = fn(p, len(p), t, len(t), limits[0], limits[1], limits[2], max_l, done, out, cap)
+        assert 0 <= c <= cap, (c, p, t, limits, max_l)
+        got = [(out[i].start, out[i].end, out[i].dist, out[i].block) for i in range(c)]
+        assert got == [tuple(r) for r in want], (p, t, limits, max_l)
+        done += 1
+        total += c
+    assert total > 20000
