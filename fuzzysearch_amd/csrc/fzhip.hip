@@ -31,6 +31,7 @@
 #include <thread>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -2364,54 +2365,76 @@ int fz_debug_launch_plan(const uint8_t *p, uint32_t m, uint32_t L, uint32_t *out
     return FZ_OK;
 }
 
-// Faithful group-list-order version (common.py:161-177), needed by the substitutions-only path.
+// Faithful group-list-order version (common.py:161-177), needed by the substitutions-only path: a match joins
+// the group(s) whose hull it overlaps; one group is extended in place, several are removed and their union is
+// appended at the END of the list; the result is in final list order.  The reference tests every group for
+// every match (O(M * groups): 2 ms for the 2e3 raw matches of configs[2], 50 ms for 2e4).  Group hulls never
+// overlap each other (a match that would make two hulls overlap overlaps both groups and merges them; a
+// zero-length group is a point that is never strictly inside another hull), so the groups are kept ordered by
+// (hull start, hull end) and the groups a match overlaps are a contiguous run found by one search; the list
+// position of a group is a sequence number handed out on creation and on merges.
 int fz_group_best(const fz_match *in, uint64_t n, fz_match **out, uint64_t *n_out) {
     if (!out || !n_out || (!in && n)) return fail(FZ_EINVAL, "null argument");
     *out = nullptr; *n_out = 0;
-    struct Grp { int64_t s, e; fz_match best; };
-    std::vector<Grp> groups;
+    struct Key {
+        int64_t s, e; uint64_t seq;
+        bool operator<(const Key &o) const { return s != o.s ? s < o.s : (e != o.e ? e < o.e : seq < o.seq); }
+    };
     auto better = [](const fz_match &a, const fz_match &b) {
         const int64_t la = a.end - a.start, lb = b.end - b.start;
         return a.dist < b.dist || (a.dist == b.dist && (la > lb || (la == lb && a.start < b.start)));
     };
-    std::vector<size_t> ov;
+    std::map<Key, fz_match> groups;                            // key: hull + list position, value: best match
+    uint64_t next_seq = 0;
+    std::vector<std::map<Key, fz_match>::iterator> ov;
     for (uint64_t i = 0; i < n; ++i) {
         const fz_match &mt = in[i];
+        auto overlaps = [&](const Key &g) { return !(mt.end <= g.s || mt.start >= g.e); };
         ov.clear();
-        // Matches arrive mostly in ascending order: scan from the back and stop early is NOT
-        // valid in general (merges reorder groups), so test every group like the reference.
-        for (size_t g = 0; g < groups.size(); ++g)
-            if (!(mt.end <= groups[g].s || mt.start >= groups[g].e)) ov.push_back(g);
+        auto it = groups.lower_bound(Key{mt.start, INT64_MIN, 0});     // first group starting at or after the match
+        // before it: points cannot overlap (they lie left of the match's start), and of the groups with a length
+        // only the nearest one can reach across the match's start
+        for (auto pb = it; pb != groups.begin();) {
+            --pb;
+            if (pb->first.e == pb->first.s) continue;
+            if (overlaps(pb->first)) ov.push_back(pb);
+            break;
+        }
+        for (; it != groups.end() && it->first.s < mt.end; ++it)
+            if (overlaps(it->first)) ov.push_back(it);
         if (ov.empty()) {
-            groups.push_back({mt.start, mt.end, mt});
-        } else if (ov.size() == 1) {
-            Grp &g = groups[ov[0]];
-            g.s = std::min(g.s, mt.start);
-            g.e = std::max(g.e, mt.end);
-            if (better(mt, g.best)) g.best = mt;
-        } else {
-            Grp u{mt.start, mt.end, mt};
-            for (size_t gi : ov) {
-                u.s = std::min(u.s, groups[gi].s);
-                u.e = std::max(u.e, groups[gi].e);
-                if (better(groups[gi].best, u.best)) u.best = groups[gi].best;
+            groups.emplace(Key{mt.start, mt.end, next_seq++}, mt);
+        } else if (ov.size() == 1) {                           // extended in place: same list position
+            auto node = groups.extract(ov[0]);
+            node.key().s = std::min(node.key().s, mt.start);
+            node.key().e = std::max(node.key().e, mt.end);
+            if (better(mt, node.mapped())) node.mapped() = mt;
+            groups.insert(std::move(node));
+        } else {                                               // union appended at the end of the list
+            std::sort(ov.begin(), ov.end(), [](const auto &x, const auto &y) { return x->first.seq < y->first.seq; });
+            Key u{mt.start, mt.end, 0};
+            fz_match best = mt;
+            for (auto g : ov) {
+                u.s = std::min(u.s, g->first.s);
+                u.e = std::max(u.e, g->first.e);
+                if (better(g->second, best)) best = g->second;
             }
-            size_t w = 0, qi = 0;
-            for (size_t g = 0; g < groups.size(); ++g) {
-                if (qi < ov.size() && ov[qi] == g) { ++qi; continue; }
-                groups[w++] = groups[g];
-            }
-            groups.resize(w);
-            groups.push_back(u);
+            for (auto g : ov) groups.erase(g);
+            u.seq = next_seq++;
+            groups.emplace(u, best);
         }
     }
+    std::vector<std::pair<uint64_t, fz_match>> ordered;
+    ordered.reserve(groups.size());
+    for (const auto &g : groups) ordered.emplace_back(g.first.seq, g.second);
+    std::sort(ordered.begin(), ordered.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
     void *mem = nullptr;
-    int rc = alloc_out(groups.size(), sizeof(fz_match), &mem);
+    int rc = alloc_out(ordered.size(), sizeof(fz_match), &mem);
     if (rc) return rc;
     fz_match *o = static_cast<fz_match *>(mem);
-    for (size_t g = 0; g < groups.size(); ++g) o[g] = groups[g].best;
+    for (size_t g = 0; g < ordered.size(); ++g) o[g] = ordered[g].second;
     *out = o;
-    *n_out = groups.size();
+    *n_out = ordered.size();
     return FZ_OK;
 }
 

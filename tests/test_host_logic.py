@@ -124,6 +124,17 @@ def test_fz_consolidate_and_group_best_against_oracle_and_golden():
         raw = golden_io.triples(list(rec["args"][0]))
         got = [b[:3] for b in _native.consolidate(raw)]
         assert golden_io.equal_modulo_ties(got, golden_io.triples(rec["result"]), raw)
+    # fz_group_best keeps the groups ordered by hull instead of testing every group for every match: dense and
+    # sparse streams with zero-length matches, many merges, up to 1500 rows
+    for trial in range(300):
+        n = rnd.choice([5, 50, 300, 1500])
+        span = rnd.choice([30, 200, 5000, 100000])
+        raw = []
+        for _ in range(n):
+            s = rnd.randint(0, span)
+            raw.append((s, s + rnd.choice([0, 0, 1, 2, 3, 5, 8, 40]), rnd.randint(0, 3), rnd.randint(0, 2)))
+        best, _hull = oracle.group_best(raw)
+        assert [b[:3] for b in _native.group_best(raw)] == [b[:3] for b in best], (trial, n, span)
     # Large streams: the run-folding pass followed by the radix order of the hulls (>= 2048 of them), with
     # zero-length rows at hull edges, rows in block-major runs like the generic search emits, and shuffled.
     for n, span, run in [(3000, 60000, 1), (2600, 2000000, 1), (4000, 30000, 1), (60000, 4000000, 20), (30000, 90000, 7)]:
