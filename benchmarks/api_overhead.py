@@ -31,3 +31,22 @@ ms_abi, raw = best(lambda: eng.lev_ngrams(res.handle if hasattr(res, "handle") e
 ms_api, out = best(lambda: fa.find_near_matches(p, res, max_l_dist=5))
 print(json.dumps({"case": "configs[3a] levenshtein k=5", "MiB": mib, "raw_matches": int(len(raw)), "result_matches": len(out),
                   "c_abi_ms": round(ms_abi, 3), "find_near_matches_ms": round(ms_api, 3), "ratio": round(ms_api / ms_abi, 2)}), flush=True)
+res.release()
+# configs[2]: substitutions-only (group-list-order reduction, fz_group_best) and configs[1]: DNA, k = 2
+seq, pat, _ = workloads.cfg3(n, 1024 * mib // 1024 or 64)
+p = pat.tobytes()
+res = fa.resident(seq)
+ms_abi, raw = best(lambda: eng.subs_ngrams(res.handle, p, 3, as_array=True))
+ms_api, out = best(lambda: fa.find_near_matches(p, res, max_substitutions=3, max_insertions=0, max_deletions=0))
+print(json.dumps({"case": "configs[2] substitutions <= 3", "MiB": mib, "raw_matches": int(len(raw)), "result_matches": len(out),
+                  "c_abi_ms": round(ms_abi, 3), "find_near_matches_ms": round(ms_api, 3), "ratio": round(ms_api / ms_abi, 2)}), flush=True)
+res.release()
+seq = workloads.dna(n, 20250925)
+pat = workloads.dna(20, 1)
+workloads.plant_variants(seq, pat, 1024 * mib // 1024 or 64, 7)
+p = pat.tobytes()
+res = fa.resident(seq)
+ms_abi, raw = best(lambda: eng.lev_ngrams(res.handle, p, 2, as_array=True))
+ms_api, out = best(lambda: fa.find_near_matches(p, res, max_l_dist=2))
+print(json.dumps({"case": "configs[1] DNA levenshtein k=2", "MiB": mib, "raw_matches": int(len(raw)), "result_matches": len(out),
+                  "c_abi_ms": round(ms_abi, 3), "find_near_matches_ms": round(ms_api, 3), "ratio": round(ms_api / ms_abi, 2)}), flush=True)
