@@ -2404,6 +2404,8 @@ int fz_group_best(const fz_match *in, uint64_t n, fz_match **out, uint64_t *n_ou
             if (overlaps(it->first)) ov.push_back(it);
         if (ov.empty()) {
             groups.emplace(Key{mt.start, mt.end, next_seq++}, mt);
+        } else if (ov.size() == 1 && mt.start >= ov[0]->first.s && mt.end <= ov[0]->first.e) {
+            if (better(mt, ov[0]->second)) ov[0]->second = mt;   // inside the hull (cross-block duplicates): nothing moves
         } else if (ov.size() == 1) {                           // extended in place: same list position
             auto node = groups.extract(ov[0]);
             node.key().s = std::min(node.key().s, mt.start);
