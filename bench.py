@@ -220,9 +220,125 @@ def measured_traffic(shard_bytes):
     return None, None
 
 
+def main_multi_device(args):
+    """--gpus N > 1 launched as ONE process (no torchrun, no torch): a torch-free multi-device context.  BASELINE
+    configs[4]: N shards of --mib MiB (4 GiB) each, built shard by shard (never a 4N GiB host array), one per device
+    of the context (fz_seq_new / fz_seq_add_shard), (m + k)-byte halos, hits owned by index, copies of the pattern
+    planted around every shard boundary and asserted in the merged stream.  A step = one search over ALL shards:
+    every device scans its shard concurrently, the host merges the per-device record lists into the reference's
+    global order; two searches in flight (fz_lev_ngrams_begin / _end).  FZ_DEVICES="0,0" maps the N device states
+    onto the listed devices (several states on one GPU: a functional check of the code path, not a scaling number)."""
+    from fuzzysearch_amd import _native
+    from tests import workloads
+    N = args.gpus
+    lib = _native.load_library()
+    import ctypes
+    have = ctypes.c_int(0)
+    _native._check(lib.fz_device_count(ctypes.byref(have)))
+    env = os.environ.get("FZ_DEVICES", "").strip()
+    devices = [int(x) for x in env.split(",") if x.strip()] if env else list(range(N))
+    if len(devices) != N:
+        raise SystemExit("bench.py: FZ_DEVICES lists %d devices but --gpus is %d" % (len(devices), N))
+    if max(devices) >= have.value:
+        raise SystemExit("bench.py: --gpus %d needs devices %r but only %d HIP device(s) are visible "
+                         "(launch under torch.distributed.run for one rank per GPU, or set FZ_DEVICES)" % (N, devices, have.value))
+    k = 2
+    if args.mib <= 0:
+        args.mib = 4096
+    shard_bytes = args.mib << 20
+    pattern = workloads.dna(20, 1)
+    m = len(pattern)
+    p = pattern.tobytes()
+    global_n = shard_bytes * N
+    engine = _native.Engine(devices)
+    t_build = time.perf_counter()
+    fill, edge_plants = workloads.cfg5_fill(shard_bytes, N, pattern, k)
+    handle = engine.new_sequence(global_n)
+    for r, buf, off, lo, hi in workloads.iter_shard_buffers(N, shard_bytes, m + k, fill):
+        engine.add_shard(handle, r, buf, off, lo, hi)
+    t_build = time.perf_counter() - t_build
+
+    first = engine.lev_ngrams(handle, p, k, as_array=True)
+    t_settle = time.perf_counter()
+    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+        assert np.array_equal(engine.lev_ngrams(handle, p, k, as_array=True), first), "non-deterministic result"
+    for _ in range(args.warmup):
+        engine.lev_ngrams(handle, p, k, as_array=True)
+    per_dev = []
+    t0 = time.perf_counter()
+    if args.sync:
+        for _ in range(args.steps):
+            matches = engine.lev_ngrams(handle, p, k, as_array=True)
+            per_dev.append(engine.device_ms())
+    else:
+        engine.lev_ngrams_begin(handle, p, k)
+        for i in range(args.steps):
+            if i + 1 < args.steps:
+                engine.lev_ngrams_begin(handle, p, k)
+            matches = engine.lev_ngrams_end(as_array=True)
+            per_dev.append(engine.device_ms())
+    elapsed = time.perf_counter() - t0
+    st = engine.stats()
+    assert np.array_equal(matches, first), "pipelined and synchronous searches returned different streams"
+    t1 = time.perf_counter()
+    for _ in range(20):
+        engine.lev_ngrams(handle, p, k, as_array=True)
+    sync_ms = (time.perf_counter() - t1) / 20 * 1e3
+    rows = [tuple(int(x) for x in r) for r in matches.tolist()]
+    keys = [(g, s_) for (s_, e_, d_, g) in rows]
+    found = {(s_, e_, d_) for (s_, e_, d_, _g) in rows}
+    missing = [q for q in edge_plants if (q, q + m, 0) not in found]
+    assert not missing, "matches across shard boundaries are missing: %r" % (missing[:8],)
+    import fuzzysearch_amd as fa
+    consolidated = fa.common._native.consolidate(rows)
+    per_dev = np.asarray(per_dev)                                # steps x devices
+    f_ms = float(per_dev.mean())
+    achieved = shard_bytes / (f_ms * 1e-3) / 1e9
+    out = {
+        "metric": "GB/s of sequence scanned at |p|=20 max_l_dist=2 (levenshtein_ngram path)",
+        "value": round(global_n * args.steps / elapsed / 1e9, 2),
+        "unit": "GB/s",
+        "n_gpus": N,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {"workload": "%d MiB iid random DNA bytes per GPU, |pattern|=20, max_l_dist=2, 1024 planted variants per GiB "
+                               "(BASELINE configs[4]: %d GiB over %d GPUs, copies of the pattern around every shard boundary); "
+                               "resident in HBM" % (args.mib, args.mib * N >> 10, N),
+                   "bytes_per_gpu": shard_bytes, "pattern_len": m, "max_l_dist": k,
+                   "calls_in_flight": 1 if args.sync else 2,
+                   "devices": devices,
+                   "sharding": "one process, one device state per GPU (torch-free fz_ctx): contiguous shards, (m+k)-byte halo, "
+                               "hits owned by index, per-device record lists merged on the host; no collective"},
+        "matches_per_s": round(len(rows) * args.steps / elapsed, 1),
+        "raw_matches": len(rows),
+        "consolidated_matches": len(consolidated),
+        "boundary_plants_found": len(edge_plants),
+        "stream_in_reference_order": keys == sorted(keys),
+        "ngram_hits": st["ngram_hits"],
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel": "fz_scan_kernel", "avg_kernel_ms": round(f_ms, 4),
+                     "algorithmic_bytes_per_launch": shard_bytes,
+                     "note": "per GPU: one launch scans one shard; average over devices and steps"},
+        "kernel_ms": {"filter_per_device": [round(float(x), 4) for x in per_dev.mean(axis=0)]},
+        "sync_ms_per_call": round(sync_ms, 4),
+        "build_s": round(t_build, 2),
+        "cpu_baseline": None,
+    }
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1 and os.environ.get("FZ_BENCH_FORCE_DIST") != "1":
+        return main_multi_device(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None

@@ -25,6 +25,7 @@ from .engine import is_byteslike
 
 MODE_EXACT, MODE_LEV, MODE_SUBS, MODE_GENERIC = 0, 1, 2, 3
 BATCH_BYTES = 64 << 20
+MAX_STREAM_CHUNK = 256 << 20
 
 
 class Unsupported(Exception):
@@ -68,6 +69,8 @@ def plan(search_class, subsequence, search_params, chunk_size, keep, binary, seq
         return None
     if chunk_size < 2 * keep + 2 or keep < 0:
         return None
+    if chunk_size > MAX_STREAM_CHUNK:
+        return None                       # the stream pins two staging buffers of two chunks each: per-chunk path instead
     p.binary, p.chunk_size, p.keep = binary, chunk_size, keep
     if binary:
         if not is_byteslike(subsequence):
@@ -90,8 +93,17 @@ def _seekable(f):
 
 
 def _regular_fd(f):
+    """File descriptor to pread() from — only for objects whose logical bytes ARE the descriptor's bytes:
+    io.FileIO itself, or io.BufferedReader / BufferedRandom directly over one.  Everything else that has a
+    fileno() (GzipFile, BZ2File, LZMAFile, decrypting or translating wrappers, subclasses) goes through
+    readinto(), as in the reference (__init__.py:140-171)."""
     try:
-        fd = f.fileno()
+        raw = f
+        if type(f) in (io.BufferedReader, io.BufferedRandom):
+            raw = f.raw
+        if type(raw) is not io.FileIO:
+            return None
+        fd = raw.fileno()
         if stat.S_ISREG(os.fstat(fd).st_mode):
             return fd
     except Exception:
@@ -136,7 +148,14 @@ class _TextEncoder(object):
 
 def run(p, search_class, subsequence, f):
     engine = _native.default_engine()
-    text_pieces = None
+    # the whole stream — open .. finish — owns the engine: a fz_ctx runs one stream OR one search at a time,
+    # and the default engine is shared between threads (the lock is re-entrant: the stream's own calls nest)
+    with engine._lock:
+        return _run_locked(engine, p, search_class, subsequence, f)
+
+
+def _run_locked(engine, p, search_class, subsequence, f):
+    store = None
     if p.binary:
         pattern = bytes(bytearray(subsequence)) if not isinstance(subsequence, (bytes, bytearray)) else subsequence
         encoder = None
@@ -162,9 +181,9 @@ def run(p, search_class, subsequence, f):
                 return bytearray(f.read(e - s))
             end_pos = start + total
         else:
-            text_pieces = []
-            _feed_text(stream, f, encoder, text_pieces)
-            fetch = _TextStore(text_pieces).get
+            store = _TextStore(f)
+            _feed_text(stream, f, encoder, store)
+            fetch = store.get
             end_pos = None
         raw, seg = stream.finish()
     finally:
@@ -173,6 +192,8 @@ def run(p, search_class, subsequence, f):
     matches = [Match(s, e, d, matched=fetch(s, e)) for (s, e, d) in out]
     if end_pos is not None:
         f.seek(end_pos)
+    if store is not None:
+        store.done()
     return matches
 
 
@@ -197,39 +218,104 @@ def _feed_readinto(stream, f):
     return total
 
 
-def _feed_text(stream, f, encoder, pieces):
+def _feed_text(stream, f, encoder, store):
     while True:
         view = stream.buffer()
         room = len(view)
         if room == 0:
             break
-        text = f.read(room)
+        cookie = store.mark()
+        # read(n) may return fewer than n characters before the end of the file (codecs.StreamReader, network
+        # and custom wrappers): only '' means EOF, as in the reference's loop (__init__.py:174-200)
+        parts, have, last = [], 0, False
+        while have < room:
+            piece = f.read(room - have)
+            if not piece:
+                last = True
+                break
+            parts.append(piece)
+            have += len(piece)
+        text = parts[0] if len(parts) == 1 else ''.join(parts)
         data = encoder.encode(text) if text else b''
         view[:len(data)] = data
-        last = len(text) < room
         del view
         if text:
-            pieces.append(text)
+            store.add(text, cookie)
         stream.submit(len(data), last)
         if last:
             break
 
 
 class _TextStore(object):
-    def __init__(self, pieces):
-        self.pieces = pieces
-        self.starts = np.cumsum([0] + [len(x) for x in pieces])
+    """Where `matched` of a text-file result comes from.  The reference needs O(_chunk_size) memory; holding every
+    decoded piece until the end would need O(file).  For seekable files only (tell() cookie, length) of every piece
+    is kept and the pieces that hold a surviving match are read again at the end (results are sorted: one cached
+    piece); files that cannot tell()/seek() keep their pieces (they cannot be read twice)."""
+
+    def __init__(self, f):
+        self.f = f
+        self.reread = False
+        try:
+            if f.seekable():
+                f.tell()
+                self.reread = True
+        except Exception:
+            self.reread = False
+        self.pieces = []          # text, or None when it can be read again
+        self.cookies = []
+        self.lengths = []
+        self.starts = None
+        self._cached = (-1, None)
+        self.end_cookie = None
+
+    def mark(self):
+        if self.reread:
+            try:
+                return self.f.tell()
+            except Exception:                      # e.g. "telling position disabled by next() call"
+                self.reread = False
+        return None
+
+    def add(self, text, cookie):
+        keep = cookie is None or not self.reread
+        self.pieces.append(text if keep else None)
+        self.cookies.append(cookie)
+        self.lengths.append(len(text))
+
+    def _piece(self, i):
+        if self.pieces[i] is not None:
+            return self.pieces[i]
+        if self._cached[0] != i:
+            if self.end_cookie is None:
+                self.end_cookie = self.f.tell()
+            self.f.seek(self.cookies[i])
+            parts, have = [], 0
+            while have < self.lengths[i]:
+                piece = self.f.read(self.lengths[i] - have)
+                if not piece:
+                    break
+                parts.append(piece)
+                have += len(piece)
+            self._cached = (i, ''.join(parts))
+        return self._cached[1]
 
     def get(self, s, e):
+        if self.starts is None:
+            self.starts = np.cumsum([0] + self.lengths)
         i = int(np.searchsorted(self.starts, s, side='right')) - 1
         out = []
-        while s < e and i < len(self.pieces):
+        while s < e and i < len(self.lengths):
             base = int(self.starts[i])
-            piece = self.pieces[i]
-            out.append(piece[s - base:e - base])
-            s = base + len(piece)
+            out.append(self._piece(i)[s - base:e - base])
+            s = base + self.lengths[i]
             i += 1
         return ''.join(out)
+
+    def done(self):
+        """Leave the file where the reference leaves it: at its end."""
+        if self.end_cookie is not None:
+            self.f.seek(self.end_cookie)
+        self._cached = (-1, None)
 
 
 def _post_process(p, raw, seg, search_class, text):

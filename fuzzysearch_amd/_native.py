@@ -17,11 +17,11 @@ UINT64_MAX = (1 << 64) - 1
 # every symbol include/fzhip.h declares (tests check the library exports exactly these)
 EXPORTED_SYMBOLS = (
     "fz_abi_version", "fz_last_error", "fz_device_count", "fz_create", "fz_destroy",
-    "fz_seq_upload", "fz_seq_upload_shard", "fz_seq_len", "fz_seq_release",
+    "fz_seq_upload", "fz_seq_upload_shard", "fz_seq_new", "fz_seq_add_shard", "fz_seq_len", "fz_seq_release",
     "fz_search_exact", "fz_lev_ngrams", "fz_lev_ngrams_begin", "fz_lev_ngrams_end", "fz_subs_ngrams", "fz_generic_ngrams",
     "fz_lev_lp", "fz_subs_lp", "fz_generic_lp",
     "fz_stream_open", "fz_stream_buffer", "fz_stream_submit", "fz_stream_read_fd", "fz_stream_finish", "fz_stream_close",
-    "fz_consolidate", "fz_group_best", "fz_merge_ranks", "fz_wire_pack", "fz_wire_merge", "fz_debug_launch_plan", "fz_stats", "fz_free",
+    "fz_consolidate", "fz_group_best", "fz_merge_ranks", "fz_wire_pack", "fz_wire_merge", "fz_debug_launch_plan", "fz_stats", "fz_device_ms", "fz_free",
 )
 
 
@@ -74,6 +74,12 @@ def load_library():
         L.fz_seq_upload.argtypes = [vp, u8p, u64, ctypes.POINTER(vp)]
         L.fz_seq_upload_shard.restype = ci
         L.fz_seq_upload_shard.argtypes = [vp, u8p, u64, u64, u64, u64, u64, ctypes.POINTER(vp)]
+        L.fz_seq_new.restype = ci
+        L.fz_seq_new.argtypes = [vp, u64, ctypes.POINTER(vp)]
+        L.fz_seq_add_shard.restype = ci
+        L.fz_seq_add_shard.argtypes = [vp, ci, u8p, u64, u64, u64, u64]
+        L.fz_device_ms.restype = ci
+        L.fz_device_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ci]
         L.fz_seq_len.restype = u64
         L.fz_seq_len.argtypes = [vp]
         L.fz_seq_release.restype = None
@@ -331,10 +337,10 @@ class FileStream(object):
         return _take_matches_array(self._lib, ptr, n), segs
 
     def close(self):
-        if self._h is not None and self.engine._h is not None:
-            with self.engine._lock:
+        with self.engine._lock:                    # the engine may be closed (fz_destroy) by another thread: test under the lock
+            if self._h is not None and self.engine._h is not None:
                 self._lib.fz_stream_close(self._h)
-        self._h = None
+            self._h = None
 
     def __del__(self):
         try:
@@ -355,10 +361,10 @@ class ResidentSequence(object):
         return self.nbytes
 
     def release(self):
-        if self._h is not None and self.engine._h is not None:
-            with self.engine._lock:
+        with self.engine._lock:                    # fz_destroy frees live sequences: test the engine under its lock
+            if self._h is not None and self.engine._h is not None:
                 self.engine._lib.fz_seq_release(self._h)
-        self._h = None
+            self._h = None
 
     def __del__(self):
         try:
@@ -419,6 +425,30 @@ class Engine(object):
                                                   global_n, ctypes.byref(h)))
         del keep
         return ResidentSequence(self, h, global_n)
+
+    def new_sequence(self, global_n):
+        """An empty sharded sequence of global_n bytes; fill it with add_shard() (one shard per device of the engine)."""
+        h = ctypes.c_void_p()
+        with self._lock:
+            _check(self._lib.fz_seq_new(self._h, global_n, ctypes.byref(h)))
+        return ResidentSequence(self, h, global_n)
+
+    def add_shard(self, seq, dev_index, data, buf_global_off, own_lo, own_hi):
+        """Upload bytes [buf_global_off, +len(data)) to device number dev_index of this engine; it owns the n-gram
+        hits in [own_lo, own_hi) and needs (m + k) halo bytes on both sides (fz_seq_add_shard)."""
+        addr, n, keep = _buffer_address(data)
+        with self._lock:
+            _check(self._lib.fz_seq_add_shard(seq._h, dev_index, addr, n, buf_global_off, own_lo, own_hi))
+        del keep
+
+    def device_ms(self):
+        """Scan-kernel hipEvent span of the search collected last, one value per device of the engine."""
+        n = len(self.devices)
+        out = (ctypes.c_double * n)()
+        rc = self._lib.fz_device_ms(self._h, out, n)
+        if rc < 0:
+            _raise(rc)
+        return list(out)
 
     # -- searches (raw streams, tuples (start, end, dist, block)) ------------------------------
     def search_exact(self, seq, pattern, lo=0, hi=None):

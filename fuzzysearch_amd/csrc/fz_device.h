@@ -140,9 +140,12 @@ struct FzScanArgs {
     uint8_t  pat[FZ_MAX_M];                     // whole pattern
 };
 
-// A hit: (block g << 56) | global idx.   A record: what verification produced for one hit.
+// A hit: (block g << FZ_IDX_BITS) | global idx (48-bit index: sequences below 256 TiB; 16-bit block number).
+// A record: what verification produced for one hit.
+#define FZ_IDX_BITS 48
+#define FZ_MAX_BLOCKS 65535u           // n-gram blocks of one search (block numbers must fit the key's upper 16 bits)
 struct FzRec {
-    uint64_t key;        // (g << 56) | idx  -> sorting by key restores the reference's order
+    uint64_t key;        // (g << FZ_IDX_BITS) | idx  -> sorting by key restores the reference's order
     uint32_t l;          // bytes consumed to the left of idx   (start = idx - l)
     uint32_t r;          // bytes consumed right of the n-gram  (end   = idx + L + r)
     uint32_t dist;
@@ -151,9 +154,9 @@ struct FzRec {
 
 #define FZ_REC_NONE 0xffffffffu        // FzRec.dist of a slot whose hit did not verify (slot-per-hit kernels)
 
-FZ_HD uint64_t fz_hit_pack(uint32_t g, uint64_t idx) { return ((uint64_t)g << 56) | idx; }
-FZ_HD uint32_t fz_hit_block(uint64_t h) { return (uint32_t)(h >> 56); }
-FZ_HD uint64_t fz_hit_index(uint64_t h) { return h & 0x00ffffffffffffffull; }
+FZ_HD uint64_t fz_hit_pack(uint32_t g, uint64_t idx) { return ((uint64_t)g << FZ_IDX_BITS) | idx; }
+FZ_HD uint32_t fz_hit_block(uint64_t h) { return (uint32_t)(h >> FZ_IDX_BITS); }
+FZ_HD uint64_t fz_hit_index(uint64_t h) { return h & ((1ull << FZ_IDX_BITS) - 1ull); }
 
 // Hash of the first min(L, 8) bytes of an n-gram window as the filter's fast path computes it:
 //   L > 4:  x  = bytes [0, 4)                  (little-endian dword)
@@ -602,7 +605,7 @@ FZ_HD bool fz_generic_final(const FzGCand &c, uint32_t m, uint32_t max_dels, uin
 
 // Record of the generic search: one emitted match of the automaton run on the window of hit `key`.
 struct FzGenRec {
-    uint64_t key;        // per-hit mode: (block << 56) | idx of the n-gram hit; tiled modes: global step index
+    uint64_t key;        // per-hit mode: (block << FZ_IDX_BITS) | idx of the n-gram hit; tiled modes: global step index
     uint32_t seq;        // emission number within the work item (hit window / tile)
     uint32_t se;         // window-relative start | end << 16
     uint32_t dist;

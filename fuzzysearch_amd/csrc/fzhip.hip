@@ -123,6 +123,7 @@ struct DevState {
     // that a search collected in between may have grown)
     uint64_t hit_cap_used = 0, rec_cap_used = 0;
     bool fused_used = false;
+    double last_filter_ms = 0;                   // scan span of the search collected last on this device (fz_device_ms)
     // The second result slot: fz_lev_ngrams_begin with one search already in flight launches into it, so
     // that the host orders the records of search i while search i + 1 scans (two-deep pipeline).
     struct Slot {
@@ -607,6 +608,7 @@ int collect_shard(fz_ctx *ctx, const Shard &sh, bool with_verify, bool view_ok, 
     HIP_TRY(hipEventElapsedTime(&f, d.ev[0], d.ev[d.scan_end_event]));
     if (d.verify_launched) HIP_TRY(hipEventElapsedTime(&v, d.ev[1], d.ev[2]));
     HIP_TRY(hipEventElapsedTime(&t, d.ev[0], d.ev[3]));
+    d.last_filter_ms = f;
     ctx->stats.filter_ms = std::max<double>(ctx->stats.filter_ms, f);
     ctx->stats.verify_ms = std::max<double>(ctx->stats.verify_ms, v);
     ctx->stats.device_ms = std::max<double>(ctx->stats.device_ms, t);
@@ -941,7 +943,7 @@ int emit_matches(const FzRec *recs, size_t cnt, uint32_t L, fz_match **out, uint
             gmax = std::max(gmax, fz_hit_block(recs[i].key));
         }
         int ibits = 0, gbits = 0, pbits = 0;                   // index range, block number, record position
-        while (ibits < 56 && ((imax - imin) >> ibits)) ++ibits;
+        while (ibits < FZ_IDX_BITS && ((imax - imin) >> ibits)) ++ibits;
         while ((gmax >> gbits)) ++gbits;
         while (((cnt - 1) >> pbits)) ++pbits;
         if (ibits + gbits + pbits <= 64) {
@@ -1133,7 +1135,7 @@ static int upload_one(fz_ctx *ctx, int dev_index, const uint8_t *host_buf, const
 
 int fz_seq_upload(fz_ctx *ctx, const uint8_t *host, uint64_t n, fz_seq **out) {
     if (!ctx || !out || (!host && n)) return fail(FZ_EINVAL, "null argument");
-    if (n >= (1ull << 56)) return fail(FZ_EUNSUPPORTED, "sequence too long");
+    if (n >= (1ull << FZ_IDX_BITS)) return fail(FZ_EUNSUPPORTED, "sequence too long");
     *out = nullptr;
     fz_seq *seq = new (std::nothrow) fz_seq();
     if (!seq) return fail(FZ_ENOMEM, "out of memory");
@@ -1168,7 +1170,7 @@ int fz_seq_upload(fz_ctx *ctx, const uint8_t *host, uint64_t n, fz_seq **out) {
 int fz_seq_upload_shard(fz_ctx *ctx, const uint8_t *host_buf, uint64_t buf_len, uint64_t buf_global_off,
                         uint64_t own_lo, uint64_t own_hi, uint64_t global_n, fz_seq **out) {
     if (!ctx || !out || (!host_buf && buf_len)) return fail(FZ_EINVAL, "null argument");
-    if (global_n >= (1ull << 56)) return fail(FZ_EUNSUPPORTED, "sequence too long");
+    if (global_n >= (1ull << FZ_IDX_BITS)) return fail(FZ_EUNSUPPORTED, "sequence too long");
     if (buf_global_off + buf_len > global_n || own_lo > own_hi || own_hi > global_n)
         return fail(FZ_EINVAL, "shard ranges outside the global sequence");
     if (own_hi > own_lo && (own_lo < buf_global_off || own_hi > buf_global_off + buf_len))
@@ -1194,6 +1196,59 @@ int fz_seq_upload_shard(fz_ctx *ctx, const uint8_t *host_buf, uint64_t buf_len, 
     ctx->live.push_back(seq);
     *out = seq;
     return FZ_OK;
+}
+
+int fz_seq_new(fz_ctx *ctx, uint64_t global_n, fz_seq **out) {
+    if (!ctx || !out) return fail(FZ_EINVAL, "null argument");
+    *out = nullptr;
+    if (global_n >= (1ull << FZ_IDX_BITS)) return fail(FZ_EUNSUPPORTED, "sequence too long");
+    fz_seq *seq = new (std::nothrow) fz_seq();
+    if (!seq) return fail(FZ_ENOMEM, "out of memory");
+    seq->ctx = ctx;
+    seq->n = global_n;
+    ctx->live.push_back(seq);
+    *out = seq;
+    return FZ_OK;
+}
+
+int fz_seq_add_shard(fz_seq *seq, int dev_index, const uint8_t *host_buf, uint64_t buf_len, uint64_t buf_global_off,
+                     uint64_t own_lo, uint64_t own_hi) {
+    if (!seq || !seq->ctx || (!host_buf && buf_len)) return fail(FZ_EINVAL, "null argument");
+    fz_ctx *ctx = seq->ctx;
+    if (ctx->npend || ctx->stream_inflight) return fail(FZ_EINVAL, "a search of this context is in flight");
+    if (dev_index < 0 || dev_index >= (int)ctx->devs.size()) return fail(FZ_EINVAL, "device index %d outside the context (%zu devices)", dev_index, ctx->devs.size());
+    if (buf_global_off + buf_len > seq->n || own_lo > own_hi || own_hi > seq->n)
+        return fail(FZ_EINVAL, "shard ranges outside the global sequence");
+    if (own_hi > own_lo && (own_lo < buf_global_off || own_hi > buf_global_off + buf_len))
+        return fail(FZ_EINVAL, "owned range not inside the shard buffer");
+    for (const Shard &o : seq->shards) {
+        if (o.dev == dev_index) return fail(FZ_EINVAL, "device %d already holds a shard of this sequence", dev_index);
+        if (own_lo < o.geom.own_hi && o.geom.own_lo < own_hi) return fail(FZ_EINVAL, "owned ranges of two shards overlap");
+    }
+    FzGeom g{};
+    g.n = seq->n;
+    g.buf_off = buf_global_off;
+    g.buf_len = buf_len;
+    g.own_lo = own_lo;
+    g.own_hi = own_hi;
+    seq->shards.emplace_back();
+    int rc = upload_one(ctx, dev_index, host_buf, g, seq->shards.back());
+    if (rc == FZ_OK) {
+        hipError_t e = hipStreamSynchronize(ctx->devs[dev_index].stream);     // host_buf is only borrowed for this call
+        if (e != hipSuccess) rc = fail(FZ_EDEVICE, "upload failed: %s", hipGetErrorString(e));
+    }
+    if (rc) {
+        Shard &sh = seq->shards.back();
+        if (sh.d_alloc) { (void)hipSetDevice(ctx->devs[dev_index].device); (void)hipFree(sh.d_alloc); }
+        seq->shards.pop_back();
+    }
+    return rc;
+}
+
+int fz_device_ms(fz_ctx *ctx, double *filter_ms, int cap) {
+    if (!ctx || (!filter_ms && cap > 0)) return fail(FZ_EINVAL, "null argument");
+    for (int i = 0; i < cap && i < (int)ctx->devs.size(); ++i) filter_ms[i] = ctx->devs[i].last_filter_ms;
+    return (int)ctx->devs.size();
 }
 
 uint64_t fz_seq_len(const fz_seq *seq) { return seq ? seq->n : 0; }
@@ -1339,6 +1394,7 @@ int fz_lev_ngrams_end(fz_ctx *ctx, fz_match **out, uint64_t *n) {
             ctx->pend[0].launched = true;
         }
     }
+    if (rc != FZ_OK && *out) { release_out(*out); *out = nullptr; *n = 0; }   // an error never hands a buffer over
     return rc;
 }
 
@@ -1820,6 +1876,9 @@ int stream_collect(fz_stream *st) {
 // Upload the staged bytes the segments [j0, j1) need and launch their search (asynchronous).
 int stream_launch(fz_stream *st, uint64_t j0, uint64_t j1, uint64_t data_hi) {
     fz_ctx *ctx = st->ctx;
+    // the context's result slots, counters and hit list serve ONE search at a time
+    if (ctx->npend || (ctx->stream_inflight && ctx->stream_inflight != st))
+        return fail(FZ_EINVAL, "another search or file stream of this context is in flight");
     DevState &d = ctx->devs[0];
     Shard &sh = st->seq->shards[0];
     HIP_TRY(hipSetDevice(d.device));
@@ -1886,7 +1945,7 @@ int fz_stream_open(fz_ctx *ctx, uint32_t mode, const uint8_t *p, uint32_t m, uin
     int rc = stream_build_search(st);
     if (rc) { delete st; return rc; }
     const uint64_t ext = (uint64_t)seg_pre + seg_post;
-    st->cap = std::max<uint64_t>(batch_bytes, 4 * (seg_stride + ext)) + seg_stride + ext;
+    st->cap = std::max<uint64_t>(batch_bytes, seg_stride + ext) + seg_stride + ext;   // >= one whole chunk + the carried overlap
     DevState &d = ctx->devs[0];
     auto init = [&]() -> int {
         HIP_TRY(hipSetDevice(d.device));

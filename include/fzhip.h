@@ -97,6 +97,14 @@ int  fz_seq_upload(fz_ctx *ctx, const uint8_t *host, uint64_t n, fz_seq **out);
 int  fz_seq_upload_shard(fz_ctx *ctx, const uint8_t *host_buf, uint64_t buf_len,
                          uint64_t buf_global_off, uint64_t own_lo, uint64_t own_hi,
                          uint64_t global_n, fz_seq **out);
+/* Several-devices-in-one-process form of the same thing, without a host copy of the whole sequence (32 GiB over
+ * 8 GPUs is built shard by shard): fz_seq_new creates an empty sequence of global_n bytes, fz_seq_add_shard uploads
+ * one shard — same meaning of the ranges as fz_seq_upload_shard — to device number dev_index OF THE CTX (one shard
+ * per device; host_buf is borrowed for the call).  Every later search runs on all shards concurrently and the host
+ * merges their streams (__init__.py:129-171 is the reference's only analogue: chunks with overlap). */
+int  fz_seq_new(fz_ctx *ctx, uint64_t global_n, fz_seq **out);
+int  fz_seq_add_shard(fz_seq *seq, int dev_index, const uint8_t *host_buf, uint64_t buf_len, uint64_t buf_global_off,
+                      uint64_t own_lo, uint64_t own_hi);
 uint64_t fz_seq_len(const fz_seq *seq);       /* global length */
 void fz_seq_release(fz_seq *seq);
 
@@ -208,6 +216,9 @@ void fz_stream_close(fz_stream *st);
 int fz_debug_launch_plan(const uint8_t *p, uint32_t m, uint32_t L, uint32_t *out, uint32_t cap, uint32_t *n_launches);
 
 int  fz_stats(fz_ctx *ctx, fz_stats_t *out);
+/* hipEvent span of the filter kernel(s) of the search collected last, per device of the ctx (at most `cap` values
+ * are written); returns the number of devices, or a negative FZ_E* code. */
+int  fz_device_ms(fz_ctx *ctx, double *filter_ms, int cap);
 void fz_free(void *p);
 
 #ifdef __cplusplus

@@ -211,7 +211,7 @@ int64_t emul_generic_ngrams_ordered(const uint8_t *p, uint32_t m, const uint8_t 
     uint32_t g = 0;
     for (uint32_t s = 0; s + L <= m; s += L, ++g)
         for (uint64_t idx = 0; idx + L <= n; ++idx)
-            if (memcmp(t + idx, p + s, L) == 0) hits.push_back(((uint64_t)g << 56) | idx);
+            if (memcmp(t + idx, p + s, L) == 0) hits.push_back(fz_hit_pack(g, idx));
     // the scan kernel appends hits with atomics: any order
     uint64_t x = 0x9E3779B97F4A7C15ull * (scramble + 1);
     for (size_t i = hits.size(); i > 1; --i) {
