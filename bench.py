@@ -343,9 +343,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     torch = None
-    # FZ_BENCH_FORCE_DIST=1: take the RCCL code path with a single rank too (1-GPU smoke of it)
+    # FZ_BENCH_FORCE_DIST=1: take the multi-rank code path with a single rank too (1-GPU smoke of it)
     use_dist = world > 1 or os.environ.get("FZ_BENCH_FORCE_DIST") == "1"
-    if use_dist:
+    # N > 1 ranks: RCCL behind the C-ABI (fz_comm_*; the unique id travels through a rendezvous file) — no torch in
+    # this process.  FZ_BENCH_TORCH=1 takes the torch.distributed glue instead (same data path, torch collectives).
+    use_torch = use_dist and os.environ.get("FZ_BENCH_TORCH") == "1"
+    if use_torch:
         # import torch BEFORE libfzhip so both share one HIP runtime (same libamdhip64 SONAME)
         import torch
         import torch.distributed as dist
@@ -372,43 +375,45 @@ def main():
     else:
         # BASELINE configs[4]: every rank generates its own shard (seed + rank, 1 GiB pieces), 1024 planted
         # variants per GiB, plus exact copies around every shard boundary at deltas {-m-k ... +1}
-        # (tests/workloads.py::boundary_plants; every rank writes the bytes that fall into its shard)
+        # (tests/workloads.py::cfg5_fill; every rank writes the bytes that fall into its shard)
         seq = np.empty(shard_bytes, dtype=np.uint8)
-        piece = 1 << 30
-        for i, lo in enumerate(range(0, shard_bytes, piece)):
-            seq[lo:lo + piece] = workloads.dna(min(piece, shard_bytes - lo), 20250925 + 64 * rank + i)
-        workloads.plant_variants(seq, pattern, 1024 * max(1, args.mib // 1024), 7 + rank)
-        edge_plants = workloads.boundary_plants(m, k, shard_bytes, world)
-        workloads.apply_plants(seq, rank * shard_bytes, edge_plants, pattern)
+        fill, edge_plants = workloads.cfg5_fill(shard_bytes, world, pattern, k)
+        fill(rank, seq)
 
     cpu = None
     if world == 1 and not use_dist and not args.no_cpu_baseline and rank == 0:
         cpu = cpu_baseline(seq, pattern, k, args.cpu_sample_mib)      # forks: before the HIP runtime exists
 
     engine = _native.Engine([local_rank])
+    if use_dist and not use_torch:
+        fzd.init_engine_from_env(engine)          # joins the job's RCCL communicator: searches are collective from here on
     if not use_dist:
         handle = engine.upload(seq)
     else:
-        # halo exchange, once at load: neighbours' (m + k) edge bytes (RCCL all_gather)
-        left, right = fzd.exchange_halos(seq, halo)
+        # halo exchange, once at load: neighbours' (m + k) edge bytes (one all-gather)
+        left, right = fzd.exchange_halos(seq, halo) if use_torch else fzd.exchange_halos_native(engine, seq, halo)
         buf = np.concatenate([left, seq, right])
         own_lo = rank * shard_bytes
         handle = engine.upload_shard(buf, own_lo - len(left), own_lo, own_lo + shard_bytes, global_n)
         del buf
 
     def sync():
-        if use_dist:
+        if use_torch:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
+        elif use_dist:
+            engine.comm_barrier()                 # waits for this rank's streams, then an all-reduce over the ranks
+
+    def finish(raw):
+        # torch glue: this rank's stream -> the merged global stream (ONE all_gather: counts + packed records);
+        # native: the search itself was collective and `raw` already is the merged stream
+        return fzd.allgather_matches(raw, as_array=True) if use_torch else raw
 
     def step():
         # synchronous: on return the ordered raw match stream is on the host (numpy view of the
         # C-ABI's fz_match array; no per-record Python objects inside the timed region)
-        raw = engine.lev_ngrams(handle, p, k, as_array=True)
-        if use_dist:
-            return fzd.allgather_matches(raw, as_array=True)   # ONE RCCL all_gather: counts + packed records
-        return raw
+        return finish(engine.lev_ngrams(handle, p, k, as_array=True))
 
     # setup self-check + clock settle (untimed): repeated searches must return the identical stream
     t_settle = time.perf_counter()
@@ -444,13 +449,15 @@ def main():
             filter_ms.append(f_)
             verify_ms.append(v_)
             device_ms.append(d_)
-            matches = fzd.allgather_matches(raw, as_array=True) if use_dist else raw
+            matches = finish(raw)
     sync()
     elapsed = time.perf_counter() - t0
-    if use_dist:
+    if use_torch:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    elif use_dist:
+        elapsed = engine.comm_max(elapsed)
 
     st = engine.stats()
     sync_ms = None
@@ -493,8 +500,10 @@ def main():
                                       "around every shard boundary" % (args.mib * world >> 10, world)),
                        "bytes_per_gpu": shard_bytes, "pattern_len": m, "max_l_dist": k,
                        "calls_in_flight": 1 if (args.sync and not use_dist) else 2,
-                       "sharding": "none" if not use_dist else "contiguous shards, (m+k)-byte halo, RCCL all_gather of "
-                                   "matches; the all_gather of step i overlaps the scan of step i+1"},
+                       "sharding": "none" if not use_dist else "one process per GPU; contiguous shards, (m+k)-byte halo, hits owned by "
+                                   "index; ONE RCCL all-gather of the ranks' record lists per search (%s); the all-gather of "
+                                   "step i overlaps the scan of step i+1" % ("torch.distributed glue" if use_torch else
+                                                                            "ncclAllGather behind the C-ABI, no torch")},
             "matches_per_s": round(len(matches) * args.steps / elapsed, 1),
             "raw_matches": len(matches),
             "consolidated_matches": len(consolidated),
@@ -514,8 +523,11 @@ def main():
             del seq
             out.update(extra_blocks(engine, workloads, max(20, args.steps // 2)))
         print(json.dumps(out), flush=True)
-    if use_dist:
+    if use_torch:
         dist.destroy_process_group()
+    elif use_dist:
+        engine.comm_barrier()
+        engine.comm_destroy()
 
 
 if __name__ == "__main__":

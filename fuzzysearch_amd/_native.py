@@ -22,6 +22,8 @@ EXPORTED_SYMBOLS = (
     "fz_lev_lp", "fz_subs_lp", "fz_generic_lp",
     "fz_stream_open", "fz_stream_buffer", "fz_stream_submit", "fz_stream_read_fd", "fz_stream_finish", "fz_stream_close",
     "fz_consolidate", "fz_group_best", "fz_merge_ranks", "fz_wire_pack", "fz_wire_merge", "fz_debug_launch_plan", "fz_stats", "fz_device_ms", "fz_free",
+    "fz_comm_unique_id", "fz_comm_init_rank", "fz_comm_init_all", "fz_comm_info", "fz_comm_set_collective",
+    "fz_comm_allgather", "fz_comm_max_f64", "fz_comm_barrier", "fz_comm_destroy",
 )
 
 
@@ -80,6 +82,24 @@ def load_library():
         L.fz_seq_add_shard.argtypes = [vp, ci, u8p, u64, u64, u64, u64]
         L.fz_device_ms.restype = ci
         L.fz_device_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ci]
+        L.fz_comm_unique_id.restype = ci
+        L.fz_comm_unique_id.argtypes = [vp, u64]
+        L.fz_comm_init_rank.restype = ci
+        L.fz_comm_init_rank.argtypes = [vp, vp, ci, ci]
+        L.fz_comm_init_all.restype = ci
+        L.fz_comm_init_all.argtypes = [vp]
+        L.fz_comm_info.restype = ci
+        L.fz_comm_info.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci)]
+        L.fz_comm_set_collective.restype = ci
+        L.fz_comm_set_collective.argtypes = [vp, ci]
+        L.fz_comm_allgather.restype = ci
+        L.fz_comm_allgather.argtypes = [vp, vp, u64, vp]
+        L.fz_comm_max_f64.restype = ci
+        L.fz_comm_max_f64.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
+        L.fz_comm_barrier.restype = ci
+        L.fz_comm_barrier.argtypes = [vp]
+        L.fz_comm_destroy.restype = None
+        L.fz_comm_destroy.argtypes = [vp]
         L.fz_seq_len.restype = u64
         L.fz_seq_len.argtypes = [vp]
         L.fz_seq_release.restype = None
@@ -449,6 +469,63 @@ class Engine(object):
         if rc < 0:
             _raise(rc)
         return list(out)
+
+    # -- RCCL without PyTorch (fz_comm_*) -----------------------------------------------------
+    COMM_ID_BYTES = 128
+
+    def comm_unique_id(self):
+        """ncclGetUniqueId -> 128 bytes that rank 0 hands to the other ranks (file, socket, ...)."""
+        buf = ctypes.create_string_buffer(self.COMM_ID_BYTES)
+        _check(self._lib.fz_comm_unique_id(buf, self.COMM_ID_BYTES))
+        return buf.raw
+
+    def comm_init_rank(self, unique_id, world, rank):
+        """One process per GPU: this (single-device) engine becomes rank `rank` of `world`.  From now on its
+        lev_ngrams / lev_ngrams_begin / _end are COLLECTIVE and deliver the merged stream of all ranks."""
+        if len(unique_id) != self.COMM_ID_BYTES:
+            raise ValueError("unique id must be %d bytes" % self.COMM_ID_BYTES)
+        with self._lock:
+            _check(self._lib.fz_comm_init_rank(self._h, ctypes.c_char_p(bytes(unique_id)), world, rank))
+
+    def comm_init_all(self):
+        """One process, several GPUs: every device of the engine becomes one rank (ncclCommInitAll)."""
+        with self._lock:
+            _check(self._lib.fz_comm_init_all(self._h))
+
+    def comm_info(self):
+        """-> (world, rank of device 0, collective searches on?); world == 0: no communicator."""
+        w, r, c = ctypes.c_int(0), ctypes.c_int(-1), ctypes.c_int(0)
+        _check(self._lib.fz_comm_info(self._h, ctypes.byref(w), ctypes.byref(r), ctypes.byref(c)))
+        return w.value, r.value, bool(c.value)
+
+    def comm_set_collective(self, on):
+        with self._lock:
+            _check(self._lib.fz_comm_set_collective(self._h, 1 if on else 0))
+
+    def comm_allgather(self, data):
+        """Equal-sized bytes from every rank -> list of bytes in rank order (ncclAllGather through device buffers)."""
+        data = bytes(data)
+        world = self.comm_info()[0]
+        out = ctypes.create_string_buffer(max(1, world * len(data)))
+        with self._lock:
+            _check(self._lib.fz_comm_allgather(self._h, ctypes.c_char_p(data), len(data), out))
+        raw = out.raw
+        return [raw[i * len(data):(i + 1) * len(data)] for i in range(world)]
+
+    def comm_max(self, value):
+        v = ctypes.c_double(value)
+        with self._lock:
+            _check(self._lib.fz_comm_max_f64(self._h, ctypes.byref(v)))
+        return v.value
+
+    def comm_barrier(self):
+        with self._lock:
+            _check(self._lib.fz_comm_barrier(self._h))
+
+    def comm_destroy(self):
+        with self._lock:
+            if self._h is not None:
+                self._lib.fz_comm_destroy(self._h)
 
     # -- searches (raw streams, tuples (start, end, dist, block)) ------------------------------
     def search_exact(self, seq, pattern, lo=0, hi=None):

@@ -38,7 +38,9 @@ def build(force=False, report=False):
            "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
     if report:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+    # RCCL (the all-gather of match lists, fz_comm_*): linked, not dlopen-ed, so a missing librccl fails at load time
+    rocm_lib = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")
+    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-L" + rocm_lib, "-lrccl", "-Wl,-rpath," + rocm_lib, "-o", LIB + ".tmp"]
     subprocess.check_call(cmd, cwd=CSRC)
     os.replace(LIB + ".tmp", LIB)
     return LIB

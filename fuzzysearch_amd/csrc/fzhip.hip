@@ -17,6 +17,7 @@
 // Every search is synchronous: when a fz_* call returns its results are on the host and nothing is
 // in flight on the sequence.  Buffers that turn out too small are grown and the search re-runs.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <atomic>
@@ -124,6 +125,19 @@ struct DevState {
     uint64_t hit_cap_used = 0, rec_cap_used = 0;
     bool fused_used = false;
     double last_filter_ms = 0;                   // scan span of the search collected last on this device (fz_device_ms)
+    int slot_id = 0;                             // which of the two result slots is the current one
+    // RCCL (fz_comm_*): this device state is rank comm_rank of a communicator.  A search of such a context leaves
+    // its counters + records in d_out; a device-to-device snapshot (d_send[slot], taken on the scan stream right
+    // behind the kernels, so a younger search may reuse d_out) is what the all-gather sends.
+    ncclComm_t comm = nullptr;
+    int comm_rank = -1;
+    hipStream_t comm_stream = nullptr;           // default priority: the collective runs next to the (low-priority) scan
+    uint8_t *d_send[2] = {nullptr, nullptr};
+    uint64_t send_cap = 0;                       // records a snapshot holds
+    uint8_t *d_recv = nullptr, *h_recv = nullptr;
+    uint64_t recv_bytes = 0;
+    hipEvent_t ev_snap[2] = {nullptr, nullptr}, ev_done = nullptr;
+    bool snap_taken[2] = {false, false};
     // The second result slot: fz_lev_ngrams_begin with one search already in flight launches into it, so
     // that the host orders the records of search i while search i + 1 scans (two-deep pipeline).
     struct Slot {
@@ -132,8 +146,10 @@ struct DevState {
         bool last_direct = false, verify_launched = false, fused_used = false;
         int scan_end_event = 1;
         uint64_t hit_cap_used = 0, rec_cap_used = 0;
+        int slot_id = 1;
     } other;
     void swap_slot() {
+        std::swap(slot_id, other.slot_id);
         for (int i = 0; i < 4; ++i) std::swap(ev[i], other.ev[i]);
         std::swap(h_stage, other.h_stage);
         std::swap(h_stage_dev, other.h_stage_dev);
@@ -185,6 +201,11 @@ struct fz_ctx {
     int npend = 0;
     // sequences still resident (fz_destroy frees what the caller did not release)
     std::vector<fz_seq *> live;
+    // RCCL: number of ranks of the communicator this context joined (0: none) and whether its Levenshtein n-gram
+    // searches are collective (every rank gets the merged global stream)
+    int comm_world = 0;
+    bool snapshot = false;
+    uint64_t gcap = 4096;                        // records per rank the all-gather carries (follows the counts, on all ranks alike)
 };
 
 struct fz_seq {
@@ -192,6 +213,8 @@ struct fz_seq {
     uint64_t n = 0;                              // global length
     std::vector<Shard> shards;
 };
+
+namespace { void comm_teardown(fz_ctx *ctx); }
 
 namespace {
 
@@ -246,6 +269,27 @@ int ensure_gen_rows(DevState &d) {
     if (d.d_gen_rows) { HIP_TRY(hipFree(d.d_gen_rows)); d.d_gen_rows = nullptr; d.gen_rows_cap = 0; }
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d.d_gen_rows), d.rec_cap * sizeof(FzOutRow)));
     d.gen_rows_cap = d.rec_cap;
+    return FZ_OK;
+}
+
+// Snapshot buffers of a communicator's device state: at least `cap` records each; contents are kept (a snapshot
+// that is waiting for its all-gather survives the growth).
+int ensure_send(DevState &d, uint64_t cap) {
+    if (d.send_cap >= cap && d.d_send[0]) return FZ_OK;
+    HIP_TRY(hipSetDevice(d.device));
+    for (int i = 0; i < 2; ++i) {
+        uint8_t *nb = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&nb), kHeaderBytes + cap * sizeof(FzRec)));
+        if (d.d_send[i]) {
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipMemcpy(nb, d.d_send[i], kHeaderBytes + d.send_cap * sizeof(FzRec), hipMemcpyDeviceToDevice));
+            HIP_TRY(hipFree(d.d_send[i]));
+        } else {
+            HIP_TRY(hipMemset(nb, 0, kHeaderBytes));
+        }
+        d.d_send[i] = nb;
+    }
+    d.send_cap = cap;
     return FZ_OK;
 }
 
@@ -385,6 +429,7 @@ struct Search {
     uint32_t max_subs = 0, max_ins = 0, max_dels = 0;      // generic search only
     const uint8_t *p = nullptr;
     BlockPlan plan;
+    bool collective = false;       // the context joined a communicator: every rank gets the merged stream of all ranks
 };
 
 static const uint32_t kFusedLdsBudget = []() { const char *e = getenv("FZ_FUSED_LDS_KB"); int v = e ? atoi(e) : 0; return (uint32_t)(v > 0 ? v : 64) * 1024u; }();   // dynamic LDS per scan workgroup when verification is fused
@@ -415,7 +460,8 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     FzRec *recs = reinterpret_cast<FzRec *>(d.d_out + kHeaderBytes);
     static const bool no_direct = getenv("FZ_NO_DIRECT") != nullptr;
     // direct mode needs a kernel to publish the counters: an empty buffer launches none
-    const bool direct = copy_back && d.direct && !no_direct && sh.geom.buf_len > 0 && !q.plan.s.empty();
+    const bool snapshot = copy_back && with_verify && q.collective;      // collective search: records stay on the device
+    const bool direct = copy_back && d.direct && !no_direct && !snapshot && sh.geom.buf_len > 0 && !q.plan.s.empty();
     if (direct && with_verify) recs = reinterpret_cast<FzRec *>(d.h_stage_dev + kHeaderBytes);
     d.last_direct = direct;
     if (!d.header_zeroed) HIP_TRY(hipMemsetAsync(d.d_out, 0, kHeaderBytes, d.stream));
@@ -555,7 +601,15 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     }
     if (copy_back) {
         if (d.verify_launched) HIP_TRY(hipEventRecord(d.ev[2], d.stream));
-        if (!direct) {
+        if (snapshot) {
+            // counters to the host (overflow checks, statistics); counters + records to this slot's snapshot
+            HIP_TRY(hipMemcpyAsync(d.h_stage, d.d_out, kHeaderBytes, hipMemcpyDeviceToHost, d.stream));
+            int rc = ensure_send(d, d.rec_cap);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(d.d_send[d.slot_id], d.d_out, kHeaderBytes + d.rec_cap * sizeof(FzRec), hipMemcpyDeviceToDevice, d.stream));
+            HIP_TRY(hipEventRecord(d.ev_snap[d.slot_id], d.stream));
+            d.snap_taken[d.slot_id] = true;
+        } else if (!direct) {
             d.first_copy = std::min<uint64_t>(std::min<uint64_t>(d.first_copy, kFirstCopyRecs), d.rec_cap);
             HIP_TRY(hipMemcpyAsync(d.h_stage, d.d_out, kHeaderBytes + d.first_copy * sizeof(FzRec), hipMemcpyDeviceToHost,
                                    d.stream));
@@ -576,7 +630,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
 
 // Wait for a shard, handle overflow (returns 1 = capacities grown, caller must re-run), collect.
 int collect_shard(fz_ctx *ctx, const Shard &sh, bool with_verify, bool view_ok, std::vector<FzRec> &recs_out,
-                  std::vector<uint64_t> &hits_out, bool &rerun) {
+                  std::vector<uint64_t> &hits_out, bool &rerun, bool collective = false) {
     DevState &d = ctx->devs[sh.dev];
     HIP_TRY(hipSetDevice(d.device));
     Trace tr;
@@ -614,7 +668,9 @@ int collect_shard(fz_ctx *ctx, const Shard &sh, bool with_verify, bool view_ok, 
     ctx->stats.device_ms = std::max<double>(ctx->stats.device_ms, t);
     ctx->stats.bytes_scanned += sh.geom.buf_len;
     ctx->stats.ngram_hits += nh;
-    if (with_verify && view_ok && d.last_direct) {
+    if (with_verify && collective) {
+        // collective search: the records travel in the all-gather (gather_records), not through this host
+    } else if (with_verify && view_ok && d.last_direct) {
         ctx->stats.raw_matches += nr;
         ctx->view = reinterpret_cast<const FzRec *>(d.h_stage + kHeaderBytes);
         ctx->view_n = nr;
@@ -648,6 +704,81 @@ int check_halo(const fz_seq *seq, uint64_t need) {
     return FZ_OK;
 }
 
+#define NCCL_TRY(expr)                                                                             \
+    do {                                                                                           \
+        ncclResult_t r_ = (expr);                                                                  \
+        if (r_ != ncclSuccess) return fail(FZ_EDEVICE, "%s failed: %s", #expr, ncclGetErrorString(r_)); \
+    } while (0)
+
+// The exchange step of a sharded search: every rank of the communicator contributes the
+// snapshot of its counters + records (FzRec, unordered), ONE ncclAllGather of kHeaderBytes + gcap records per
+// rank (a group call over the device states of this process), one D2H copy of the gathered block, and every rank
+// holds all records of the global search; the caller orders them by (block, index) as it does for one shard.
+// gcap follows the counts: the gathered headers show every rank the same numbers, so all ranks grow / shrink
+// alike; an overflow re-gathers from the same snapshots (they hold everything the search produced).
+int gather_records(fz_ctx *ctx, fz_seq *seq, std::vector<FzRec> &recs) {
+    const int world = ctx->comm_world;
+    if (world <= 0) return fail(FZ_EINVAL, "the context has not joined a communicator");
+    recs.clear();
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        const uint64_t bytes = kHeaderBytes + ctx->gcap * sizeof(FzRec);
+        for (DevState &d : ctx->devs) {
+            HIP_TRY(hipSetDevice(d.device));
+            int rc = ensure_send(d, std::max<uint64_t>(d.rec_cap, ctx->gcap));
+            if (rc) return rc;
+            if (d.recv_bytes < (uint64_t)world * bytes) {
+                HIP_TRY(hipStreamSynchronize(d.comm_stream));
+                if (d.d_recv) HIP_TRY(hipFree(d.d_recv));
+                if (d.h_recv) HIP_TRY(hipHostFree(d.h_recv));
+                d.d_recv = nullptr; d.h_recv = nullptr; d.recv_bytes = 0;
+                HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d.d_recv), (uint64_t)world * bytes));
+                HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&d.h_recv), (uint64_t)world * bytes, hipHostMallocDefault));
+                d.recv_bytes = (uint64_t)world * bytes;
+            }
+            bool has_shard = false;
+            for (const Shard &sh : seq->shards) has_shard |= &ctx->devs[sh.dev] == &d;
+            if (has_shard && d.snap_taken[d.slot_id]) HIP_TRY(hipStreamWaitEvent(d.comm_stream, d.ev_snap[d.slot_id], 0));
+            else HIP_TRY(hipMemsetAsync(d.d_send[d.slot_id], 0, kHeaderBytes, d.comm_stream));   // this rank holds nothing of the sequence
+        }
+        NCCL_TRY(ncclGroupStart());
+        for (DevState &d : ctx->devs)
+            NCCL_TRY(ncclAllGather(d.d_send[d.slot_id], d.d_recv, bytes, ncclChar, d.comm, d.comm_stream));
+        NCCL_TRY(ncclGroupEnd());
+        DevState &d0 = ctx->devs[0];
+        HIP_TRY(hipSetDevice(d0.device));
+        HIP_TRY(hipMemcpyAsync(d0.h_recv, d0.d_recv, (uint64_t)world * bytes, hipMemcpyDeviceToHost, d0.comm_stream));
+        HIP_TRY(hipEventRecord(d0.ev_done, d0.comm_stream));
+        HIP_TRY(hipEventSynchronize(d0.ev_done));
+        for (size_t i = 1; i < ctx->devs.size(); ++i) {      // the other device states of this process: only wait
+            HIP_TRY(hipSetDevice(ctx->devs[i].device));
+            HIP_TRY(hipStreamSynchronize(ctx->devs[i].comm_stream));
+        }
+        uint64_t top = 0, total = 0;
+        for (int r = 0; r < world; ++r) {
+            const unsigned long long *cnt = reinterpret_cast<const unsigned long long *>(d0.h_recv + (uint64_t)r * bytes);
+            top = std::max<uint64_t>(top, cnt[1]);
+            total += cnt[1];
+        }
+        if (top > ctx->gcap) {                               // identical decision on every rank
+            ctx->gcap = (top + top / 4 + 1023) / 1024 * 1024;
+            continue;
+        }
+        recs.resize(total);
+        uint64_t o = 0;
+        for (int r = 0; r < world; ++r) {
+            const uint8_t *blk = d0.h_recv + (uint64_t)r * bytes;
+            const uint64_t c = reinterpret_cast<const unsigned long long *>(blk)[1];
+            if (c) memcpy(recs.data() + o, blk + kHeaderBytes, c * sizeof(FzRec));
+            o += c;
+        }
+        ctx->stats.raw_matches = total;
+        const uint64_t want = std::max<uint64_t>(1024, (top + top / 4 + 1023) / 1024 * 1024);
+        if (want * 2 <= ctx->gcap) ctx->gcap = want;         // follow the counts down as well (hysteresis: a factor of two)
+        return FZ_OK;
+    }
+    return fail(FZ_EDEVICE, "all-gather capacity kept overflowing");
+}
+
 // Launch a search on every shard (no host synchronisation).
 int search_enqueue(fz_ctx *ctx, fz_seq *seq, const Search &q, bool with_verify) {
     ctx->view = nullptr;
@@ -676,12 +807,19 @@ int search_collect(fz_ctx *ctx, fz_seq *seq, const Search &q, bool with_verify, 
         bool any_rerun = false;
         for (const Shard &sh : seq->shards) {
             bool rr = false;
-            int rc = collect_shard(ctx, sh, with_verify, seq->shards.size() == 1, recs, hits, rr);
+            int rc = collect_shard(ctx, sh, with_verify, seq->shards.size() == 1, recs, hits, rr, q.collective);
             if (rc) return rc;
             any_rerun |= rr;
         }
         tr.mark(" collect");
-        if (!any_rerun) return FZ_OK;
+        if (!any_rerun) {
+            if (with_verify && q.collective) {
+                int rc = gather_records(ctx, seq, recs);
+                if (rc) return rc;
+                tr.mark(" all-gather");
+            }
+            return FZ_OK;
+        }
         int rc = search_enqueue(ctx, seq, q, with_verify);
         if (rc) return rc;
     }
@@ -1086,6 +1224,7 @@ void fz_destroy(fz_ctx *ctx) {
         for (DevState &d : ctx->devs) { (void)hipSetDevice(d.device); if (d.stream) (void)hipStreamSynchronize(d.stream); }
         fz_seq_release(ctx->live.back());
     }
+    comm_teardown(ctx);
     for (DevState &d : ctx->devs) {
         (void)hipSetDevice(d.device);
         if (d.stream) (void)hipStreamSynchronize(d.stream);
@@ -1317,6 +1456,7 @@ static int lev_plan(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint
     rc = check_halo(seq, (uint64_t)m + k);
     if (rc) return rc;
     q.mode = FZ_MODE_LEV; q.m = m; q.k = k; q.p = p;
+    q.collective = ctx->snapshot;
     q.plan.L = L;
     for (uint32_t s = 0; s + L <= m; s += L) q.plan.s.push_back(s);   // levenshtein_ngram.py:171-176 (ranges: fz_block_range)
     if (q.plan.s.size() > 255) return fail(FZ_EUNSUPPORTED, "more than 255 n-gram blocks");
@@ -1359,7 +1499,7 @@ int fz_lev_ngrams_begin(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, 
     // search would overwrite it), then the launch waits for fz_lev_ngrams_end of the older search
     const bool second = ctx->npend == 1;
     pd.launched = true;
-    if (second) for (const DevState &d : ctx->devs) if (!d.direct) pd.launched = false;
+    if (second && !ctx->snapshot) for (const DevState &d : ctx->devs) if (!d.direct) pd.launched = false;
     if (pd.launched) {
         if (second) for (DevState &d : ctx->devs) d.swap_slot();
         rc = search_enqueue(ctx, seq, q, true);
@@ -1523,6 +1663,169 @@ int emit_generic(fz_ctx *ctx, fz_seq *seq, const std::vector<FzGenRec> &recs_vec
 }
 
 }  // namespace
+
+// ---- RCCL without PyTorch ------------------------------------------------
+namespace {
+
+int comm_setup_dev(DevState &d) {
+    HIP_TRY(hipSetDevice(d.device));
+    if (!d.comm_stream) HIP_TRY(hipStreamCreateWithFlags(&d.comm_stream, hipStreamNonBlocking));
+    for (auto &ev : d.ev_snap) if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    if (!d.ev_done) HIP_TRY(hipEventCreateWithFlags(&d.ev_done, hipEventDisableTiming));
+    return ensure_send(d, d.rec_cap);
+}
+
+void comm_teardown(fz_ctx *ctx) {
+    for (DevState &d : ctx->devs) {
+        (void)hipSetDevice(d.device);
+        if (d.comm_stream) (void)hipStreamSynchronize(d.comm_stream);
+        if (d.comm) { (void)ncclCommDestroy(d.comm); d.comm = nullptr; }
+        for (auto &b : d.d_send) if (b) { (void)hipFree(b); b = nullptr; }
+        d.send_cap = 0;
+        if (d.d_recv) { (void)hipFree(d.d_recv); d.d_recv = nullptr; }
+        if (d.h_recv) { (void)hipHostFree(d.h_recv); d.h_recv = nullptr; }
+        d.recv_bytes = 0;
+        for (auto &ev : d.ev_snap) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
+        if (d.ev_done) { (void)hipEventDestroy(d.ev_done); d.ev_done = nullptr; }
+        if (d.comm_stream) { (void)hipStreamDestroy(d.comm_stream); d.comm_stream = nullptr; }
+        d.comm_rank = -1;
+        d.snap_taken[0] = d.snap_taken[1] = false;
+    }
+    ctx->comm_world = 0;
+    ctx->snapshot = false;
+}
+
+int comm_busy(fz_ctx *ctx) {
+    if (!ctx) return fail(FZ_EINVAL, "null argument");
+    if (ctx->npend || ctx->stream_inflight) return fail(FZ_EINVAL, "a search of this context is in flight");
+    return FZ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fz_comm_unique_id(void *id, uint64_t id_bytes) {
+    static_assert(FZ_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
+    if (!id || id_bytes < FZ_COMM_ID_BYTES) return fail(FZ_EINVAL, "the id buffer must hold %d bytes", FZ_COMM_ID_BYTES);
+    ncclUniqueId u;
+    NCCL_TRY(ncclGetUniqueId(&u));
+    memcpy(id, u.internal, FZ_COMM_ID_BYTES);
+    return FZ_OK;
+}
+
+int fz_comm_init_rank(fz_ctx *ctx, const void *id, int world, int rank) {
+    int rc = comm_busy(ctx);
+    if (rc) return rc;
+    if (!id || world < 1 || rank < 0 || rank >= world) return fail(FZ_EINVAL, "bad communicator arguments");
+    if (ctx->devs.size() != 1) return fail(FZ_EINVAL, "fz_comm_init_rank needs a single-device context (one process per GPU); use fz_comm_init_all");
+    if (ctx->comm_world) return fail(FZ_EINVAL, "the context already joined a communicator");
+    DevState &d = ctx->devs[0];
+    rc = comm_setup_dev(d);
+    if (rc) return rc;
+    ncclUniqueId u;
+    memcpy(u.internal, id, FZ_COMM_ID_BYTES);
+    NCCL_TRY(ncclCommInitRank(&d.comm, world, u, rank));
+    d.comm_rank = rank;
+    ctx->comm_world = world;
+    ctx->snapshot = true;
+    return FZ_OK;
+}
+
+int fz_comm_init_all(fz_ctx *ctx) {
+    int rc = comm_busy(ctx);
+    if (rc) return rc;
+    if (ctx->comm_world) return fail(FZ_EINVAL, "the context already joined a communicator");
+    const int nd = (int)ctx->devs.size();
+    std::vector<int> ids(nd);
+    for (int i = 0; i < nd; ++i) {
+        ids[i] = ctx->devs[i].device;
+        for (int j = 0; j < i; ++j)
+            if (ids[j] == ids[i]) return fail(FZ_EUNSUPPORTED, "device %d appears twice in the context: RCCL needs one rank per GPU", ids[i]);
+    }
+    for (DevState &d : ctx->devs) { rc = comm_setup_dev(d); if (rc) return rc; }
+    std::vector<ncclComm_t> comms(nd, nullptr);
+    NCCL_TRY(ncclCommInitAll(comms.data(), nd, ids.data()));
+    for (int i = 0; i < nd; ++i) { ctx->devs[i].comm = comms[i]; ctx->devs[i].comm_rank = i; }
+    ctx->comm_world = nd;
+    ctx->snapshot = true;
+    return FZ_OK;
+}
+
+int fz_comm_info(fz_ctx *ctx, int *world, int *rank, int *collective) {
+    if (!ctx) return fail(FZ_EINVAL, "null argument");
+    if (world) *world = ctx->comm_world;
+    if (rank) *rank = ctx->comm_world ? ctx->devs[0].comm_rank : -1;
+    if (collective) *collective = ctx->snapshot ? 1 : 0;
+    return FZ_OK;
+}
+
+int fz_comm_set_collective(fz_ctx *ctx, int on) {
+    int rc = comm_busy(ctx);
+    if (rc) return rc;
+    if (!ctx->comm_world) return fail(FZ_EINVAL, "the context has not joined a communicator");
+    ctx->snapshot = on != 0;
+    return FZ_OK;
+}
+
+void fz_comm_destroy(fz_ctx *ctx) {
+    if (ctx) comm_teardown(ctx);
+}
+
+// host buffers: nbytes from every rank, rank order (load-time exchanges: halos, the job's clock)
+int fz_comm_allgather(fz_ctx *ctx, const void *send, uint64_t nbytes, void *recv) {
+    int rc = comm_busy(ctx);
+    if (rc) return rc;
+    if (!ctx->comm_world) return fail(FZ_EINVAL, "the context has not joined a communicator");
+    if (ctx->devs.size() != 1) return fail(FZ_EINVAL, "fz_comm_allgather is for one-process-per-GPU jobs (a multi-device context holds every rank's data itself)");
+    if (!nbytes) return FZ_OK;
+    if (!send || !recv) return fail(FZ_EINVAL, "null argument");
+    DevState &d = ctx->devs[0];
+    HIP_TRY(hipSetDevice(d.device));
+    const uint64_t world = (uint64_t)ctx->comm_world;
+    uint8_t *tmp = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), (world + 1) * nbytes));
+    auto body = [&]() -> int {
+        HIP_TRY(hipMemcpyAsync(tmp, send, nbytes, hipMemcpyHostToDevice, d.comm_stream));
+        NCCL_TRY(ncclAllGather(tmp, tmp + nbytes, nbytes, ncclChar, d.comm, d.comm_stream));
+        HIP_TRY(hipMemcpyAsync(recv, tmp + nbytes, world * nbytes, hipMemcpyDeviceToHost, d.comm_stream));
+        HIP_TRY(hipStreamSynchronize(d.comm_stream));
+        return FZ_OK;
+    };
+    rc = body();
+    (void)hipFree(tmp);
+    return rc;
+}
+
+// max over the ranks of one double per rank (the job's step time); doubles as a barrier
+int fz_comm_max_f64(fz_ctx *ctx, double *value) {
+    int rc = comm_busy(ctx);
+    if (rc) return rc;
+    if (!ctx->comm_world || !value) return fail(FZ_EINVAL, "no communicator / null argument");
+    if (ctx->devs.size() != 1) return FZ_OK;               // one process holds every rank: nothing to reduce
+    DevState &d = ctx->devs[0];
+    HIP_TRY(hipSetDevice(d.device));
+    double *tmp = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), sizeof(double)));
+    auto body = [&]() -> int {
+        HIP_TRY(hipMemcpyAsync(tmp, value, sizeof(double), hipMemcpyHostToDevice, d.comm_stream));
+        NCCL_TRY(ncclAllReduce(tmp, tmp, 1, ncclDouble, ncclMax, d.comm, d.comm_stream));
+        HIP_TRY(hipMemcpyAsync(value, tmp, sizeof(double), hipMemcpyDeviceToHost, d.comm_stream));
+        HIP_TRY(hipStreamSynchronize(d.comm_stream));
+        return FZ_OK;
+    };
+    rc = body();
+    (void)hipFree(tmp);
+    return rc;
+}
+
+int fz_comm_barrier(fz_ctx *ctx) {
+    if (ctx) for (DevState &d : ctx->devs) { (void)hipSetDevice(d.device); (void)hipStreamSynchronize(d.stream); }
+    double one = 1.0;
+    return fz_comm_max_f64(ctx, &one);
+}
+
+}  // extern "C"
 
 // ---- (f)3: the reference's linear-programming fallbacks for short patterns, on the GPU ---------
 namespace {

@@ -14,11 +14,132 @@ n-gram hit index and the bytes within (m + k) of it, so
     index ranges.
 Consolidation then runs once on the gathered list (overlap groups can span shard boundaries).
 
-torch is imported lazily: the single-GPU product path never needs it.
+Two ways to run it:
+  * torch-free (the product path): the collective lives behind the C-ABI (fz_comm_*, RCCL linked into libfzhip.so).
+    `init_engine_from_env()` turns the launcher's environment (RANK / WORLD_SIZE / LOCAL_RANK, as set by
+    torch.distributed.run, mpirun wrappers, ...) into a single-device engine that has joined the job's communicator:
+    rank 0 creates the RCCL unique id and hands it over through a small rendezvous file; from then on
+    engine.lev_ngrams() is collective and returns the merged global stream.  One process with several GPUs needs no
+    rendezvous at all: Engine([0, 1, ...]).comm_init_all().
+  * torch.distributed (optional launcher glue, and the CPU test double: "gloo"): exchange_halos / allgather_matches
+    below move the same data through torch collectives; torch is imported lazily and never by the product path.
 """
+import os
+import time
+
 import numpy as np
 
-__all__ = ['shard_bounds', 'exchange_halos', 'allgather_matches', 'merge_rank_streams']
+__all__ = ['shard_bounds', 'exchange_halos', 'allgather_matches', 'merge_rank_streams',
+           'init_engine_from_env', 'share_blob', 'exchange_halos_native']
+
+_rdzv_seq = [0]
+
+
+def _job_key():
+    """What every rank of one job on this node agrees on and no other live job shares: the launcher process (all
+    ranks are its children) with its start time, the rendezvous port and the restart count.  FZ_RENDEZVOUS_KEY
+    overrides (ranks started by different parents)."""
+    key = os.environ.get("FZ_RENDEZVOUS_KEY")
+    if key:
+        return key
+    ppid = os.getppid()
+    try:
+        with open("/proc/%d/stat" % ppid) as f:
+            start = f.read().rsplit(")", 1)[1].split()[19]          # field 22: starttime
+    except Exception:
+        start = "0"
+    return "%d_%s_%s_%s" % (ppid, start, os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"))
+
+
+def share_blob(make_blob, world, rank, timeout=300.0, directory=None):
+    """Rank 0 calls make_blob() and every rank returns those bytes: a file written atomically under a name that only
+    the ranks of this job derive (single node, as the bench contract has it).  Torch-free rendezvous for the RCCL
+    unique id; every call of a process uses a fresh name, rank 0 removes the file once every rank has confirmed."""
+    seq = _rdzv_seq[0]
+    _rdzv_seq[0] += 1
+    if world == 1:
+        return make_blob()
+    directory = directory or os.environ.get("FZ_RENDEZVOUS_DIR") or ("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
+    base = os.path.join(directory, "fz_rdzv_%s_%d" % (_job_key(), seq))
+    deadline = time.monotonic() + timeout
+    if rank == 0:
+        blob = make_blob()
+        tmp = base + ".tmp%d" % os.getpid()
+        with open(tmp, "wb") as f:
+            f.write(blob)
+        os.replace(tmp, base)
+        acks = [base + ".ack%d" % r for r in range(1, world)]
+        while not all(os.path.exists(a) for a in acks):
+            if time.monotonic() > deadline:
+                raise TimeoutError("rendezvous: ranks %r never read %s" % ([r for r in range(1, world) if not os.path.exists(base + ".ack%d" % r)], base))
+            time.sleep(0.002)
+        for a in acks + [base]:
+            try:
+                os.remove(a)
+            except OSError:
+                pass
+        return blob
+    while True:
+        try:
+            with open(base, "rb") as f:
+                blob = f.read()
+            break
+        except FileNotFoundError:
+            if time.monotonic() > deadline:
+                raise TimeoutError("rendezvous: rank 0 never wrote %s" % base)
+            time.sleep(0.002)
+    with open(base + ".ack%d" % rank, "wb"):
+        pass
+    return blob
+
+
+def init_engine_from_env(engine=None):
+    """One process per GPU under any launcher that sets RANK / WORLD_SIZE / LOCAL_RANK (torch.distributed.run does):
+    -> (engine, world, rank), the engine on device LOCAL_RANK and a member of the job's RCCL communicator.  No torch."""
+    from . import _native
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if engine is None:
+        engine = _native.Engine([local_rank])
+    uid = share_blob(engine.comm_unique_id, world, rank)
+    engine.comm_init_rank(uid, world, rank)
+    return engine, world, rank
+
+
+def exchange_halos_native(engine, shard, halo):
+    """exchange_halos() over the engine's own communicator (fz_comm_allgather): -> (left, right)."""
+    world, rank, _ = engine.comm_info()
+    shard = np.asarray(shard, dtype=np.uint8)
+    head, tail = shard[:halo], (shard[-halo:] if halo else shard[:0])
+    blob = np.zeros(16 + 2 * halo, dtype=np.uint8)
+    blob[:16].view(np.uint64)[:] = (len(head), len(tail))
+    blob[16:16 + len(head)] = head
+    blob[16 + halo:16 + halo + len(tail)] = tail
+    parts = [np.frombuffer(b, dtype=np.uint8) for b in engine.comm_allgather(blob.tobytes())]
+    return _halos_from_edges([(p[16:16 + int(p[:8].view(np.uint64)[0])], p[16 + halo:16 + halo + int(p[8:16].view(np.uint64)[0])])
+                              for p in parts], rank, halo)
+
+
+def _halos_from_edges(edges, rank, halo):
+    """edges[r] = (first, last) `halo` bytes of rank r's shard (all of it when it is shorter) -> (left, right) of
+    `rank`: a shard shorter than the halo contributes all of itself, so keep walking."""
+    world = len(edges)
+    left_parts, need, r = [], halo, rank - 1
+    while need > 0 and r >= 0:
+        t = edges[r][1][-need:] if need else edges[r][1][:0]
+        left_parts.insert(0, t)
+        need -= len(t)
+        r -= 1
+    right_parts, need, r = [], halo, rank + 1
+    while need > 0 and r < world:
+        h = edges[r][0][:need]
+        right_parts.append(h)
+        need -= len(h)
+        r += 1
+    left = np.concatenate(left_parts) if left_parts else np.empty(0, np.uint8)
+    right = np.concatenate(right_parts) if right_parts else np.empty(0, np.uint8)
+    return left.astype(np.uint8), right.astype(np.uint8)
 
 
 def shard_bounds(n, world, rank):
@@ -64,27 +185,8 @@ def exchange_halos(shard, halo, group=None):
     dist.all_gather(gathered, mine, group=group)
     edges = [g.cpu().numpy() for g in gathered]
 
-    def head_of(r):
-        return edges[r][2:2 + int(edges[r][0])].astype(np.uint8)
-
-    def tail_of(r):
-        return edges[r][2 + halo:2 + halo + int(edges[r][1])].astype(np.uint8)
-    # a shard shorter than the halo contributes all of itself (head == tail == shard): keep walking
-    left_parts, need, r = [], halo, rank - 1
-    while need > 0 and r >= 0:
-        t = tail_of(r)[-need:] if need else tail_of(r)[:0]
-        left_parts.insert(0, t)
-        need -= len(t)
-        r -= 1
-    right_parts, need, r = [], halo, rank + 1
-    while need > 0 and r < world:
-        h = head_of(r)[:need]
-        right_parts.append(h)
-        need -= len(h)
-        r += 1
-    left = np.concatenate(left_parts) if left_parts else np.empty(0, np.uint8)
-    right = np.concatenate(right_parts) if right_parts else np.empty(0, np.uint8)
-    return left, right
+    return _halos_from_edges([(e[2:2 + int(e[0])].astype(np.uint8), e[2 + halo:2 + halo + int(e[1])].astype(np.uint8))
+                              for e in edges], rank, halo)
 
 
 MATCH_DTYPE = np.dtype([("start", "<i8"), ("end", "<i8"), ("dist", "<i4"), ("block", "<i4")])   # = fz_match

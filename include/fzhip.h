@@ -152,6 +152,30 @@ int fz_generic_lp(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m,
                   uint32_t max_subs, uint32_t max_ins, uint32_t max_dels, uint32_t max_l,
                   fz_match **out, uint64_t *n);
 
+/* RCCL over xGMI without PyTorch (the reference's only scale-out analogue is the chunk loop of
+ * __init__.py:129-171).  A context that joined a communicator searches COLLECTIVELY: fz_lev_ngrams and
+ * fz_lev_ngrams_begin / _end must be called by every rank in the same order, every rank scans the shard(s) it
+ * holds (fz_seq_upload_shard / fz_seq_add_shard), the ranks' record lists are exchanged by ONE ncclAllGather of
+ * device buffers per search (capacity follows the counts) and every rank receives the merged stream of the whole
+ * sequence in the reference's order.  With _begin / _end the all-gather of search i runs on its own stream next to
+ * the scan of search i + 1.
+ *   one process per GPU:   rank 0 calls fz_comm_unique_id and hands the FZ_COMM_ID_BYTES bytes to the other ranks
+ *                          (file, socket, MPI: not this library's business), every rank calls fz_comm_init_rank on
+ *                          its single-device context;
+ *   one process, N GPUs:   fz_comm_init_all on the multi-device context (ncclCommInitAll; every device = one rank).
+ * fz_comm_allgather / fz_comm_max_f64 / fz_comm_barrier serve load-time exchanges (halo bytes) and the job's clock.
+ * fz_comm_set_collective(ctx, 0) makes the searches of the context local again (the communicator stays). */
+#define FZ_COMM_ID_BYTES 128
+int  fz_comm_unique_id(void *id, uint64_t id_bytes);
+int  fz_comm_init_rank(fz_ctx *ctx, const void *id, int world, int rank);
+int  fz_comm_init_all(fz_ctx *ctx);
+int  fz_comm_info(fz_ctx *ctx, int *world, int *rank, int *collective);
+int  fz_comm_set_collective(fz_ctx *ctx, int on);
+int  fz_comm_allgather(fz_ctx *ctx, const void *send, uint64_t nbytes, void *recv);
+int  fz_comm_max_f64(fz_ctx *ctx, double *value);
+int  fz_comm_barrier(fz_ctx *ctx);
+void fz_comm_destroy(fz_ctx *ctx);
+
 /* consolidate_overlapping_matches: overlap groups -> best (dist, -len) per group -> sorted by
  * (start, end, dist).  Ties inside a group (the reference breaks them by set iteration order, i.e.
  * by PYTHONHASHSEED) are broken deterministically: smallest start. */

@@ -69,3 +69,36 @@ def test_shard_bounds_and_merge():
         exp = fzd.merge_rank_streams(parts)
         got = fzd.merge_rank_arrays([fzd._as_match_array(p) for p in parts])
         assert [tuple(x) for x in got.tolist()] == [tuple(x) for x in exp.tolist()]
+
+
+def _rdzv_child(args):
+    rank, world, directory = args
+    from fuzzysearch_amd import distributed as fzd
+    first = fzd.share_blob(lambda: os.urandom(128), world, rank, timeout=60, directory=directory)
+    second = fzd.share_blob(lambda: os.urandom(128), world, rank, timeout=60, directory=directory)
+    return first, second
+
+
+def test_torch_free_rendezvous_hands_rank0_bytes_to_every_rank():
+    """share_blob: what init_engine_from_env uses to distribute the RCCL unique id (no torch, no network)."""
+    import multiprocessing as mp
+    world = 3
+    with tempfile.TemporaryDirectory() as d:
+        with mp.get_context("fork").Pool(world) as pool:
+            res = pool.map(_rdzv_child, [(r, world, d) for r in range(world)], chunksize=1)
+        assert len({a for a, _b in res}) == 1 and len({b for _a, b in res}) == 1
+        assert res[0][0] != res[0][1] and len(res[0][0]) == 128
+        assert os.listdir(d) == []                      # rank 0 cleaned up
+
+
+def test_halos_from_edges_walks_over_short_shards():
+    import numpy as np
+    from fuzzysearch_amd import distributed as fzd
+    seq = np.arange(40, dtype=np.uint8)
+    cuts = [0, 17, 19, 20, 33, 40]                      # shards of 17, 2, 1, 13, 7 bytes; halo 5
+    halo = 5
+    edges = [(seq[a:b][:halo], seq[a:b][-halo:]) for a, b in zip(cuts, cuts[1:])]
+    for r, (a, b) in enumerate(zip(cuts, cuts[1:])):
+        left, right = fzd._halos_from_edges(edges, r, halo)
+        assert left.tobytes() == seq[max(0, a - halo):a].tobytes(), r
+        assert right.tobytes() == seq[b:b + halo].tobytes(), r
