@@ -60,10 +60,10 @@ def find_near_matches(subsequence, sequence,
 
     Every route runs on the GPU; there is no CPU fallback.  What the engine does not support raises
     ``UnsupportedSearch`` (a ``NotImplementedError``) before anything is searched: a subsequence of more
-    than 1024 items, a budget (``max_l_dist`` / ``max_substitutions``) above 255, more than 255 n-gram
-    blocks, more than 255 distinct symbols in a subsequence that is neither bytes nor latin-1 text, and
-    generic searches whose candidate sets outgrow 2**18 entries.  The reference accepts all of these:
-    catch the exception to route such a call there.
+    than 65 535 items, ``max_l_dist`` above 1 023 (above 255 for searches with separate substitution /
+    insertion / deletion limits and for the short-pattern routes), more than 255 distinct symbols in a
+    subsequence that is neither bytes nor latin-1 text, and generic searches whose candidate sets outgrow
+    2**18 entries.  The reference accepts all of these: catch the exception to route such a call there.
     """
     search_params = LevenshteinSearchParams(max_substitutions, max_insertions,
                                             max_deletions, max_l_dist)

@@ -157,10 +157,11 @@ def load_library():
 
 
 class UnsupportedSearch(NotImplementedError):
-    """The search is outside what the GPU engine supports (subsequence longer than 1024 items, a budget above
-    255, more than 255 n-gram blocks, more than 255 distinct symbols in a non-bytes subsequence, automaton
-    candidate sets beyond 2^18 entries).  Nothing was searched and there is no CPU fallback: a caller that needs
-    such a search catches this and routes it to the reference implementation."""
+    """The search is outside what the GPU engine supports: a subsequence of more than 65 535 items, a Levenshtein
+    budget above 1 023, a generic search (separate limits) or a linear-programming route with max_l_dist above 255,
+    more than 255 distinct symbols in a subsequence that is neither bytes nor latin-1 text, automaton candidate sets
+    beyond 2^18 entries.  Nothing was searched and there is no CPU fallback: a caller that needs such a search
+    catches this and routes it to the reference implementation."""
 
 
 def _raise(rc):

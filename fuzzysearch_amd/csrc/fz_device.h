@@ -27,8 +27,10 @@
 #endif
 
 #define FZ_MAX_BLOCKS_PER_LAUNCH 8     // n-gram blocks tested by one filter launch
-#define FZ_MAX_M 1024                  // pattern bytes carried in the kernel argument block
-#define FZ_MAX_K 255                   // largest edit budget the verify kernels support
+#define FZ_MAX_M 1024                  // pattern bytes carried in the kernel argument block (longer patterns: FzScanArgs.pat_g)
+#define FZ_MAX_K 255                   // largest budget of the LDS-ring verification and of the candidate automata (8-bit counters)
+#define FZ_MAX_M_ANY 65535u            // longest subsequence any path accepts (16-bit window-relative coordinates)
+#define FZ_MAX_K_ANY 1023u             // largest Levenshtein / substitution budget (fz_verify_big_kernel: 2k + 1 <= 64 lanes x 32 cells)
 
 // What fz_lp_kernel iterates over.
 enum FzLpKind : uint32_t {
@@ -137,7 +139,8 @@ struct FzScanArgs {
                                                 // area (FZ_GEN_ORDER_MAX x {u64 first row, u32 row count}); 0: the host orders
     uint64_t host_hdr;                          // device-visible address of the host copy of the counters
                                                 // (0: none); the last workgroup of the launch fills it
-    uint8_t  pat[FZ_MAX_M];                     // whole pattern
+    uint64_t pat_g;                             // m > FZ_MAX_M: device address of the pattern (pat[] unused); else 0
+    uint8_t  pat[FZ_MAX_M];                     // whole pattern (m <= FZ_MAX_M)
 };
 
 // A hit: (block g << FZ_IDX_BITS) | global idx (48-bit index: sequences below 256 TiB; 16-bit block number).

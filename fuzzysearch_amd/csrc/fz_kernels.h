@@ -77,6 +77,11 @@ typedef __attribute__((address_space(3))) uint8_t FzLdsU8;
 
 __device__ __forceinline__ uint32_t fz_lane() { return threadIdx.x & 63u; }
 
+// Pattern byte i: from the kernel-argument block, or (patterns longer than FZ_MAX_M) from HBM.
+__device__ __forceinline__ uint8_t fz_pat_byte(const FzScanArgs &a, uint32_t i) {
+    return a.pat_g ? reinterpret_cast<const uint8_t *>(a.pat_g)[i] : a.pat[i];
+}
+
 __device__ __forceinline__ uint32_t fz_rank(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
@@ -349,7 +354,7 @@ __device__ __forceinline__ bool fz_confirm(const uint8_t *__restrict__ buf, cons
     if ((fz_load_win(buf, (int64_t)local) & a.mask1) != a.A[blk]) return false;
     if (a.L > 4 && (fz_load_win(buf, (int64_t)local + a.d2) & a.mask2) != a.B[blk]) return false;
     for (uint32_t b = 8; b < a.L; ++b)
-        if (buf[local + b] != a.pat[a.s[blk] + b]) return false;
+        if (buf[local + b] != fz_pat_byte(a, a.s[blk] + b)) return false;
     return true;
 }
 
@@ -609,14 +614,15 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
     constexpr bool PREF = FUSED && !SEG;              // candidate windows are prefetched by LDS-DMA
     FZ_LAB_STAMP(0);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t mpad = (a.m + 15u) & ~15u;
+    const uint32_t mpad = FUSED ? (a.m + 15u) & ~15u : 0u;   // only the fused verification reads the pattern from LDS (m <= FZ_MAX_M there)
     // [32] hash living in the slot.  The kernel has no static LDS, so the dynamic area, and with it this
     // table, starts at LDS address 0 and a slot's byte offset is its address (saves one VALU add per
     // lookup); trap if a toolchain ever lays LDS out differently.
     uint32_t *lut = reinterpret_cast<uint32_t *>(smem);
     if (reinterpret_cast<uintptr_t>((FzLdsU8 *)smem) != 0) __builtin_trap();
     uint8_t *pat_lds = smem + FZ_TABLE_BYTES;
-    for (uint32_t i = threadIdx.x; i < a.m; i += FZ_FILTER_THREADS) pat_lds[i] = a.pat[i];
+    if constexpr (FUSED)
+        for (uint32_t i = threadIdx.x; i < a.m; i += FZ_FILTER_THREADS) pat_lds[i] = a.pat[i];
     if (threadIdx.x < FZ_LUT_SLOTS) {
         uint32_t t = ((threadIdx.x + 1u) & (FZ_LUT_SLOTS - 1u)) << a.lut_shift;   // free slot: a value of the next slot
         uint32_t who = 0xffu;                                                     // ... and the block that lives in the slot
@@ -844,7 +850,7 @@ __global__ void fz_verify_kernel(const uint8_t *__restrict__ buf, const FzScanAr
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t mpad = (a.m + 15u) & ~15u;
     uint8_t *pat_lds = smem;
-    for (uint32_t i = threadIdx.x; i < a.m; i += blockDim.x) pat_lds[i] = a.pat[i];
+    for (uint32_t i = threadIdx.x; i < a.m; i += blockDim.x) pat_lds[i] = fz_pat_byte(a, i);
     __syncthreads();
     const FzWaveLds w = fz_wave_lds(smem + mpad, threadIdx.x >> 6, a.win_dwords, a.band_w, a.vlanes, false);
     unsigned long long nh = counters[0];
@@ -987,7 +993,7 @@ __global__ __launch_bounds__(1024) void fz_verify_wf_kernel(const uint8_t *__res
     constexpr uint32_t NH = 64u / (uint32_t)GW;                         // hits per wave
     const uint32_t mpad = (a.m + 15u) & ~15u;
     uint8_t *pat_lds = smem + 16;                                       // 16 bytes of slack below p[0] (reversed reads)
-    for (uint32_t i = threadIdx.x; i < a.m; i += blockDim.x) pat_lds[i] = a.pat[i];
+    for (uint32_t i = threadIdx.x; i < a.m; i += blockDim.x) pat_lds[i] = fz_pat_byte(a, i);
     __syncthreads();
     const uint32_t lane = fz_lane();
     const uint32_t grp = lane / (uint32_t)GW, gl = lane % (uint32_t)GW;
@@ -1068,6 +1074,181 @@ __global__ __launch_bounds__(1024) void fz_verify_wf_kernel(const uint8_t *__res
 }
 
 // ---------------------------------------------------------------------------------------------
+// fz_verify_big_kernel<CPL> — verification without size limits: ONE WAVE PER HIT, lane-per-DP-cell with CPL band
+// cells per lane (2k + 1 <= 64 * CPL cells: budgets up to 1023), pattern and sequence read from HBM / L2 as they
+// are (no LDS staging: subsequences up to FZ_MAX_M_ANY).  Used where the other verifications do not fit: patterns
+// longer than the kernel-argument block, budgets above FZ_MAX_K, windows or score rings beyond LDS
+// (levenshtein_ngram.py:159-198 has no limit on either).  Same table as fz_expand / c_expand_*
+// (_levenshtein_ngrams.pyx:9-154): lane gl owns the cells x = gl * CPL + c of a row, cell x of row i is
+// D[i][i + x - K]; the upper neighbour is cell x + 1 of the previous row (the next lane's first cell: one DPP wave
+// shift), the left-neighbour recurrence v[x] = min_{e <= x} (a[e] + x - e) is a prefix-min of a[e] - e: sequential
+// inside the lane, one exclusive wave scan (DPP row shifts + row broadcasts) across lanes.  Cells beyond 2K are
+// computed as well (a wider band is still exact).  The 64 pattern characters and the 64 characters entering the
+// band's right edge of the next 64 rows are fetched with one coalesced load each and handed out by v_readlane.
+__device__ __forceinline__ uint32_t fz_dpp_wave_shl1(uint32_t v, uint32_t edge) {     // lane l <- lane l + 1; lane 63 <- edge
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t fz_dpp_wave_shr1(uint32_t v, uint32_t edge) {     // lane l <- lane l - 1; lane 0 <- edge
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138, 0xf, 0xf, false);
+}
+// inclusive prefix-min over the 64 lanes (lanes without a source keep their value)
+__device__ __forceinline__ uint32_t fz_wave_incl_min(uint32_t v) {
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xf, 0xf, false));   // row_shr:1
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x112, 0xf, 0xf, false));   // row_shr:2
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114, 0xf, 0xf, false));   // row_shr:4
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118, 0xf, 0xf, false));   // row_shr:8
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// One bounded expansion by the whole wave; every argument is wave-uniform.  sub(i) = psub[i * sstep] (i < sublen),
+// win(j) = pwin[j * wstep] (j < winlen), both in global memory.  -> (ok, dist, consumed) as fz_expand.
+template <int CPL>
+__device__ __forceinline__ bool fz_big_expand(const uint8_t *psub, int sstep, uint32_t sublen, const uint8_t *pwin, int wstep,
+                                              uint32_t winlen, uint32_t K, uint32_t budget, uint32_t &dist, uint32_t &consumed) {
+    if (sublen == 0) { dist = 0; consumed = 0; return true; }       // pyx:28-30
+    constexpr uint32_t INF = 0x3fffffffu;
+    constexpr uint32_t NX = 64u * (uint32_t)CPL;
+    const uint32_t lane = fz_lane();
+    const uint32_t x0 = lane * (uint32_t)CPL;
+    uint32_t cell[CPL], chr[CPL];
+    int jb = (int)x0 - (int)K;                                       // column of cell 0 of this lane in row i: jb + c (row 0 now)
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const int j = jb + c;
+        cell[c] = (j >= 0 && (uint32_t)j <= winlen) ? (uint32_t)j : INF;                       // row 0: D[0][j] = j
+        chr[c] = (j >= 0 && (uint32_t)j < winlen) ? (uint32_t)pwin[(int64_t)j * wstep] : 0x100u;   // row 1 compares win[j]
+    }
+    uint32_t pvec = 0, wvec = 0;
+    for (uint32_t i = 1; i <= sublen; ++i) {
+        const uint32_t r = (i - 1u) & 63u;
+        if (r == 0) {
+            const uint32_t pi = i - 1u + lane;                                                // pattern characters of rows i .. i + 63
+            pvec = pi < sublen ? (uint32_t)psub[(int64_t)pi * sstep] : 0u;
+            const int64_t wj = (int64_t)(i + lane) + (int64_t)NX - 1 - (int64_t)K;           // right-edge character after row i + lane
+            wvec = (wj >= 0 && wj < (int64_t)winlen) ? (uint32_t)pwin[wj * wstep] : 0x100u;
+        }
+        const uint32_t pc = (uint32_t)__builtin_amdgcn_readlane((int)pvec, (int)r);
+        const uint32_t edge = (uint32_t)__builtin_amdgcn_readlane((int)wvec, (int)r);
+        jb += 1;
+        const uint32_t up_last = fz_dpp_wave_shl1(cell[0], INF);                             // D[i-1][..] of the next lane's first cell
+        // a[c] = min(diag + cost, up + 1), forced at column 0 and outside the table; t[c] = running min of a[e] + (NX - e)
+        uint32_t run = 0xffffffffu;
+        uint32_t t[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int j = jb + c;
+            const uint32_t up = (c + 1 < CPL) ? cell[(c + 1 < CPL) ? c + 1 : 0] : up_last;
+            uint32_t v = min(cell[c] + (chr[c] != pc ? 1u : 0u), up + 1u);
+            if (j == 0) v = i;                                                               // D[i][0] = i
+            if (j < 0 || (uint32_t)j > winlen) v = INF;
+            run = min(run, v + (NX - (x0 + (uint32_t)c)));
+            t[c] = run;
+        }
+        const uint32_t incl = fz_wave_incl_min(run);
+        const uint32_t excl = fz_dpp_wave_shr1(incl, 0xffffffffu);
+        uint32_t any_low = 0;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int j = jb + c;
+            uint32_t v = min(excl, t[c]) - (NX - (x0 + (uint32_t)c));
+            v = min(v, INF);
+            if (j < 0 || (uint32_t)j > winlen) v = INF;
+            cell[c] = v;
+            any_low |= (v <= budget) ? 1u : 0u;
+        }
+        // next row's characters: every cell takes its right neighbour's
+        const uint32_t in = fz_dpp_wave_shl1(chr[0], edge);
+#pragma unroll
+        for (int c = 0; c + 1 < CPL; ++c) chr[c] = chr[c + 1];
+        chr[CPL - 1] = in;
+        // row minima never decrease: once no cell is within the budget nothing can pass (pyx:61-65)
+        if ((i & 3u) == 0u && !__ballot(any_low != 0u)) return false;
+    }
+    // bottom row: min over the columns 1 .. winlen, the LARGEST column among equals, from the column-0 baseline
+    uint32_t key = 0xffffffffu;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const int j = jb + c;
+        if (j >= 1 && (uint32_t)j <= winlen) key = min(key, (min(cell[c], 0xfffffu) << 12) | (NX - 1u - (x0 + (uint32_t)c)));
+    }
+    key = fz_wave_incl_min(key);
+    key = (uint32_t)__builtin_amdgcn_readlane((int)key, 63);
+    uint32_t best = sublen, arg = 0;
+    if (key != 0xffffffffu && (key >> 12) <= sublen) {
+        best = key >> 12;
+        arg = (uint32_t)((int)sublen + (int)(NX - 1u - (key & 0xfffu)) - (int)K);
+    }
+    dist = best;
+    consumed = arg;
+    return best <= budget;
+}
+
+template <int CPL>
+__global__ __launch_bounds__(64) void fz_verify_big_kernel(const uint8_t *__restrict__ buf, const FzScanArgs a,
+                                                           const uint64_t *__restrict__ hits, FzRec *__restrict__ recs,
+                                                           unsigned long long *__restrict__ counters) {
+    __shared__ uint32_t flag;
+    const uint32_t lane = fz_lane();
+    const uint8_t *pat = reinterpret_cast<const uint8_t *>(a.pat_g);   // the host stages the pattern in HBM for this kernel
+    unsigned long long nh = counters[0];
+    if (nh > a.hit_cap) nh = a.hit_cap;
+    const uint32_t ncand = fz_segment_candidates(a.geom);
+    for (uint64_t q = blockIdx.x; q < nh; q += gridDim.x) {
+        const uint64_t hit = hits[q];
+        const uint32_t g = fz_hit_block(hit);
+        const uint64_t idx = fz_hit_index(hit);
+        const uint32_t s = g * a.L;
+        for (uint32_t c = 0; c < ncand; ++c) {
+            const FzSeg sg = fz_segment(a.geom, idx, c);
+            if (!fz_hit_in_range_s(a, s, idx, sg)) continue;                               // wave-uniform
+            FzRec rec;
+            bool ok;
+            if (a.mode == FZ_MODE_SUBS) {
+                // Hamming distance of the window [idx - s, idx - s + m) (_substitutions_only_ngrams_template.h:103-121)
+                const uint8_t *t = buf + (int64_t)(idx - s - a.geom.buf_off);
+                uint32_t nd = 0;
+                for (uint32_t q0 = 0; q0 < a.m; q0 += 4096u) {
+                    for (uint32_t qq = q0 + lane; qq < a.m && qq < q0 + 4096u; qq += 64u) nd += (pat[qq] != t[qq]) ? 1u : 0u;
+                    if (!__ballot(nd <= a.k)) break;                                        // some lane alone is over the budget
+                }
+                uint32_t tot = nd;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) tot += (uint32_t)__shfl_xor((int)tot, d, 64);
+                ok = tot <= a.k;                                                            // (after an early exit tot is partial, but > k)
+                rec.l = s; rec.r = a.m - s - a.L; rec.dist = tot;
+            } else {
+                // levenshtein_ngram.py:177-198: right expansion with budget k, then left with what is left of it
+                const uint32_t rlen = a.m - s - a.L;
+                uint64_t rbeg = idx + a.L, rend = idx + a.m + a.k - s;
+                if (rend > sg.se) rend = sg.se;
+                if (rbeg > sg.se) rbeg = sg.se;
+                if (rend < rbeg) rend = rbeg;
+                uint32_t dR = 0, r = 0, dL = 0, l = 0;
+                ok = fz_big_expand<CPL>(pat + s + a.L, 1, rlen, buf + (int64_t)(rbeg - a.geom.buf_off), 1, (uint32_t)(rend - rbeg),
+                                        a.k, a.k, dR, r);
+                if (ok) {
+                    const uint32_t bl = a.k - dR;
+                    const uint64_t want = (uint64_t)s + bl;
+                    const uint64_t lbeg = (idx - sg.sa > want) ? idx - want : sg.sa;
+                    ok = fz_big_expand<CPL>(pat + s - 1, -1, s, buf + (int64_t)(idx - a.geom.buf_off) - 1, -1, (uint32_t)(idx - lbeg),
+                                            a.k, bl, dL, l);
+                }
+                rec.l = l; rec.r = r; rec.dist = dL + dR;
+            }
+            if (ok && lane == 0) {
+                const unsigned long long slot = atomicAdd(&counters[1], 1ull);
+                rec.key = hit;
+                rec.aux = sg.j;
+                if (slot < a.rec_cap) recs[slot] = rec;
+            }
+        }
+    }
+    fz_finish_launch(a, counters, &flag);
+}
+
+// ---------------------------------------------------------------------------------------------
 // K4  fz_generic_kernel: the generic (mixed-limit) search's per-hit verification — the greedy
 // candidate-set automaton of generic_search.py:57-177 run on the window
 // seq[max(0, idx-s-k) : idx-s+m+k] of every exact n-gram hit (generic_search.py:222-237).
@@ -1125,7 +1306,7 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
                              : reinterpret_cast<FzGCand *>(smem + mpad + wpad);
     FzGCand *nxt = cur + a.cand_cap;
     uint64_t *mbuf = reinterpret_cast<uint64_t *>(smem + mpad + wpad + (HBM_LISTS ? 0u : 2u * a.cand_cap * (uint32_t)sizeof(FzGCand)));
-    for (uint32_t i = lane; i < a.m; i += 64u) pat[i] = a.pat[i];
+    for (uint32_t i = lane; i < a.m; i += 64u) pat[i] = fz_pat_byte(a, i);
     fz_wave_lds_sync();
     auto patf = [&](uint32_t i) -> uint8_t { return pat[i]; };
     constexpr bool per_hit = KIND == FZ_LP_GENERIC_HIT;
@@ -1352,9 +1533,11 @@ __global__ __launch_bounds__(256) void fz_gen_scatter_kernel(const uint64_t *__r
 __global__ __launch_bounds__(256) void fz_hamming_kernel(const uint8_t *__restrict__ buf, const FzScanArgs a,
                                                          FzRec *__restrict__ recs,
                                                          unsigned long long *__restrict__ counters) {
-    __shared__ uint8_t pat[FZ_MAX_M];
-    for (uint32_t i = threadIdx.x; i < a.m; i += blockDim.x) pat[i] = a.pat[i];
+    __shared__ uint8_t pat_s[FZ_MAX_M];
+    const bool in_lds = a.m <= FZ_MAX_M;                               // longer patterns are read from HBM (uniform address: one broadcast load)
+    if (in_lds) for (uint32_t i = threadIdx.x; i < a.m; i += blockDim.x) pat_s[i] = a.pat[i];
     __syncthreads();
+    const uint8_t *pat_g = reinterpret_cast<const uint8_t *>(a.pat_g);
     const uint64_t lo = a.geom.own_lo;
     uint64_t hi = a.geom.own_hi;                                       // starts i with i + m <= n
     if (a.geom.n < a.m) hi = lo;
@@ -1367,7 +1550,8 @@ __global__ __launch_bounds__(256) void fz_hamming_kernel(const uint8_t *__restri
         uint32_t d = 0;
         if (ok) {
             const uint8_t *t = buf + (i - a.geom.buf_off);
-            for (uint32_t q = 0; q < a.m && d <= a.k; ++q) d += (pat[q] != t[q]) ? 1u : 0u;
+            if (in_lds) { for (uint32_t q = 0; q < a.m && d <= a.k; ++q) d += (pat_s[q] != t[q]) ? 1u : 0u; }
+            else { for (uint32_t q = 0; q < a.m && d <= a.k; ++q) d += (pat_g[q] != t[q]) ? 1u : 0u; }
             ok = d <= a.k;
         }
         const unsigned long long mask = __ballot(ok);

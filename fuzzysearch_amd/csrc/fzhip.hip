@@ -125,6 +125,8 @@ struct DevState {
     uint64_t hit_cap_used = 0, rec_cap_used = 0;
     bool fused_used = false;
     double last_filter_ms = 0;                   // scan span of the search collected last on this device (fz_device_ms)
+    uint8_t *d_pat = nullptr;                    // pattern in HBM (subsequences longer than FZ_MAX_M, fz_verify_big_kernel)
+    uint64_t pat_cap = 0;
     int slot_id = 0;                             // which of the two result slots is the current one
     // RCCL (fz_comm_*): this device state is rank comm_rank of a communicator.  A search of such a context leaves
     // its counters + records in d_out; a device-to-device snapshot (d_send[slot], taken on the scan stream right
@@ -233,6 +235,7 @@ constexpr unsigned kCandScratchGrid = 256;        // workgroups of a launch that
 
 // LDS bytes and (if the lists do not fit LDS) the HBM scratch of one automaton launch.
 int cand_lists(DevState &d, uint32_t cand_cap, size_t fixed_lds, size_t &lds, uint64_t &scratch) {
+    if (fixed_lds > 150 * 1024) return fail(FZ_EUNSUPPORTED, "subsequence + window too long for the automaton kernel's LDS (%zu bytes)", fixed_lds);
     lds = fixed_lds + 2 * (size_t)cand_cap * sizeof(FzGCand);
     scratch = 0;
     const char *knob = getenv("FZ_CAND_LDS_MAX");              // test knob: force the HBM lists at small sizes
@@ -445,11 +448,58 @@ void fill_common_args(FzScanArgs &fa, const Shard &sh, const Search &q) {
     fa.max_subs = q.max_subs; fa.max_ins = q.max_ins; fa.max_dels = q.max_dels;
     fa.abs_lo = q.plan.abs_lo;
     fa.abs_hi = q.plan.abs_hi;
-    memcpy(fa.pat, q.p, q.m);
+    if (q.m <= FZ_MAX_M) memcpy(fa.pat, q.p, q.m);
+}
+
+// The pattern in HBM, for kernels that do not (or cannot) take it from the kernel-argument block.  The copy is
+// ordered on the device's stream like the kernels that read it (searches of one context run one after the other
+// on that stream, so two searches in flight can share the buffer).
+int stage_pattern(DevState &d, FzScanArgs &fa, const uint8_t *p, uint32_t m, bool force = false) {
+    fa.pat_g = 0;
+    if (m <= FZ_MAX_M && !force) return FZ_OK;
+    HIP_TRY(hipSetDevice(d.device));
+    if (d.pat_cap < m) {
+        HIP_TRY(hipStreamSynchronize(d.stream));
+        if (d.d_pat) { HIP_TRY(hipFree(d.d_pat)); d.d_pat = nullptr; d.pat_cap = 0; }
+        const uint64_t cap = std::max<uint64_t>(4096, (uint64_t)m * 2);
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d.d_pat), cap));
+        d.pat_cap = cap;
+    }
+    HIP_TRY(hipMemcpyAsync(d.d_pat, p, m, hipMemcpyHostToDevice, d.stream));
+    fa.pat_g = reinterpret_cast<uint64_t>(d.d_pat);
+    return FZ_OK;
 }
 
 // Lanes per candidate of the lane-per-cell verification: the 2k + 1 band cells of a row must fit.
 int wavefront_group(uint32_t k) { return 2 * k + 1 <= 16 ? 16 : 2 * k + 1 <= 32 ? 32 : 64; }
+
+// Which stand-alone verification a search takes when it is not fused into the scan: lane-per-cell with LDS windows
+// (Levenshtein budgets 5 .. 31), lane-per-candidate with an LDS score ring (everything else that fits LDS), or —
+// patterns beyond the argument block, budgets beyond FZ_MAX_K, windows / rings beyond LDS — one wave per hit straight
+// from HBM (fz_verify_big_kernel).
+struct VerifyPlan {
+    bool want_wf = false, big = false;
+    int gw = 16;
+    size_t wf_lds = 0, ring_lds = 0;
+    unsigned waves = 4;
+};
+
+VerifyPlan plan_verify(const Search &q) {
+    static const bool force_big = getenv("FZ_FORCE_BIG_VERIFY") != nullptr;     // test knob: every stand-alone verification by fz_verify_big_kernel
+    static const bool no_wf = getenv("FZ_NO_WAVEFRONT") != nullptr;
+    VerifyPlan v;
+    const uint32_t mpad = (q.m + 15u) & ~15u;
+    const uint32_t win_dwords = (q.m + 2 * q.k + 6) / 4 + 1;
+    const uint32_t band_w = q.mode == FZ_MODE_LEV ? 2 * q.k + 2 : 0;
+    v.gw = wavefront_group(q.k);
+    const uint32_t wf_per_wave = (64u / v.gw) * (win_dwords * 4u + 16u);       // one window per hit (at most 64 / gw hits per wave)
+    v.wf_lds = 16 + mpad + 16 + 16 * (size_t)wf_per_wave;                       // 16 waves per workgroup
+    while (v.waves > 1 && mpad + v.waves * (size_t)fz_wave_lds_bytes(win_dwords, band_w, 64, false) > 64 * 1024) v.waves >>= 1;
+    v.ring_lds = mpad + (size_t)v.waves * fz_wave_lds_bytes(win_dwords, band_w, 64, false);
+    v.want_wf = q.mode == FZ_MODE_LEV && q.k >= 5 && q.k <= 31 && !no_wf;
+    v.big = force_big || q.m > FZ_MAX_M || q.k > FZ_MAX_K || (v.want_wf ? v.wf_lds > 64 * 1024 : v.ring_lds > 160 * 1024);
+    return v;
+}
 
 // Enqueue scan (+ separate verify when it cannot be fused) for one shard on its device stream.
 // No host synchronisation.
@@ -490,6 +540,12 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
 
     FzScanArgs fa;
     fill_common_args(fa, sh, q);
+    static const bool force_big = getenv("FZ_FORCE_BIG_VERIFY") != nullptr;
+    const VerifyPlan vp = plan_verify(q);
+    {
+        int rc = stage_pattern(d, fa, q.p, q.m, with_verify && vp.big);
+        if (rc) return rc;
+    }
     const HashGeom hgeom(L);
     const int nwin = hgeom.nwin, dh = hgeom.dh;
     fa.d2 = nwin == 2 ? std::min<uint32_t>(L, 8) - 4 : 0;
@@ -522,8 +578,10 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
         fused_lds = mpad + FZ_TABLE_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, fa.vlanes, true);
     }
     // k > 4 (register band too wide for the scan kernel's VGPR budget) -> verify in a kernel of its own
-    fa.fused = (with_verify && fused_lds <= kFusedLdsBudget && (q.mode != FZ_MODE_LEV || q.k <= 4)) ? 1u : 0u;
-    const uint32_t scan_lds = fa.fused ? fused_lds : mpad + FZ_TABLE_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(0, 0, 64, true);
+    fa.fused = (with_verify && !force_big && q.m <= FZ_MAX_M && q.k <= FZ_MAX_K && fused_lds <= kFusedLdsBudget &&
+                (q.mode != FZ_MODE_LEV || q.k <= 4)) ? 1u : 0u;
+    // (the hit-emitting form keeps no pattern in LDS: fz_confirm reads it from the argument block / HBM)
+    const uint32_t scan_lds = fa.fused ? fused_lds : FZ_TABLE_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(0, 0, 64, true);
 
     uint32_t launches = 0;
     for (uint32_t g0 = 0; g0 < G && ntiles > 0;) {
@@ -571,30 +629,35 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
         fa.nblk = 0;
         fa.g0 = 0;
         fa.host_hdr = direct ? reinterpret_cast<uint64_t>(d.h_stage_dev) : 0;
-        static const bool no_wf = getenv("FZ_NO_WAVEFRONT") != nullptr;
-        if (q.mode == FZ_MODE_LEV && q.k >= 5 && q.k <= 31 && !no_wf) {
+        const int gw = vp.gw;
+        const size_t wf_lds = vp.wf_lds, ring_lds = vp.ring_lds;
+        const unsigned waves = vp.waves;
+        const bool want_wf = vp.want_wf, big = vp.big;
+        if (big) {
+            if (!fa.pat_g) return fail(FZ_EDEVICE, "internal: the pattern was not staged for the big verification");
+            const uint32_t cells = q.mode == FZ_MODE_LEV ? 2 * q.k + 1 : 1;
+            const dim3 bgrid(d.n_cus * 32), bblock(64);
+            if (cells <= 64) hipLaunchKernelGGL(fz_verify_big_kernel<1>, bgrid, bblock, 0, d.stream, sh.d_buf, fa, d.d_hits, recs, counters);
+            else if (cells <= 128) hipLaunchKernelGGL(fz_verify_big_kernel<2>, bgrid, bblock, 0, d.stream, sh.d_buf, fa, d.d_hits, recs, counters);
+            else if (cells <= 256) hipLaunchKernelGGL(fz_verify_big_kernel<4>, bgrid, bblock, 0, d.stream, sh.d_buf, fa, d.d_hits, recs, counters);
+            else if (cells <= 512) hipLaunchKernelGGL(fz_verify_big_kernel<8>, bgrid, bblock, 0, d.stream, sh.d_buf, fa, d.d_hits, recs, counters);
+            else if (cells <= 1024) hipLaunchKernelGGL(fz_verify_big_kernel<16>, bgrid, bblock, 0, d.stream, sh.d_buf, fa, d.d_hits, recs, counters);
+            else hipLaunchKernelGGL(fz_verify_big_kernel<32>, bgrid, bblock, 0, d.stream, sh.d_buf, fa, d.d_hits, recs, counters);
+        } else if (want_wf) {
             // lane-per-cell: 64 / gw candidates per wave, one contiguous byte window per candidate
-            const int gw = wavefront_group(q.k);
             fa.gw = (uint32_t)gw;
-            const uint32_t per_wave = (64u / gw) * (fa.win_dwords * 4u + 16u);     // one window per hit (at most 64 / gw hits per wave)
             // 16 waves per workgroup: few workgroups = few finish tickets (every ticket is an atomic on one word)
-            const size_t lds = 16 + mpad + 16 + 16 * per_wave;
-            if (lds > 64 * 1024) return fail(FZ_EUNSUPPORTED, "pattern too long for the verify kernel (m=%u, k=%u)", q.m, q.k);
             const dim3 vgrid(d.n_cus * 2), vblock(1024);
-            if (gw == 16) hipLaunchKernelGGL(fz_verify_wf_kernel<16>, vgrid, vblock, lds, d.stream, sh.d_buf, fa, d.d_hits, recs, counters);
-            else if (gw == 32) hipLaunchKernelGGL(fz_verify_wf_kernel<32>, vgrid, vblock, lds, d.stream, sh.d_buf, fa, d.d_hits, recs, counters);
-            else hipLaunchKernelGGL(fz_verify_wf_kernel<64>, vgrid, vblock, lds, d.stream, sh.d_buf, fa, d.d_hits, recs, counters);
+            if (gw == 16) hipLaunchKernelGGL(fz_verify_wf_kernel<16>, vgrid, vblock, wf_lds, d.stream, sh.d_buf, fa, d.d_hits, recs, counters);
+            else if (gw == 32) hipLaunchKernelGGL(fz_verify_wf_kernel<32>, vgrid, vblock, wf_lds, d.stream, sh.d_buf, fa, d.d_hits, recs, counters);
+            else hipLaunchKernelGGL(fz_verify_wf_kernel<64>, vgrid, vblock, wf_lds, d.stream, sh.d_buf, fa, d.d_hits, recs, counters);
         } else {
-            // LDS: pattern + per-wave window and score ring; shrink the block until it fits.
-            unsigned waves = 4;
+            // LDS: pattern + per-wave window and score ring; the block was shrunk until it fits.
             fa.vlanes = 64;
-            while (waves > 1 && mpad + waves * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, 64, false) > 64 * 1024) waves >>= 1;
-            const size_t lds = mpad + (size_t)waves * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, 64, false);
-            if (lds > 160 * 1024) return fail(FZ_EUNSUPPORTED, "pattern/budget too large for the verify kernel (m=%u, k=%u)", q.m, q.k);
-            if (lds > 64 * 1024)
+            if (ring_lds > 64 * 1024)
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fz_verify_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(fz_verify_kernel, dim3(d.n_cus * 4), dim3(64 * waves), lds, d.stream, sh.d_buf, fa, d.d_hits, recs,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_lds));
+            hipLaunchKernelGGL(fz_verify_kernel, dim3(d.n_cus * 4), dim3(64 * waves), ring_lds, d.stream, sh.d_buf, fa, d.d_hits, recs,
                                counters);
         }
         HIP_TRY(hipGetLastError());
@@ -866,6 +929,8 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             if (rc) return rc;
             FzScanArgs fa;
             fill_common_args(fa, sh, q);
+            rc = stage_pattern(d, fa, q.p, q.m);
+            if (rc) return rc;
             fa.cand_cap = cand_cap;
             fa.cand_scratch = scratch;
             fa.lp_kind = FZ_LP_GENERIC_HIT;
@@ -1012,7 +1077,7 @@ int validate(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, bool in_pip
     if (ctx->npend && !in_pipeline) return fail(FZ_EINVAL, "a search started with fz_lev_ngrams_begin is still in flight");
     if (ctx->stream_inflight) return fail(FZ_EINVAL, "a file stream of this context has a batch in flight (finish or close it first)");
     if (!p || m == 0) return fail(FZ_EINVAL, "subsequence must not be empty");
-    if (m > FZ_MAX_M) return fail(FZ_EUNSUPPORTED, "subsequence longer than %d bytes", FZ_MAX_M);
+    if (m > FZ_MAX_M_ANY) return fail(FZ_EUNSUPPORTED, "subsequence longer than %u bytes", FZ_MAX_M_ANY);
     return FZ_OK;
 }
 
@@ -1236,6 +1301,7 @@ void fz_destroy(fz_ctx *ctx) {
         for (auto &ev : d.other.ev) if (ev) (void)hipEventDestroy(ev);
         if (d.h_big) (void)hipHostFree(d.h_big);
         if (d.d_cand) (void)hipFree(d.d_cand);
+        if (d.d_pat) (void)hipFree(d.d_pat);
         if (d.d_gen_order) (void)hipFree(d.d_gen_order);
         if (d.d_gen_rows) (void)hipFree(d.d_gen_rows);
         for (int i = 0; i < 2; ++i) if (d.stream_h[i]) (void)hipHostFree(d.stream_h[i]);
@@ -1281,7 +1347,7 @@ int fz_seq_upload(fz_ctx *ctx, const uint8_t *host, uint64_t n, fz_seq **out) {
     seq->ctx = ctx;
     seq->n = n;
     const uint64_t R = ctx->devs.size();
-    const uint64_t halo = 2 * FZ_MAX_M + 64;          // >= m + k for every supported query
+    const uint64_t halo = 2 * (uint64_t)FZ_MAX_M_ANY + 2 * FZ_MAX_K_ANY + 64;   // >= m + k for every supported query
     for (uint64_t r = 0; r < R; ++r) {
         FzGeom g{};
         g.n = n;
@@ -1452,14 +1518,14 @@ static int lev_plan(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint
     if (rc) return rc;
     const uint32_t L = m / (k + 1);
     if (L == 0) return fail(FZ_EINVAL, "the subsequence length must be greater than max_l_dist");
-    if (k > FZ_MAX_K) return fail(FZ_EUNSUPPORTED, "max_l_dist above %d is not supported by the verify kernels", FZ_MAX_K);
+    if (k > FZ_MAX_K_ANY) return fail(FZ_EUNSUPPORTED, "max_l_dist above %u is not supported by the verify kernels", FZ_MAX_K_ANY);
     rc = check_halo(seq, (uint64_t)m + k);
     if (rc) return rc;
     q.mode = FZ_MODE_LEV; q.m = m; q.k = k; q.p = p;
     q.collective = ctx->snapshot;
     q.plan.L = L;
     for (uint32_t s = 0; s + L <= m; s += L) q.plan.s.push_back(s);   // levenshtein_ngram.py:171-176 (ranges: fz_block_range)
-    if (q.plan.s.size() > 255) return fail(FZ_EUNSUPPORTED, "more than 255 n-gram blocks");
+    if (q.plan.s.size() > FZ_MAX_BLOCKS) return fail(FZ_EUNSUPPORTED, "more than %u n-gram blocks", FZ_MAX_BLOCKS);
     return FZ_OK;
 }
 
@@ -1553,7 +1619,7 @@ int fz_subs_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint3
     q.mode = FZ_MODE_SUBS; q.m = m; q.k = k; q.p = p;
     q.plan.L = L;
     for (uint32_t s = 0; s + L <= m; s += L) q.plan.s.push_back(s);   // template :92-101 (ranges: fz_block_range)
-    if (q.plan.s.size() > 255) return fail(FZ_EUNSUPPORTED, "more than 255 n-gram blocks");
+    if (q.plan.s.size() > FZ_MAX_BLOCKS) return fail(FZ_EUNSUPPORTED, "more than %u n-gram blocks", FZ_MAX_BLOCKS);
     std::vector<FzRec> recs;
     std::vector<uint64_t> hits;
     rc = run_search(ctx, seq, q, true, recs, hits);
@@ -1578,7 +1644,7 @@ int fz_generic_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, ui
     q.max_subs = std::min(max_subs, 255u); q.max_ins = std::min(max_ins, 255u); q.max_dels = std::min(max_dels, 255u);
     q.plan.L = L;
     for (uint32_t s = 0; s + L <= m; s += L) q.plan.s.push_back(s);   // generic_search.py:221-228 (ranges: fz_block_range)
-    if (q.plan.s.size() > 255) return fail(FZ_EUNSUPPORTED, "more than 255 n-gram blocks");
+    if (q.plan.s.size() > FZ_MAX_BLOCKS) return fail(FZ_EUNSUPPORTED, "more than %u n-gram blocks", FZ_MAX_BLOCKS);
     std::vector<FzGenRec> recs_vec;
     Trace tr;
     rc = run_generic(ctx, seq, q, recs_vec);
@@ -1868,7 +1934,8 @@ int run_lp(fz_ctx *ctx, fz_seq *seq, const Search &q, uint32_t lp_kind, std::vec
             fa.lp_kind = lp_kind;
             fa.lp_starts = kLpStarts;
             fa.rec_cap = d.rec_cap;
-            memcpy(fa.pat, q.p, q.m);
+            if (q.m <= FZ_MAX_M) memcpy(fa.pat, q.p, q.m);
+            { int rcp = stage_pattern(d, fa, q.p, q.m); if (rcp) return rcp; }
             const uint64_t own = sh.geom.own_hi - sh.geom.own_lo;
             const uint64_t nwin = (own + kLpStarts - 1) / kLpStarts;
             if (lds > 64 * 1024)
@@ -2012,7 +2079,9 @@ extern "C" int fz_subs_lp(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m
             FzScanArgs fa;
             memset(&fa, 0, sizeof fa);
             fa.geom = sh.geom; fa.mode = FZ_MODE_SUBS; fa.m = m; fa.k = k; fa.rec_cap = d.rec_cap;
-            memcpy(fa.pat, p, m);
+            if (m <= FZ_MAX_M) memcpy(fa.pat, p, m);
+            rc = stage_pattern(d, fa, p, m);
+            if (rc) return rc;
             const uint64_t own = sh.geom.own_hi - sh.geom.own_lo;
             const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((own + 255) / 256, (uint64_t)d.n_cus * 16));
             hipLaunchKernelGGL(fz_hamming_kernel, dim3(grid), dim3(256), 0, d.stream, sh.d_buf, fa, drecs, counters);
@@ -2109,7 +2178,7 @@ int stream_build_search(fz_stream *st) {
     if (L == 0) return fail(FZ_EINVAL, "the subsequence length must be greater than the distance limit");
     q.plan.L = L;
     for (uint32_t s = 0; s + L <= st->m; s += L) q.plan.s.push_back(s);
-    if (q.plan.s.size() > 255) return fail(FZ_EUNSUPPORTED, "more than 255 n-gram blocks");
+    if (q.plan.s.size() > FZ_MAX_BLOCKS) return fail(FZ_EUNSUPPORTED, "more than %u n-gram blocks", FZ_MAX_BLOCKS);
     return FZ_OK;
 }
 
@@ -2231,9 +2300,9 @@ int fz_stream_open(fz_ctx *ctx, uint32_t mode, const uint8_t *p, uint32_t m, uin
     if (ctx->devs.size() != 1) return fail(FZ_EUNSUPPORTED, "file streams run on a single-device context");
     if (ctx->npend || ctx->stream_inflight) return fail(FZ_EINVAL, "another search of this context is in flight");
     if (!p || m == 0) return fail(FZ_EINVAL, "subsequence must not be empty");
-    if (m > FZ_MAX_M) return fail(FZ_EUNSUPPORTED, "subsequence longer than %d bytes", FZ_MAX_M);
-    if (k > FZ_MAX_K) return fail(FZ_EUNSUPPORTED, "distance limit above %d is not supported", FZ_MAX_K);
+    if (m > FZ_MAX_M_ANY) return fail(FZ_EUNSUPPORTED, "subsequence longer than %u bytes", FZ_MAX_M_ANY);
     if (mode > FZ_MODE_GENERIC) return fail(FZ_EINVAL, "bad mode");
+    if (k > (mode == FZ_MODE_GENERIC ? (uint32_t)FZ_MAX_K : FZ_MAX_K_ANY)) return fail(FZ_EUNSUPPORTED, "distance limit %u is not supported", k);
     if (seg_stride == 0 || (seg_pre && seg_post)) return fail(FZ_EINVAL, "bad segment geometry");
     // a position may lie in at most two segments, and a chunk must hold a whole pattern window with its reach
     if ((uint64_t)seg_pre + seg_post > seg_stride / 2 || (uint64_t)m + 2ull * k + 2 > seg_stride)

@@ -1,0 +1,95 @@
+"""Random GPU-vs-oracle cases that also run in a SUBPROCESS (`python -m tests.gpu_cases <what> ...`): several switches
+of the library are process-wide statics read from the environment (FZ_FORCE_BIG_VERIFY, FZ_NO_SLOT_AND,
+FZ_MAX_BLOCKS), so a test that wants them set starts a fresh interpreter.  Prints "OK <n cases> <n records>"."""
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def edited(rnd, p, n_edits, alpha):
+    v = bytearray(p)
+    for _ in range(n_edits):
+        q = rnd.randrange(len(v))
+        op = rnd.random()
+        if op < 0.4:
+            v[q] = rnd.choice(alpha)
+        elif op < 0.7 and len(v) > 2:
+            del v[q]
+        else:
+            v.insert(q, rnd.choice(alpha))
+    return bytes(v)
+
+
+def random_cases(rnd, n_cases, ks, max_m, max_n):
+    """(pattern, text, k) with planted edited copies at ragged positions (both ends included)."""
+    out = []
+    while len(out) < n_cases:
+        alpha = bytes(rnd.sample(range(1, 256), rnd.choice([2, 3, 4, 4, 20, 200])))
+        k = rnd.choice(ks)
+        m = rnd.randint(k + 1, max(k + 1, min(max_m, rnd.choice([8, 24, 64, max_m]))))
+        n = rnd.randint(0, max_n)
+        t = bytearray(rnd.choice(alpha) for _ in range(n))
+        p = bytes(rnd.choice(alpha) for _ in range(m))
+        for _rep in range(3):
+            if n > m + 10 and rnd.random() < 0.8:
+                v = edited(rnd, p, rnd.randint(0, k), alpha)
+                st = rnd.choice([0, 1, n - len(v) - 1, n - len(v), rnd.randint(0, max(0, n - len(v)))])
+                st = max(0, min(st, n - len(v)))
+                t[st:st + len(v)] = v
+        if len(p) // (k + 1) == 0:
+            continue
+        out.append((p, bytes(t), k))
+    return out
+
+
+def run_lev_subs(engine, cases):
+    import oracle
+    n_rec = 0
+    for (p, t, k) in cases:
+        h = engine.upload(t)
+        got = engine.lev_ngrams(h, p, k)
+        assert got == oracle.lev_ngrams_raw(p, t, k), ("lev", p, t, k)
+        n_rec += len(got)
+        got = engine.subs_ngrams(h, p, k)
+        assert got == oracle.subs_ngrams_raw(p, t, k), ("subs", p, t, k)
+        n_rec += len(got)
+        h.release()
+    return n_rec
+
+
+def main(argv):
+    from fuzzysearch_amd import _native
+    what = argv[0]
+    eng = _native.Engine([0])
+    rnd = random.Random(int(argv[2]) if len(argv) > 2 else 5)
+    n = int(argv[1]) if len(argv) > 1 else 300
+    if what == "big":
+        # FZ_FORCE_BIG_VERIFY=1: every verification by fz_verify_big_kernel — small budgets (one cell per lane) up to
+        # wide ones (CPL 2, 4), short and long pieces, segment ends
+        cases = random_cases(rnd, n, [1, 2, 3, 5, 8, 12, 31, 32, 40, 70, 100], 260, 700)
+    elif what == "slots":
+        # FZ_NO_SLOT_AND=1 (the general slot form of the filter) and FZ_MAX_BLOCKS (several launches per search)
+        cases = random_cases(rnd, n, [1, 2, 3, 4, 5, 7], 120, 3000)
+        import numpy as np
+        from tests import workloads
+        seq = workloads.dna(4 << 20, 31)
+        pat = workloads.dna(20, 1)
+        workloads.plant_variants(seq, pat, 256, 3)
+        cases.append((pat.tobytes(), seq.tobytes(), 2))
+        seq = workloads.text65(2 << 20, 32)
+        pat = workloads.text65(36, 2)
+        workloads.plant_edits(seq, pat, 128, 4, workloads.TEXT65, lambda i: i % 4)
+        cases.append((pat.tobytes(), seq.tobytes(), 3))
+    else:
+        raise SystemExit("unknown case set %r" % what)
+    n_rec = run_lev_subs(eng, cases)
+    eng.close()
+    print("OK %d %d" % (len(cases), n_rec))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
