@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = (
     "fz_abi_version", "fz_last_error", "fz_device_count", "fz_create", "fz_destroy",
     "fz_seq_upload", "fz_seq_upload_shard", "fz_seq_new", "fz_seq_add_shard", "fz_seq_len", "fz_seq_release",
     "fz_search_exact", "fz_lev_ngrams", "fz_lev_ngrams_begin", "fz_lev_ngrams_end", "fz_subs_ngrams", "fz_generic_ngrams",
-    "fz_lev_lp", "fz_subs_lp", "fz_generic_lp",
+    "fz_lev_lp", "fz_subs_lp", "fz_generic_lp", "fz_subs_ngrams_any", "fz_subs_lp_any", "fz_generic_ngrams_any",
     "fz_stream_open", "fz_stream_buffer", "fz_stream_submit", "fz_stream_read_fd", "fz_stream_finish", "fz_stream_close",
     "fz_consolidate", "fz_group_best", "fz_merge_ranks", "fz_wire_pack", "fz_wire_merge", "fz_debug_launch_plan", "fz_stats", "fz_device_ms", "fz_free",
     "fz_comm_unique_id", "fz_comm_init_rank", "fz_comm_init_all", "fz_comm_info", "fz_comm_set_collective",
@@ -122,6 +122,12 @@ def load_library():
         L.fz_subs_lp.argtypes = [vp, vp, u8p, u32, u32, mpp, u64p]
         L.fz_generic_lp.restype = ci
         L.fz_generic_lp.argtypes = [vp, vp, u8p, u32, u32, u32, u32, u32, mpp, u64p]
+        L.fz_subs_ngrams_any.restype = ci
+        L.fz_subs_ngrams_any.argtypes = [vp, vp, u8p, u32, u32, ctypes.POINTER(ci)]
+        L.fz_subs_lp_any.restype = ci
+        L.fz_subs_lp_any.argtypes = [vp, vp, u8p, u32, u32, ctypes.POINTER(ci)]
+        L.fz_generic_ngrams_any.restype = ci
+        L.fz_generic_ngrams_any.argtypes = [vp, vp, u8p, u32, u32, u32, u32, u32, ctypes.POINTER(ci)]
         L.fz_stream_open.restype = ci
         L.fz_stream_open.argtypes = [vp, u32, u8p, u32, u32, u32, u32, u32, u64, u32, u32, u64, ctypes.POINTER(vp)]
         L.fz_stream_buffer.restype = ci
@@ -529,7 +535,9 @@ class Engine(object):
                 self._lib.fz_comm_destroy(self._h)
 
     # -- searches (raw streams, tuples (start, end, dist, block)) ------------------------------
-    def search_exact(self, seq, pattern, lo=0, hi=None):
+    def search_exact(self, seq, pattern, lo=0, hi=None, as_array=False):
+        """Ascending start indices of every occurrence: a list of ints, or (as_array=True) a numpy int64 array."""
+        import numpy as np
         paddr, m, keep = _buffer_address(pattern)
         ptr = ctypes.POINTER(ctypes.c_uint64)()
         cnt = ctypes.c_uint64(0)
@@ -537,9 +545,12 @@ class Engine(object):
             _check(self._lib.fz_search_exact(self._h, seq._h, paddr, m, max(0, lo),
                                              UINT64_MAX if hi is None else max(0, hi),
                                              ctypes.byref(ptr), ctypes.byref(cnt)))
-        out = list(ptr[:cnt.value])
+        n = cnt.value
+        arr = np.empty(n, dtype=np.int64)
+        if n:
+            ctypes.memmove(arr.ctypes.data, ptr, 8 * n)
         self._lib.fz_free(ptr)
-        return out
+        return arr if as_array else arr.tolist()
 
     def _match_call(self, fn, seq, pattern, *ints, **kw):
         if type(pattern) is bytes:                 # ctypes passes a bytes object as a pointer to its buffer
@@ -597,6 +608,24 @@ class Engine(object):
     def generic_lp(self, seq, pattern, max_subs, max_ins, max_dels, max_l, as_array=False):
         return self._match_call(self._lib.fz_generic_lp, seq, pattern, max_subs, max_ins, max_dels, max_l,
                                 as_array=as_array)
+
+    def _any_call(self, fn, seq, pattern, *ints):
+        paddr, m, keep = _buffer_address(pattern)
+        found = ctypes.c_int(0)
+        with self._lock:
+            _check(fn(self._h, seq._h, paddr, m, *ints, ctypes.byref(found)))
+        del keep
+        return bool(found.value)
+
+    def subs_ngrams_any(self, seq, pattern, k):
+        """has_near_match_substitutions_ngrams: is the raw stream of subs_ngrams non-empty? (flag only, early exit)"""
+        return self._any_call(self._lib.fz_subs_ngrams_any, seq, pattern, k)
+
+    def subs_lp_any(self, seq, pattern, k):
+        return self._any_call(self._lib.fz_subs_lp_any, seq, pattern, k)
+
+    def generic_ngrams_any(self, seq, pattern, max_subs, max_ins, max_dels, max_l):
+        return self._any_call(self._lib.fz_generic_ngrams_any, seq, pattern, max_subs, max_ins, max_dels, max_l)
 
     def stats(self):
         st = FzStats()

@@ -60,6 +60,8 @@
                                                            // + the four waves' final queue fills (pooled last flush)
                                                            // (same byte offset as the hash: no address arithmetic in the rare path)
 #define FZ_FLAG_DUP_HASHES 1u                              // FzScanArgs.flags: two blocks of the launch have the same hash
+#define FZ_FLAG_ANY 2u                                     // has_near_match_*: the caller only asks WHETHER a record exists — work that starts
+                                                           // after the first record has been counted is skipped
 #if FZ_LUT_BITS == 5
 #define FZ_LUT_ADDR_MASK_STR "0x7c"                        // (FZ_LUT_SLOTS - 1) * 4: byte address of a slot
 #else
@@ -656,6 +658,9 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
     uint32_t confirmed = 0;                           // wave-uniform statistics
     uint32_t titer = 0;                               // tile iteration of this workgroup
     uint64_t tile = blockIdx.x;
+    // has_near_match_* (substitutions_only.py:218-233 stops at the first match): a workgroup that starts after a record
+    // has been counted skips its tiles (thousands of short workgroups per launch: the ones not yet started are the saving)
+    if ((a.flags & FZ_FLAG_ANY) && __hip_atomic_load(&counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) tile = ntiles;
     bool slow = false;                                // a tile is being re-scanned by enumeration
     uint32_t slow_pos = 0;
 
@@ -1320,6 +1325,7 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
     unsigned long long *order_first = reinterpret_cast<unsigned long long *>(a.gen_order);
     uint32_t *order_count = reinterpret_cast<uint32_t *>(order_first + FZ_GEN_ORDER_MAX);
     for (uint64_t qc = blockIdx.x; qc < nitems * ncand; qc += gridDim.x) {
+        if ((a.flags & FZ_FLAG_ANY) && __hip_atomic_load(&counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;   // has_near_match_*
         const uint64_t q = qc / ncand;
         uint64_t key_base, w0, w1;
         uint32_t spawn_len, seg_j = 0;
@@ -1545,6 +1551,7 @@ __global__ __launch_bounds__(256) void fz_hamming_kernel(const uint8_t *__restri
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t span = hi > lo ? hi - lo : 0;
     for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < span; base += stride) {
+        if ((a.flags & FZ_FLAG_ANY) && __hip_atomic_load(&counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;   // has_near_match_*
         const uint64_t i = lo + base + threadIdx.x;
         bool ok = base + threadIdx.x < span;
         uint32_t d = 0;

@@ -205,6 +205,7 @@ struct fz_ctx {
     std::vector<fz_seq *> live;
     // RCCL: number of ranks of the communicator this context joined (0: none) and whether its Levenshtein n-gram
     // searches are collective (every rank gets the merged global stream)
+    bool any_found = false;                      // result of the last has_near_match_* (fz_*_any) search
     int comm_world = 0;
     bool snapshot = false;
     uint64_t gcap = 4096;                        // records per rank the all-gather carries (follows the counts, on all ranks alike)
@@ -433,6 +434,7 @@ struct Search {
     const uint8_t *p = nullptr;
     BlockPlan plan;
     bool collective = false;       // the context joined a communicator: every rank gets the merged stream of all ranks
+    bool any = false;              // has_near_match_*: only whether a record exists
 };
 
 static const uint32_t kFusedLdsBudget = []() { const char *e = getenv("FZ_FUSED_LDS_KB"); int v = e ? atoi(e) : 0; return (uint32_t)(v > 0 ? v : 64) * 1024u; }();   // dynamic LDS per scan workgroup when verification is fused
@@ -606,7 +608,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
         const bool verify_follows = with_verify && !fa.fused;
         fa.host_hdr = (direct && !verify_follows && g0 + nblk >= G) ? reinterpret_cast<uint64_t>(d.h_stage_dev) : 0;
         // equal n-grams (equal hashes) share a table slot: the rare path then compares with every block
-        fa.flags = 0;
+        fa.flags = q.any ? FZ_FLAG_ANY : 0u;
         for (uint32_t b = 1; b < nblk; ++b)
             for (uint32_t c = 0; c < b; ++c)
                 if (fa.H[b] == fa.H[c]) fa.flags |= FZ_FLAG_DUP_HASHES;
@@ -910,6 +912,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
     uint32_t cand_cap = ctx->gen_cand_cap;
     for (int attempt = 0; attempt < 9; ++attempt) {
         recs_out.clear();
+        ctx->any_found = false;
         ctx->gen_view = nullptr;
         ctx->gen_view_n = 0;
         ctx->gen_rows_dev = nullptr;
@@ -931,6 +934,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             fill_common_args(fa, sh, q);
             rc = stage_pattern(d, fa, q.p, q.m);
             if (rc) return rc;
+            fa.flags = q.any ? FZ_FLAG_ANY : 0u;
             fa.cand_cap = cand_cap;
             fa.cand_scratch = scratch;
             fa.lp_kind = FZ_LP_GENERIC_HIT;
@@ -948,7 +952,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             // keeps the host's run ordering (emit_generic), which also serves searches with more than
             // FZ_GEN_ORDER_MAX hits, several shards and the file API's segments.
             static const bool host_order = getenv("FZ_GEN_HOST_ORDER") != nullptr;
-            const bool dev_order = !gen_direct && !host_order && seq->shards.size() == 1 && sh.geom.seg_stride == 0;
+            const bool dev_order = !gen_direct && !host_order && !q.any && seq->shards.size() == 1 && sh.geom.seg_stride == 0;
             if (dev_order) {
                 rc = ensure_gen_rows(d);
                 if (rc) return rc;
@@ -989,6 +993,15 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             trg.mark(" generic sync");
             const unsigned long long *cnt = reinterpret_cast<const unsigned long long *>(d.h_stage);
             const uint64_t nh = cnt[0], nr = cnt[1], novf = cnt[2];
+            if (q.any) {                                      // has_near_match_generic_ngrams: a record anywhere settles it
+                ctx->any_found |= nr > 0;
+                if (nr > 0) continue;
+                if (nh > d.hit_cap) { int rc = ensure_hits(d, nh + nh / 8 + 1024); if (rc) return rc; rerun = true; }
+                if (novf) { lists_overflowed = true; rerun = true; }
+                ctx->stats.bytes_scanned += sh.geom.buf_len;
+                ctx->stats.ngram_hits += nh;
+                continue;
+            }
             static const bool gen_direct2 = getenv("FZ_GEN_DIRECT") != nullptr;
             if (nh > d.hit_cap) { int rc = ensure_hits(d, nh + nh / 8 + 1024); if (rc) return rc; rerun = true; }
             if (nr > d.big_cap) { int rc = ensure_big(d, nr + nr / 8 + 1024); if (rc) return rc; if (gen_direct2) rerun = true; }
@@ -1023,6 +1036,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             }
         }
         if (lists_overflowed) cand_cap *= 4;
+        if (q.any && ctx->any_found) return FZ_OK;
         if (!rerun) {
             ctx->gen_cand_cap = std::min<uint32_t>(cand_cap, kCandLdsMax);   // remember what worked, never the HBM fallback
             return FZ_OK;
@@ -1604,9 +1618,7 @@ int fz_lev_ngrams_end(fz_ctx *ctx, fz_match **out, uint64_t *n) {
     return rc;
 }
 
-int fz_subs_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, fz_match **out, uint64_t *n) {
-    if (!out || !n) return fail(FZ_EINVAL, "null argument");
-    *out = nullptr; *n = 0;
+static int subs_ngrams_impl(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, fz_match **out, uint64_t *n, int *found) {
     int rc = validate(ctx, seq, p, m);
     if (rc) return rc;
     const uint32_t L = m / (k + 1);
@@ -1617,6 +1629,7 @@ int fz_subs_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint3
     if (N < m) return FZ_OK;                                   // template :66-68
     Search q;
     q.mode = FZ_MODE_SUBS; q.m = m; q.k = k; q.p = p;
+    q.any = found != nullptr;
     q.plan.L = L;
     for (uint32_t s = 0; s + L <= m; s += L) q.plan.s.push_back(s);   // template :92-101 (ranges: fz_block_range)
     if (q.plan.s.size() > FZ_MAX_BLOCKS) return fail(FZ_EUNSUPPORTED, "more than %u n-gram blocks", FZ_MAX_BLOCKS);
@@ -1624,13 +1637,41 @@ int fz_subs_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint3
     std::vector<uint64_t> hits;
     rc = run_search(ctx, seq, q, true, recs, hits);
     if (rc) return rc;
+    if (found) { *found = (ctx->view ? ctx->view_n : (uint64_t)recs.size()) > 0 ? 1 : 0; return FZ_OK; }
     return emit_matches(ctx, recs, L, out, n);
 }
+
+int fz_subs_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, fz_match **out, uint64_t *n) {
+    if (!out || !n) return fail(FZ_EINVAL, "null argument");
+    *out = nullptr; *n = 0;
+    return subs_ngrams_impl(ctx, seq, p, m, k, out, n, nullptr);
+}
+
+int fz_subs_ngrams_any(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, int *found) {
+    if (!found) return fail(FZ_EINVAL, "null argument");
+    *found = 0;
+    return subs_ngrams_impl(ctx, seq, p, m, k, nullptr, nullptr, found);
+}
+
+static int generic_ngrams_impl(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t max_subs, uint32_t max_ins,
+                               uint32_t max_dels, uint32_t max_l, fz_match **out, uint64_t *n, int *found);
 
 int fz_generic_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t max_subs, uint32_t max_ins,
                       uint32_t max_dels, uint32_t max_l, fz_match **out, uint64_t *n) {
     if (!out || !n) return fail(FZ_EINVAL, "null argument");
     *out = nullptr; *n = 0;
+    return generic_ngrams_impl(ctx, seq, p, m, max_subs, max_ins, max_dels, max_l, out, n, nullptr);
+}
+
+int fz_generic_ngrams_any(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t max_subs, uint32_t max_ins,
+                          uint32_t max_dels, uint32_t max_l, int *found) {
+    if (!found) return fail(FZ_EINVAL, "null argument");
+    *found = 0;
+    return generic_ngrams_impl(ctx, seq, p, m, max_subs, max_ins, max_dels, max_l, nullptr, nullptr, found);
+}
+
+static int generic_ngrams_impl(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t max_subs, uint32_t max_ins,
+                               uint32_t max_dels, uint32_t max_l, fz_match **out, uint64_t *n, int *found) {
     int rc = validate(ctx, seq, p, m);
     if (rc) return rc;
     const uint32_t k = max_l;
@@ -1641,6 +1682,7 @@ int fz_generic_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, ui
     if (rc) return rc;
     Search q;
     q.mode = FZ_MODE_GENERIC; q.m = m; q.k = k; q.p = p;
+    q.any = found != nullptr;
     q.max_subs = std::min(max_subs, 255u); q.max_ins = std::min(max_ins, 255u); q.max_dels = std::min(max_dels, 255u);
     q.plan.L = L;
     for (uint32_t s = 0; s + L <= m; s += L) q.plan.s.push_back(s);   // generic_search.py:221-228 (ranges: fz_block_range)
@@ -1650,6 +1692,7 @@ int fz_generic_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, ui
     rc = run_generic(ctx, seq, q, recs_vec);
     if (rc) return rc;
     tr.mark("generic: kernels");
+    if (found) { *found = ctx->any_found ? 1 : 0; return FZ_OK; }
     rc = emit_generic(ctx, seq, recs_vec, L, k, out, n, nullptr);
     tr.mark("generic: rows");
     return rc;
@@ -2056,9 +2099,21 @@ extern "C" int fz_generic_lp(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_
     return emit_lp(recs, /*newest_first=*/false, out, n);
 }
 
+static int subs_lp_impl(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, fz_match **out, uint64_t *n, int *found);
+
 extern "C" int fz_subs_lp(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, fz_match **out, uint64_t *n) {
     if (!out || !n) return fail(FZ_EINVAL, "null argument");
     *out = nullptr; *n = 0;
+    return subs_lp_impl(ctx, seq, p, m, k, out, n, nullptr);
+}
+
+extern "C" int fz_subs_lp_any(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, int *found) {
+    if (!found) return fail(FZ_EINVAL, "null argument");
+    *found = 0;
+    return subs_lp_impl(ctx, seq, p, m, k, nullptr, nullptr, found);
+}
+
+static int subs_lp_impl(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, fz_match **out, uint64_t *n, int *found) {
     int rc = validate(ctx, seq, p, m);
     if (rc) return rc;
     rc = check_halo(seq, m);
@@ -2079,6 +2134,7 @@ extern "C" int fz_subs_lp(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m
             FzScanArgs fa;
             memset(&fa, 0, sizeof fa);
             fa.geom = sh.geom; fa.mode = FZ_MODE_SUBS; fa.m = m; fa.k = k; fa.rec_cap = d.rec_cap;
+            fa.flags = found ? FZ_FLAG_ANY : 0u;
             if (m <= FZ_MAX_M) memcpy(fa.pat, p, m);
             rc = stage_pattern(d, fa, p, m);
             if (rc) return rc;
@@ -2095,6 +2151,7 @@ extern "C" int fz_subs_lp(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m
             HIP_TRY(hipStreamSynchronize(d.stream));
             const unsigned long long *cnt = reinterpret_cast<const unsigned long long *>(d.h_stage);
             const uint64_t nr = cnt[1];
+            if (found) { if (nr) *found = 1; continue; }
             if (nr > d.rec_cap) { rc = ensure_recs(d, nr + nr / 8 + 1024); if (rc) return rc; rerun = true; continue; }
             const size_t base = recs.size();
             recs.resize(base + nr);
@@ -2108,6 +2165,7 @@ extern "C" int fz_subs_lp(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m
         if (!rerun) break;
         if (attempt == 3) return fail(FZ_EDEVICE, "result buffers kept overflowing");
     }
+    if (found) return FZ_OK;
     sort_recs(recs);
     void *mem = nullptr;
     rc = alloc_out(recs.size(), sizeof(fz_match), &mem);

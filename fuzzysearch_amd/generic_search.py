@@ -4,7 +4,7 @@ Mirrors src/fuzzysearch/generic_search.py:25-54, :198-237, :256-273.
 """
 from .common import FuzzySearchBase, Match, RawMatches, consolidate_overlapping_matches
 from .engine import prepare
-from .search_exact import search_exact
+from .search_exact import exact_raw
 
 __all__ = ['find_near_matches_generic', 'find_near_matches_generic_ngrams',
            'find_near_matches_generic_linear_programming', 'has_near_match_generic_ngrams',
@@ -39,7 +39,7 @@ def raw_generic(subsequence, sequence, search_params):
         raise ValueError('Given subsequence is empty!')
     m = len(subsequence)
     if search_params.max_l_dist == 0:
-        return [Match(i, i + m, 0, matched=sequence[i:i + m]) for i in search_exact(subsequence, sequence)]
+        return exact_raw(subsequence, sequence)
     if m // (search_params.max_l_dist + 1) >= 3:
         return raw_generic_ngrams(subsequence, sequence, search_params)
     return raw_generic_lp(subsequence, sequence, search_params)
@@ -68,8 +68,18 @@ def raw_generic_lp(subsequence, sequence, search_params):
 
 
 def has_near_match_generic_ngrams(subsequence, sequence, search_params):
-    """generic_search.py:240-253."""
-    return len(find_near_matches_generic_ngrams(subsequence, sequence, search_params)) > 0
+    """generic_search.py:240-253: is there any match?  A flag-only search (fz_generic_ngrams_any): no rows are
+    ordered, copied or turned into Match objects, and automaton work that starts after the first match is skipped."""
+    if not len(subsequence):
+        raise ValueError('Given subsequence is empty!')
+    max_subs, max_ins, max_dels, max_l = search_params.unpacked
+    if len(subsequence) // (max_l + 1) == 0:
+        raise ValueError('the subsequence length must be greater than max_l_dist')
+    pr = prepare(subsequence, sequence)
+    try:
+        return pr.engine.generic_ngrams_any(pr.handle, pr.pattern, max_subs, max_ins, max_dels, max_l)
+    finally:
+        pr.release()
 
 
 class GenericSearch(FuzzySearchBase):

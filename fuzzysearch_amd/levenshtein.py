@@ -2,7 +2,7 @@
 from .common import FuzzySearchBase, Match, RawMatches, consolidate_overlapping_matches
 from .engine import prepare
 from .levenshtein_ngram import raw_levenshtein_ngrams
-from .search_exact import search_exact
+from .search_exact import exact_raw
 
 __all__ = ['find_near_matches_levenshtein', 'find_near_matches_levenshtein_linear_programming',
            'LevenshteinSearch']
@@ -20,7 +20,7 @@ def raw_levenshtein(subsequence, sequence, max_l_dist):
         raise ValueError('Maximum Levenshtein distance must be >= 0!')
     m = len(subsequence)
     if max_l_dist == 0:
-        return [Match(i, i + m, 0, sequence[i:i + m]) for i in search_exact(subsequence, sequence)]
+        return exact_raw(subsequence, sequence)
     if m // (max_l_dist + 1) >= 3:
         return raw_levenshtein_ngrams(subsequence, sequence, max_l_dist)
     return raw_levenshtein_lp(subsequence, sequence, max_l_dist)

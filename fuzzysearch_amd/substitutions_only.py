@@ -7,7 +7,7 @@ same GPU raw stream (fz_subs_ngrams).
 """
 from .common import FuzzySearchBase, Match, RawMatches, best_of_groups_in_discovery_order
 from .engine import prepare
-from .search_exact import search_exact
+from .search_exact import exact_raw, search_exact
 
 __all__ = ['find_near_matches_substitutions', 'find_near_matches_substitutions_ngrams',
            'find_near_matches_substitutions_lp',
@@ -56,7 +56,7 @@ def find_near_matches_substitutions(subsequence, sequence, max_substitutions):
     _check_arguments(subsequence, sequence, max_substitutions)
     m = len(subsequence)
     if max_substitutions == 0:
-        return [Match(i, i + m, 0, sequence[i:i + m]) for i in search_exact(subsequence, sequence)]
+        return exact_raw(subsequence, sequence).materialize()
     if m // (max_substitutions + 1) >= 3:
         return find_near_matches_substitutions_ngrams(subsequence, sequence, max_substitutions)
     return find_near_matches_substitutions_lp(subsequence, sequence, max_substitutions)
@@ -75,28 +75,30 @@ def find_near_matches_substitutions_lp(subsequence, sequence, max_substitutions)
 
 
 def _any_raw(call, subsequence, sequence, max_substitutions):
+    """Flag-only searches (fz_subs_ngrams_any / fz_subs_lp_any): nothing is ordered or copied, and scan work that
+    starts after the first match has been counted is skipped (the reference stops at its first match, :218-233)."""
     pr = prepare(subsequence, sequence)
     try:
-        return len(call(pr.engine)(pr.handle, pr.pattern, max_substitutions, as_array=True)) > 0
+        return call(pr.engine)(pr.handle, pr.pattern, max_substitutions)
     finally:
         pr.release()
 
 
 def has_near_match_substitutions_ngrams(subsequence, sequence, max_substitutions):
     """substitutions_only.py:218-233: does any window have at most max_substitutions mismatches?
-    (The reference stops at the first one; the GPU scan is one pass either way.)"""
+    (The reference stops at the first one; here workgroups that start after the first match skip their tiles.)"""
     _check_arguments(subsequence, sequence, max_substitutions)
     if len(subsequence) // (max_substitutions + 1) == 0:
         if isinstance(subsequence, str):
             raise ValueError("The subsequence's length must be greater than max_substitutions!")
         return len(sequence) >= len(subsequence)          # template.h:76-88: every window matches
-    return _any_raw(lambda eng: eng.subs_ngrams, subsequence, sequence, max_substitutions)
+    return _any_raw(lambda eng: eng.subs_ngrams_any, subsequence, sequence, max_substitutions)
 
 
 def has_near_match_substitutions_lp(subsequence, sequence, max_substitutions):
     """substitutions_only.py:139-145."""
     _check_arguments(subsequence, sequence, max_substitutions)
-    return _any_raw(lambda eng: eng.subs_lp, subsequence, sequence, max_substitutions)
+    return _any_raw(lambda eng: eng.subs_lp_any, subsequence, sequence, max_substitutions)
 
 
 def has_near_match_substitutions(subsequence, sequence, max_substitutions):

@@ -140,6 +140,14 @@ int fz_generic_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m,
                       uint32_t max_subs, uint32_t max_ins, uint32_t max_dels, uint32_t max_l,
                       fz_match **out, uint64_t *n);
 
+/* has_near_match_* (substitutions_only.py:139-145, :218-233; generic_search.py:240-253): *found = 1 iff the
+ * corresponding search would return at least one record.  Nothing is ordered or copied, and device work that starts
+ * after the first record has been counted is skipped (workgroups of the scan, hits of the automaton kernel). */
+int fz_subs_ngrams_any(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, int *found);
+int fz_subs_lp_any(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, int *found);
+int fz_generic_ngrams_any(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m,
+                          uint32_t max_subs, uint32_t max_ins, uint32_t max_dels, uint32_t max_l, int *found);
+
 /* The reference's linear-programming fallbacks, used by its dispatchers when
  * len(subsequence) // (k + 1) < 3 (short patterns).  Whole-sequence candidate automata, tiled by
  * start position on the GPU; ordered emission lists exactly as the reference yields them.

@@ -105,3 +105,98 @@ def test_file_api_default_chunks_many_batches(engine, tmp_path):
             got = fa.find_near_matches_in_file(p, f, **kw)
         got_t = [(m.start, m.end, m.dist) for m in got]
         assert _same_modulo_group_ties(got_t, exp), kw
+
+
+def test_file_and_memory_searches_from_several_threads(engine, tmp_path):
+    """The default engine is shared between threads: a file stream owns it from open to finish (advisor finding,
+    round 2: a search from another thread used to fail — or corrupt the stream — between two batches).  File
+    searches (regular file, in-memory file, text file, gzip wrapper) and in-memory searches run concurrently."""
+    import io
+    import threading
+
+    class Wrapper(io.BytesIO):
+        """A reader whose fileno() is NOT its logical content (like GzipFile / BZ2File / decrypting readers)."""
+        mode = 'rb'
+
+        def __init__(self, data, other_fd):
+            super().__init__(data)
+            self._fd = other_fd
+
+        def fileno(self):
+            return self._fd
+    n = 24 << 20
+    seq = workloads.dna(n, 99)
+    pattern = workloads.dna(20, 1)
+    p = pattern.tobytes()
+    workloads.plant_variants(seq, pattern, 200, 5)
+    data = seq.tobytes()
+    fn = tmp_path / "t.bin"
+    fn.write_bytes(data)
+    other = tmp_path / "other.bin"
+    other.write_bytes(workloads.dna(n, 5).tobytes())
+    text = data.decode('ascii')
+    tfn = tmp_path / "t.txt"
+    tfn.write_text(text, encoding='ascii')
+    want_file = [(m.start, m.end, m.dist) for m in fa.find_near_matches_in_file(p, io.BytesIO(data), max_l_dist=2, _chunk_size=1 << 18)]
+    want_mem = [(m.start, m.end, m.dist) for m in fa.find_near_matches(p, data[:4 << 20], max_l_dist=2)]
+    assert len(want_file) > 150
+    errs, res = [], {}
+
+    def work(i):
+        try:
+            for rep in range(3):
+                if i % 5 == 0:
+                    with open(fn, 'rb') as f:
+                        got = fa.find_near_matches_in_file(p, f, max_l_dist=2, _chunk_size=1 << 18)
+                elif i % 5 == 1:
+                    got = fa.find_near_matches_in_file(p, io.BytesIO(data), max_l_dist=2, _chunk_size=1 << 18)
+                elif i % 5 == 2:
+                    with open(other, 'rb') as o:               # fileno() is ANOTHER regular file: must go through readinto()
+                        got = fa.find_near_matches_in_file(p, Wrapper(data, o.fileno()), max_l_dist=2, _chunk_size=1 << 18)
+                elif i % 5 == 3:
+                    with open(tfn, 'r', encoding='ascii') as f:
+                        got = fa.find_near_matches_in_file(p.decode('ascii'), f, max_l_dist=2, _chunk_size=1 << 18)
+                    assert all(m.matched == text[m.start:m.end] for m in got)
+                else:
+                    got = fa.find_near_matches(p, data[:4 << 20], max_l_dist=2)
+                    assert [(m.start, m.end, m.dist) for m in got] == want_mem
+                    continue
+                assert [(m.start, m.end, m.dist) for m in got] == want_file, i
+            res[i] = True
+        except Exception as e:          # noqa: BLE001
+            errs.append((i, repr(e)))
+    th = [threading.Thread(target=work, args=(i,)) for i in range(10)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errs, errs
+    assert len(res) == 10
+
+
+def test_text_file_short_reads_and_reread(tmp_path):
+    """read(n) may return fewer than n characters before EOF (only '' ends the file), and `matched` of a seekable
+    text file is read back from the file instead of being held in memory."""
+    import io
+
+    class Dribble(io.StringIO):
+        def read(self, n=-1):
+            return super().read(min(n, 1000) if n and n > 0 else n)
+    seq = workloads.dna(3 << 20, 7)
+    pattern = workloads.dna(20, 1)
+    workloads.plant_variants(seq, pattern, 64, 5)
+    text = seq.tobytes().decode('ascii')
+    p = pattern.tobytes().decode('ascii')
+    want = [(m.start, m.end, m.dist) for m in fa.find_near_matches(p, text, max_l_dist=2)]
+    f = Dribble(text)
+    got = fa.find_near_matches_in_file(p, f, max_l_dist=2)
+    assert [(m.start, m.end, m.dist) for m in got] == want and len(want) > 30
+    assert all(m.matched == text[m.start:m.end] for m in got)
+    assert f.read() == ''                                       # left at the end of the file, like the reference
+    fn = tmp_path / "u.txt"
+    fn.write_text(text.replace('A', 'é'), encoding='utf-8')   # multi-byte encoding: tell() cookies, not offsets
+    text2 = text.replace('A', 'é')
+    p2 = p.replace('A', 'é')
+    with open(fn, 'r', encoding='utf-8') as f2:
+        got2 = fa.find_near_matches_in_file(p2, f2, max_l_dist=2, _chunk_size=1 << 16)
+        assert f2.read() == ''
+    assert [(m.start, m.end, m.dist) for m in got2] == want
+    assert all(m.matched == text2[m.start:m.end] for m in got2)

@@ -533,3 +533,63 @@ def test_threads_share_the_default_engine(engine):
     [x.join() for x in th]
     assert not errs, errs
     assert res == exp
+
+
+def test_has_near_match_flag_only_paths(engine):
+    """has_near_match_* (substitutions_only.py:139-145, :218-233; generic_search.py:240-253) through the flag-only
+    entry points: same answer as "the raw stream is non-empty", for matches at the start, the end, nowhere."""
+    import fuzzysearch_amd.generic_search as gs
+    import fuzzysearch_amd.substitutions_only as so
+    from fuzzysearch_amd.common import LevenshteinSearchParams
+    rnd = random.Random(41)
+    seen = {True: 0, False: 0}
+    for it in range(300):
+        p, t, k = _rand_case(rnd, max_n=400)
+        h = engine.upload(t)
+        if len(p) // (k + 1):
+            want = len(oracle.subs_ngrams_raw(p, t, k)) > 0
+            assert engine.subs_ngrams_any(h, p, k) == want, (p, t, k)
+            lim = (rnd.randint(0, k), rnd.randint(0, k), rnd.randint(0, k), k)
+            assert engine.generic_ngrams_any(h, p, *lim) == (len(oracle.generic_ngrams_raw(p, t, *lim)) > 0), (p, t, lim)
+            seen[want] += 1
+        assert engine.subs_lp_any(h, p, k) == (len(oracle.subs_lp_raw(p, t, k)) > 0), (p, t, k)
+        h.release()
+    assert seen[True] > 50 and seen[False] > 50
+    # large input, match only in the last tile / nowhere; the public functions
+    seq = workloads.text65(64 << 20, 5)
+    pat = workloads.text65(32, 6)
+    t_no = seq.tobytes()
+    assert so.has_near_match_substitutions_ngrams(pat.tobytes(), t_no, 3) is False
+    assert gs.has_near_match_generic_ngrams(pat.tobytes(), t_no, LevenshteinSearchParams(2, 1, 1, 3)) is False
+    v = pat.copy()
+    v[5] = ord('#'); v[20] = ord('#')
+    seq[-40:-8] = v
+    t_yes = seq.tobytes()
+    assert so.has_near_match_substitutions_ngrams(pat.tobytes(), t_yes, 3) is True
+    assert so.has_near_match_substitutions(pat.tobytes(), t_yes, 3) is True
+    assert so.has_near_match_substitutions_lp(pat.tobytes()[:6], t_yes, 3) is True
+    assert gs.has_near_match_generic_ngrams(pat.tobytes(), t_yes, LevenshteinSearchParams(2, 1, 1, 3)) is True
+    seq[100:132] = pat                                            # ... and at the very start: later workgroups skip their tiles
+    h = engine.upload(seq)
+    assert engine.subs_ngrams_any(h, pat.tobytes(), 3) is True
+    st_any = engine.stats()
+    full = engine.subs_ngrams(h, pat.tobytes(), 3)
+    h.release()
+    assert len(full) >= 2 and st_any["bytes_scanned"] == len(seq)
+
+
+def test_exact_routes_return_lazy_streams(engine):
+    """ExactSearch and the k == 0 routes hand RawMatches (an index array) to consolidation: same results as before."""
+    import fuzzysearch_amd as fa
+    from fuzzysearch_amd.common import RawMatches, LevenshteinSearchParams
+    t = (b"abcabcabd" * 5000) + b"xyz"
+    p = b"abcabd"
+    exp = oracle.search_exact(p, t)
+    res = fa.ExactSearch.search(p, t, LevenshteinSearchParams(0, 0, 0, 0))
+    assert isinstance(res, RawMatches) and len(res) == len(exp) == 5000
+    assert [(m.start, m.end, m.dist, bytes(m.matched)) for m in res[:3]] == [(i, i + 6, 0, p) for i in exp[:3]]
+    api = fa.find_near_matches(p, t, max_l_dist=0)
+    assert [(m.start, m.end, m.dist) for m in api] == [(i, i + 6, 0) for i in exp]
+    assert fa.find_near_matches(p, t, max_substitutions=0, max_insertions=0, max_deletions=0) == api
+    from fuzzysearch_amd.search_exact import search_exact
+    assert search_exact(p, t) == exp and search_exact(p, t, 10, 100) == [i for i in exp if 10 <= i and i + 6 <= 100]
