@@ -13,6 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfzhip.so")
+RESOURCES = os.path.join(HERE, "libfzhip.resources.txt")
 SOURCES = ["fzhip.hip"]
 DEPS = ["fzhip.hip", "fz_kernels.h", "fz_device.h", os.path.join("..", "..", "include", "fzhip.h")]
 
@@ -34,16 +35,50 @@ def needs_build():
 def build(force=False, report=False):
     if not force and not needs_build():
         return LIB
+    # the compiler's per-kernel resource remarks are always collected (they cost nothing): libfzhip.resources.txt next to
+    # the library, checked by tests/test_host_logic.py (a kernel that silently starts using scratch memory is a bug)
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
-    if report:
-        cmd.append("-Rpass-analysis=kernel-resource-usage")
+           "-Wall", "-Wno-unused-function", "-Wno-pass-failed", "-Rpass-analysis=kernel-resource-usage"]
     # RCCL (the all-gather of match lists, fz_comm_*): linked, not dlopen-ed, so a missing librccl fails at load time
     rocm_lib = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")
     cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-L" + rocm_lib, "-lrccl", "-Wl,-rpath," + rocm_lib, "-o", LIB + ".tmp"]
-    subprocess.check_call(cmd, cwd=CSRC)
+    res = subprocess.run(cmd, cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    err = res.stderr.decode("utf-8", "replace")
+    remarks = [ln for ln in err.splitlines() if "-Rpass-analysis=kernel-resource-usage" in ln]
+    other = [ln for ln in err.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in ln]
+    if other:
+        sys.stderr.write("\n".join(other) + "\n")
+    if res.returncode != 0:
+        raise subprocess.CalledProcessError(res.returncode, cmd)
+    with open(RESOURCES, "w") as f:
+        f.write(kernel_resources_summary(remarks))
+    if report:
+        sys.stderr.write(open(RESOURCES).read())
     os.replace(LIB + ".tmp", LIB)
     return LIB
+
+
+def kernel_resources_summary(remarks):
+    """One line per kernel: name, VGPRs, scratch bytes per lane, occupancy, SGPR / VGPR spills, static LDS."""
+    import re
+    rows, cur = [], None
+    for ln in remarks:
+        m = re.search(r"remark:\s+(.*?)\s+\[-Rpass", ln)
+        if not m:
+            continue
+        text = m.group(1).strip()
+        if text.startswith("Function Name:"):
+            cur = {"name": text.split(":", 1)[1].strip()}
+            rows.append(cur)
+        elif cur is not None and ":" in text:
+            k, v = text.rsplit(":", 1)
+            cur[k.strip()] = v.strip()
+    out = []
+    for r in rows:
+        out.append("%s vgprs=%s scratch=%s occupancy=%s sgpr_spill=%s vgpr_spill=%s lds=%s" % (
+            r["name"], r.get("VGPRs", "?"), r.get("ScratchSize [bytes/lane]", "?"), r.get("Occupancy [waves/SIMD]", "?"),
+            r.get("SGPRs Spill", "?"), r.get("VGPRs Spill", "?"), r.get("LDS Size [bytes/block]", "?")))
+    return "\n".join(out) + "\n"
 
 
 def match_ext_path():

@@ -79,9 +79,17 @@ typedef __attribute__((address_space(3))) uint8_t FzLdsU8;
 
 __device__ __forceinline__ uint32_t fz_lane() { return threadIdx.x & 63u; }
 
-// Pattern byte i: from the kernel-argument block, or (patterns longer than FZ_MAX_M) from HBM.
-__device__ __forceinline__ uint8_t fz_pat_byte(const FzScanArgs &a, uint32_t i) {
-    return a.pat_g ? reinterpret_cast<const uint8_t *>(a.pat_g)[i] : a.pat[i];
+// The pattern into LDS: from the kernel-argument block, or (patterns longer than FZ_MAX_M, fz_verify_big_kernel's
+// callers) from HBM.  Two loops under one uniform branch, NOT a select per byte between the two sources: a select
+// between an argument-block address and a global one makes hipcc copy the whole 1.5 KB argument struct to scratch
+// memory (1472 bytes per lane in every kernel that did it; the exact-search scan ran 3.4x slower).
+__device__ __forceinline__ void fz_copy_pattern(uint8_t *dst, const FzScanArgs &a, uint32_t tid, uint32_t nthreads) {
+    if (a.pat_g) {
+        const uint8_t *pg = reinterpret_cast<const uint8_t *>(a.pat_g);
+        for (uint32_t i = tid; i < a.m; i += nthreads) dst[i] = pg[i];
+    } else {
+        for (uint32_t i = tid; i < a.m; i += nthreads) dst[i] = a.pat[i];
+    }
 }
 
 __device__ __forceinline__ uint32_t fz_rank(unsigned long long mask) {
@@ -355,8 +363,16 @@ __device__ __forceinline__ bool fz_confirm(const uint8_t *__restrict__ buf, cons
                                            uint64_t local) {
     if ((fz_load_win(buf, (int64_t)local) & a.mask1) != a.A[blk]) return false;
     if (a.L > 4 && (fz_load_win(buf, (int64_t)local + a.d2) & a.mask2) != a.B[blk]) return false;
-    for (uint32_t b = 8; b < a.L; ++b)
-        if (buf[local + b] != fz_pat_byte(a, a.s[blk] + b)) return false;
+    if (a.L > 8) {                                         // (two loops under a uniform branch: see fz_copy_pattern)
+        if (a.pat_g) {
+            const uint8_t *pg = reinterpret_cast<const uint8_t *>(a.pat_g) + a.s[blk];
+            for (uint32_t b = 8; b < a.L; ++b)
+                if (buf[local + b] != pg[b]) return false;
+        } else {
+            for (uint32_t b = 8; b < a.L; ++b)
+                if (buf[local + b] != a.pat[a.s[blk] + b]) return false;
+        }
+    }
     return true;
 }
 
@@ -698,6 +714,30 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
             const bool fire = __ballot(acc == 0) != 0;
             if (__builtin_expect(fire, 0)) {              // wave-uniform, rare: some lane, some offset
                 if (__builtin_expect(!dup_hashes, 1)) {
+#ifndef FZ_RARE_VECTOR
+                    // Resolved one firing lane at a time (nearly always exactly one), mostly on the SCALAR unit: the lane's
+                    // four xor words come over by v_readlane, offset and table slot are scalar arithmetic, the block is one
+                    // wave-uniform LDS read (the dword behind the hash table says which block lives in a slot), the code is
+                    // stored by a wave-uniform LDS write.  ~9 vector-issue slots per hit instead of ~16 (four ballots + slot
+                    // / block lookup / rank / code per firing offset): the scan is bound by vector issue, and 788 000 of
+                    // these run per GiB of DNA.
+                    unsigned long long fm = __ballot(acc == 0);
+                    do {
+                        const uint32_t fl = (uint32_t)__builtin_ctzll(fm);
+                        fm &= fm - 1ull;
+#pragma unroll
+                        for (int i = 0; i < GRP; ++i) {
+                            if (__builtin_amdgcn_readlane((int)am[i], (int)fl) == 0) {
+                                const uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)hv[i], (int)fl);
+                                const uint32_t sl = (SA ? (h >> 2) : (h >> a.lut_shift)) & (FZ_LUT_SLOTS - 1u);
+                                const uint32_t g = lut[FZ_LUT_SLOTS + sl];                    // the same word in every lane
+                                const uint32_t off = ((wave * 64u + fl) << 4) + (uint32_t)(r * FZ_ROW_BYTES + GRP * j + i);
+                                if (qn < qcap) w.queue[qn] = fz_code(off, g, titer);
+                                ++qn;
+                            }
+                        }
+                    } while (fm);
+#else
 #pragma unroll
                     for (int i = 0; i < GRP; ++i) {
                         const unsigned long long mi = __ballot(hv[i] == lv[i]);      // which offset (scalar branch)
@@ -718,6 +758,7 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                             qn += (uint32_t)__popcll(mi);
                         }
                     }
+#endif
                 } else {
                     // equal n-grams share a slot: compare with every block of the launch
 #pragma unroll 1
@@ -855,7 +896,7 @@ __global__ void fz_verify_kernel(const uint8_t *__restrict__ buf, const FzScanAr
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t mpad = (a.m + 15u) & ~15u;
     uint8_t *pat_lds = smem;
-    for (uint32_t i = threadIdx.x; i < a.m; i += blockDim.x) pat_lds[i] = fz_pat_byte(a, i);
+    fz_copy_pattern(pat_lds, a, threadIdx.x, blockDim.x);
     __syncthreads();
     const FzWaveLds w = fz_wave_lds(smem + mpad, threadIdx.x >> 6, a.win_dwords, a.band_w, a.vlanes, false);
     unsigned long long nh = counters[0];
@@ -998,7 +1039,7 @@ __global__ __launch_bounds__(1024) void fz_verify_wf_kernel(const uint8_t *__res
     constexpr uint32_t NH = 64u / (uint32_t)GW;                         // hits per wave
     const uint32_t mpad = (a.m + 15u) & ~15u;
     uint8_t *pat_lds = smem + 16;                                       // 16 bytes of slack below p[0] (reversed reads)
-    for (uint32_t i = threadIdx.x; i < a.m; i += blockDim.x) pat_lds[i] = fz_pat_byte(a, i);
+    fz_copy_pattern(pat_lds, a, threadIdx.x, blockDim.x);
     __syncthreads();
     const uint32_t lane = fz_lane();
     const uint32_t grp = lane / (uint32_t)GW, gl = lane % (uint32_t)GW;
@@ -1311,7 +1352,7 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
                              : reinterpret_cast<FzGCand *>(smem + mpad + wpad);
     FzGCand *nxt = cur + a.cand_cap;
     uint64_t *mbuf = reinterpret_cast<uint64_t *>(smem + mpad + wpad + (HBM_LISTS ? 0u : 2u * a.cand_cap * (uint32_t)sizeof(FzGCand)));
-    for (uint32_t i = lane; i < a.m; i += 64u) pat[i] = fz_pat_byte(a, i);
+    fz_copy_pattern(pat, a, lane, 64u);
     fz_wave_lds_sync();
     auto patf = [&](uint32_t i) -> uint8_t { return pat[i]; };
     constexpr bool per_hit = KIND == FZ_LP_GENERIC_HIT;

@@ -17,6 +17,7 @@
 // Every search is synchronous: when a fz_* call returns its results are on the host and nothing is
 // in flight on the sequence.  Buffers that turn out too small are grown and the search re-runs.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -124,6 +125,7 @@ struct DevState {
     // that a search collected in between may have grown)
     uint64_t hit_cap_used = 0, rec_cap_used = 0;
     bool fused_used = false;
+    bool timed = true;                           // the search being collected recorded its start event
     double last_filter_ms = 0;                   // scan span of the search collected last on this device (fz_device_ms)
     uint8_t *d_pat = nullptr;                    // pattern in HBM (subsequences longer than FZ_MAX_M, fz_verify_big_kernel)
     uint64_t pat_cap = 0;
@@ -145,7 +147,7 @@ struct DevState {
     struct Slot {
         hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
         uint8_t *h_stage = nullptr, *h_stage_dev = nullptr;
-        bool last_direct = false, verify_launched = false, fused_used = false;
+        bool last_direct = false, verify_launched = false, fused_used = false, timed = true;
         int scan_end_event = 1;
         uint64_t hit_cap_used = 0, rec_cap_used = 0;
         int slot_id = 1;
@@ -157,6 +159,7 @@ struct DevState {
         std::swap(h_stage_dev, other.h_stage_dev);
         std::swap(last_direct, other.last_direct);
         std::swap(verify_launched, other.verify_launched);
+        std::swap(timed, other.timed);
         std::swap(fused_used, other.fused_used);
         std::swap(scan_end_event, other.scan_end_event);
         std::swap(hit_cap_used, other.hit_cap_used);
@@ -206,6 +209,9 @@ struct fz_ctx {
     // RCCL: number of ranks of the communicator this context joined (0: none) and whether its Levenshtein n-gram
     // searches are collective (every rank gets the merged global stream)
     bool any_found = false;                      // result of the last has_near_match_* (fz_*_any) search
+    // hipEvent timing of the kernels (fz_stats: filter_ms / verify_ms / device_ms).  One event record is one more packet
+    // in front of the kernel and two hipEventElapsedTime calls behind it: fz_set_timing(ctx, 0) drops them.
+    bool timing = getenv("FZ_NO_TIMING") == nullptr;
     int comm_world = 0;
     bool snapshot = false;
     uint64_t gcap = 4096;                        // records per rank the all-gather carries (follows the counts, on all ranks alike)
@@ -518,7 +524,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     d.last_direct = direct;
     if (!d.header_zeroed) HIP_TRY(hipMemsetAsync(d.d_out, 0, kHeaderBytes, d.stream));
     d.header_zeroed = false;
-    HIP_TRY(hipEventRecord(d.ev[0], d.stream));
+    d.timed = ctx->timing;
 
     const uint32_t L = q.plan.L;
     const uint32_t G = (uint32_t)q.plan.s.size();
@@ -585,6 +591,13 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     // (the hit-emitting form keeps no pattern in LDS: fz_confirm reads it from the argument block / HBM)
     const uint32_t scan_lds = fa.fused ? fused_lds : FZ_TABLE_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(0, 0, 64, true);
 
+    // When the scan's last launch is also the search's last kernel (fused verification, results written straight to
+    // the host), the start / completion events ride on the kernels' own dispatch packets (hipExtLaunchKernelGGL)
+    // instead of two extra packets around them: fewer packets on the critical path of a synchronous call, and
+    // filter_ms becomes the kernels' own span.
+    static const bool no_ext = getenv("FZ_NO_EXT_LAUNCH") != nullptr;
+    const bool ext_events = !no_ext && copy_back && direct && !(with_verify && !fa.fused) && ntiles > 0 && G > 0;
+    if (ctx->timing && !ext_events) HIP_TRY(hipEventRecord(d.ev[0], d.stream));
     uint32_t launches = 0;
     for (uint32_t g0 = 0; g0 < G && ntiles > 0;) {
         // Blocks [g0, g0 + nblk) of this launch and the hash multiplier: the longest run of blocks (at
@@ -615,8 +628,14 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
         ScanKernel kern = scan_kernel(nwin, dh, fa.fused != 0, sh.geom.seg_stride != 0, fa.lut_shift == 2);
         if (!kern) return fail(FZ_EUNSUPPORTED, "this (lab) build carries no scan kernel for nwin=%d dh=%d", nwin, dh);
         static const uint32_t extra_lds = []() { const char *e = getenv("FZ_EXTRA_LDS_KB"); return e ? (uint32_t)atoi(e) * 1024u : 0u; }();
-        hipLaunchKernelGGL(kern, grid, dim3(FZ_FILTER_THREADS), scan_lds + extra_lds, d.stream, sh.d_buf, fa, ntiles, d.d_hits, recs,
-                           counters);
+        hipEvent_t ev_start = (ext_events && ctx->timing && g0 == 0) ? d.ev[0] : nullptr;
+        hipEvent_t ev_stop = (ext_events && g0 + nblk >= G) ? d.ev[3] : nullptr;
+        if (ev_start || ev_stop)
+            hipExtLaunchKernelGGL(kern, grid, dim3(FZ_FILTER_THREADS), scan_lds + extra_lds, d.stream, ev_start, ev_stop, 0u, sh.d_buf, fa,
+                                  ntiles, d.d_hits, recs, counters);
+        else
+            hipLaunchKernelGGL(kern, grid, dim3(FZ_FILTER_THREADS), scan_lds + extra_lds, d.stream, sh.d_buf, fa, ntiles, d.d_hits, recs,
+                               counters);
         HIP_TRY(hipGetLastError());
         ++launches;
         g0 += nblk;
@@ -624,7 +643,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     // ev[1] = end of the scan.  When the results need no copy and no verify kernel follows, ev[3] is
     // recorded at the same point of the stream: one event packet less on the critical path.
     d.scan_end_event = (copy_back && direct && !(with_verify && !fa.fused)) ? 3 : 1;
-    if (d.scan_end_event == 1) HIP_TRY(hipEventRecord(d.ev[1], d.stream));
+    if (d.scan_end_event == 1 && ctx->timing) HIP_TRY(hipEventRecord(d.ev[1], d.stream));
     d.verify_launched = false;
     if (with_verify && !fa.fused && ntiles > 0 && G > 0) {
         d.verify_launched = true;
@@ -665,7 +684,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
         HIP_TRY(hipGetLastError());
     }
     if (copy_back) {
-        if (d.verify_launched) HIP_TRY(hipEventRecord(d.ev[2], d.stream));
+        if (d.verify_launched && ctx->timing) HIP_TRY(hipEventRecord(d.ev[2], d.stream));
         if (snapshot) {
             // counters to the host (overflow checks, statistics); counters + records to this slot's snapshot
             HIP_TRY(hipMemcpyAsync(d.h_stage, d.d_out, kHeaderBytes, hipMemcpyDeviceToHost, d.stream));
@@ -679,7 +698,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
             HIP_TRY(hipMemcpyAsync(d.h_stage, d.d_out, kHeaderBytes + d.first_copy * sizeof(FzRec), hipMemcpyDeviceToHost,
                                    d.stream));
         }
-        HIP_TRY(hipEventRecord(d.ev[3], d.stream));
+        if (!ext_events) HIP_TRY(hipEventRecord(d.ev[3], d.stream));
         // the counters are zeroed for the NEXT search now, off the critical path of that call: by the
         // publishing workgroup itself in direct mode, by a memset behind the copy otherwise
         if (!direct) HIP_TRY(hipMemsetAsync(d.d_out, 0, kHeaderBytes, d.stream));
@@ -724,9 +743,11 @@ int collect_shard(fz_ctx *ctx, const Shard &sh, bool with_verify, bool view_ok, 
     if (!d.last_direct && nr * 4 < kHostRecs) d.direct = true;
     if (rerun) return FZ_OK;
     float f = 0, v = 0, t = 0;
-    HIP_TRY(hipEventElapsedTime(&f, d.ev[0], d.ev[d.scan_end_event]));
-    if (d.verify_launched) HIP_TRY(hipEventElapsedTime(&v, d.ev[1], d.ev[2]));
-    HIP_TRY(hipEventElapsedTime(&t, d.ev[0], d.ev[3]));
+    if (d.timed) {
+        HIP_TRY(hipEventElapsedTime(&f, d.ev[0], d.ev[d.scan_end_event]));
+        if (d.verify_launched) HIP_TRY(hipEventElapsedTime(&v, d.ev[1], d.ev[2]));
+        HIP_TRY(hipEventElapsedTime(&t, d.ev[0], d.ev[3]));
+    }
     d.last_filter_ms = f;
     ctx->stats.filter_ms = std::max<double>(ctx->stats.filter_ms, f);
     ctx->stats.verify_ms = std::max<double>(ctx->stats.verify_ms, v);
@@ -973,7 +994,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             hipLaunchKernelGGL(lp_kernel(FZ_LP_GENERIC_HIT, scratch != 0), dim3(scratch ? kCandScratchGrid : d.n_cus * grid_per_cu), dim3(64),
                                lds, d.stream, sh.d_buf, fa, d.d_hits, (uint64_t)0, recs, counters);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(d.ev[2], d.stream));
+            if (ctx->timing) HIP_TRY(hipEventRecord(d.ev[2], d.stream));
             if (dev_order) {
                 hipLaunchKernelGGL(fz_gen_order_kernel, dim3(d.n_cus * 8), dim3(256), 0, d.stream, d.d_hits, fa, counters);
                 hipLaunchKernelGGL(fz_gen_scatter_kernel, dim3(d.n_cus * 8), dim3(256), 0, d.stream, d.d_hits, fa, recs,
@@ -1014,9 +1035,11 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             if (novf) { lists_overflowed = true; rerun = true; }
             if (rerun) continue;
             float f = 0, v = 0, t = 0;
-            HIP_TRY(hipEventElapsedTime(&f, d.ev[0], d.ev[1]));
-            HIP_TRY(hipEventElapsedTime(&v, d.ev[1], d.ev[2]));
-            HIP_TRY(hipEventElapsedTime(&t, d.ev[0], d.ev[3]));
+            if (d.timed) {
+                HIP_TRY(hipEventElapsedTime(&f, d.ev[0], d.ev[1]));
+                HIP_TRY(hipEventElapsedTime(&v, d.ev[1], d.ev[2]));
+                HIP_TRY(hipEventElapsedTime(&t, d.ev[0], d.ev[3]));
+            }
             ctx->stats.filter_ms = std::max<double>(ctx->stats.filter_ms, f);
             ctx->stats.verify_ms = std::max<double>(ctx->stats.verify_ms, v);
             ctx->stats.device_ms = std::max<double>(ctx->stats.device_ms, t);
@@ -1135,11 +1158,28 @@ bool drop_empty_slots(const FzRec *recs, size_t cnt, std::vector<FzRec> &kept) {
     return true;
 }
 
-int emit_matches(const FzRec *recs, size_t cnt, uint32_t L, fz_match **out, uint64_t *n) {
-    std::vector<FzRec> kept;
-    if (drop_empty_slots(recs, cnt, kept)) return emit_matches(kept.data(), kept.size(), L, out, n);
+// idx_bound / blk_bound (0: unknown): every hit index is below idx_bound and every block number below blk_bound
+// (sequence length and block count of the search) — saves the pass that finds the key ranges; may_have_empty: some
+// records may be empty slots (the slot-per-hit verification).
+int emit_matches(const FzRec *recs, size_t cnt, uint32_t L, fz_match **out, uint64_t *n, uint64_t idx_bound = 0,
+                 uint32_t blk_bound = 0, bool may_have_empty = true) {
+    size_t nv = 0;
+    uint64_t imin = ~0ull, imax = 0;
+    uint32_t gmax = 0;
+    if (idx_bound && blk_bound && !may_have_empty) {
+        nv = cnt; imin = 0; imax = idx_bound - 1; gmax = blk_bound - 1;
+    } else {
+        // one pass for the empty slots (slot-per-hit kernels) and the key ranges
+        for (size_t i = 0; i < cnt; ++i) {
+            if (recs[i].dist == FZ_REC_NONE) continue;
+            const uint64_t idx = fz_hit_index(recs[i].key);
+            imin = std::min(imin, idx); imax = std::max(imax, idx);
+            gmax = std::max(gmax, fz_hit_block(recs[i].key));
+            ++nv;
+        }
+    }
     void *mem = nullptr;
-    int rc = alloc_out(cnt, sizeof(fz_match), &mem);
+    int rc = alloc_out(nv, sizeof(fz_match), &mem);
     if (rc) return rc;
     fz_match *mo = static_cast<fz_match *>(mem);
     auto put = [&](size_t i, const FzRec &r) {
@@ -1150,41 +1190,64 @@ int emit_matches(const FzRec *recs, size_t cnt, uint32_t L, fz_match **out, uint
         mo[i].block = (int32_t)fz_hit_block(r.key);
     };
     *out = mo;
-    *n = cnt;
-    if (cnt >= 64) {
-        uint64_t imin = ~0ull, imax = 0;
-        uint32_t gmax = 0;
+    *n = nv;
+    if (nv == 0) return FZ_OK;
+    int ibits = 0, gbits = 0, pbits = 0;                       // index range, block number, record position
+    while (ibits < FZ_IDX_BITS && ((imax - imin) >> ibits)) ++ibits;
+    while ((gmax >> gbits)) ++gbits;
+    while (((cnt - 1) >> pbits)) ++pbits;
+    const int kbits = ibits + gbits;
+    if (kbits + pbits <= 64) {
+        // One 64-bit word per record: (block, index - imin) above the record's position.  ONE distribution pass on the
+        // top digit of the key (about two buckets per record), then the buckets — a record or two each unless the
+        // matches cluster — are put in order: sorting the whole words orders equal keys by position, and a search
+        // never has two records with one key.  (2409 records: 14 -> ~7 us against three LSD passes with their own
+        // range pass and two freshly allocated word arrays.)
+        static thread_local std::vector<uint64_t> wa, wb;
+        static thread_local std::vector<uint32_t> hist;
+        if (wa.size() < nv) { wa.resize(nv + nv / 2 + 64); wb.resize(wa.size()); }
+        int dbits = 1;                                         // about two records per bucket: the prefix sum and the bucket walk cost per bucket
+        while (dbits < 16 && (2ull << dbits) < nv) ++dbits;
+        dbits = std::max(1, std::min(dbits, std::max(1, kbits)));
+        const int shift = pbits + kbits - dbits;
+        const size_t nb = (size_t)1 << dbits;
+        hist.assign(nb + 1, 0);
+        uint64_t *a = wa.data(), *b = wb.data();
+        size_t w = 0;
         for (size_t i = 0; i < cnt; ++i) {
-            const uint64_t idx = fz_hit_index(recs[i].key);
-            imin = std::min(imin, idx); imax = std::max(imax, idx);
-            gmax = std::max(gmax, fz_hit_block(recs[i].key));
+            if (recs[i].dist == FZ_REC_NONE) continue;
+            const uint64_t key = ((uint64_t)fz_hit_block(recs[i].key) << ibits) | (fz_hit_index(recs[i].key) - imin);
+            const uint64_t word = (pbits < 64 ? key << pbits : 0) | (uint64_t)i;
+            a[w++] = word;
+            ++hist[(shift >= 0 ? (size_t)(word >> shift) : 0) + 1];
         }
-        int ibits = 0, gbits = 0, pbits = 0;                   // index range, block number, record position
-        while (ibits < FZ_IDX_BITS && ((imax - imin) >> ibits)) ++ibits;
-        while ((gmax >> gbits)) ++gbits;
-        while (((cnt - 1) >> pbits)) ++pbits;
-        if (ibits + gbits + pbits <= 64) {
-            std::vector<uint64_t> a(cnt), b(cnt);
-            for (size_t i = 0; i < cnt; ++i) {
-                const uint64_t key = ((uint64_t)fz_hit_block(recs[i].key) << ibits) | (fz_hit_index(recs[i].key) - imin);
-                a[i] = (key << pbits) | (uint64_t)i;
+        for (size_t d = 0; d < nb; ++d) hist[d + 1] += hist[d];
+        for (size_t i = 0; i < nv; ++i) b[hist[shift >= 0 ? (size_t)(a[i] >> shift) : 0]++] = a[i];
+        // hist[d] is now the END of bucket d
+        size_t s0 = 0;
+        for (size_t d = 0; d < nb; ++d) {
+            const size_t e0 = hist[d];
+            const size_t len = e0 - s0;
+            if (len > 24) std::sort(b + s0, b + e0);
+            else if (len > 1) {
+                for (size_t i = s0 + 1; i < e0; ++i) {
+                    const uint64_t v = b[i];
+                    size_t j = i;
+                    while (j > s0 && b[j - 1] > v) { b[j] = b[j - 1]; --j; }
+                    b[j] = v;
+                }
             }
-            uint64_t *src = a.data(), *dst = b.data();
-            for (int shift = pbits; shift < pbits + ibits + gbits; shift += 11) {
-                uint32_t count[2049] = {0};
-                for (size_t i = 0; i < cnt; ++i) ++count[((src[i] >> shift) & 0x7ff) + 1];
-                for (int d = 0; d < 2048; ++d) count[d + 1] += count[d];
-                for (size_t i = 0; i < cnt; ++i) dst[count[(src[i] >> shift) & 0x7ff]++] = src[i];
-                std::swap(src, dst);
-            }
-            const uint64_t pmask = pbits ? ((1ull << pbits) - 1) : 0;
-            for (size_t i = 0; i < cnt; ++i) put(i, recs[src[i] & pmask]);
-            return FZ_OK;
+            s0 = e0;
         }
+        const uint64_t pmask = pbits ? ((1ull << pbits) - 1) : 0;
+        for (size_t i = 0; i < nv; ++i) put(i, recs[b[i] & pmask]);
+        return FZ_OK;
     }
-    std::vector<FzRec> copy(recs, recs + cnt);
+    std::vector<FzRec> copy;
+    copy.reserve(nv);
+    for (size_t i = 0; i < cnt; ++i) if (recs[i].dist != FZ_REC_NONE) copy.push_back(recs[i]);
     sort_recs(copy);
-    for (size_t i = 0; i < cnt; ++i) put(i, copy[i]);
+    for (size_t i = 0; i < nv; ++i) put(i, copy[i]);
     return FZ_OK;
 }
 
@@ -1219,8 +1282,13 @@ int emit_matches_seg(const FzRec *recs, size_t cnt, uint32_t L, fz_match **out, 
 }
 
 // the records of the search that just ran: the staging-buffer view or the collected vector
-int emit_matches(const fz_ctx *ctx, const std::vector<FzRec> &recs, uint32_t L, fz_match **out, uint64_t *n) {
-    return ctx->view ? emit_matches(ctx->view, (size_t)ctx->view_n, L, out, n) : emit_matches(recs.data(), recs.size(), L, out, n);
+int emit_matches(const fz_ctx *ctx, const std::vector<FzRec> &recs, uint32_t L, fz_match **out, uint64_t *n,
+                 uint64_t idx_bound = 0, uint32_t blk_bound = 0) {
+    // (the fused scan appends real records only; the stand-alone verifications may leave empty slots)
+    bool dense = true;                                     // (of the search being collected: its slot is the current one)
+    for (const DevState &d : ctx->devs) dense = dense && d.fused_used;
+    return ctx->view ? emit_matches(ctx->view, (size_t)ctx->view_n, L, out, n, idx_bound, blk_bound, !dense)
+                     : emit_matches(recs.data(), recs.size(), L, out, n, idx_bound, blk_bound, !dense);
 }
 
 }  // namespace
@@ -1555,7 +1623,7 @@ int fz_lev_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32
     rc = run_search(ctx, seq, q, true, recs, hits);
     if (rc) return rc;
     tr.mark("run_search");
-    rc = emit_matches(ctx, recs, q.plan.L, out, n);
+    rc = emit_matches(ctx, recs, q.plan.L, out, n, seq->n, (uint32_t)q.plan.s.size());
     tr.mark("sort+emit");
     if (rc == FZ_OK) ctx->stats.raw_matches = *n;
     return rc;
@@ -1600,7 +1668,7 @@ int fz_lev_ngrams_end(fz_ctx *ctx, fz_match **out, uint64_t *n) {
     std::vector<FzRec> recs;
     std::vector<uint64_t> hits;
     if (rc == FZ_OK) rc = search_collect(ctx, pd.seq, q, true, recs, hits);
-    if (rc == FZ_OK) rc = emit_matches(ctx, recs, q.plan.L, out, n);
+    if (rc == FZ_OK) rc = emit_matches(ctx, recs, q.plan.L, out, n, pd.seq->n, (uint32_t)q.plan.s.size());
     // the younger search (if any) becomes the oldest: its slot becomes the current one
     if (--ctx->npend == 1) {
         std::swap(ctx->pend[0], ctx->pend[1]);
@@ -1638,7 +1706,7 @@ static int subs_ngrams_impl(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t
     rc = run_search(ctx, seq, q, true, recs, hits);
     if (rc) return rc;
     if (found) { *found = (ctx->view ? ctx->view_n : (uint64_t)recs.size()) > 0 ? 1 : 0; return FZ_OK; }
-    return emit_matches(ctx, recs, L, out, n);
+    return emit_matches(ctx, recs, L, out, n, seq->n, (uint32_t)q.plan.s.size());
 }
 
 int fz_subs_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, fz_match **out, uint64_t *n) {
@@ -2836,6 +2904,12 @@ int fz_wire_merge(const void *recv, uint32_t world, uint64_t rows_per_rank, uint
     return FZ_OK;
 }
 
+int fz_debug_order_records(const void *recs, uint64_t n, uint32_t L, fz_match **out, uint64_t *n_out) {
+    if ((!recs && n) || !out || !n_out) return fail(FZ_EINVAL, "null argument");
+    static_assert(sizeof(FzRec) == 24, "record layout");
+    return emit_matches(static_cast<const FzRec *>(recs), (size_t)n, L, out, n_out);
+}
+
 int fz_debug_launch_plan(const uint8_t *p, uint32_t m, uint32_t L, uint32_t *out, uint32_t cap, uint32_t *n_launches) {
     if (!p || !out || !n_launches || L == 0 || L > m) return fail(FZ_EINVAL, "bad argument");
     std::vector<uint32_t> starts;
@@ -2926,6 +3000,13 @@ int fz_group_best(const fz_match *in, uint64_t n, fz_match **out, uint64_t *n_ou
     for (size_t g = 0; g < ordered.size(); ++g) o[g] = ordered[g].second;
     *out = o;
     *n_out = ordered.size();
+    return FZ_OK;
+}
+
+int fz_set_timing(fz_ctx *ctx, int on) {
+    if (!ctx) return fail(FZ_EINVAL, "null argument");
+    if (ctx->npend || ctx->stream_inflight) return fail(FZ_EINVAL, "a search of this context is in flight");
+    ctx->timing = on != 0;
     return FZ_OK;
 }
 

@@ -247,7 +247,16 @@ void fz_stream_close(fz_stream *st);
  * hash multiplier, slot shift of launch i (at most `cap` launches are written); *n_launches = total. */
 int fz_debug_launch_plan(const uint8_t *p, uint32_t m, uint32_t L, uint32_t *out, uint32_t cap, uint32_t *n_launches);
 
+/* Test hook (no device needed): the host step that turns the device's unordered 24-byte records
+ * {u64 key = block << 48 | hit index, u32 left, u32 right, u32 dist (0xffffffff: empty slot), u32 aux} into fz_match
+ * rows in the reference's emission order (block ascending, hit index ascending; n-gram length L). */
+int fz_debug_order_records(const void *recs, uint64_t n, uint32_t L, fz_match **out, uint64_t *n_out);
+
 int  fz_stats(fz_ctx *ctx, fz_stats_t *out);
+/* hipEvent timing of the kernels (filter_ms / verify_ms / device_ms of fz_stats, fz_device_ms): on by default.
+ * Off, a search enqueues one packet less in front of its kernel and makes no hipEventElapsedTime calls (the *_ms
+ * fields then read 0): a few microseconds per call for callers that do not look at the timings. */
+int  fz_set_timing(fz_ctx *ctx, int on);
 /* hipEvent span of the filter kernel(s) of the search collected last, per device of the ctx (at most `cap` values
  * are written); returns the number of devices, or a negative FZ_E* code. */
 int  fz_device_ms(fz_ctx *ctx, double *filter_ms, int cap);

@@ -339,3 +339,72 @@ def test_scan_launch_plan_separates_block_hashes():
         assert nxt == m // L
         n_multi += nl.value > -(-(m // L) // 8)
     assert n_multi < 200            # splitting beyond ceil(G / 8) launches is the exception (low-entropy patterns)
+
+
+def test_record_ordering_host_step():
+    """emit_matches (fz_debug_order_records): unordered device records -> rows in (block, hit index) order, empty
+    slots dropped; uniform, clustered and single-key distributions, counts around the bucket / std::sort switch."""
+    import ctypes
+    import numpy as np
+    from fuzzysearch_amd import _native
+    lib = _native.load_library()
+    rec_dt = np.dtype([("key", "<u8"), ("l", "<u4"), ("r", "<u4"), ("dist", "<u4"), ("aux", "<u4")])
+    rng = np.random.default_rng(5)
+    L = 6
+    for n, span, nblocks, clusters in [(0, 10, 1, 0), (1, 10, 1, 0), (2, 5, 3, 0), (63, 1 << 20, 3, 0), (64, 1 << 20, 3, 0),
+                                       (2409, 1 << 30, 3, 0), (2409, 1 << 30, 3, 2), (5000, 1 << 40, 300, 3), (40000, 1 << 33, 2, 1),
+                                       (3000, 4096, 1, 0), (70000, 1 << 20, 1000, 0)]:
+        if clusters:
+            centers = rng.integers(0, span, clusters)
+            idx = (centers[rng.integers(0, clusters, n)] + rng.integers(0, 5000, n)).astype(np.uint64)
+        else:
+            idx = rng.integers(0, span, n).astype(np.uint64)
+        blk = rng.integers(0, nblocks, n).astype(np.uint64)
+        key = (blk << np.uint64(48)) | idx
+        key, first = np.unique(key, return_index=True)              # one record per (block, index), as in a search
+        order = rng.permutation(len(key))
+        key = key[order]
+        recs = np.zeros(len(key), dtype=rec_dt)
+        recs["key"] = key
+        recs["l"] = rng.integers(0, 9, len(key))
+        recs["r"] = rng.integers(0, 20, len(key))
+        recs["dist"] = rng.integers(0, 3, len(key))
+        empty = rng.random(len(key)) < (0.3 if n % 2 else 0.0)
+        recs["dist"][empty] = 0xffffffff
+        ptr = ctypes.POINTER(_native.FzMatch)()
+        cnt = ctypes.c_uint64(0)
+        _native._check(lib.fz_debug_order_records(recs.ctypes.data, len(recs), L, ctypes.byref(ptr), ctypes.byref(cnt)))
+        got = _native._take_matches_array(lib, ptr, cnt.value)
+        keep = recs[~empty]
+        keep = keep[np.argsort(keep["key"], kind="stable")]
+        kidx = (keep["key"] & np.uint64((1 << 48) - 1)).astype(np.int64)
+        assert cnt.value == len(keep)
+        assert np.array_equal(got["start"], kidx - keep["l"].astype(np.int64))
+        assert np.array_equal(got["end"], kidx + L + keep["r"].astype(np.int64))
+        assert np.array_equal(got["dist"], keep["dist"].astype(np.int32))
+        assert np.array_equal(got["block"], (keep["key"] >> np.uint64(48)).astype(np.int32))
+
+
+def test_no_kernel_spills_to_scratch():
+    """Compiler resource remarks collected by fuzzysearch_amd/build.py: the streaming and automaton kernels must not
+    use scratch memory (round 3 caught a 1.5 KB-per-lane copy of the argument struct in every hit-emitting scan
+    instance — exact search 3.4x slower, every parity test green)."""
+    import os
+    import pytest
+    from fuzzysearch_amd import build as fzbuild
+    if not os.path.exists(fzbuild.RESOURCES):
+        pytest.skip("no resource summary next to libfzhip.so (built by an older build.py)")
+    rows = {}
+    for ln in open(fzbuild.RESOURCES):
+        parts = ln.split()
+        if len(parts) >= 3:
+            rows[parts[0]] = dict(kv.split("=") for kv in parts[1:])
+    scan = {k: v for k, v in rows.items() if "fz_scan_kernel" in k}
+    assert len(scan) == 40
+    for name, r in rows.items():
+        hot = ("fz_scan_kernel" in name or "fz_verify_wf_kernel" in name or "fz_verify_big_kernel" in name or
+               "fz_lp_kernelILi0E" in name or "fz_gen_" in name or "fz_hamming" in name)
+        if hot:
+            assert int(r["scratch"]) == 0 and int(r["vgpr_spill"]) == 0, (name, r)
+    headline = [v for k, v in scan.items() if "ILi2ELi3ELb1ELb0ELb1EE" in k]
+    assert len(headline) == 1 and int(headline[0]["occupancy"]) == 7 and int(headline[0]["vgprs"]) <= 72
