@@ -714,13 +714,13 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
             const bool fire = __ballot(acc == 0) != 0;
             if (__builtin_expect(fire, 0)) {              // wave-uniform, rare: some lane, some offset
                 if (__builtin_expect(!dup_hashes, 1)) {
-#ifndef FZ_RARE_VECTOR
-                    // Resolved one firing lane at a time (nearly always exactly one), mostly on the SCALAR unit: the lane's
-                    // four xor words come over by v_readlane, offset and table slot are scalar arithmetic, the block is one
-                    // wave-uniform LDS read (the dword behind the hash table says which block lives in a slot), the code is
-                    // stored by a wave-uniform LDS write.  ~9 vector-issue slots per hit instead of ~16 (four ballots + slot
-                    // / block lookup / rank / code per firing offset): the scan is bound by vector issue, and 788 000 of
-                    // these run per GiB of DNA.
+#ifdef FZ_RARE_SCALAR
+                    // (Lab variant, measured in round 3 and NOT kept: the firing lane resolved on the scalar unit — the
+                    // lane's four xor words by v_readlane, offset and table slot as scalar arithmetic, the block by one
+                    // wave-uniform LDS read, the code by a wave-uniform LDS write: ~9 vector-issue slots per hit instead of
+                    // ~16, 6M fewer VALU wave-instructions per GiB — and 0.2205 instead of 0.2150 ms: the dependent
+                    // readlane -> compare -> branch chain per hit costs more than the issue slots it frees, and the
+                    // SGPR spills grow from 71 to 119.)
                     unsigned long long fm = __ballot(acc == 0);
                     do {
                         const uint32_t fl = (uint32_t)__builtin_ctzll(fm);
