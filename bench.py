@@ -71,7 +71,7 @@ def _cpu_worker(args):
     return [(s + lo, e + lo, d) for (s, e, d, *_r) in fn(p, t[lo:hi], k)]
 
 
-def cpu_baseline(seq, pattern, k, sample_mib, one_core_mib=256):
+def cpu_baseline(seq, pattern, k, sample_mib, one_core_mib=1024):
     """The reference CPU path on the host cores of this box: (i) one core, as shipped
     (the reference has no parallelism), best of 3 on a bounded sample; (ii) all cores: the sample cut into
     os.cpu_count() contiguous shards overlapping by m - 1 + k bytes (the reference's own chunk overlap,
@@ -89,8 +89,8 @@ def cpu_baseline(seq, pattern, k, sample_mib, one_core_mib=256):
         dt = time.perf_counter() - t0
         best1 = dt if best1 is None else min(best1, dt)
     out = {"value": round(n1 / best1 / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": kind,
-           "sample": "first %d MiB of the same DNA workload, |p|=20 k=2, single thread (the reference has no "
-                     "parallelism), best of 3; %d raw matches in %.2f s" % (n1 >> 20, len(res1), best1)}
+           "sample": "%s %d MiB of the same DNA workload, |p|=20 k=2, single thread (the reference has no "
+                     "parallelism), best of 3; %d raw matches in %.2f s" % ("the whole" if n1 == len(seq) else "first", n1 >> 20, len(res1), best1)}
     cores = os.cpu_count() or 1
     n = min(len(seq), sample_mib << 20)
     t = seq[:n].tobytes()
@@ -196,10 +196,14 @@ def extra_blocks(engine, workloads, reps):
         "scan_kernel_ms": round(f_ms, 4),
         "verify_kernel_ms": round(v_ms, 4), "raw_matches": int(len(res))}
     ms, f_ms, v_ms, res = time_call(engine, lambda: engine.generic_ngrams(h, p3, 5, 2, 2, 5, as_array=True), max(20, reps // 4))
+    cms, _f, cv_ms, cres = time_call(engine, lambda: engine.generic_ngrams_consolidated(h, p3, 5, 2, 2, 5, as_array=True), max(20, reps // 4))
     h.release()
     cfgs["configs[3b] UTF-8 m=64 limits (5,2,2,5) (generic_search)"] = {
         "ms_per_call": round(ms, 4), "GB_per_s": round(gib / ms / 1e6, 1), "scan_kernel_ms": round(f_ms, 4),
-        "automaton_kernel_ms": round(v_ms, 4), "raw_matches": int(len(res))}
+        "automaton_kernel_ms": round(v_ms, 4), "raw_matches": int(len(res)),
+        "consolidated_ms_per_call": round(cms, 4), "consolidated_GB_per_s": round(gib / cms / 1e6, 1),
+        "consolidated_automaton_kernel_ms": round(cv_ms, 4), "consolidated_matches": int(len(cres)),
+        "note": "consolidated = fz_generic_ngrams_consolidated: search + consolidate_overlapping_matches, first stage on the device"}
     out["configs"] = cfgs
     return out
 
@@ -482,8 +486,10 @@ def main():
         achieved = shard_bytes / (f_ms * 1e-3) / 1e9           # algorithmic bytes: N read once
         traffic_gb, traffic_src = measured_traffic(shard_bytes)
         out = {
-            "metric": "GB/s of sequence scanned at |p|=20 max_l_dist=2 (levenshtein_ngram path)",
+            "metric": "GB/s of sequence scanned at |p|=20 max_l_dist=2 (levenshtein_ngram path%s)"
+                      % ("" if (args.sync and not use_dist) else "; two searches in flight: see value_sync for one synchronous call at a time"),
             "value": round(value, 2),
+            "value_sync": None if sync_ms is None else round(global_n / (sync_ms * 1e-3) / 1e9, 2),
             "unit": "GB/s",
             "n_gpus": world,
             "steps": args.steps,

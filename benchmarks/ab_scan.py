@@ -45,13 +45,11 @@ p = pat.tobytes()
 run("cfg1 DNA m=20 k=2", seq, lambda h: eng.lev_ngrams(h, p, 2, as_array=True))
 run("cfg0 DNA m=20 exact", seq, lambda h: eng.search_exact(h, p))
 if "--all" in sys.argv:
-    seq = workloads.text65(n, 3)
-    pat = workloads.text65(32, 33)
-    workloads.plant_variants(seq, pat, 1024 * mib // 1024 or 64, 8, workloads.TEXT65)
+    seq, pat, _ = workloads.cfg3(n, 1024 * mib // 1024 or 64)
     p2 = pat.tobytes()
     run("cfg2 ASCII m=32 subs<=3", seq, lambda h: eng.subs_ngrams(h, p2, 3, as_array=True))
-    seq, pat = workloads.utf8_text(n, 4), workloads.utf8_text(64, 44)
-    workloads.plant_variants(seq, pat, 1024 * mib // 1024 or 64, 9, workloads.TEXT65)
+    seq, pat, _ = workloads.cfg4(n, 1024 * mib // 1024 or 64)
     p3 = pat.tobytes()
     run("cfg3a UTF-8 m=64 k=5", seq, lambda h: eng.lev_ngrams(h, p3, 5, as_array=True))
     run("cfg3b UTF-8 m=64 (5,2,2,5)", seq, lambda h: eng.generic_ngrams(h, p3, 5, 2, 2, 5, as_array=True))
+    run("cfg3b consolidated on the device", seq, lambda h: eng.generic_ngrams_consolidated(h, p3, 5, 2, 2, 5, as_array=True))

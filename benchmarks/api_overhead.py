@@ -25,8 +25,10 @@ res = fa.resident(seq)
 eng = _native.default_engine()
 ms_abi, raw = best(lambda: eng.generic_ngrams(res.handle if hasattr(res, "handle") else res._handle, p, 5, 2, 2, 5, as_array=True))
 ms_api, out = best(lambda: fa.find_near_matches(p, res, max_substitutions=5, max_insertions=2, max_deletions=2, max_l_dist=5))
+ms_cons, rows = best(lambda: eng.generic_ngrams_consolidated(res.handle, p, 5, 2, 2, 5, as_array=True))
 print(json.dumps({"case": "configs[3b] generic (5,2,2,5)", "MiB": mib, "raw_matches": int(len(raw)), "result_matches": len(out),
-                  "c_abi_ms": round(ms_abi, 3), "find_near_matches_ms": round(ms_api, 3), "ratio": round(ms_api / ms_abi, 2)}), flush=True)
+                  "c_abi_ms": round(ms_abi, 3), "c_abi_consolidated_ms": round(ms_cons, 3), "consolidated_rows": int(len(rows)),
+                  "find_near_matches_ms": round(ms_api, 3), "ratio": round(ms_api / ms_abi, 2)}), flush=True)
 ms_abi, raw = best(lambda: eng.lev_ngrams(res.handle if hasattr(res, "handle") else res._handle, p, 5, as_array=True))
 ms_api, out = best(lambda: fa.find_near_matches(p, res, max_l_dist=5))
 print(json.dumps({"case": "configs[3a] levenshtein k=5", "MiB": mib, "raw_matches": int(len(raw)), "result_matches": len(out),

@@ -48,11 +48,9 @@ for name, gen, run, orc in cases:
     if gen is not None:
         seq, pat = gen()
     elif "ASCII" in name:
-        seq, pat = workloads.text65(n, 3), workloads.text65(32, 33)
-        workloads.plant_variants(seq, pat, 1024 * mib // 1024 or 64, 8, workloads.TEXT65)
+        seq, pat, _ = workloads.cfg3(n, 1024 * mib // 1024 or 64)
     else:
-        seq, pat = utf8_text(n, 4), utf8_text(64, 44)
-        workloads.plant_variants(seq, pat, 1024 * mib // 1024 or 64, 9, workloads.TEXT65)
+        seq, pat, _ = workloads.cfg4(n, 1024 * mib // 1024 or 64)
     h = eng.upload(seq)
     p = pat.tobytes()
     dt, res = timeit(lambda: run(h, p))

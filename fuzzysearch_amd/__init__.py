@@ -68,6 +68,11 @@ def find_near_matches(subsequence, sequence,
     search_params = LevenshteinSearchParams(max_substitutions, max_insertions,
                                             max_deletions, max_l_dist)
     search_class = choose_search_class(search_params)
+    fused = getattr(search_class, 'search_consolidated', None)
+    if fused is not None:                          # search + consolidation in one device round trip (generic n-gram route)
+        result = fused(subsequence, sequence, search_params)
+        if result is not None:
+            return result
     matches = search_class.search(subsequence, sequence, search_params)
     return search_class.consolidate_matches(matches)
 

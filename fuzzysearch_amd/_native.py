@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = (
     "fz_abi_version", "fz_last_error", "fz_device_count", "fz_create", "fz_destroy",
     "fz_seq_upload", "fz_seq_upload_shard", "fz_seq_new", "fz_seq_add_shard", "fz_seq_len", "fz_seq_release",
     "fz_search_exact", "fz_lev_ngrams", "fz_lev_ngrams_begin", "fz_lev_ngrams_end", "fz_subs_ngrams", "fz_generic_ngrams",
-    "fz_lev_lp", "fz_subs_lp", "fz_generic_lp", "fz_subs_ngrams_any", "fz_subs_lp_any", "fz_generic_ngrams_any",
+    "fz_lev_lp", "fz_subs_lp", "fz_generic_lp", "fz_subs_ngrams_any", "fz_subs_lp_any", "fz_generic_ngrams_any", "fz_generic_ngrams_consolidated",
     "fz_stream_open", "fz_stream_buffer", "fz_stream_submit", "fz_stream_read_fd", "fz_stream_finish", "fz_stream_close",
     "fz_consolidate", "fz_group_best", "fz_merge_ranks", "fz_wire_pack", "fz_wire_merge", "fz_debug_launch_plan", "fz_debug_order_records", "fz_stats", "fz_set_timing", "fz_device_ms", "fz_free",
     "fz_comm_unique_id", "fz_comm_init_rank", "fz_comm_init_all", "fz_comm_info", "fz_comm_set_collective",
@@ -122,6 +122,8 @@ def load_library():
         L.fz_subs_lp.argtypes = [vp, vp, u8p, u32, u32, mpp, u64p]
         L.fz_generic_lp.restype = ci
         L.fz_generic_lp.argtypes = [vp, vp, u8p, u32, u32, u32, u32, u32, mpp, u64p]
+        L.fz_generic_ngrams_consolidated.restype = ci
+        L.fz_generic_ngrams_consolidated.argtypes = [vp, vp, u8p, u32, u32, u32, u32, u32, mpp, u64p]
         L.fz_subs_ngrams_any.restype = ci
         L.fz_subs_ngrams_any.argtypes = [vp, vp, u8p, u32, u32, ctypes.POINTER(ci)]
         L.fz_subs_lp_any.restype = ci
@@ -601,6 +603,12 @@ class Engine(object):
 
     def generic_ngrams(self, seq, pattern, max_subs, max_ins, max_dels, max_l, as_array=False):
         return self._match_call(self._lib.fz_generic_ngrams, seq, pattern, max_subs, max_ins, max_dels, max_l,
+                                as_array=as_array)
+
+    def generic_ngrams_consolidated(self, seq, pattern, max_subs, max_ins, max_dels, max_l, as_array=False):
+        """consolidate_overlapping_matches(find_near_matches_generic_ngrams(...)) with the first stage of the consolidation
+        on the device (fz_generic_ngrams_consolidated): rows (start, end, dist, block) sorted by (start, end, dist)."""
+        return self._match_call(self._lib.fz_generic_ngrams_consolidated, seq, pattern, max_subs, max_ins, max_dels, max_l,
                                 as_array=as_array)
 
     def lev_lp(self, seq, pattern, k, as_array=False):

@@ -46,8 +46,8 @@ def build(force=False, report=False):
     err = res.stderr.decode("utf-8", "replace")
     remarks = [ln for ln in err.splitlines() if "-Rpass-analysis=kernel-resource-usage" in ln]
     other = [ln for ln in err.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in ln]
-    if other:
-        sys.stderr.write("\n".join(other) + "\n")
+    if res.returncode != 0 or any("warning:" in ln or "error:" in ln for ln in other):
+        sys.stderr.write("\n".join(other) + "\n")        # (otherwise only the source context of the remarks)
     if res.returncode != 0:
         raise subprocess.CalledProcessError(res.returncode, cmd)
     with open(RESOURCES, "w") as f:

@@ -60,6 +60,8 @@
                                                            // + the four waves' final queue fills (pooled last flush)
                                                            // (same byte offset as the hash: no address arithmetic in the rare path)
 #define FZ_FLAG_DUP_HASHES 1u                              // FzScanArgs.flags: two blocks of the launch have the same hash
+#define FZ_FLAG_FOLD 4u                                    // per-hit automaton: fold the matches of a hit into (hull, best match) pairs on
+                                                           // the device (consolidate_overlapping_matches, common.py:145-189, first stage)
 #define FZ_FLAG_ANY 2u                                     // has_near_match_*: the caller only asks WHETHER a record exists — work that starts
                                                            // after the first record has been counted is skipped
 #if FZ_LUT_BITS == 5
@@ -1302,6 +1304,9 @@ __global__ __launch_bounds__(64) void fz_verify_big_kernel(const uint8_t *__rest
 // lanes; successor candidates and matches are written through wave prefix sums, so both lists keep
 // exactly the reference's order (its emitted *list*, not just the set, is reproduced).  The
 // character loop is inherently sequential; parallelism comes from hits x candidates.
+#ifndef FZ_LP_PAIR
+#define FZ_LP_PAIR 1                                       // the per-hit automaton steps two 64-candidate slices per trip
+#endif
 #ifndef FZ_GEN_MCAP
 #define FZ_GEN_MCAP 128                                    // match-buffer entries per wave (1 KB: with 256-entry candidate lists
                                                            // 24 waves per CU are resident, every hit of configs[3b] at once)
@@ -1403,9 +1408,67 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
 
         uint32_t ncur = 0, mb = 0, mseq = 0;
         bool overflow = false;
+        // FZ_FLAG_FOLD (fz_generic_ngrams_consolidated): what leaves the kernel is not the hit's matches but (hull, best
+        // match) pairs — every match that overlaps the running hull of the hit's earlier matches is folded into it
+        // (the group test of common.py:150-159; "best" = smallest distance, then longest, then smallest start: a total
+        // order, so the fold order does not matter).  The matches of one hit nearly always overlap: ~1 pair per hit
+        // instead of ~34 rows (configs[3b]: 6e3 pairs instead of 2.1e5 rows cross PCIe), and the host only merges hulls.
+        const bool fold = per_hit && (a.flags & FZ_FLAG_FOLD);
+        bool f_have = false;
+        uint32_t f_lo = 0, f_hi = 0, f_k1 = 0, f_k2 = 0, f_pairs = 0;   // hull [lo, hi), best = (dist << 16 | 0xffff - len, start)
+        auto emit_pair = [&]() {
+            if (lane == 0) {
+                const unsigned long long slot = atomicAdd(&counters[1], 1ull);
+                if (slot < a.rec_cap) {
+                    const uint32_t len = 0xffffu - (f_k1 & 0xffffu);
+                    FzGenRec r;
+                    r.key = key_base; r.seq = f_pairs; r.se = f_k2 | ((f_k2 + len) << 16); r.dist = f_k1 >> 16; r.win = f_lo | (f_hi << 16);
+                    recs[slot] = r;
+                }
+            }
+            ++f_pairs;
+            f_have = false;
+        };
+        auto wave_min = [&](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)fz_wave_incl_min(v), 63); };
+        auto fold_matches = [&]() {
+            fz_wave_lds_sync();
+            for (uint32_t e0 = 0; e0 < mb; e0 += 64u) {
+                const bool have_row = e0 + lane < mb;
+                const uint64_t v = have_row ? mbuf[e0 + lane] : 0ull;
+                const uint32_t rs = (uint32_t)v & 0xffffu, re = ((uint32_t)v >> 16) & 0xffffu, rd = (uint32_t)(v >> 32) & 0xffffu;
+                const uint32_t k1 = (rd << 16) | (0xffffu - (re - rs));
+                unsigned long long pending = __ballot(have_row);
+                while (pending) {
+                    if (!f_have) {                                 // a new hull starts with the first row that is left
+                        const uint32_t l0 = (uint32_t)__builtin_ctzll(pending);
+                        f_lo = (uint32_t)__builtin_amdgcn_readlane((int)rs, (int)l0);
+                        f_hi = (uint32_t)__builtin_amdgcn_readlane((int)re, (int)l0);
+                        f_k1 = (uint32_t)__builtin_amdgcn_readlane((int)k1, (int)l0);
+                        f_k2 = f_lo;
+                        f_have = true;
+                        pending &= pending - 1ull;
+                        continue;
+                    }
+                    const bool mine = ((pending >> lane) & 1ull) && !(re <= f_lo || rs >= f_hi);
+                    const unsigned long long ov = __ballot(mine);
+                    if (!ov) { emit_pair(); continue; }            // nothing left overlaps this hull: it is complete for now
+                    const uint32_t mlo = wave_min(mine ? rs : 0xffffffffu), mhi = ~wave_min(mine ? ~re : 0xffffffffu);
+                    const uint32_t mk1 = wave_min(mine ? k1 : 0xffffffffu);
+                    const uint32_t mk2 = wave_min((mine && k1 == mk1) ? rs : 0xffffffffu);
+                    f_lo = mlo < f_lo ? mlo : f_lo;
+                    f_hi = mhi > f_hi ? mhi : f_hi;
+                    if (mk1 < f_k1 || (mk1 == f_k1 && mk2 < f_k2)) { f_k1 = mk1; f_k2 = mk2; }
+                    pending &= ~ov;
+                }
+            }
+            mseq += mb;
+            mb = 0;
+            fz_wave_lds_sync();
+        };
         // match buffer entry: se (32) | dist (16) | step-in-window (16)
         auto flush_matches = [&]() {
             if (mb == 0) return;
+            if (fold) { fold_matches(); return; }
             fz_wave_lds_sync();
             unsigned long long base = 0;
             if (lane == 0) base = atomicAdd(&counters[1], (unsigned long long)mb);
@@ -1481,16 +1544,62 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
                 // the hot loop (its own copy of `emit`: no register shuffling where the two forms would join).  Every
                 // lane steps — positions below cand_cap are readable, lanes past the list step an all-zero candidate
                 // and have their five output flags cleared: no divergence
-                for (uint32_t c0 = 0; c0 < ncur; c0 += 64u) {
+                auto load_step = [&](uint32_t c0, FzGStep &st) {
                     const bool valid = c0 + lane < ncur;
                     uint2 cw = reinterpret_cast<const uint2 *>(cur)[c0 + lane];
                     const bool fresh = c0 + lane == fresh_at;
                     cw.x = valid ? (fresh ? index : cw.x) : 0u;
                     cw.y = valid && !fresh ? cw.y : 0u;
-                    FzGStep st;
                     fz_generic_step_packed(cw.x, cw.y, ch, index, a.m, patf, a.max_subs, a.max_ins, a.max_dels, a.k, st);
                     const uint32_t vm = valid ? 1u : 0u;
                     st.fa &= vm; st.fb &= vm; st.fc &= vm; st.f1 &= vm; st.f2 &= vm;
+                };
+                uint32_t c0 = 0;
+#if FZ_LP_PAIR
+                // Two slices of 64 candidates per trip while the list has more than one: their loads, steps and prefix
+                // scans are independent chains the hardware can overlap (a hit's time is this dependent chain, character
+                // after character, and the kernel takes as long as its slowest hits — the ones with long lists); only
+                // the output offsets of the second slice wait for the first one's totals.  (Lists in LDS only: the
+                // second slice may read up to 127 entries past the list, which there is still this wave's LDS.)
+                if constexpr (!HBM_LISTS) {
+                    for (; c0 + 64u < ncur && !overflow; c0 += 128u) {
+                        FzGStep sa, sb;
+                        load_step(c0, sa);
+                        load_step(c0 + 64u, sb);
+                        const uint32_t pa = (sa.fa + sa.fb + sa.fc) | ((sa.f1 + sa.f2) << 16);
+                        const uint32_t pb = (sb.fa + sb.fb + sb.fc) | ((sb.f1 + sb.f2) << 16);
+                        const uint32_t ia = fz_wave_incl_scan(pa), ib = fz_wave_incl_scan(pb);
+                        const uint32_t ta = __builtin_amdgcn_readlane(ia, 63), tb = __builtin_amdgcn_readlane(ib, 63);
+                        const uint32_t tot_s = (ta & 0xffffu) + (tb & 0xffffu), tot_m = (ta >> 16) + (tb >> 16);
+                        if (nnext + tot_s > a.cand_cap) { overflow = true; break; }
+                        if (tot_m > FZ_GEN_MCAP) {                 // more matches than the buffer holds at once: one slice at a time
+                            if (!emit(sa) || !emit(sb)) overflow = true;
+                            continue;
+                        }
+                        if (mb + tot_m > FZ_GEN_MCAP) flush_matches();
+                        const uint32_t ea = ia - pa, eb = ib - pb + ta;
+                        uint2 *nxa = reinterpret_cast<uint2 *>(nxt) + nnext + (ea & 0xffffu);
+                        uint2 *nxb = reinterpret_cast<uint2 *>(nxt) + nnext + (eb & 0xffffu);
+                        if (sa.fa) nxa[0] = make_uint2(sa.a0, sa.a1);
+                        if (sa.fb) nxa[sa.fa] = make_uint2(sa.b0, sa.b1);
+                        if (sa.fc) nxa[sa.fa + sa.fb] = make_uint2(sa.c0, sa.c1);
+                        if (sb.fa) nxb[0] = make_uint2(sb.a0, sb.a1);
+                        if (sb.fb) nxb[sb.fa] = make_uint2(sb.b0, sb.b1);
+                        if (sb.fc) nxb[sb.fa + sb.fb] = make_uint2(sb.c0, sb.c1);
+                        uint64_t *mpa = mbuf + mb + (ea >> 16), *mpb = mbuf + mb + (eb >> 16);
+                        const uint64_t stamp = (uint64_t)index << 48;
+                        if (sa.f1) mpa[0] = (uint64_t)sa.m1 | ((uint64_t)sa.d1 << 32) | stamp;
+                        if (sa.f2) mpa[sa.f1] = (uint64_t)sa.m2 | ((uint64_t)sa.d2 << 32) | stamp;
+                        if (sb.f1) mpb[0] = (uint64_t)sb.m1 | ((uint64_t)sb.d1 << 32) | stamp;
+                        if (sb.f2) mpb[sb.f1] = (uint64_t)sb.m2 | ((uint64_t)sb.d2 << 32) | stamp;
+                        nnext += tot_s;
+                        mb += tot_m;
+                    }
+                }
+#endif
+                for (; c0 < ncur && !overflow; c0 += 64u) {
+                    FzGStep st;
+                    load_step(c0, st);
                     if (!emit(st)) { overflow = true; break; }
                 }
             } else {
@@ -1524,6 +1633,7 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
             if (lane == 0) atomicAdd(&counters[2], 1ull);              // host retries with bigger lists
         } else {
             flush_matches();
+            if (fold && f_have) emit_pair();
         }
         if (order && q < FZ_GEN_ORDER_MAX && lane == 0) { order_first[q] = 0; order_count[q] = overflow ? 0u : mseq; }
         fz_wave_lds_sync();

@@ -127,6 +127,7 @@ struct DevState {
     bool fused_used = false;
     bool timed = true;                           // the search being collected recorded its start event
     double last_filter_ms = 0;                   // scan span of the search collected last on this device (fz_device_ms)
+    uint64_t fold_guess = 8192, fold_copied = 0; // folded generic search: pairs fetched with the counters
     uint8_t *d_pat = nullptr;                    // pattern in HBM (subsequences longer than FZ_MAX_M, fz_verify_big_kernel)
     uint64_t pat_cap = 0;
     int slot_id = 0;                             // which of the two result slots is the current one
@@ -431,6 +432,10 @@ uint32_t choose_launch_blocks(const uint8_t *p, const uint32_t *starts, uint32_t
     return nblk;
 }
 
+// a connected set of matches: its hull [h0, h1) and its best match (fz_consolidate, fz_generic_ngrams_consolidated)
+struct Hull { int64_t h0, h1; fz_match best; };
+int consolidate_hulls(std::vector<Hull> &hulls, fz_match **out, uint64_t *n_out);
+
 int emit_generic(fz_ctx *ctx, fz_seq *seq, const std::vector<FzGenRec> &recs_vec, uint32_t L, uint32_t k, fz_match **out,
                  uint64_t *n, uint32_t **seg_out);
 
@@ -441,6 +446,7 @@ struct Search {
     BlockPlan plan;
     bool collective = false;       // the context joined a communicator: every rank gets the merged stream of all ranks
     bool any = false;              // has_near_match_*: only whether a record exists
+    bool fold = false;             // generic search: the device folds every hit's matches into (hull, best match) pairs
 };
 
 static const uint32_t kFusedLdsBudget = []() { const char *e = getenv("FZ_FUSED_LDS_KB"); int v = e ? atoi(e) : 0; return (uint32_t)(v > 0 ? v : 64) * 1024u; }();   // dynamic LDS per scan workgroup when verification is fused
@@ -955,7 +961,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             fill_common_args(fa, sh, q);
             rc = stage_pattern(d, fa, q.p, q.m);
             if (rc) return rc;
-            fa.flags = q.any ? FZ_FLAG_ANY : 0u;
+            fa.flags = (q.any ? FZ_FLAG_ANY : 0u) | (q.fold ? FZ_FLAG_FOLD : 0u);
             fa.cand_cap = cand_cap;
             fa.cand_scratch = scratch;
             fa.lp_kind = FZ_LP_GENERIC_HIT;
@@ -973,7 +979,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             // keeps the host's run ordering (emit_generic), which also serves searches with more than
             // FZ_GEN_ORDER_MAX hits, several shards and the file API's segments.
             static const bool host_order = getenv("FZ_GEN_HOST_ORDER") != nullptr;
-            const bool dev_order = !gen_direct && !host_order && !q.any && seq->shards.size() == 1 && sh.geom.seg_stride == 0;
+            const bool dev_order = !gen_direct && !host_order && !q.any && !q.fold && seq->shards.size() == 1 && sh.geom.seg_stride == 0;
             if (dev_order) {
                 rc = ensure_gen_rows(d);
                 if (rc) return rc;
@@ -1001,7 +1007,9 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
                                    reinterpret_cast<FzOutRow *>(d.d_gen_rows), counters);
                 HIP_TRY(hipGetLastError());
             }
-            HIP_TRY(hipMemcpyAsync(d.h_stage, d.d_out, kHeaderBytes, hipMemcpyDeviceToHost, d.stream));
+            // folded search: the (few) pairs come back with the counters in ONE copy — as many as the previous search had
+            d.fold_copied = q.fold ? std::min<uint64_t>(std::min<uint64_t>(d.fold_guess, kHostRecs), d.rec_cap) : 0;
+            HIP_TRY(hipMemcpyAsync(d.h_stage, d.d_out, kHeaderBytes + d.fold_copied * sizeof(FzGenRec), hipMemcpyDeviceToHost, d.stream));
             HIP_TRY(hipEventRecord(d.ev[3], d.stream));
         }
         bool lists_overflowed = false;
@@ -1028,9 +1036,11 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             if (nr > d.big_cap) { int rc = ensure_big(d, nr + nr / 8 + 1024); if (rc) return rc; if (gen_direct2) rerun = true; }
             if (!gen_direct2 && nr > d.rec_cap) { int rc = ensure_recs(d, nr + nr / 8 + 1024); if (rc) return rc; rerun = true; }
             static const bool host_order2 = getenv("FZ_GEN_HOST_ORDER") != nullptr;
-            const bool rows_ready = !gen_direct2 && !host_order2 && seq->shards.size() == 1 && sh.geom.seg_stride == 0 &&
+            const bool rows_ready = !gen_direct2 && !host_order2 && !q.fold && seq->shards.size() == 1 && sh.geom.seg_stride == 0 &&
                                     nh <= FZ_GEN_ORDER_MAX && nr <= d.gen_rows_cap;
-            if (!gen_direct2 && !rerun && !novf && nr && !rows_ready)
+            const bool in_stage = q.fold && nr <= d.fold_copied && seq->shards.size() == 1;   // the pairs are in h_stage already
+            if (q.fold) d.fold_guess = std::max<uint64_t>(4096, nr + nr / 4 + 256);
+            if (!gen_direct2 && !rerun && !novf && nr && !rows_ready && !in_stage)
                 HIP_TRY(hipMemcpy(d.h_big, d.d_out + kHeaderBytes, nr * sizeof(FzGenRec), hipMemcpyDeviceToHost));
             if (novf) { lists_overflowed = true; rerun = true; }
             if (rerun) continue;
@@ -1050,7 +1060,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
                 ctx->gen_rows_n = nr;
                 ctx->gen_rows_device = d.device;
             } else if (seq->shards.size() == 1) {             // read in place (valid until the next search)
-                ctx->gen_view = reinterpret_cast<const FzGenRec *>(d.h_big);
+                ctx->gen_view = reinterpret_cast<const FzGenRec *>(in_stage ? d.h_stage + kHeaderBytes : d.h_big);
                 ctx->gen_view_n = nr;
             } else {
                 const size_t base = recs_out.size();
@@ -1722,7 +1732,14 @@ int fz_subs_ngrams_any(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, u
 }
 
 static int generic_ngrams_impl(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t max_subs, uint32_t max_ins,
-                               uint32_t max_dels, uint32_t max_l, fz_match **out, uint64_t *n, int *found);
+                               uint32_t max_dels, uint32_t max_l, fz_match **out, uint64_t *n, int *found, bool consolidated = false);
+
+int fz_generic_ngrams_consolidated(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t max_subs, uint32_t max_ins,
+                                   uint32_t max_dels, uint32_t max_l, fz_match **out, uint64_t *n) {
+    if (!out || !n) return fail(FZ_EINVAL, "null argument");
+    *out = nullptr; *n = 0;
+    return generic_ngrams_impl(ctx, seq, p, m, max_subs, max_ins, max_dels, max_l, out, n, nullptr, true);
+}
 
 int fz_generic_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t max_subs, uint32_t max_ins,
                       uint32_t max_dels, uint32_t max_l, fz_match **out, uint64_t *n) {
@@ -1739,7 +1756,7 @@ int fz_generic_ngrams_any(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m
 }
 
 static int generic_ngrams_impl(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t max_subs, uint32_t max_ins,
-                               uint32_t max_dels, uint32_t max_l, fz_match **out, uint64_t *n, int *found) {
+                               uint32_t max_dels, uint32_t max_l, fz_match **out, uint64_t *n, int *found, bool consolidated) {
     int rc = validate(ctx, seq, p, m);
     if (rc) return rc;
     const uint32_t k = max_l;
@@ -1751,6 +1768,7 @@ static int generic_ngrams_impl(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint3
     Search q;
     q.mode = FZ_MODE_GENERIC; q.m = m; q.k = k; q.p = p;
     q.any = found != nullptr;
+    q.fold = consolidated;
     q.max_subs = std::min(max_subs, 255u); q.max_ins = std::min(max_ins, 255u); q.max_dels = std::min(max_dels, 255u);
     q.plan.L = L;
     for (uint32_t s = 0; s + L <= m; s += L) q.plan.s.push_back(s);   // generic_search.py:221-228 (ranges: fz_block_range)
@@ -1761,6 +1779,23 @@ static int generic_ngrams_impl(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint3
     if (rc) return rc;
     tr.mark("generic: kernels");
     if (found) { *found = ctx->any_found ? 1 : 0; return FZ_OK; }
+    if (consolidated) {
+        // the device's (hull, best match) pairs, one or a few per n-gram hit -> second stage of the consolidation
+        const FzGenRec *prs = ctx->gen_view ? ctx->gen_view : recs_vec.data();
+        const size_t npr = ctx->gen_view ? (size_t)ctx->gen_view_n : recs_vec.size();
+        static thread_local std::vector<Hull> hulls;
+        hulls.clear();
+        hulls.reserve(npr);
+        for (size_t i = 0; i < npr; ++i) {
+            const FzOutRow best = fz_gen_row(prs[i].key, L, k, 0, prs[i].se, prs[i].dist);
+            const FzOutRow hull = fz_gen_row(prs[i].key, L, k, 0, prs[i].win, 0);
+            hulls.push_back(Hull{hull.start, hull.end, fz_match{best.start, best.end, best.dist, best.block}});
+        }
+        ctx->stats.raw_matches = npr;
+        rc = consolidate_hulls(hulls, out, n);
+        tr.mark("generic: hulls");
+        return rc;
+    }
     rc = emit_generic(ctx, seq, recs_vec, L, k, out, n, nullptr);
     tr.mark("generic: rows");
     return rc;
@@ -2713,48 +2748,21 @@ void fz_stream_close(fz_stream *st) {
 
 }  // extern "C"
 
-extern "C" {
+namespace {
 
-// ---- host-side consolidation (common.py:145-189) -------------------------------------------
-// The partition into overlap groups is input-order independent (SURVEY.md a8), so for
-// fz_consolidate a sort + sweep replaces the reference's O(M * groups) loop.
-int fz_consolidate(const fz_match *in, uint64_t n, fz_match **out, uint64_t *n_out) {
-    if (!out || !n_out || (!in && n)) return fail(FZ_EINVAL, "null argument");
-    *out = nullptr; *n_out = 0;
+// Second stage of the consolidation: (hull, best match) pairs of connected sets of matches — from the host's run
+// folding (fz_consolidate) or from the device's per-hit folding (fz_generic_ngrams_consolidated) — are ordered by
+// (hull start, zero-length first) and a sweep merges overlapping hulls; the survivors are sorted by (start, end, dist).
+int consolidate_hulls(std::vector<Hull> &hulls, fz_match **out, uint64_t *n_out) {
     auto by_start_end_dist = [](const fz_match &a, const fz_match &b) {
         if (a.start != b.start) return a.start < b.start;
         if (a.end != b.end) return a.end < b.end;
         return a.dist < b.dist;
     };
-    // Two stages.  (1) One pass in input order folds every row that overlaps the running hull of the rows right
-    // before it into that hull (the reference's own group test, common.py:150-159, applied to consecutive rows;
-    // the partition is order independent).  The records of one n-gram hit are emitted back to back and nearly all
-    // overlap, so the 2.1e5 rows of configs[3b] leave ~6e3 (hull, best row) pairs; streams without such runs pass
-    // through unchanged.  (2) The pairs are ordered by (hull start, zero-length first) — 11-bit LSD radix passes on
-    // one 64-bit word per pair when there are many, a comparison sort otherwise (2e5 24-byte rows: ~6 ms) — and a
-    // sweep merges overlapping hulls.  Zero-length matches (start == end) never overlap anything under
-    // `not (end <= g.start or start >= g.end)` unless strictly inside a group, so both stages use that predicate
-    // against the running hull instead of assuming sorted-interval merging.
     auto better = [](const fz_match &x, const fz_match &y) {
         const int64_t lx = x.end - x.start, ly = y.end - y.start;
         return x.dist < y.dist || (x.dist == y.dist && (lx > ly || (lx == ly && x.start < y.start)));
     };
-    struct Hull { int64_t h0, h1; fz_match best; };
-    static thread_local std::vector<Hull> hulls;                // scratch kept per thread between calls
-    hulls.clear();
-    for (uint64_t i = 0; i < n; ++i) {
-        const fz_match &mt = in[i];
-        if (!hulls.empty()) {
-            Hull &h = hulls.back();
-            if (!(mt.end <= h.h0 || mt.start >= h.h1)) {
-                h.h0 = std::min(h.h0, mt.start);
-                h.h1 = std::max(h.h1, mt.end);
-                if (better(mt, h.best)) h.best = mt;
-                continue;
-            }
-        }
-        hulls.push_back(Hull{mt.start, mt.end, mt});
-    }
     const uint64_t nh = hulls.size();
     static thread_local std::vector<uint64_t> wa, wb;
     std::vector<uint32_t> order;                                // hull numbers in sweep order
@@ -2819,6 +2827,47 @@ int fz_consolidate(const fz_match *in, uint64_t n, fz_match **out, uint64_t *n_o
     *out = static_cast<fz_match *>(mem);
     *n_out = best.size();
     return FZ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- host-side consolidation (common.py:145-189) -------------------------------------------
+// The partition into overlap groups is input-order independent (SURVEY.md a8), so for
+// fz_consolidate a sort + sweep replaces the reference's O(M * groups) loop.
+int fz_consolidate(const fz_match *in, uint64_t n, fz_match **out, uint64_t *n_out) {
+    if (!out || !n_out || (!in && n)) return fail(FZ_EINVAL, "null argument");
+    *out = nullptr; *n_out = 0;
+    // Two stages.  (1) One pass in input order folds every row that overlaps the running hull of the rows right
+    // before it into that hull (the reference's own group test, common.py:150-159, applied to consecutive rows;
+    // the partition is order independent).  The records of one n-gram hit are emitted back to back and nearly all
+    // overlap, so the 2.1e5 rows of configs[3b] leave ~6e3 (hull, best row) pairs; streams without such runs pass
+    // through unchanged.  (2) The pairs are ordered by (hull start, zero-length first) — 11-bit LSD radix passes on
+    // one 64-bit word per pair when there are many, a comparison sort otherwise (2e5 24-byte rows: ~6 ms) — and a
+    // sweep merges overlapping hulls.  Zero-length matches (start == end) never overlap anything under
+    // `not (end <= g.start or start >= g.end)` unless strictly inside a group, so both stages use that predicate
+    // against the running hull instead of assuming sorted-interval merging.
+    auto better = [](const fz_match &x, const fz_match &y) {
+        const int64_t lx = x.end - x.start, ly = y.end - y.start;
+        return x.dist < y.dist || (x.dist == y.dist && (lx > ly || (lx == ly && x.start < y.start)));
+    };
+    static thread_local std::vector<Hull> hulls;                // scratch kept per thread between calls
+    hulls.clear();
+    for (uint64_t i = 0; i < n; ++i) {
+        const fz_match &mt = in[i];
+        if (!hulls.empty()) {
+            Hull &h = hulls.back();
+            if (!(mt.end <= h.h0 || mt.start >= h.h1)) {
+                h.h0 = std::min(h.h0, mt.start);
+                h.h1 = std::max(h.h1, mt.end);
+                if (better(mt, h.best)) h.best = mt;
+                continue;
+            }
+        }
+        hulls.push_back(Hull{mt.start, mt.end, mt});
+    }
+    return consolidate_hulls(hulls, out, n_out);
 }
 
 int fz_merge_ranks(const fz_match *const *parts, const uint64_t *counts, const uint64_t *block_counts,

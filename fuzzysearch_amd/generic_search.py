@@ -88,6 +88,24 @@ class GenericSearch(FuzzySearchBase):
         return raw_generic(subsequence, sequence, search_params)
 
     @classmethod
+    def search_consolidated(cls, subsequence, sequence, search_params):
+        """search() + consolidate_matches() in one device round trip for the n-gram route (what find_near_matches
+        needs: generic_search.py:198-237 + common.py:185-189): the automaton kernel folds every hit's matches into
+        (hull, best match) pairs, so a few thousand pairs cross PCIe instead of every raw match
+        (fz_generic_ngrams_consolidated).  -> list of Match, or None when the call takes another route."""
+        if not len(subsequence):
+            raise ValueError('Given subsequence is empty!')
+        max_subs, max_ins, max_dels, max_l = search_params.unpacked
+        if max_l == 0 or len(subsequence) // (max_l + 1) < 3:
+            return None
+        pr = prepare(subsequence, sequence)
+        try:
+            rows = pr.engine.generic_ngrams_consolidated(pr.handle, pr.pattern, max_subs, max_ins, max_dels, max_l, as_array=True)
+        finally:
+            pr.release()
+        return RawMatches(rows, pr.original).materialize()
+
+    @classmethod
     def consolidate_matches(cls, matches):
         return consolidate_overlapping_matches(matches)
 

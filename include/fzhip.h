@@ -140,6 +140,16 @@ int fz_generic_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m,
                       uint32_t max_subs, uint32_t max_ins, uint32_t max_dels, uint32_t max_l,
                       fz_match **out, uint64_t *n);
 
+/* find_near_matches_generic_ngrams + consolidate_overlapping_matches in one call (what GenericSearch.search followed by
+ * GenericSearch.consolidate_matches computes: generic_search.py:198-237, :256-273, common.py:185-189) — the same rows
+ * as fz_consolidate(fz_generic_ngrams(...)).  The first stage of the consolidation runs on the device: the automaton
+ * kernel folds the matches of every n-gram hit into (hull, best match) pairs, a few thousand pairs cross PCIe instead
+ * of every raw match (BASELINE configs[3b]: 6e3 instead of 2.1e5 rows), the host merges overlapping hulls.  In-memory
+ * sequences only (no file segments). */
+int fz_generic_ngrams_consolidated(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m,
+                                   uint32_t max_subs, uint32_t max_ins, uint32_t max_dels, uint32_t max_l,
+                                   fz_match **out, uint64_t *n);
+
 /* has_near_match_* (substitutions_only.py:139-145, :218-233; generic_search.py:240-253): *found = 1 iff the
  * corresponding search would return at least one record.  Nothing is ordered or copied, and device work that starts
  * after the first record has been counted is skipped (workgroups of the scan, hits of the automaton kernel). */

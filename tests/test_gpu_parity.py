@@ -593,3 +593,38 @@ def test_exact_routes_return_lazy_streams(engine):
     assert fa.find_near_matches(p, t, max_substitutions=0, max_insertions=0, max_deletions=0) == api
     from fuzzysearch_amd.search_exact import search_exact
     assert search_exact(p, t) == exp and search_exact(p, t, 10, 100) == [i for i in exp if 10 <= i and i + 6 <= 100]
+
+
+def test_generic_consolidated_equals_consolidation_of_the_raw_stream(engine):
+    """fz_generic_ngrams_consolidated (first stage of consolidate_overlapping_matches on the device: every hit's
+    matches folded into hull / best pairs) == fz_consolidate(fz_generic_ngrams) row for row, and the public API takes it."""
+    import fuzzysearch_amd as fa
+    from fuzzysearch_amd import _native
+    rnd = random.Random(61)
+    n_rows = 0
+    for it in range(400):
+        p, t, k = _rand_case(rnd, max_n=600, max_m=40, max_k=5)
+        if len(p) // (k + 1) == 0:
+            continue
+        lim = (rnd.randint(0, k), rnd.randint(0, k), rnd.randint(0, k), k)
+        h = engine.upload(t)
+        raw = engine.generic_ngrams(h, p, *lim, as_array=True)
+        want = _native.consolidate_array(raw).tolist()
+        got = engine.generic_ngrams_consolidated(h, p, *lim, as_array=True).tolist()
+        h.release()
+        assert [r[:3] for r in got] == [r[:3] for r in want], (p, t, lim)
+        n_rows += len(got)
+    assert n_rows > 100
+    # zero-length matches (deletions only) and a medium text with planted variants
+    seq, pat, _pl = workloads.cfg4(8 << 20, 64)
+    h = engine.upload(seq)
+    for lim in ((5, 2, 2, 5), (1, 0, 3, 3), (0, 2, 0, 2), (2, 2, 2, 6)):
+        raw = engine.generic_ngrams(h, pat.tobytes(), *lim, as_array=True)
+        want = _native.consolidate_array(raw).tolist()
+        got = engine.generic_ngrams_consolidated(h, pat.tobytes(), *lim, as_array=True).tolist()
+        assert [r[:3] for r in got] == [r[:3] for r in want], lim
+    h.release()
+    res = fa.find_near_matches(pat.tobytes(), seq.tobytes(), max_substitutions=5, max_insertions=2, max_deletions=2, max_l_dist=5)
+    raw = oracle.generic_ngrams_raw(pat.tobytes(), seq.tobytes(), 5, 2, 2, 5)
+    assert [(m.start, m.end, m.dist) for m in res] == oracle.consolidate(raw)
+    assert all(bytes(m.matched) == seq[m.start:m.end].tobytes() for m in res)
