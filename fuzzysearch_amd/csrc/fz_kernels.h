@@ -379,7 +379,9 @@ __device__ __forceinline__ bool fz_confirm(const uint8_t *__restrict__ buf, cons
 }
 
 #define FZ_HDR_WORDS 128                                   // 64-bit counters in the result header
-#define FZ_HDR_TICKET 3                                    // counters[3]: workgroups that finished (final launch)
+#define FZ_HDR_TICKET 3                                    // counters[3]: ticket shards that are complete (final launch)
+#define FZ_HDR_SHARD0 96                                   // counters[96 .. 111]: workgroups that finished, by blockIdx % 16
+#define FZ_TICKET_SHARDS 16u
 
 // End of the final kernel of a search: the LAST workgroup to get here copies the counters into
 // host-visible memory (a.host_hdr), so the host needs no D2H copy command after the kernel (the
@@ -397,8 +399,17 @@ __device__ __forceinline__ void fz_finish_launch(const FzScanArgs &a, unsigned l
     if (!a.host_hdr) return;
     if (participants == 0) participants = gridDim.x;       // workgroups that take a ticket (all, unless the caller says fewer)
     __syncthreads();                                       // all waves' counter atomics are complete, LDS is free
-    if (threadIdx.x == 0)
-        *flag = atomicAdd(&counters[FZ_HDR_TICKET], 1ull) == (unsigned long long)participants - 1ull;
+    if (threadIdx.x == 0) {
+        // Two-level ticket: 16 shard words, then one word for the shards' last arrivals.  One word only sustains ~90
+        // atomics per microsecond chip-wide, and the workgroups of a short launch all finish together (1536 of them on a
+        // 64 MiB scan: 10 us of its 42 us were this queue).
+        const uint32_t nshard = participants < FZ_TICKET_SHARDS ? participants : FZ_TICKET_SHARDS;
+        const uint32_t r = blockIdx.x % nshard;
+        const unsigned long long members = (participants - r + nshard - 1u) / nshard;   // workgroups b < participants with b % nshard == r
+        bool last = atomicAdd(&counters[FZ_HDR_SHARD0 + r], 1ull) == members - 1ull;
+        if (last) last = atomicAdd(&counters[FZ_HDR_TICKET], 1ull) == (unsigned long long)nshard - 1ull;
+        *flag = last ? 1u : 0u;
+    }
     __syncthreads();
     if (*flag) {
         unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.host_hdr);
