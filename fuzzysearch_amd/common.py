@@ -90,10 +90,24 @@ class LevenshteinSearchParams(object):
 
 
 def count_differences_with_maximum(sequence1, sequence2, max_differences):
-    """common.py:119-142 — tiny helper kept for API completeness (host side, not a hot path)."""
+    """common.py:119-142 / _common.c:115-173 (count_differences_with_maximum_byteslike): min(number of positions
+    that differ, max_differences).  Bytes-like inputs of equal length are compared in one vectorised pass (the
+    reference's native takes the same inputs and raises the same ValueError on unequal lengths); everything else
+    item by item with the early exit.  Host side: the device paths count mismatches in their kernels."""
+    try:
+        a, b = memoryview(sequence1), memoryview(sequence2)
+        simple = a.itemsize == 1 and b.itemsize == 1 and a.ndim == 1 and b.ndim == 1 and a.c_contiguous and b.c_contiguous
+    except TypeError:
+        simple = False
+    if simple:
+        if a.nbytes != b.nbytes:
+            raise ValueError('The lengths of the given sequences must be equal.')
+        import numpy as np
+        n = int(np.count_nonzero(np.frombuffer(a, dtype=np.uint8) != np.frombuffer(b, dtype=np.uint8)))
+        return min(n, max_differences) if max_differences >= 0 else n
     n_different = 0
-    for a, b in zip(sequence1, sequence2):
-        if a != b:
+    for x, y in zip(sequence1, sequence2):
+        if x != y:
             n_different += 1
             if n_different == max_differences:
                 break

@@ -21,6 +21,25 @@ from ._native import UnsupportedSearch
 __all__ = ['DeviceSequence', 'resident', 'encode_pair', 'is_byteslike']
 
 
+def _bio_seq():
+    """Bio.Seq.Seq when Biopython is installed (search_exact.py:13-19 registers it as a sequence type), else None."""
+    try:
+        from Bio.Seq import Seq
+        return Seq
+    except ImportError:
+        return None
+
+
+def _unwrap_bio(x):
+    """A Biopython Seq -> its letters as bytes (indices are the same: one byte per letter); anything else unchanged.
+    Such inputs take the reference's pure-Python semantics (no buffer protocol -> its natives refuse them), i.e. they
+    are not "bytes-like" for the substitutions-only result form (SURVEY.md trap 5)."""
+    Seq = _bio_seq()
+    if Seq is not None and isinstance(x, Seq):
+        return bytes(x), True
+    return x, False
+
+
 def is_byteslike(x):
     if isinstance(x, (bytes, bytearray)):
         return True
@@ -61,6 +80,14 @@ def _remap_items(subsequence, sequence):
 
 def encode_pair(subsequence, sequence):
     """-> (pattern_bytes_like, sequence_bytes_like, byteslike: bool)."""
+    subsequence, bio_p = _unwrap_bio(subsequence)
+    sequence, bio_t = _unwrap_bio(sequence)
+    if bio_p or bio_t:                               # a Seq on either side: compare letters (str patterns as latin-1)
+        if isinstance(subsequence, str):
+            subsequence = subsequence.encode('latin-1')
+        if isinstance(sequence, str):
+            sequence = sequence.encode('latin-1')
+        return subsequence, sequence, False
     sub_b, seq_b = is_byteslike(subsequence), is_byteslike(sequence)
     if sub_b and seq_b:
         return subsequence, sequence, True
@@ -125,6 +152,9 @@ class _Prepared(object):
 def prepare(subsequence, sequence):
     pr = _Prepared()
     if isinstance(sequence, DeviceSequence):
+        subsequence, was_bio = _unwrap_bio(subsequence)
+        if was_bio and not sequence.byteslike:
+            subsequence = subsequence.decode('latin-1')
         pr.engine = sequence.engine
         pr.handle = sequence.handle
         pr.original = sequence.original

@@ -408,3 +408,51 @@ def test_no_kernel_spills_to_scratch():
             assert int(r["scratch"]) == 0 and int(r["vgpr_spill"]) == 0, (name, r)
     headline = [v for k, v in scan.items() if "ILi2ELi3ELb1ELb0ELb1EE" in k]
     assert len(headline) == 1 and int(headline[0]["occupancy"]) == 7 and int(headline[0]["vgprs"]) <= 72
+
+
+def test_count_differences_with_maximum_matches_the_reference():
+    import random
+    from fuzzysearch_amd.common import count_differences_with_maximum as cd
+    rnd = random.Random(3)
+    for _ in range(300):
+        n = rnd.randint(0, 40)
+        a = bytes(rnd.choice(b"ab") for _ in range(n))
+        b = bytes(rnd.choice(b"ab") for _ in range(n))
+        mx = rnd.randint(0, 10)
+        want = min(sum(x != y for x, y in zip(a, b)), mx)
+        assert cd(a, b, mx) == want and cd(bytearray(a), memoryview(b), mx) == want
+        assert cd(list(a), list(b), mx) == (want if mx else sum(x != y for x, y in zip(a, b)))
+    import pytest
+    with pytest.raises(ValueError):
+        cd(b"abc", b"ab", 3)
+
+
+def test_biopython_seq_inputs_are_unwrapped(monkeypatch):
+    """search_exact.py:13-19: a Bio.Seq.Seq is a sequence type when Biopython is installed (it is not here: a stand-in
+    module with the same surface)."""
+    import sys
+    import types
+    from fuzzysearch_amd import engine
+
+    class Seq(object):
+        def __init__(self, data):
+            self._data = bytes(data)
+
+        def __bytes__(self):
+            return self._data
+
+        def __len__(self):
+            return len(self._data)
+
+        def __getitem__(self, i):
+            return Seq(self._data[i]) if isinstance(i, slice) else chr(self._data[i])
+    bio, bio_seq = types.ModuleType("Bio"), types.ModuleType("Bio.Seq")
+    bio_seq.Seq = Seq
+    bio.Seq = bio_seq
+    monkeypatch.setitem(sys.modules, "Bio", bio)
+    monkeypatch.setitem(sys.modules, "Bio.Seq", bio_seq)
+    p, t, byteslike = engine.encode_pair("ACGT", Seq(b"TTACGTTT"))
+    assert (bytes(p), bytes(t), byteslike) == (b"ACGT", b"TTACGTTT", False)
+    p, t, byteslike = engine.encode_pair(Seq(b"ACGT"), Seq(b"TTACGTTT"))
+    assert (bytes(p), bytes(t), byteslike) == (b"ACGT", b"TTACGTTT", False)
+    assert engine.encode_pair(b"ACGT", b"TTACGTTT")[2] is True
