@@ -210,6 +210,10 @@ struct fz_ctx {
     // RCCL: number of ranks of the communicator this context joined (0: none) and whether its Levenshtein n-gram
     // searches are collective (every rank gets the merged global stream)
     bool any_found = false;                      // result of the last has_near_match_* (fz_*_any) search
+    // sharded searches: where every shard's (rank's) records end in the collected vector, and the shards in ascending
+    // order of the index range they own (emit_matches orders shard by shard)
+    std::vector<size_t> seg_ends;
+    std::vector<uint32_t> seg_order;
     // hipEvent timing of the kernels (fz_stats: filter_ms / verify_ms / device_ms).  One event record is one more packet
     // in front of the kernel and two hipEventElapsedTime calls behind it: fz_set_timing(ctx, 0) drops them.
     bool timing = getenv("FZ_NO_TIMING") == nullptr;
@@ -857,11 +861,20 @@ int gather_records(fz_ctx *ctx, fz_seq *seq, std::vector<FzRec> &recs) {
         }
         recs.resize(total);
         uint64_t o = 0;
-        for (int r = 0; r < world; ++r) {
+        ctx->seg_ends.clear();
+        ctx->seg_order.clear();
+        for (int r = 0; r < world; ++r) {                    // ranks own ascending index ranges
             const uint8_t *blk = d0.h_recv + (uint64_t)r * bytes;
             const uint64_t c = reinterpret_cast<const unsigned long long *>(blk)[1];
             if (c) memcpy(recs.data() + o, blk + kHeaderBytes, c * sizeof(FzRec));
             o += c;
+            ctx->seg_ends.push_back(o);
+            ctx->seg_order.push_back((uint32_t)r);
+        }
+        if ((int)ctx->devs.size() == world) {                // every rank is a device of this process: order them by what they own
+            std::vector<uint64_t> lo(world, ~0ull);
+            for (const Shard &sh : seq->shards) lo[sh.dev] = sh.geom.own_lo;
+            std::stable_sort(ctx->seg_order.begin(), ctx->seg_order.end(), [&](uint32_t x, uint32_t y) { return lo[x] < lo[y]; });
         }
         ctx->stats.raw_matches = total;
         const uint64_t want = std::max<uint64_t>(1024, (top + top / 4 + 1023) / 1024 * 1024);
@@ -897,12 +910,19 @@ int search_collect(fz_ctx *ctx, fz_seq *seq, const Search &q, bool with_verify, 
         ctx->stats.filter_ms = ctx->stats.verify_ms = ctx->stats.device_ms = 0;
         Trace tr;
         bool any_rerun = false;
+        ctx->seg_ends.clear();
+        ctx->seg_order.clear();
         for (const Shard &sh : seq->shards) {
             bool rr = false;
             int rc = collect_shard(ctx, sh, with_verify, seq->shards.size() == 1, recs, hits, rr, q.collective);
             if (rc) return rc;
             any_rerun |= rr;
+            ctx->seg_ends.push_back(recs.size());
         }
+        for (uint32_t si = 0; si < seq->shards.size(); ++si) ctx->seg_order.push_back(si);
+        std::sort(ctx->seg_order.begin(), ctx->seg_order.end(), [&](uint32_t x, uint32_t y) {
+            return seq->shards[x].geom.own_lo < seq->shards[y].geom.own_lo;
+        });
         tr.mark(" collect");
         if (!any_rerun) {
             if (with_verify && q.collective) {
@@ -1171,8 +1191,9 @@ bool drop_empty_slots(const FzRec *recs, size_t cnt, std::vector<FzRec> &kept) {
 // idx_bound / blk_bound (0: unknown): every hit index is below idx_bound and every block number below blk_bound
 // (sequence length and block count of the search) — saves the pass that finds the key ranges; may_have_empty: some
 // records may be empty slots (the slot-per-hit verification).
+// `into` (optional): the rows go into this vector instead of a result buffer (per-shard ordering of a sharded search).
 int emit_matches(const FzRec *recs, size_t cnt, uint32_t L, fz_match **out, uint64_t *n, uint64_t idx_bound = 0,
-                 uint32_t blk_bound = 0, bool may_have_empty = true) {
+                 uint32_t blk_bound = 0, bool may_have_empty = true, std::vector<fz_match> *into = nullptr) {
     size_t nv = 0;
     uint64_t imin = ~0ull, imax = 0;
     uint32_t gmax = 0;
@@ -1188,10 +1209,18 @@ int emit_matches(const FzRec *recs, size_t cnt, uint32_t L, fz_match **out, uint
             ++nv;
         }
     }
-    void *mem = nullptr;
-    int rc = alloc_out(nv, sizeof(fz_match), &mem);
-    if (rc) return rc;
-    fz_match *mo = static_cast<fz_match *>(mem);
+    fz_match *mo = nullptr;
+    if (into) {
+        into->resize(nv);
+        mo = into->data();
+    } else {
+        void *mem = nullptr;
+        int rc = alloc_out(nv, sizeof(fz_match), &mem);
+        if (rc) return rc;
+        mo = static_cast<fz_match *>(mem);
+        *out = mo;
+        *n = nv;
+    }
     auto put = [&](size_t i, const FzRec &r) {
         const uint64_t idx = fz_hit_index(r.key);
         mo[i].start = (int64_t)(idx - r.l);
@@ -1199,8 +1228,6 @@ int emit_matches(const FzRec *recs, size_t cnt, uint32_t L, fz_match **out, uint
         mo[i].dist = (int32_t)r.dist;
         mo[i].block = (int32_t)fz_hit_block(r.key);
     };
-    *out = mo;
-    *n = nv;
     if (nv == 0) return FZ_OK;
     int ibits = 0, gbits = 0, pbits = 0;                       // index range, block number, record position
     while (ibits < FZ_IDX_BITS && ((imax - imin) >> ibits)) ++ibits;
@@ -1291,12 +1318,57 @@ int emit_matches_seg(const FzRec *recs, size_t cnt, uint32_t L, fz_match **out, 
     return FZ_OK;
 }
 
+// A sharded search (several devices, or the ranks of an all-gather): every shard's records are ordered on their own —
+// 10^4 records stay in the host's L2, one 8 x 10^4-record ordering does not (0.8 ms on 77 000 records) — and, shards
+// owning ascending index ranges (seg_order lists them that way), the reference's order is, block by block, the shards'
+// runs of that block one after the other.  seg_ends[i] = end of shard i's records in `recs`.
+int emit_matches_segments(const FzRec *recs, const std::vector<size_t> &seg_ends, const std::vector<uint32_t> &seg_order, uint32_t L,
+                          fz_match **out, uint64_t *n, uint64_t idx_bound, uint32_t blk_bound, bool may_have_empty) {
+    const size_t ns = seg_ends.size();
+    static thread_local std::vector<std::vector<fz_match>> rows;
+    if (rows.size() < ns) rows.resize(ns);
+    size_t total = 0;
+    for (size_t si = 0; si < ns; ++si) {
+        const size_t b = si ? seg_ends[si - 1] : 0, e = seg_ends[si];
+        int rc = emit_matches(recs + b, e - b, L, nullptr, nullptr, idx_bound, blk_bound, may_have_empty, &rows[si]);
+        if (rc) return rc;
+        total += rows[si].size();
+    }
+    void *mem = nullptr;
+    int rc = alloc_out(total, sizeof(fz_match), &mem);
+    if (rc) return rc;
+    fz_match *mo = static_cast<fz_match *>(mem);
+    std::vector<size_t> pos(ns, 0);
+    size_t o = 0;
+    while (o < total) {
+        int32_t g = INT32_MAX;                             // the smallest block any shard still holds
+        for (size_t k = 0; k < ns; ++k) {
+            const size_t si = seg_order[k];
+            if (pos[si] < rows[si].size()) g = std::min(g, rows[si][pos[si]].block);
+        }
+        for (size_t k = 0; k < ns; ++k) {
+            const size_t si = seg_order[k];
+            const std::vector<fz_match> &r = rows[si];
+            size_t q = pos[si];
+            while (q < r.size() && r[q].block == g) ++q;
+            if (q > pos[si]) memcpy(mo + o, r.data() + pos[si], (q - pos[si]) * sizeof(fz_match));
+            o += q - pos[si];
+            pos[si] = q;
+        }
+    }
+    *out = mo;
+    *n = total;
+    return FZ_OK;
+}
+
 // the records of the search that just ran: the staging-buffer view or the collected vector
 int emit_matches(const fz_ctx *ctx, const std::vector<FzRec> &recs, uint32_t L, fz_match **out, uint64_t *n,
                  uint64_t idx_bound = 0, uint32_t blk_bound = 0) {
     // (the fused scan appends real records only; the stand-alone verifications may leave empty slots)
     bool dense = true;                                     // (of the search being collected: its slot is the current one)
     for (const DevState &d : ctx->devs) dense = dense && d.fused_used;
+    if (!ctx->view && ctx->seg_ends.size() > 1 && ctx->seg_ends.back() == recs.size())
+        return emit_matches_segments(recs.data(), ctx->seg_ends, ctx->seg_order, L, out, n, idx_bound, blk_bound, !dense);
     return ctx->view ? emit_matches(ctx->view, (size_t)ctx->view_n, L, out, n, idx_bound, blk_bound, !dense)
                      : emit_matches(recs.data(), recs.size(), L, out, n, idx_bound, blk_bound, !dense);
 }
@@ -2957,6 +3029,14 @@ int fz_debug_order_records(const void *recs, uint64_t n, uint32_t L, fz_match **
     if ((!recs && n) || !out || !n_out) return fail(FZ_EINVAL, "null argument");
     static_assert(sizeof(FzRec) == 24, "record layout");
     return emit_matches(static_cast<const FzRec *>(recs), (size_t)n, L, out, n_out);
+}
+
+int fz_debug_order_segments(const void *recs, const uint64_t *seg_ends, uint32_t n_segments, uint32_t L, fz_match **out, uint64_t *n_out) {
+    if ((!recs && n_segments) || !seg_ends || !out || !n_out || n_segments == 0) return fail(FZ_EINVAL, "null argument");
+    std::vector<size_t> ends(seg_ends, seg_ends + n_segments);
+    std::vector<uint32_t> order(n_segments);
+    for (uint32_t i = 0; i < n_segments; ++i) order[i] = i;
+    return emit_matches_segments(static_cast<const FzRec *>(recs), ends, order, L, out, n_out, 0, 0, true);
 }
 
 int fz_debug_launch_plan(const uint8_t *p, uint32_t m, uint32_t L, uint32_t *out, uint32_t cap, uint32_t *n_launches) {

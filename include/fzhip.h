@@ -261,6 +261,9 @@ int fz_debug_launch_plan(const uint8_t *p, uint32_t m, uint32_t L, uint32_t *out
  * {u64 key = block << 48 | hit index, u32 left, u32 right, u32 dist (0xffffffff: empty slot), u32 aux} into fz_match
  * rows in the reference's emission order (block ascending, hit index ascending; n-gram length L). */
 int fz_debug_order_records(const void *recs, uint64_t n, uint32_t L, fz_match **out, uint64_t *n_out);
+/* ... and the sharded form: recs = the shards' records one shard after the other (seg_ends[i] = end of shard i), shards
+ * owning ascending index ranges; every shard is ordered on its own and the rows are merged block by block. */
+int fz_debug_order_segments(const void *recs, const uint64_t *seg_ends, uint32_t n_segments, uint32_t L, fz_match **out, uint64_t *n_out);
 
 int  fz_stats(fz_ctx *ctx, fz_stats_t *out);
 /* hipEvent timing of the kernels (filter_ms / verify_ms / device_ms of fz_stats, fz_device_ms): on by default.

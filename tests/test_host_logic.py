@@ -456,3 +456,41 @@ def test_biopython_seq_inputs_are_unwrapped(monkeypatch):
     p, t, byteslike = engine.encode_pair(Seq(b"ACGT"), Seq(b"TTACGTTT"))
     assert (bytes(p), bytes(t), byteslike) == (b"ACGT", b"TTACGTTT", False)
     assert engine.encode_pair(b"ACGT", b"TTACGTTT")[2] is True
+
+
+def test_sharded_record_ordering_equals_the_global_one():
+    """fz_debug_order_segments (per-shard ordering + block-wise merge, what a multi-device / all-gathered search does)
+    == fz_debug_order_records on the concatenation, for shards owning ascending index ranges."""
+    import ctypes
+    import numpy as np
+    from fuzzysearch_amd import _native
+    lib = _native.load_library()
+    rec_dt = np.dtype([("key", "<u8"), ("l", "<u4"), ("r", "<u4"), ("dist", "<u4"), ("aux", "<u4")])
+    rng = np.random.default_rng(9)
+    for nshards, per, nblocks in [(2, 50, 3), (3, 0, 2), (8, 3000, 3), (8, 9600, 3), (5, 700, 40), (4, 1, 1)]:
+        parts, ends, total = [], [], 0
+        shard_span = 1 << 32
+        for sidx in range(nshards):
+            n = int(rng.integers(0, per + 1)) if per else 0
+            idx = (sidx * shard_span + rng.integers(0, shard_span, n)).astype(np.uint64)
+            key = np.unique((rng.integers(0, nblocks, n).astype(np.uint64) << np.uint64(48)) | idx)
+            key = key[rng.permutation(len(key))]
+            r = np.zeros(len(key), dtype=rec_dt)
+            r["key"] = key
+            r["l"] = rng.integers(0, 5, len(key)); r["r"] = rng.integers(0, 9, len(key)); r["dist"] = rng.integers(0, 3, len(key))
+            if sidx % 2:
+                r["dist"][rng.random(len(key)) < 0.2] = 0xffffffff
+            parts.append(r)
+            total += len(r)
+            ends.append(total)
+        recs = np.concatenate(parts) if total else np.zeros(0, dtype=rec_dt)
+        ends_a = np.asarray(ends, dtype=np.uint64)
+
+        def call(fn, *args):
+            ptr = ctypes.POINTER(_native.FzMatch)()
+            cnt = ctypes.c_uint64(0)
+            _native._check(fn(*args, ctypes.byref(ptr), ctypes.byref(cnt)))
+            return _native._take_matches_array(lib, ptr, cnt.value)
+        whole = call(lib.fz_debug_order_records, recs.ctypes.data, len(recs), 6)
+        seg = call(lib.fz_debug_order_segments, recs.ctypes.data, ends_a.ctypes.data, nshards, 6)
+        assert np.array_equal(whole, seg), (nshards, per, nblocks)
