@@ -197,10 +197,24 @@ def extra_blocks(engine, workloads, reps):
         "verify_kernel_ms": round(v_ms, 4), "raw_matches": int(len(res))}
     ms, f_ms, v_ms, res = time_call(engine, lambda: engine.generic_ngrams(h, p3, 5, 2, 2, 5, as_array=True), max(20, reps // 4))
     cms, _f, cv_ms, cres = time_call(engine, lambda: engine.generic_ngrams_consolidated(h, p3, 5, 2, 2, 5, as_array=True), max(20, reps // 4))
+    # two generic searches in flight (two lanes: the scan of one next to the automaton kernel of the other)
+    g_reps = max(20, reps // 4)
+    engine.generic_ngrams_begin(h, p3, 5, 2, 2, 5)
+    for _ in range(5):
+        engine.generic_ngrams_begin(h, p3, 5, 2, 2, 5)
+        engine.search_end(as_array=True)
+    t0 = time.perf_counter()
+    for _ in range(g_reps):
+        engine.generic_ngrams_begin(h, p3, 5, 2, 2, 5)
+        graw = engine.search_end(as_array=True)
+    gpipe_ms = (time.perf_counter() - t0) / g_reps * 1e3
+    glast = engine.search_end(as_array=True)
+    assert np.array_equal(graw, res) and np.array_equal(glast, res), "pipelined generic search returned a different stream"
     h.release()
     cfgs["configs[3b] UTF-8 m=64 limits (5,2,2,5) (generic_search)"] = {
         "ms_per_call": round(ms, 4), "GB_per_s": round(gib / ms / 1e6, 1), "scan_kernel_ms": round(f_ms, 4),
         "automaton_kernel_ms": round(v_ms, 4), "raw_matches": int(len(res)),
+        "two_in_flight_ms_per_call": round(gpipe_ms, 4), "two_in_flight_GB_per_s": round(gib / gpipe_ms / 1e6, 1),
         "consolidated_ms_per_call": round(cms, 4), "consolidated_GB_per_s": round(gib / cms / 1e6, 1),
         "consolidated_automaton_kernel_ms": round(cv_ms, 4), "consolidated_matches": int(len(cres)),
         "note": "consolidated = fz_generic_ngrams_consolidated: search + consolidate_overlapping_matches, first stage on the device"}

@@ -19,6 +19,7 @@ EXPORTED_SYMBOLS = (
     "fz_abi_version", "fz_last_error", "fz_device_count", "fz_create", "fz_destroy",
     "fz_seq_upload", "fz_seq_upload_shard", "fz_seq_new", "fz_seq_add_shard", "fz_seq_len", "fz_seq_release",
     "fz_search_exact", "fz_lev_ngrams", "fz_lev_ngrams_begin", "fz_lev_ngrams_end", "fz_subs_ngrams", "fz_generic_ngrams",
+    "fz_subs_ngrams_begin", "fz_generic_ngrams_begin", "fz_search_end",
     "fz_lev_lp", "fz_subs_lp", "fz_generic_lp", "fz_subs_ngrams_any", "fz_subs_lp_any", "fz_generic_ngrams_any", "fz_generic_ngrams_consolidated",
     "fz_stream_open", "fz_stream_buffer", "fz_stream_submit", "fz_stream_read_fd", "fz_stream_finish", "fz_stream_close",
     "fz_consolidate", "fz_group_best", "fz_merge_ranks", "fz_wire_pack", "fz_wire_merge", "fz_debug_launch_plan", "fz_debug_order_records", "fz_debug_order_segments", "fz_stats", "fz_set_timing", "fz_device_ms", "fz_free",
@@ -112,6 +113,12 @@ def load_library():
         L.fz_lev_ngrams_begin.argtypes = [vp, vp, u8p, u32, u32]
         L.fz_lev_ngrams_end.restype = ci
         L.fz_lev_ngrams_end.argtypes = [vp, mpp, u64p]
+        L.fz_search_end.restype = ci
+        L.fz_search_end.argtypes = [vp, mpp, u64p]
+        L.fz_subs_ngrams_begin.restype = ci
+        L.fz_subs_ngrams_begin.argtypes = [vp, vp, u8p, u32, u32]
+        L.fz_generic_ngrams_begin.restype = ci
+        L.fz_generic_ngrams_begin.argtypes = [vp, vp, u8p, u32, u32, u32, u32, u32, ci]
         L.fz_subs_ngrams.restype = ci
         L.fz_subs_ngrams.argtypes = [vp, vp, u8p, u32, u32, mpp, u64p]
         L.fz_generic_ngrams.restype = ci
@@ -590,6 +597,24 @@ class Engine(object):
             paddr, m, keep = _buffer_address(pattern)
         with self._lock:
             _check(self._lib.fz_lev_ngrams_begin(self._h, seq._h, paddr, m, k))
+
+    def subs_ngrams_begin(self, seq, pattern, k):
+        """subs_ngrams launched, not collected: search_end() delivers it (same two-deep pipeline as lev_ngrams_begin)."""
+        paddr, m, keep = (pattern, len(pattern), None) if type(pattern) is bytes else _buffer_address(pattern)
+        with self._lock:
+            _check(self._lib.fz_subs_ngrams_begin(self._h, seq._h, paddr, m, k))
+
+    def generic_ngrams_begin(self, seq, pattern, max_subs, max_ins, max_dels, max_l, consolidated=False):
+        """generic_ngrams (or generic_ngrams_consolidated) launched, not collected.  Two generic searches in flight run
+        on two lanes: the younger one's scan next to the older one's automaton kernel."""
+        paddr, m, keep = (pattern, len(pattern), None) if type(pattern) is bytes else _buffer_address(pattern)
+        with self._lock:
+            _check(self._lib.fz_generic_ngrams_begin(self._h, seq._h, paddr, m, max_subs, max_ins, max_dels, max_l,
+                                                     1 if consolidated else 0))
+
+    def search_end(self, as_array=False):
+        """The result of the OLDEST search in flight (lev / subs / generic begin), as its synchronous call returns it."""
+        return self.lev_ngrams_end(as_array=as_array)
 
     def lev_ngrams_end(self, as_array=False):
         ptr = ctypes.POINTER(FzMatch)()

@@ -203,8 +203,17 @@ struct fz_ctx {
         std::vector<uint8_t> pattern;
         uint32_t m = 0, k = 0;
         bool launched = false;                       // false: deferred until the older search has been collected
+        uint32_t kind = FZ_MODE_LEV;                 // FZ_MODE_LEV / FZ_MODE_SUBS (result slots of lane 0) or FZ_MODE_GENERIC (lanes)
+        uint32_t max_subs = 0, max_ins = 0, max_dels = 0;
+        bool consolidated = false;                   // generic: deliver fz_generic_ngrams_consolidated's rows
+        int lane = 0;                                // generic: which lane carries it
     } pend[2];
     int npend = 0;
+    // Lanes: a second complete set of per-device state (stream, hit list, counters + records, ordering areas, staging).
+    // A generic search in flight keeps its hit list and records on the device until it is collected, so the next one
+    // needs buffers and a stream of its own: then its scan runs next to the older search's automaton kernel.
+    std::vector<DevState> devs2;
+    int lane = 0;                                // the lane the code below works on (0 except inside generic begin / end)
     // sequences still resident (fz_destroy frees what the caller did not release)
     std::vector<fz_seq *> live;
     // RCCL: number of ranks of the communicator this context joined (0: none) and whether its Levenshtein n-gram
@@ -228,7 +237,10 @@ struct fz_seq {
     std::vector<Shard> shards;
 };
 
-namespace { void comm_teardown(fz_ctx *ctx); }
+namespace {
+void comm_teardown(fz_ctx *ctx);
+inline DevState &lane_dev(fz_ctx *ctx, int dev) { return ctx->lane ? ctx->devs2[dev] : ctx->devs[dev]; }
+}
 
 namespace {
 
@@ -522,7 +534,7 @@ VerifyPlan plan_verify(const Search &q) {
 // Enqueue scan (+ separate verify when it cannot be fused) for one shard on its device stream.
 // No host synchronisation.
 int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verify, bool copy_back = true) {
-    DevState &d = ctx->devs[sh.dev];
+    DevState &d = lane_dev(ctx, sh.dev);
     HIP_TRY(hipSetDevice(d.device));
     unsigned long long *counters = reinterpret_cast<unsigned long long *>(d.d_out);
     FzRec *recs = reinterpret_cast<FzRec *>(d.d_out + kHeaderBytes);
@@ -952,7 +964,10 @@ int run_search(fz_ctx *ctx, fz_seq *seq, const Search &q, bool with_verify, std:
 
 // Generic search: scan (emit exact hits) -> fz_generic_kernel (one wave per hit) -> records.
 // Re-runs with larger buffers on overflow: hit list, record list, then candidate lists.
-int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec> &recs_out) {
+// `phase`: 0 = the whole search; 1 = launch only (fz_generic_ngrams_begin: the kernels of the first attempt are enqueued on
+// the current lane and the call returns); 2 = collect what phase 1 launched (fz_search_end), then carry on as phase 0 if
+// a buffer turned out too small.
+int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec> &recs_out, int phase = 0) {
     memset(&ctx->stats, 0, sizeof ctx->stats);
     ctx->stats.n_devices = (uint32_t)ctx->devs.size();
     static_assert(sizeof(FzGenRec) == sizeof(FzRec), "record buffers are shared");
@@ -970,9 +985,10 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
         ctx->stats.filter_ms = ctx->stats.verify_ms = ctx->stats.device_ms = 0;
         const uint32_t mpad = (q.m + 15u) & ~15u, wpad = (q.m + 2 * q.k + 15u) & ~15u;
         for (const Shard &sh : seq->shards) {
+            if (phase == 2 && attempt == 0) break;            // launched by fz_generic_ngrams_begin
             int rc = enqueue_shard(ctx, sh, q, /*with_verify=*/false, /*copy_back=*/false);
             if (rc) return rc;
-            DevState &d = ctx->devs[sh.dev];
+            DevState &d = lane_dev(ctx, sh.dev);
             size_t lds = 0;
             uint64_t scratch = 0;
             rc = cand_lists(d, cand_cap, mpad + wpad + FZ_GEN_MCAP * 8, lds, scratch);
@@ -1032,11 +1048,12 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             HIP_TRY(hipMemcpyAsync(d.h_stage, d.d_out, kHeaderBytes + d.fold_copied * sizeof(FzGenRec), hipMemcpyDeviceToHost, d.stream));
             HIP_TRY(hipEventRecord(d.ev[3], d.stream));
         }
+        if (phase == 1) return FZ_OK;
         bool lists_overflowed = false;
         Trace trg;
         trg.mark(" generic enqueue");
         for (const Shard &sh : seq->shards) {
-            DevState &d = ctx->devs[sh.dev];
+            DevState &d = lane_dev(ctx, sh.dev);
             HIP_TRY(hipSetDevice(d.device));
             HIP_TRY(hipStreamSynchronize(d.stream));
             trg.mark(" generic sync");
@@ -1390,6 +1407,66 @@ int fz_device_count(int *n) {
     return FZ_OK;
 }
 
+static int devstate_init(DevState &d) {
+    HIP_TRY(hipSetDevice(d.device));
+    // Lowest priority: a different hardware queue than the default-priority streams of the rest of
+    // the process, and the dispatcher prefers their workgroups.  Measured with RCCL on torch's
+    // stream: at default priority an all_gather launched while a scan was running only started
+    // after it (250 us); the scan alone is not slower at low priority.
+    int prio_least = 0, prio_greatest = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    static const bool default_prio = getenv("FZ_STREAM_DEFAULT_PRIORITY") != nullptr;
+    HIP_TRY(hipStreamCreateWithPriority(&d.stream, hipStreamNonBlocking, default_prio ? 0 : prio_least));
+    for (auto &ev : d.ev) HIP_TRY(hipEventCreate(&ev));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&d.h_stage), kHeaderBytes + kHostRecs * sizeof(FzRec), hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&d.h_stage_dev), d.h_stage, 0));
+    for (auto &ev : d.other.ev) HIP_TRY(hipEventCreate(&ev));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&d.other.h_stage), kHeaderBytes + kHostRecs * sizeof(FzRec), hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&d.other.h_stage_dev), d.other.h_stage, 0));
+    int rc = ensure_hits(d, 1u << 20);
+    if (rc == FZ_OK) rc = ensure_recs(d, 1u << 16);
+    return rc;
+}
+
+static void devstate_destroy(DevState &d) {
+    (void)hipSetDevice(d.device);
+    if (d.stream) (void)hipStreamSynchronize(d.stream);
+    if (d.d_hits) (void)hipFree(d.d_hits);
+    if (d.d_out) (void)hipFree(d.d_out);
+    if (d.spare_alloc) (void)hipFree(d.spare_alloc);
+    if (d.h_stage) (void)hipHostFree(d.h_stage);
+    if (d.other.h_stage) (void)hipHostFree(d.other.h_stage);
+    for (auto &ev : d.other.ev) if (ev) (void)hipEventDestroy(ev);
+    if (d.h_big) (void)hipHostFree(d.h_big);
+    if (d.d_cand) (void)hipFree(d.d_cand);
+    if (d.d_pat) (void)hipFree(d.d_pat);
+    if (d.d_gen_order) (void)hipFree(d.d_gen_order);
+    if (d.d_gen_rows) (void)hipFree(d.d_gen_rows);
+    for (int i = 0; i < 2; ++i) if (d.stream_h[i]) (void)hipHostFree(d.stream_h[i]);
+    if (d.stream_d) (void)hipFree(d.stream_d);
+    for (auto &ev : d.ev) if (ev) (void)hipEventDestroy(ev);
+    if (d.stream) (void)hipStreamDestroy(d.stream);
+}
+
+// the second lane (generic searches in flight): created on first use, hit lists as large as lane 0's
+static int ensure_lane2(fz_ctx *ctx) {
+    if (ctx->devs2.size() != ctx->devs.size()) {
+        ctx->devs2.clear();
+        ctx->devs2.resize(ctx->devs.size());
+        for (size_t i = 0; i < ctx->devs.size(); ++i) {
+            ctx->devs2[i].device = ctx->devs[i].device;
+            ctx->devs2[i].n_cus = ctx->devs[i].n_cus;
+            int rc = devstate_init(ctx->devs2[i]);
+            if (rc) return rc;
+        }
+    }
+    for (size_t i = 0; i < ctx->devs.size(); ++i) {
+        int rc = ensure_hits(ctx->devs2[i], ctx->devs[i].hit_cap);
+        if (rc) return rc;
+    }
+    return FZ_OK;
+}
+
 int fz_create(const int *device_ids, int n_devices, fz_ctx **out) {
     if (!out) return fail(FZ_EINVAL, "null argument");
     *out = nullptr;
@@ -1418,28 +1495,7 @@ int fz_create(const int *device_ids, int n_devices, fz_ctx **out) {
         DevState &d = ctx->devs.back();
         d.device = id;
         d.n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        int rc = FZ_OK;
-        auto init = [&]() -> int {
-            HIP_TRY(hipSetDevice(id));
-            // Lowest priority: a different hardware queue than the default-priority streams of the rest of
-            // the process, and the dispatcher prefers their workgroups.  Measured with RCCL on torch's
-            // stream: at default priority an all_gather launched while a scan was running only started
-            // after it (250 us); the scan alone is not slower at low priority.
-            int prio_least = 0, prio_greatest = 0;
-            HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-            static const bool default_prio = getenv("FZ_STREAM_DEFAULT_PRIORITY") != nullptr;
-            HIP_TRY(hipStreamCreateWithPriority(&d.stream, hipStreamNonBlocking, default_prio ? 0 : prio_least));
-            for (auto &ev : d.ev) HIP_TRY(hipEventCreate(&ev));
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&d.h_stage), kHeaderBytes + kHostRecs * sizeof(FzRec), hipHostMallocMapped));
-            HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&d.h_stage_dev), d.h_stage, 0));
-            for (auto &ev : d.other.ev) HIP_TRY(hipEventCreate(&ev));
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&d.other.h_stage), kHeaderBytes + kHostRecs * sizeof(FzRec), hipHostMallocMapped));
-            HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&d.other.h_stage_dev), d.other.h_stage, 0));
-            return FZ_OK;
-        };
-        rc = init();
-        if (rc == FZ_OK) rc = ensure_hits(d, 1u << 20);
-        if (rc == FZ_OK) rc = ensure_recs(d, 1u << 16);
+        int rc = devstate_init(d);
         if (rc) { fz_destroy(ctx); return rc; }
     }
     *out = ctx;
@@ -1454,25 +1510,8 @@ void fz_destroy(fz_ctx *ctx) {
         fz_seq_release(ctx->live.back());
     }
     comm_teardown(ctx);
-    for (DevState &d : ctx->devs) {
-        (void)hipSetDevice(d.device);
-        if (d.stream) (void)hipStreamSynchronize(d.stream);
-        if (d.d_hits) (void)hipFree(d.d_hits);
-        if (d.d_out) (void)hipFree(d.d_out);
-        if (d.spare_alloc) (void)hipFree(d.spare_alloc);
-        if (d.h_stage) (void)hipHostFree(d.h_stage);
-        if (d.other.h_stage) (void)hipHostFree(d.other.h_stage);
-        for (auto &ev : d.other.ev) if (ev) (void)hipEventDestroy(ev);
-        if (d.h_big) (void)hipHostFree(d.h_big);
-        if (d.d_cand) (void)hipFree(d.d_cand);
-        if (d.d_pat) (void)hipFree(d.d_pat);
-        if (d.d_gen_order) (void)hipFree(d.d_gen_order);
-        if (d.d_gen_rows) (void)hipFree(d.d_gen_rows);
-        for (int i = 0; i < 2; ++i) if (d.stream_h[i]) (void)hipHostFree(d.stream_h[i]);
-        if (d.stream_d) (void)hipFree(d.stream_d);
-        for (auto &ev : d.ev) if (ev) (void)hipEventDestroy(ev);
-        if (d.stream) (void)hipStreamDestroy(d.stream);
-    }
+    for (DevState &d : ctx->devs) devstate_destroy(d);
+    for (DevState &d : ctx->devs2) devstate_destroy(d);
     delete ctx;
 }
 
@@ -1711,42 +1750,131 @@ int fz_lev_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32
     return rc;
 }
 
-int fz_lev_ngrams_begin(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k) {
-    if (ctx && ctx->npend >= 2) return fail(FZ_EINVAL, "two searches are already in flight on this context");
-    Search q;
-    int rc = lev_plan(ctx, seq, p, m, k, q, true);
+// Argument checks and the block plan of the substitutions-only n-gram search (template :92-101).
+static int subs_plan(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, Search &q, bool in_pipeline = false) {
+    int rc = validate(ctx, seq, p, m, in_pipeline);
     if (rc) return rc;
+    const uint32_t L = m / (k + 1);
+    if (L == 0) return fail(FZ_EUNSUPPORTED, "max_substitutions >= len(subsequence): every window matches; not a GPU path");
+    rc = check_halo(seq, m);
+    if (rc) return rc;
+    q.mode = FZ_MODE_SUBS; q.m = m; q.k = k; q.p = p;
+    q.plan.L = L;
+    for (uint32_t s = 0; s + L <= m; s += L) q.plan.s.push_back(s);   // template :92-101 (ranges: fz_block_range)
+    if (q.plan.s.size() > FZ_MAX_BLOCKS) return fail(FZ_EUNSUPPORTED, "more than %u n-gram blocks", FZ_MAX_BLOCKS);
+    return FZ_OK;
+}
+
+// ... and of find_near_matches_generic_ngrams (generic_search.py:198-228).
+static int generic_plan(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t max_subs, uint32_t max_ins, uint32_t max_dels,
+                        uint32_t max_l, Search &q, bool in_pipeline = false) {
+    int rc = validate(ctx, seq, p, m, in_pipeline);
+    if (rc) return rc;
+    const uint32_t k = max_l;
+    if (k > FZ_MAX_K) return fail(FZ_EUNSUPPORTED, "max_l_dist above %d is not supported by the verify kernels", FZ_MAX_K);
+    const uint32_t L = m / (k + 1);
+    if (L == 0) return fail(FZ_EINVAL, "the subsequence length must be greater than max_l_dist");
+    rc = check_halo(seq, (uint64_t)m + k);
+    if (rc) return rc;
+    q.mode = FZ_MODE_GENERIC; q.m = m; q.k = k; q.p = p;
+    q.max_subs = std::min(max_subs, 255u); q.max_ins = std::min(max_ins, 255u); q.max_dels = std::min(max_dels, 255u);
+    q.plan.L = L;
+    for (uint32_t s = 0; s + L <= m; s += L) q.plan.s.push_back(s);   // generic_search.py:221-228 (ranges: fz_block_range)
+    if (q.plan.s.size() > FZ_MAX_BLOCKS) return fail(FZ_EUNSUPPORTED, "more than %u n-gram blocks", FZ_MAX_BLOCKS);
+    return FZ_OK;
+}
+
+static int emit_generic_result(fz_ctx *ctx, fz_seq *seq, const Search &q, const std::vector<FzGenRec> &recs_vec, bool consolidated,
+                               fz_match **out, uint64_t *n);
+
+static int pending_plan(fz_ctx *ctx, fz_ctx::Pending &pd, Search &q) {
+    const uint8_t *p = pd.pattern.data();
+    if (pd.kind == FZ_MODE_LEV) return lev_plan(ctx, pd.seq, p, pd.m, pd.k, q, true);
+    if (pd.kind == FZ_MODE_SUBS) return subs_plan(ctx, pd.seq, p, pd.m, pd.k, q, true);
+    int rc = generic_plan(ctx, pd.seq, p, pd.m, pd.max_subs, pd.max_ins, pd.max_dels, pd.k, q, true);
+    q.fold = pd.consolidated;
+    return rc;
+}
+
+// Launch a search and return (fz_lev_ngrams_begin, fz_subs_ngrams_begin, fz_generic_ngrams_begin); fz_search_end collects.
+static int pending_begin(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t kind, uint32_t k, uint32_t max_subs,
+                         uint32_t max_ins, uint32_t max_dels, bool consolidated) {
+    if (ctx && ctx->npend >= 2) return fail(FZ_EINVAL, "two searches are already in flight on this context");
+    const bool generic = kind == FZ_MODE_GENERIC;
+    if (ctx && ctx->npend == 1 && (ctx->pend[0].kind == FZ_MODE_GENERIC) != generic)
+        return fail(FZ_EINVAL, "generic searches and Levenshtein / substitutions-only searches cannot be in flight together");
+    if (!ctx || !p || m == 0) return fail(FZ_EINVAL, "bad ctx / empty subsequence");
     fz_ctx::Pending &pd = ctx->pend[ctx->npend];
     pd.pattern.assign(p, p + m);                             // the caller's buffer is only borrowed for this call
     pd.seq = seq;
     pd.m = m;
     pd.k = k;
-    q.p = pd.pattern.data();
+    pd.kind = kind;
+    pd.max_subs = max_subs; pd.max_ins = max_ins; pd.max_dels = max_dels;
+    pd.consolidated = consolidated;
+    pd.lane = 0;
+    Search q;
+    int rc = pending_plan(ctx, pd, q);
+    if (rc) return rc;
     memset(&ctx->stats, 0, sizeof ctx->stats);
     ctx->stats.n_devices = (uint32_t)ctx->devs.size();
-    // with a search in flight this one goes to the devices' second result slot — unless a device is out of
-    // direct mode (large record sets are fetched from the shared device buffer after the kernel: a second
-    // search would overwrite it), then the launch waits for fz_lev_ngrams_end of the older search
     const bool second = ctx->npend == 1;
     pd.launched = true;
-    if (second && !ctx->snapshot) for (const DevState &d : ctx->devs) if (!d.direct) pd.launched = false;
-    if (pd.launched) {
-        if (second) for (DevState &d : ctx->devs) d.swap_slot();
-        rc = search_enqueue(ctx, seq, q, true);
-        if (second) for (DevState &d : ctx->devs) d.swap_slot();
+    if (generic) {
+        // the lane the older search does not use; its scan then runs next to the older search's automaton kernel
+        pd.lane = second ? 1 - ctx->pend[0].lane : 0;
+        if (pd.lane == 1) { rc = ensure_lane2(ctx); if (rc) return rc; }
+        std::vector<FzGenRec> none;
+        ctx->lane = pd.lane;
+        rc = run_generic(ctx, seq, q, none, /*phase=*/1);
+        ctx->lane = 0;
         if (rc) return rc;
+    } else {
+        // with a search in flight this one goes to the devices' second result slot — unless a device is out of
+        // direct mode (large record sets are fetched from the shared device buffer after the kernel: a second
+        // search would overwrite it), then the launch waits for fz_search_end of the older search
+        if (second && !ctx->snapshot) for (const DevState &d : ctx->devs) if (!d.direct) pd.launched = false;
+        if (pd.launched) {
+            if (second) for (DevState &d : ctx->devs) d.swap_slot();
+            rc = search_enqueue(ctx, seq, q, true);
+            if (second) for (DevState &d : ctx->devs) d.swap_slot();
+            if (rc) return rc;
+        }
     }
     ++ctx->npend;
     return FZ_OK;
 }
 
-int fz_lev_ngrams_end(fz_ctx *ctx, fz_match **out, uint64_t *n) {
+int fz_lev_ngrams_begin(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k) {
+    return pending_begin(ctx, seq, p, m, FZ_MODE_LEV, k, 0, 0, 0, false);
+}
+
+int fz_subs_ngrams_begin(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k) {
+    return pending_begin(ctx, seq, p, m, FZ_MODE_SUBS, k, 0, 0, 0, false);
+}
+
+int fz_generic_ngrams_begin(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t max_subs, uint32_t max_ins,
+                            uint32_t max_dels, uint32_t max_l, int consolidated) {
+    return pending_begin(ctx, seq, p, m, FZ_MODE_GENERIC, max_l, max_subs, max_ins, max_dels, consolidated != 0);
+}
+
+int fz_search_end(fz_ctx *ctx, fz_match **out, uint64_t *n) {
     if (!ctx || !out || !n) return fail(FZ_EINVAL, "null argument");
     *out = nullptr; *n = 0;
     if (!ctx->npend) return fail(FZ_EINVAL, "no search in flight");
     fz_ctx::Pending &pd = ctx->pend[0];
     Search q;
-    int rc = lev_plan(ctx, pd.seq, pd.pattern.data(), pd.m, pd.k, q, true);
+    int rc = pending_plan(ctx, pd, q);
+    if (pd.kind == FZ_MODE_GENERIC) {
+        std::vector<FzGenRec> recs_vec;
+        ctx->lane = pd.lane;
+        if (rc == FZ_OK) rc = run_generic(ctx, pd.seq, q, recs_vec, /*phase=*/2);
+        if (rc == FZ_OK) rc = emit_generic_result(ctx, pd.seq, q, recs_vec, pd.consolidated, out, n);
+        ctx->lane = 0;
+        if (--ctx->npend == 1) std::swap(ctx->pend[0], ctx->pend[1]);
+        if (rc != FZ_OK && *out) { release_out(*out); *out = nullptr; *n = 0; }
+        return rc;
+    }
     std::vector<FzRec> recs;
     std::vector<uint64_t> hits;
     if (rc == FZ_OK) rc = search_collect(ctx, pd.seq, q, true, recs, hits);
@@ -1758,7 +1886,7 @@ int fz_lev_ngrams_end(fz_ctx *ctx, fz_match **out, uint64_t *n) {
             for (DevState &d : ctx->devs) d.swap_slot();
         } else {                                             // deferred: launch it now, into the slot that just became free
             Search q2;
-            int rc2 = lev_plan(ctx, ctx->pend[0].seq, ctx->pend[0].pattern.data(), ctx->pend[0].m, ctx->pend[0].k, q2, true);
+            int rc2 = pending_plan(ctx, ctx->pend[0], q2);
             if (rc2 == FZ_OK) rc2 = search_enqueue(ctx, ctx->pend[0].seq, q2, true);
             if (rc2 != FZ_OK) { ctx->npend = 0; if (rc == FZ_OK) rc = rc2; }
             ctx->pend[0].launched = true;
@@ -1768,21 +1896,15 @@ int fz_lev_ngrams_end(fz_ctx *ctx, fz_match **out, uint64_t *n) {
     return rc;
 }
 
+int fz_lev_ngrams_end(fz_ctx *ctx, fz_match **out, uint64_t *n) { return fz_search_end(ctx, out, n); }
+
 static int subs_ngrams_impl(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, fz_match **out, uint64_t *n, int *found) {
-    int rc = validate(ctx, seq, p, m);
-    if (rc) return rc;
-    const uint32_t L = m / (k + 1);
-    if (L == 0) return fail(FZ_EUNSUPPORTED, "max_substitutions >= len(subsequence): every window matches; not a GPU path");
-    rc = check_halo(seq, m);
-    if (rc) return rc;
-    const uint64_t N = seq->n;
-    if (N < m) return FZ_OK;                                   // template :66-68
     Search q;
-    q.mode = FZ_MODE_SUBS; q.m = m; q.k = k; q.p = p;
+    int rc = subs_plan(ctx, seq, p, m, k, q);
+    if (rc) return rc;
+    if (seq->n < m) return FZ_OK;                              // template :66-68
+    const uint32_t L = q.plan.L;
     q.any = found != nullptr;
-    q.plan.L = L;
-    for (uint32_t s = 0; s + L <= m; s += L) q.plan.s.push_back(s);   // template :92-101 (ranges: fz_block_range)
-    if (q.plan.s.size() > FZ_MAX_BLOCKS) return fail(FZ_EUNSUPPORTED, "more than %u n-gram blocks", FZ_MAX_BLOCKS);
     std::vector<FzRec> recs;
     std::vector<uint64_t> hits;
     rc = run_search(ctx, seq, q, true, recs, hits);
@@ -1827,48 +1949,40 @@ int fz_generic_ngrams_any(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m
     return generic_ngrams_impl(ctx, seq, p, m, max_subs, max_ins, max_dels, max_l, nullptr, nullptr, found);
 }
 
+// What a finished generic search hands over: the raw stream in the reference's order, or — consolidated — the device's
+// (hull, best match) pairs, one or a few per n-gram hit, through the second stage of the consolidation.
+static int emit_generic_result(fz_ctx *ctx, fz_seq *seq, const Search &q, const std::vector<FzGenRec> &recs_vec, bool consolidated,
+                               fz_match **out, uint64_t *n) {
+    const uint32_t L = q.plan.L, k = q.k;
+    if (!consolidated) return emit_generic(ctx, seq, recs_vec, L, k, out, n, nullptr);
+    const FzGenRec *prs = ctx->gen_view ? ctx->gen_view : recs_vec.data();
+    const size_t npr = ctx->gen_view ? (size_t)ctx->gen_view_n : recs_vec.size();
+    static thread_local std::vector<Hull> hulls;
+    hulls.clear();
+    hulls.reserve(npr);
+    for (size_t i = 0; i < npr; ++i) {
+        const FzOutRow best = fz_gen_row(prs[i].key, L, k, 0, prs[i].se, prs[i].dist);
+        const FzOutRow hull = fz_gen_row(prs[i].key, L, k, 0, prs[i].win, 0);
+        hulls.push_back(Hull{hull.start, hull.end, fz_match{best.start, best.end, best.dist, best.block}});
+    }
+    ctx->stats.raw_matches = npr;
+    return consolidate_hulls(hulls, out, n);
+}
+
 static int generic_ngrams_impl(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t max_subs, uint32_t max_ins,
                                uint32_t max_dels, uint32_t max_l, fz_match **out, uint64_t *n, int *found, bool consolidated) {
-    int rc = validate(ctx, seq, p, m);
-    if (rc) return rc;
-    const uint32_t k = max_l;
-    if (k > FZ_MAX_K) return fail(FZ_EUNSUPPORTED, "max_l_dist above %d is not supported by the verify kernels", FZ_MAX_K);
-    const uint32_t L = m / (k + 1);
-    if (L == 0) return fail(FZ_EINVAL, "the subsequence length must be greater than max_l_dist");
-    rc = check_halo(seq, (uint64_t)m + k);
-    if (rc) return rc;
     Search q;
-    q.mode = FZ_MODE_GENERIC; q.m = m; q.k = k; q.p = p;
+    int rc = generic_plan(ctx, seq, p, m, max_subs, max_ins, max_dels, max_l, q);
+    if (rc) return rc;
     q.any = found != nullptr;
     q.fold = consolidated;
-    q.max_subs = std::min(max_subs, 255u); q.max_ins = std::min(max_ins, 255u); q.max_dels = std::min(max_dels, 255u);
-    q.plan.L = L;
-    for (uint32_t s = 0; s + L <= m; s += L) q.plan.s.push_back(s);   // generic_search.py:221-228 (ranges: fz_block_range)
-    if (q.plan.s.size() > FZ_MAX_BLOCKS) return fail(FZ_EUNSUPPORTED, "more than %u n-gram blocks", FZ_MAX_BLOCKS);
     std::vector<FzGenRec> recs_vec;
     Trace tr;
     rc = run_generic(ctx, seq, q, recs_vec);
     if (rc) return rc;
     tr.mark("generic: kernels");
     if (found) { *found = ctx->any_found ? 1 : 0; return FZ_OK; }
-    if (consolidated) {
-        // the device's (hull, best match) pairs, one or a few per n-gram hit -> second stage of the consolidation
-        const FzGenRec *prs = ctx->gen_view ? ctx->gen_view : recs_vec.data();
-        const size_t npr = ctx->gen_view ? (size_t)ctx->gen_view_n : recs_vec.size();
-        static thread_local std::vector<Hull> hulls;
-        hulls.clear();
-        hulls.reserve(npr);
-        for (size_t i = 0; i < npr; ++i) {
-            const FzOutRow best = fz_gen_row(prs[i].key, L, k, 0, prs[i].se, prs[i].dist);
-            const FzOutRow hull = fz_gen_row(prs[i].key, L, k, 0, prs[i].win, 0);
-            hulls.push_back(Hull{hull.start, hull.end, fz_match{best.start, best.end, best.dist, best.block}});
-        }
-        ctx->stats.raw_matches = npr;
-        rc = consolidate_hulls(hulls, out, n);
-        tr.mark("generic: hulls");
-        return rc;
-    }
-    rc = emit_generic(ctx, seq, recs_vec, L, k, out, n, nullptr);
+    rc = emit_generic_result(ctx, seq, q, recs_vec, consolidated, out, n);
     tr.mark("generic: rows");
     return rc;
 }
@@ -2829,11 +2943,12 @@ int consolidate_hulls(std::vector<Hull> &hulls, fz_match **out, uint64_t *n_out)
     auto by_start_end_dist = [](const fz_match &a, const fz_match &b) {
         if (a.start != b.start) return a.start < b.start;
         if (a.end != b.end) return a.end < b.end;
-        return a.dist < b.dist;
+        if (a.dist != b.dist) return a.dist < b.dist;
+        return a.block < b.block;                              // (equal matches of different n-gram hits: a fixed order)
     };
     auto better = [](const fz_match &x, const fz_match &y) {
         const int64_t lx = x.end - x.start, ly = y.end - y.start;
-        return x.dist < y.dist || (x.dist == y.dist && (lx > ly || (lx == ly && x.start < y.start)));
+        return x.dist < y.dist || (x.dist == y.dist && (lx > ly || (lx == ly && (x.start < y.start || (x.start == y.start && x.block < y.block)))));
     };
     const uint64_t nh = hulls.size();
     static thread_local std::vector<uint64_t> wa, wb;
@@ -2922,7 +3037,7 @@ int fz_consolidate(const fz_match *in, uint64_t n, fz_match **out, uint64_t *n_o
     // against the running hull instead of assuming sorted-interval merging.
     auto better = [](const fz_match &x, const fz_match &y) {
         const int64_t lx = x.end - x.start, ly = y.end - y.start;
-        return x.dist < y.dist || (x.dist == y.dist && (lx > ly || (lx == ly && x.start < y.start)));
+        return x.dist < y.dist || (x.dist == y.dist && (lx > ly || (lx == ly && (x.start < y.start || (x.start == y.start && x.block < y.block)))));
     };
     static thread_local std::vector<Hull> hulls;                // scratch kept per thread between calls
     hulls.clear();

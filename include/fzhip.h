@@ -125,7 +125,18 @@ int fz_lev_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32
  * two pinned result slots); _end always delivers the OLDEST one.  `p` is copied, `seq` must stay
  * alive; every other search call on the ctx fails with FZ_EINVAL until every _begin has had its _end. */
 int fz_lev_ngrams_begin(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k);
-int fz_lev_ngrams_end(fz_ctx *ctx, fz_match **out, uint64_t *n);
+int fz_lev_ngrams_end(fz_ctx *ctx, fz_match **out, uint64_t *n);       /* = fz_search_end */
+/* The same two-deep pipeline for the other n-gram searches; fz_search_end delivers the OLDEST search in flight, whatever
+ * its kind, exactly as the synchronous call would (fz_subs_ngrams / fz_generic_ngrams, or — consolidated != 0 —
+ * fz_generic_ngrams_consolidated).  Substitutions-only searches share the Levenshtein searches' result slots and may
+ * be mixed with them.  A generic search keeps its hit list and records on the device until it is collected, so two of
+ * them run on two LANES (a second set of per-device buffers and a second stream, created on first use): the scan of
+ * the younger search runs next to the automaton kernel of the older one.  Generic searches cannot be in flight
+ * together with the other kinds (FZ_EINVAL). */
+int fz_subs_ngrams_begin(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k);
+int fz_generic_ngrams_begin(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m,
+                            uint32_t max_subs, uint32_t max_ins, uint32_t max_dels, uint32_t max_l, int consolidated);
+int fz_search_end(fz_ctx *ctx, fz_match **out, uint64_t *n);
 
 /* Raw stream of the substitutions-only n-gram search: (i, i+m, min(Hamming, k+1), block) in the
  * reference's discovery order, cross-block duplicates preserved. */
