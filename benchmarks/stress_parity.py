@@ -46,6 +46,11 @@ while time.time() < t_end:
     n_recs += len(got)
     got = eng.subs_ngrams(h, p, k); exp = oracle.subs_ngrams_raw(p, t, k)
     assert got == exp, ("subs", tag, p, seed)
+    assert eng.subs_ngrams_any(h, p, k) == (len(exp) > 0), ("subs_any", tag, p)
+    if n_cases % 7 == 0:                                         # the two-deep pipeline, mixed kinds
+        eng.subs_ngrams_begin(h, p, k); eng.lev_ngrams_begin(h, p, k)
+        assert eng.search_end() == exp, ("subs pipelined", tag, p)
+        assert eng.search_end() == oracle.lev_ngrams_raw(p, t, k), ("lev pipelined", tag, p)
     if len(t) <= 60000:
         assert eng.search_exact(h, p[:max(1, len(p) // 3)]) == oracle.search_exact(p[:max(1, len(p) // 3)], t), ("exact", tag)
         if k and len(t) <= 5000:
@@ -55,7 +60,13 @@ while time.time() < t_end:
             except NotImplementedError:                       # candidate sets beyond the LDS lists: documented limit
                 n_unsupported += 1
             else:
-                assert got == oracle.generic_ngrams_raw(p, t, *lim), ("generic", tag, lim, p)
+                want = oracle.generic_ngrams_raw(p, t, *lim)
+                assert got == want, ("generic", tag, lim, p)
+                cons = eng.generic_ngrams_consolidated(h, p, *lim)
+                assert [r[:3] for r in cons] == oracle.consolidate(want), ("generic consolidated", tag, lim, p)
+                assert eng.generic_ngrams_any(h, p, *lim) == (len(want) > 0), ("generic any", tag, lim, p)
+                eng.generic_ngrams_begin(h, p, *lim); eng.generic_ngrams_begin(h, p, *lim, consolidated=True)
+                assert eng.search_end() == want and eng.search_end() == cons, ("generic pipelined", tag, lim, p)
     if len(t) <= 5000 and len(p) <= 40:                       # the linear-programming fallbacks (short patterns)
         try:
             got = eng.lev_lp(h, p, k)
