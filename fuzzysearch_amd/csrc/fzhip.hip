@@ -128,6 +128,8 @@ struct DevState {
     bool timed = true;                           // the search being collected recorded its start event
     double last_filter_ms = 0;                   // scan span of the search collected last on this device (fz_device_ms)
     uint64_t fold_guess = 8192, fold_copied = 0; // folded generic search: pairs fetched with the counters
+    hipStream_t stream_hi = nullptr;             // generic searches in flight: the automaton and what follows it (high priority)
+    hipEvent_t ev_scan_done = nullptr;
     uint8_t *d_pat = nullptr;                    // pattern in HBM (subsequences longer than FZ_MAX_M, fz_verify_big_kernel)
     uint64_t pat_cap = 0;
     int slot_id = 0;                             // which of the two result slots is the current one
@@ -1033,20 +1035,38 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             // (measured on configs[3b], 6144 hits: 16 / 24 / 32 workgroups per CU with 512-entry match buffers 0.325 /
             //  0.310 / 0.310 ms, with 128-entry ones 0.325 / 0.303 / 0.304 ms — once every hit is resident the kernel
             //  takes as long as its slowest hit)
+            // (Lab knob FZ_GEN_HI_STREAM=1, measured and NOT the default: for a search in flight next to another one,
+            // everything behind the scan on a HIGH-priority stream of the lane, so that the automaton's waves take the
+            // slots the other lane's scan frees instead of waiting behind its grid.  configs[3b], two in flight: 0.364 ms
+            // per search against 0.310 ms with the automaton on the lane's own low-priority stream — the automaton's
+            // 4 171 waves then hold their CUs' registers for 160 us and the scan, which is what bounds the pair, starves.)
+            static const bool use_hi = getenv("FZ_GEN_HI_STREAM") != nullptr;
+            hipStream_t st2 = d.stream;
+            if (phase == 1 && use_hi) {
+                if (!d.stream_hi) {
+                    int prio_least = 0, prio_greatest = 0;
+                    HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+                    HIP_TRY(hipStreamCreateWithPriority(&d.stream_hi, hipStreamNonBlocking, prio_greatest));
+                    HIP_TRY(hipEventCreateWithFlags(&d.ev_scan_done, hipEventDisableTiming));
+                }
+                HIP_TRY(hipEventRecord(d.ev_scan_done, d.stream));
+                HIP_TRY(hipStreamWaitEvent(d.stream_hi, d.ev_scan_done, 0));
+                st2 = d.stream_hi;
+            }
             hipLaunchKernelGGL(lp_kernel(FZ_LP_GENERIC_HIT, scratch != 0), dim3(scratch ? kCandScratchGrid : d.n_cus * grid_per_cu), dim3(64),
-                               lds, d.stream, sh.d_buf, fa, d.d_hits, (uint64_t)0, recs, counters);
+                               lds, st2, sh.d_buf, fa, d.d_hits, (uint64_t)0, recs, counters);
             HIP_TRY(hipGetLastError());
-            if (ctx->timing) HIP_TRY(hipEventRecord(d.ev[2], d.stream));
+            if (ctx->timing) HIP_TRY(hipEventRecord(d.ev[2], st2));
             if (dev_order) {
-                hipLaunchKernelGGL(fz_gen_order_kernel, dim3(d.n_cus * 8), dim3(256), 0, d.stream, d.d_hits, fa, counters);
-                hipLaunchKernelGGL(fz_gen_scatter_kernel, dim3(d.n_cus * 8), dim3(256), 0, d.stream, d.d_hits, fa, recs,
+                hipLaunchKernelGGL(fz_gen_order_kernel, dim3(d.n_cus * 8), dim3(256), 0, st2, d.d_hits, fa, counters);
+                hipLaunchKernelGGL(fz_gen_scatter_kernel, dim3(d.n_cus * 8), dim3(256), 0, st2, d.d_hits, fa, recs,
                                    reinterpret_cast<FzOutRow *>(d.d_gen_rows), counters);
                 HIP_TRY(hipGetLastError());
             }
             // folded search: the (few) pairs come back with the counters in ONE copy — as many as the previous search had
             d.fold_copied = q.fold ? std::min<uint64_t>(std::min<uint64_t>(d.fold_guess, kHostRecs), d.rec_cap) : 0;
-            HIP_TRY(hipMemcpyAsync(d.h_stage, d.d_out, kHeaderBytes + d.fold_copied * sizeof(FzGenRec), hipMemcpyDeviceToHost, d.stream));
-            HIP_TRY(hipEventRecord(d.ev[3], d.stream));
+            HIP_TRY(hipMemcpyAsync(d.h_stage, d.d_out, kHeaderBytes + d.fold_copied * sizeof(FzGenRec), hipMemcpyDeviceToHost, st2));
+            HIP_TRY(hipEventRecord(d.ev[3], st2));
         }
         if (phase == 1) return FZ_OK;
         bool lists_overflowed = false;
@@ -1055,7 +1075,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
         for (const Shard &sh : seq->shards) {
             DevState &d = lane_dev(ctx, sh.dev);
             HIP_TRY(hipSetDevice(d.device));
-            HIP_TRY(hipStreamSynchronize(d.stream));
+            HIP_TRY(hipEventSynchronize(d.ev[3]));            // (recorded behind the last command of the search, on whichever stream)
             trg.mark(" generic sync");
             const unsigned long long *cnt = reinterpret_cast<const unsigned long long *>(d.h_stage);
             const uint64_t nh = cnt[0], nr = cnt[1], novf = cnt[2];
@@ -1431,6 +1451,7 @@ static int devstate_init(DevState &d) {
 static void devstate_destroy(DevState &d) {
     (void)hipSetDevice(d.device);
     if (d.stream) (void)hipStreamSynchronize(d.stream);
+    if (d.stream_hi) (void)hipStreamSynchronize(d.stream_hi);
     if (d.d_hits) (void)hipFree(d.d_hits);
     if (d.d_out) (void)hipFree(d.d_out);
     if (d.spare_alloc) (void)hipFree(d.spare_alloc);
@@ -1445,6 +1466,8 @@ static void devstate_destroy(DevState &d) {
     for (int i = 0; i < 2; ++i) if (d.stream_h[i]) (void)hipHostFree(d.stream_h[i]);
     if (d.stream_d) (void)hipFree(d.stream_d);
     for (auto &ev : d.ev) if (ev) (void)hipEventDestroy(ev);
+    if (d.ev_scan_done) (void)hipEventDestroy(d.ev_scan_done);
+    if (d.stream_hi) { (void)hipStreamSynchronize(d.stream_hi); (void)hipStreamDestroy(d.stream_hi); }
     if (d.stream) (void)hipStreamDestroy(d.stream);
 }
 
