@@ -1429,6 +1429,10 @@ int fz_device_count(int *n) {
 
 static int devstate_init(DevState &d) {
     HIP_TRY(hipSetDevice(d.device));
+    // a search call is ~0.3 ms: spin instead of sleeping on the completion interrupt — on EVERY device of the context
+    // (the flag is per device; refused with hipErrorSetOnActiveProcess once a device is in use: then it stays as it is)
+    if (!getenv("FZ_NO_SPIN")) (void)hipSetDeviceFlags(hipDeviceScheduleSpin);
+    (void)hipGetLastError();
     // Lowest priority: a different hardware queue than the default-priority streams of the rest of
     // the process, and the dispatcher prefers their workgroups.  Measured with RCCL on torch's
     // stream: at default priority an all_gather launched while a scan was running only started

@@ -462,7 +462,21 @@ def test_multi_device_context_on_one_gpu():
         assert eng.lev_ngrams(h, p, 2) == oracle.lev_ngrams_raw(p, t, 2), n
         assert eng.subs_ngrams(h, p, 2) == oracle.subs_ngrams_raw(p, t, 2), n
         assert eng.search_exact(h, p[:7]) == oracle.search_exact(p[:7], t), n
-        assert eng.generic_ngrams(h, p, 2, 1, 1, 2) == oracle.generic_ngrams_raw(p, t, 2, 1, 1, 2), n
+        gen = oracle.generic_ngrams_raw(p, t, 2, 1, 1, 2)
+        assert eng.generic_ngrams(h, p, 2, 1, 1, 2) == gen, n
+        # round 3: the consolidated / flag-only / pipelined forms and the wide-band verification over shards
+        assert [r[:3] for r in eng.generic_ngrams_consolidated(h, p, 2, 1, 1, 2)] == oracle.consolidate(gen), n
+        assert eng.generic_ngrams_any(h, p, 2, 1, 1, 2) == (len(gen) > 0), n
+        assert eng.subs_ngrams_any(h, p, 2) == (len(oracle.subs_ngrams_raw(p, t, 2)) > 0), n
+        eng.generic_ngrams_begin(h, p, 2, 1, 1, 2)
+        eng.generic_ngrams_begin(h, p, 2, 1, 1, 2)
+        assert eng.search_end() == gen and eng.search_end() == gen, n
+        eng.subs_ngrams_begin(h, p, 2)
+        eng.lev_ngrams_begin(h, p, 2)
+        assert eng.search_end() == oracle.subs_ngrams_raw(p, t, 2) and eng.search_end() == oracle.lev_ngrams_raw(p, t, 2), n
+        if n >= 4096:
+            p6 = (p + p[:5])[:25]
+            assert eng.lev_ngrams(h, p6, 6) == oracle.lev_ngrams_raw(p6, t, 6), n
         h.release()
     assert eng.stats()["n_devices"] == 3
     eng.close()
