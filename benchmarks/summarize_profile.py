@@ -9,6 +9,10 @@ alg = int(sys.argv[2]) if len(sys.argv) > 2 else 2 ** 30
 # the headline instance: hash windows (NWIN = 2, DH = 3), fused, in-memory, low-bits slot
 HEAD_KERNEL = "fz_scan_kernel<2, 3, true, false, true"
 TILES_PER_WG = 12
+# threads of the headline launch: round 1-2 (and inputs of 10+ rounds): one workgroup per 12 tiles; round 3: a whole
+# number of rounds of the 6 x 256 resident workgroups, ~9.5 tiles each (fzhip.hip: enqueue_shard)
+_tiles, _resident = alg // 16384, 256 * 6
+HEAD_GRIDS = {(_tiles // TILES_PER_WG) * 256, max(1, (2 * _tiles + _resident * 19 // 2) // (_resident * 19)) * _resident * 256}
 newest = lambda pattern: max(glob.glob(pattern), key=os.path.getmtime)   # gpurun merges runs: take the last one
 stats = newest(os.path.join(base, "stats", "*", "*_kernel_stats.csv"))
 shutil.copy(stats, os.path.join(root, "profiles", tag + "_rocprof_kernel_stats.csv"))
@@ -23,7 +27,7 @@ for r in csv.DictReader(open(trace)):
     grid = int(r.get("Grid_Size_X", r.get("Grid_Size", "0")) or 0)
     if HEAD_KERNEL in name:
         name += " [grid %d]" % grid
-        if grid == (alg // 16384 // TILES_PER_WG) * 256:
+        if grid in HEAD_GRIDS:
             head.append(dur)
     per[name].append(dur)
 total = sum(sum(v) for v in per.values())

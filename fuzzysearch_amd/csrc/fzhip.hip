@@ -564,8 +564,25 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     // (re-measured with the software-pipelined loop of round 2, 1 GiB: 8 / 10 / 12 / 14 / 16 / 20 / 24 / 32 tiles ->
     //  DNA k = 2: 0.232 / 0.223 / 0.222 / 0.222 / 0.224 / 0.240 / 0.244 / 0.260 ms; exact search: 0.191 / 0.182 /
     //  0.187 / 0.193 / 0.199 / 0.201 / 0.196 / 0.205 ms)
-    static const int tiles_per_wg = []() { const char *e = getenv("FZ_TILES_PER_WG"); int v = e ? atoi(e) : 0; return v > 0 ? v : 12; }();
-    const uint64_t max_grid = std::max<uint64_t>((uint64_t)d.n_cus * 6, ntiles / tiles_per_wg);
+    // Round 3 (two-level finish tickets in place, `profiles/r03_lab_ab.txt`): what matters below ~10 rounds of resident
+    // workgroups is that the grid is a WHOLE number of rounds (6 workgroups per CU are resident; a last round that is
+    // 56 % full costs 1 GiB 8 us) of ~9.5 tiles per workgroup: 1 GiB, 4 rounds (10.7 tiles) 0.2046 ms, 5 rounds 0.2048,
+    // 3 rounds 0.2062, 6 rounds 0.2074, 8 rounds 0.2104 against 0.2121-0.2146 for 12 tiles (3.56 rounds); 2 GiB, 9 rounds
+    // 0.3887 against 0.3989; 512 MiB, 2 rounds 0.1165 against 0.1182.  Long inputs keep 12 tiles per workgroup (4 GiB:
+    // 0.7743 against 0.7791-0.7855 for 14-18 whole rounds and 0.802 for 8 tiles: the per-workgroup cost wins there).
+    static const int tiles_per_wg_env = []() { const char *e = getenv("FZ_TILES_PER_WG"); int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+    const int tiles_per_wg = tiles_per_wg_env ? tiles_per_wg_env : 12;
+    const uint64_t resident = (uint64_t)d.n_cus * 6;
+    uint64_t max_grid = std::max<uint64_t>(resident, ntiles / tiles_per_wg);
+    if (!tiles_per_wg_env && ntiles < resident * 120) {
+        const uint64_t rounds = std::max<uint64_t>(1, (2 * ntiles + resident * 19 / 2) / (resident * 19));   // round(ntiles / (9.5 resident))
+        max_grid = resident * rounds;
+    }
+    {   // lab knobs: FZ_ROUNDS=r -> a grid of r x (FZ_WG_PER_CU workgroups per CU): whole rounds of resident workgroups
+        static const int rounds = []() { const char *e = getenv("FZ_ROUNDS"); return e ? atoi(e) : 0; }();
+        static const int per_cu = []() { const char *e = getenv("FZ_WG_PER_CU"); int v = e ? atoi(e) : 0; return v > 0 ? v : 6; }();
+        if (rounds > 0) max_grid = (uint64_t)d.n_cus * per_cu * rounds;
+    }
     // the queue codes carry a bounded per-workgroup tile iteration
     const uint64_t min_grid = (ntiles + FZ_TITER_MAX - 1) / FZ_TITER_MAX;
     dim3 grid((unsigned)std::max<uint64_t>(std::max<uint64_t>(1, min_grid), std::min<uint64_t>(ntiles, max_grid)));
