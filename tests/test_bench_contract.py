@@ -1,4 +1,4 @@
-"""The bench line's contract (driver + judge read it): the committed profiles/r02_bench_n1.json — the unedited
+"""The bench line's contract (driver + judge read it): the committed profiles/r03_bench_n1.json — the unedited
 stdout of `python bench.py` on an MI355X — carries every required key with consistent values, and bench.py's
 argument surface is the one the driver launches.  CPU only."""
 import json
@@ -6,11 +6,14 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_committed_bench_line_follows_the_contract():
-    with open(os.path.join(ROOT, "profiles", "r02_bench_n1.json")) as f:
+@pytest.mark.parametrize("name", ["r03_bench_n1.json", "r02_bench_n1.json"])
+def test_committed_bench_line_follows_the_contract(name):
+    with open(os.path.join(ROOT, "profiles", name)) as f:
         text = f.read().strip()
     assert "\n" not in text, "one JSON line"
     d = json.loads(text)
@@ -36,6 +39,20 @@ def test_committed_bench_line_follows_the_contract():
     assert r["avg_kernel_ms"] <= d["ms_per_step"] * 1.02
     for block in ("target_4gib", "configs"):
         assert block in d
+    if name.startswith("r03"):
+        # round 3: the pipelined value is labelled, the one-call-at-a-time figure stands beside it
+        assert "two searches in flight" in d["metric"] and d["value_sync"] < d["value"]
+        assert abs(d["value_sync"] - shard_bytes / (d["sync_ms_per_call"] * 1e-3) / 1e9) / d["value_sync"] < 0.01
+        assert "1024 MiB" in c["sample"] and "whole" in c["sample"]
+
+
+def test_two_device_states_line():
+    """`FZ_DEVICES=0,0 python bench.py --gpus 2` (the torch-free N > 1 form on one GPU): n_gpus follows --gpus."""
+    with open(os.path.join(ROOT, "profiles", "r03_bench_two_device_states.json")) as f:
+        d = json.loads(f.read().strip())
+    assert d["n_gpus"] == 2 and d["config"]["devices"] == [0, 0] and d["boundary_plants_found"] == 3
+    assert d["stream_in_reference_order"] is True and len(d["kernel_ms"]["filter_per_device"]) == 2
+    assert abs(d["value"] - 2 * d["config"]["bytes_per_gpu"] / (d["ms_per_step"] * 1e-3) / 1e9) / d["value"] < 0.01
 
 
 def test_bench_argument_surface():
