@@ -402,7 +402,7 @@ def main():
     if world == 1 and not use_dist and not args.no_cpu_baseline and rank == 0:
         cpu = cpu_baseline(seq, pattern, k, args.cpu_sample_mib)      # forks: before the HIP runtime exists
 
-    engine = _native.Engine([local_rank])
+    engine = _native.Engine([fzd.local_device(local_rank) if use_dist else local_rank])
     if use_dist and not use_torch:
         fzd.init_engine_from_env(engine)          # joins the job's RCCL communicator: searches are collective from here on
     if not use_dist:

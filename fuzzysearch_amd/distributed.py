@@ -30,7 +30,7 @@ import time
 import numpy as np
 
 __all__ = ['shard_bounds', 'exchange_halos', 'allgather_matches', 'merge_rank_streams',
-           'init_engine_from_env', 'share_blob', 'exchange_halos_native']
+           'init_engine_from_env', 'local_device', 'share_blob', 'exchange_halos_native']
 
 _rdzv_seq = [0]
 
@@ -93,6 +93,16 @@ def share_blob(make_blob, world, rank, timeout=300.0, directory=None):
     return blob
 
 
+def local_device(local_rank):
+    """The HIP device of this rank: LOCAL_RANK, unless the launcher already narrowed the visible devices per rank
+    (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES: then fewer devices are visible than there are local ranks)."""
+    import ctypes
+    from . import _native
+    n = ctypes.c_int(0)
+    _native._check(_native.load_library().fz_device_count(ctypes.byref(n)))
+    return local_rank if local_rank < n.value else local_rank % max(1, n.value)
+
+
 def init_engine_from_env(engine=None):
     """One process per GPU under any launcher that sets RANK / WORLD_SIZE / LOCAL_RANK (torch.distributed.run does):
     -> (engine, world, rank), the engine on device LOCAL_RANK and a member of the job's RCCL communicator.  No torch."""
@@ -101,7 +111,7 @@ def init_engine_from_env(engine=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     if engine is None:
-        engine = _native.Engine([local_rank])
+        engine = _native.Engine([local_device(local_rank)])
     uid = share_blob(engine.comm_unique_id, world, rank)
     engine.comm_init_rank(uid, world, rank)
     return engine, world, rank
