@@ -269,7 +269,7 @@ def allgather_matches(raw, group=None, as_array=False):
     world = dist.get_world_size(group)
     dev = _device_for(group)
     mine = _as_match_array(raw)
-    key = id(group) if group is not None else 0
+    key = group if group is not None else 0      # (the dict holds the group itself: its identity cannot be recycled)
     while True:
         st = _gather_state.get(key)
         # the state holds the group object (so its id cannot be handed to another group while the entry exists)
