@@ -1651,6 +1651,9 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
         if (order && q < FZ_GEN_ORDER_MAX && lane == 0) { order_first[q] = 0; order_count[q] = overflow ? 0u : mseq; }
         fz_wave_lds_sync();
     }
+    // folded search whose pairs went straight into the host's staging buffer: the last workgroup publishes the counters
+    // there as well (no D2H copy command behind the kernel) and leaves them zeroed for the next search
+    fz_finish_launch(a, counters, reinterpret_cast<volatile uint32_t *>(smem));
 }
 
 // Reference order of the generic search's rows (generic_search.py:221-237: blocks in order, the hits of a block by

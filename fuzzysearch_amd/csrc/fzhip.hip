@@ -59,6 +59,10 @@ struct Trace {
 
 thread_local std::string g_err;
 
+// FZ_NO_DIRECT=1 (test / lab knob): records and counters always come back through a D2H copy, never by the kernels' own
+// stores into the pinned staging buffer
+bool env_no_direct() { static const bool v = getenv("FZ_NO_DIRECT") != nullptr; return v; }
+
 int fail(int code, const char *fmt, ...) {
     char tmp[512];
     va_list ap;
@@ -128,6 +132,8 @@ struct DevState {
     bool timed = true;                           // the search being collected recorded its start event
     double last_filter_ms = 0;                   // scan span of the search collected last on this device (fz_device_ms)
     uint64_t fold_guess = 8192, fold_copied = 0; // folded generic search: pairs fetched with the counters
+    bool fold_direct = true;                     // ... or written straight into h_stage by the automaton kernel (while they fit)
+    bool fold_was_direct = false;                // mode of the folded search being collected
     hipStream_t stream_hi = nullptr;             // generic searches in flight: the automaton and what follows it (high priority)
     hipEvent_t ev_scan_done = nullptr;
     uint8_t *d_pat = nullptr;                    // pattern in HBM (subsequences longer than FZ_MAX_M, fz_verify_big_kernel)
@@ -228,6 +234,11 @@ struct fz_ctx {
     // hipEvent timing of the kernels (fz_stats: filter_ms / verify_ms / device_ms).  One event record is one more packet
     // in front of the kernel and two hipEventElapsedTime calls behind it: fz_set_timing(ctx, 0) drops them.
     bool timing = getenv("FZ_NO_TIMING") == nullptr;
+    // The spans are read from the events only when somebody asks (fz_stats / fz_device_ms): a hipEventElapsedTime call
+    // costs ~5 us of host time, two or three of them sat between the completion of every search and its result.  The
+    // references die with the next launch of the context (whose enqueue re-records the events).
+    struct TimingRef { DevState *d; hipEvent_t f0, f1, v0, v1, t0, t1; };
+    std::vector<TimingRef> tref;
     int comm_world = 0;
     bool snapshot = false;
     uint64_t gcap = 4096;                        // records per rank the all-gather carries (follows the counts, on all ranks alike)
@@ -242,6 +253,23 @@ struct fz_seq {
 namespace {
 void comm_teardown(fz_ctx *ctx);
 inline DevState &lane_dev(fz_ctx *ctx, int dev) { return ctx->lane ? ctx->devs2[dev] : ctx->devs[dev]; }
+
+// fz_stats / fz_device_ms: the kernel spans of the search collected last, read from its events now.
+void resolve_timing(fz_ctx *ctx) {
+    for (const fz_ctx::TimingRef &r : ctx->tref) {
+        float f = 0, v = 0, t = 0;
+        if (hipSetDevice(r.d->device) != hipSuccess) continue;
+        if (r.f0 && hipEventElapsedTime(&f, r.f0, r.f1) != hipSuccess) f = 0;
+        if (r.v0 && hipEventElapsedTime(&v, r.v0, r.v1) != hipSuccess) v = 0;
+        if (r.t0 && hipEventElapsedTime(&t, r.t0, r.t1) != hipSuccess) t = 0;
+        (void)hipGetLastError();
+        r.d->last_filter_ms = f;
+        ctx->stats.filter_ms = std::max<double>(ctx->stats.filter_ms, f);
+        ctx->stats.verify_ms = std::max<double>(ctx->stats.verify_ms, v);
+        ctx->stats.device_ms = std::max<double>(ctx->stats.device_ms, t);
+    }
+    ctx->tref.clear();
+}
 }
 
 namespace {
@@ -540,7 +568,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     HIP_TRY(hipSetDevice(d.device));
     unsigned long long *counters = reinterpret_cast<unsigned long long *>(d.d_out);
     FzRec *recs = reinterpret_cast<FzRec *>(d.d_out + kHeaderBytes);
-    static const bool no_direct = getenv("FZ_NO_DIRECT") != nullptr;
+    const bool no_direct = env_no_direct();
     // direct mode needs a kernel to publish the counters: an empty buffer launches none
     const bool snapshot = copy_back && with_verify && q.collective;      // collective search: records stay on the device
     const bool direct = copy_back && d.direct && !no_direct && !snapshot && sh.geom.buf_len > 0 && !q.plan.s.empty();
@@ -783,16 +811,9 @@ int collect_shard(fz_ctx *ctx, const Shard &sh, bool with_verify, bool view_ok, 
     }
     if (!d.last_direct && nr * 4 < kHostRecs) d.direct = true;
     if (rerun) return FZ_OK;
-    float f = 0, v = 0, t = 0;
-    if (d.timed) {
-        HIP_TRY(hipEventElapsedTime(&f, d.ev[0], d.ev[d.scan_end_event]));
-        if (d.verify_launched) HIP_TRY(hipEventElapsedTime(&v, d.ev[1], d.ev[2]));
-        HIP_TRY(hipEventElapsedTime(&t, d.ev[0], d.ev[3]));
-    }
-    d.last_filter_ms = f;
-    ctx->stats.filter_ms = std::max<double>(ctx->stats.filter_ms, f);
-    ctx->stats.verify_ms = std::max<double>(ctx->stats.verify_ms, v);
-    ctx->stats.device_ms = std::max<double>(ctx->stats.device_ms, t);
+    d.last_filter_ms = 0;
+    if (d.timed)
+        ctx->tref.push_back({&d, d.ev[0], d.ev[d.scan_end_event], d.verify_launched ? d.ev[1] : nullptr, d.ev[2], d.ev[0], d.ev[3]});
     ctx->stats.bytes_scanned += sh.geom.buf_len;
     ctx->stats.ngram_hits += nh;
     if (with_verify && collective) {
@@ -922,6 +943,7 @@ int search_enqueue(fz_ctx *ctx, fz_seq *seq, const Search &q, bool with_verify) 
     ctx->stats.filter_launches = 0;
     ctx->stats.bytes_scanned = ctx->stats.ngram_hits = ctx->stats.raw_matches = 0;
     ctx->stats.filter_ms = ctx->stats.verify_ms = ctx->stats.device_ms = 0;
+        ctx->tref.clear();
     for (const Shard &sh : seq->shards) {
         int rc = enqueue_shard(ctx, sh, q, with_verify);
         if (rc) return rc;
@@ -939,6 +961,7 @@ int search_collect(fz_ctx *ctx, fz_seq *seq, const Search &q, bool with_verify, 
         // the statistics describe the search being collected (a younger one may have been launched meanwhile)
         ctx->stats.bytes_scanned = ctx->stats.ngram_hits = ctx->stats.raw_matches = 0;
         ctx->stats.filter_ms = ctx->stats.verify_ms = ctx->stats.device_ms = 0;
+        ctx->tref.clear();
         Trace tr;
         bool any_rerun = false;
         ctx->seg_ends.clear();
@@ -972,7 +995,7 @@ int search_collect(fz_ctx *ctx, fz_seq *seq, const Search &q, bool with_verify, 
 int run_search(fz_ctx *ctx, fz_seq *seq, const Search &q, bool with_verify, std::vector<FzRec> &recs,
                std::vector<uint64_t> &hits) {
     if (ctx->npend) return fail(FZ_EINVAL, "a search started with fz_lev_ngrams_begin is still in flight");
-    memset(&ctx->stats, 0, sizeof ctx->stats);
+    memset(&ctx->stats, 0, sizeof ctx->stats); ctx->tref.clear();
     ctx->stats.n_devices = (uint32_t)ctx->devs.size();
     Trace tr;
     int rc = search_enqueue(ctx, seq, q, with_verify);
@@ -987,7 +1010,7 @@ int run_search(fz_ctx *ctx, fz_seq *seq, const Search &q, bool with_verify, std:
 // the current lane and the call returns); 2 = collect what phase 1 launched (fz_search_end), then carry on as phase 0 if
 // a buffer turned out too small.
 int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec> &recs_out, int phase = 0) {
-    memset(&ctx->stats, 0, sizeof ctx->stats);
+    memset(&ctx->stats, 0, sizeof ctx->stats); ctx->tref.clear();
     ctx->stats.n_devices = (uint32_t)ctx->devs.size();
     static_assert(sizeof(FzGenRec) == sizeof(FzRec), "record buffers are shared");
     uint32_t cand_cap = ctx->gen_cand_cap;
@@ -1002,6 +1025,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
         ctx->stats.filter_launches = 0;
         ctx->stats.bytes_scanned = ctx->stats.ngram_hits = ctx->stats.raw_matches = 0;
         ctx->stats.filter_ms = ctx->stats.verify_ms = ctx->stats.device_ms = 0;
+        ctx->tref.clear();
         const uint32_t mpad = (q.m + 15u) & ~15u, wpad = (q.m + 2 * q.k + 15u) & ~15u;
         for (const Shard &sh : seq->shards) {
             if (phase == 2 && attempt == 0) break;            // launched by fz_generic_ngrams_begin
@@ -1040,10 +1064,18 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
                 if (rc) return rc;
                 fa.gen_order = reinterpret_cast<uint64_t>(d.d_gen_order);
             }
-            fa.rec_cap = gen_direct ? d.big_cap : d.rec_cap;
+            // Folded search (a few thousand pairs): the automaton kernel writes them straight into the pinned staging
+            // buffer and its last workgroup publishes the counters there, as the fused scan does for its records — no
+            // copy command between the kernel and the host (FZ_NO_DIRECT=1, or more pairs than the buffer holds: the copy).
+            const bool no_direct = env_no_direct();
+            const bool fold_direct = q.fold && !gen_direct && !no_direct && d.fold_direct && seq->shards.size() == 1;
+            d.fold_was_direct = fold_direct;
+            fa.rec_cap = gen_direct ? d.big_cap : fold_direct ? kHostRecs : d.rec_cap;
+            if (fold_direct) fa.host_hdr = reinterpret_cast<uint64_t>(d.h_stage_dev);
             unsigned long long *counters = reinterpret_cast<unsigned long long *>(d.d_out);
             FzGenRec *recs = gen_direct ? reinterpret_cast<FzGenRec *>(d.h_big_dev)
-                                        : reinterpret_cast<FzGenRec *>(d.d_out + kHeaderBytes);
+                           : fold_direct ? reinterpret_cast<FzGenRec *>(d.h_stage_dev + kHeaderBytes)
+                                         : reinterpret_cast<FzGenRec *>(d.d_out + kHeaderBytes);
             static_assert(sizeof(FzGenRec) == sizeof(FzRec), "the generic records share the record buffer");
             if (lds > 64 * 1024)
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(lp_kernel(FZ_LP_GENERIC_HIT, scratch != 0)),
@@ -1081,9 +1113,19 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
                 HIP_TRY(hipGetLastError());
             }
             // folded search: the (few) pairs come back with the counters in ONE copy — as many as the previous search had
-            d.fold_copied = q.fold ? std::min<uint64_t>(std::min<uint64_t>(d.fold_guess, kHostRecs), d.rec_cap) : 0;
-            HIP_TRY(hipMemcpyAsync(d.h_stage, d.d_out, kHeaderBytes + d.fold_copied * sizeof(FzGenRec), hipMemcpyDeviceToHost, st2));
-            HIP_TRY(hipEventRecord(d.ev[3], st2));
+            d.fold_copied = fold_direct ? kHostRecs : q.fold ? std::min<uint64_t>(std::min<uint64_t>(d.fold_guess, kHostRecs), d.rec_cap) : 0;
+            if (!fold_direct) {
+                HIP_TRY(hipMemcpyAsync(d.h_stage, d.d_out, kHeaderBytes + d.fold_copied * sizeof(FzGenRec), hipMemcpyDeviceToHost, st2));
+                HIP_TRY(hipEventRecord(d.ev[3], st2));
+                // the counters are zeroed for the next search now, behind the copy (not in front of that search's scan)
+                if (st2 == d.stream) {
+                    HIP_TRY(hipMemsetAsync(d.d_out, 0, kHeaderBytes, st2));
+                    d.header_zeroed = true;
+                }
+            } else {
+                HIP_TRY(hipEventRecord(d.ev[3], st2));
+                d.header_zeroed = true;                       // by the publishing workgroup
+            }
         }
         if (phase == 1) return FZ_OK;
         bool lists_overflowed = false;
@@ -1108,7 +1150,10 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             static const bool gen_direct2 = getenv("FZ_GEN_DIRECT") != nullptr;
             if (nh > d.hit_cap) { int rc = ensure_hits(d, nh + nh / 8 + 1024); if (rc) return rc; rerun = true; }
             if (nr > d.big_cap) { int rc = ensure_big(d, nr + nr / 8 + 1024); if (rc) return rc; if (gen_direct2) rerun = true; }
-            if (!gen_direct2 && nr > d.rec_cap) { int rc = ensure_recs(d, nr + nr / 8 + 1024); if (rc) return rc; rerun = true; }
+            if (d.fold_was_direct) {                          // pairs beyond the staging buffer were dropped: again, through d_out
+                if (nr > kHostRecs) { d.fold_direct = false; rerun = true; }
+            } else if (q.fold && nr * 4 < kHostRecs) d.fold_direct = true;
+            if (!gen_direct2 && !d.fold_was_direct && nr > d.rec_cap) { int rc = ensure_recs(d, nr + nr / 8 + 1024); if (rc) return rc; rerun = true; }
             static const bool host_order2 = getenv("FZ_GEN_HOST_ORDER") != nullptr;
             const bool rows_ready = !gen_direct2 && !host_order2 && !q.fold && seq->shards.size() == 1 && sh.geom.seg_stride == 0 &&
                                     nh <= FZ_GEN_ORDER_MAX && nr <= d.gen_rows_cap;
@@ -1118,15 +1163,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
                 HIP_TRY(hipMemcpy(d.h_big, d.d_out + kHeaderBytes, nr * sizeof(FzGenRec), hipMemcpyDeviceToHost));
             if (novf) { lists_overflowed = true; rerun = true; }
             if (rerun) continue;
-            float f = 0, v = 0, t = 0;
-            if (d.timed) {
-                HIP_TRY(hipEventElapsedTime(&f, d.ev[0], d.ev[1]));
-                HIP_TRY(hipEventElapsedTime(&v, d.ev[1], d.ev[2]));
-                HIP_TRY(hipEventElapsedTime(&t, d.ev[0], d.ev[3]));
-            }
-            ctx->stats.filter_ms = std::max<double>(ctx->stats.filter_ms, f);
-            ctx->stats.verify_ms = std::max<double>(ctx->stats.verify_ms, v);
-            ctx->stats.device_ms = std::max<double>(ctx->stats.device_ms, t);
+            if (d.timed) ctx->tref.push_back({&d, d.ev[0], d.ev[1], d.ev[1], d.ev[2], d.ev[0], d.ev[3]});
             ctx->stats.bytes_scanned += sh.geom.buf_len;
             ctx->stats.ngram_hits += nh;
             if (rows_ready) {                                 // finished rows, fetched by emit_generic
@@ -1158,7 +1195,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
 // the payload carries the capacity; fz_free parks up to two big blocks, alloc_out takes a parked block that fits.
 struct OutHdr { uint64_t bytes; uint64_t magic; };
 constexpr uint64_t kOutMagic = 0x667a6f7574627566ull;
-constexpr uint64_t kOutRecycleMin = 256u << 10;
+constexpr uint64_t kOutRecycleMin = 32u << 10;
 std::mutex g_out_lock;
 OutHdr *g_out_parked[2] = {nullptr, nullptr};
 
@@ -1699,6 +1736,7 @@ int fz_seq_add_shard(fz_seq *seq, int dev_index, const uint8_t *host_buf, uint64
 
 int fz_device_ms(fz_ctx *ctx, double *filter_ms, int cap) {
     if (!ctx || (!filter_ms && cap > 0)) return fail(FZ_EINVAL, "null argument");
+    resolve_timing(ctx);
     for (int i = 0; i < cap && i < (int)ctx->devs.size(); ++i) filter_ms[i] = ctx->devs[i].last_filter_ms;
     return (int)ctx->devs.size();
 }
@@ -1860,7 +1898,7 @@ static int pending_begin(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m,
     Search q;
     int rc = pending_plan(ctx, pd, q);
     if (rc) return rc;
-    memset(&ctx->stats, 0, sizeof ctx->stats);
+    memset(&ctx->stats, 0, sizeof ctx->stats); ctx->tref.clear();
     ctx->stats.n_devices = (uint32_t)ctx->devs.size();
     const bool second = ctx->npend == 1;
     pd.launched = true;
@@ -1877,7 +1915,7 @@ static int pending_begin(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m,
         // with a search in flight this one goes to the devices' second result slot — unless a device is out of
         // direct mode (large record sets are fetched from the shared device buffer after the kernel: a second
         // search would overwrite it), then the launch waits for fz_search_end of the older search
-        if (second && !ctx->snapshot) for (const DevState &d : ctx->devs) if (!d.direct) pd.launched = false;
+        if (second && !ctx->snapshot) for (const DevState &d : ctx->devs) if (!d.direct || env_no_direct()) pd.launched = false;
         if (pd.launched) {
             if (second) for (DevState &d : ctx->devs) d.swap_slot();
             rc = search_enqueue(ctx, seq, q, true);
@@ -2281,7 +2319,7 @@ constexpr uint32_t kLpStarts = 256;      // start positions owned by one window 
 // at most m - 1 + k characters, so tiles are independent; only the tile reaching the sequence end
 // performs the reference's end-of-sequence flush.
 int run_lp(fz_ctx *ctx, fz_seq *seq, const Search &q, uint32_t lp_kind, std::vector<LpRec> &out) {
-    memset(&ctx->stats, 0, sizeof ctx->stats);
+    memset(&ctx->stats, 0, sizeof ctx->stats); ctx->tref.clear();
     ctx->stats.n_devices = (uint32_t)ctx->devs.size();
     uint32_t cand_cap = 1024;
     for (int attempt = 0; attempt < 8; ++attempt) {
@@ -2451,7 +2489,7 @@ static int subs_lp_impl(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, 
     if (rc) return rc;
     rc = check_halo(seq, m);
     if (rc) return rc;
-    memset(&ctx->stats, 0, sizeof ctx->stats);
+    memset(&ctx->stats, 0, sizeof ctx->stats); ctx->tref.clear();
     ctx->stats.n_devices = (uint32_t)ctx->devs.size();
     std::vector<FzRec> recs;
     for (int attempt = 0; attempt < 4; ++attempt) {
@@ -2668,7 +2706,7 @@ int stream_launch(fz_stream *st, uint64_t j0, uint64_t j1, uint64_t data_hi) {
     int rc = ensure_hits(d, std::max<uint64_t>(1u << 20, len / 64));
     if (rc) return rc;
     if (st->mode != FZ_MODE_GENERIC) {
-        memset(&ctx->stats, 0, sizeof ctx->stats);
+        memset(&ctx->stats, 0, sizeof ctx->stats); ctx->tref.clear();
         ctx->stats.n_devices = 1;
         rc = search_enqueue(ctx, st->seq, st->q, st->mode != FZ_MODE_EXACT);
         if (rc) return rc;
@@ -2995,68 +3033,79 @@ int consolidate_hulls(std::vector<Hull> &hulls, fz_match **out, uint64_t *n_out)
         return x.dist < y.dist || (x.dist == y.dist && (lx > ly || (lx == ly && (x.start < y.start || (x.start == y.start && x.block < y.block)))));
     };
     const uint64_t nh = hulls.size();
-    static thread_local std::vector<uint64_t> wa, wb;
-    std::vector<uint32_t> order;                                // hull numbers in sweep order
-    bool ordered = false;
-    if (nh >= 2048 && nh <= 0xffffffffull) {
+    if (nh > 0xffffffffull) return fail(FZ_EUNSUPPORTED, "more than 2^32 disjoint runs of matches");
+    // Sweep order = (hull start, zero-length first, input order).  The hulls of a search are spread over the sequence
+    // (one or a few per n-gram hit), so ONE counting pass over ~nh equal slices of [smin, smax] leaves almost every hull
+    // alone in its slice: count, prefix, scatter the hull numbers, then one pass over the slices that fixes the order
+    // inside the few holding several (stable insertion; a stable sort for the crowded slices of clustered input) and
+    // sweeps.  (This replaces an 11-bit LSD radix over 64-bit words — a histogram pass and three scatter passes; moving
+    // the 40-byte hulls themselves into the slices instead of their numbers measured slower.)
+    static thread_local std::vector<uint32_t> order, cnt;       // hull numbers in sweep order; slice boundaries
+    Trace trc;
+    order.resize(nh);
+    auto before = [&](uint32_t x, uint32_t y) {
+        const Hull &a = hulls[x], &b = hulls[y];
+        if (a.h0 != b.h0) return a.h0 < b.h0;
+        return (a.h1 == a.h0) && (b.h1 != b.h0);
+    };
+    uint64_t nb = 1;
+    if (nh >= 32) {
         int64_t smin = hulls[0].h0, smax = smin;
         for (const Hull &h : hulls) { smin = std::min(smin, h.h0); smax = std::max(smax, h.h0); }
-        auto bits_of = [](uint64_t range) { int b = 0; while (b < 64 && (range >> b)) ++b; return b; };
-        const int kb = bits_of((uint64_t)(smax - smin)) + 1, ib = bits_of(nh - 1), npass = (kb + 10) / 11;
-        if (kb + ib <= 64 && npass <= 4) {
-            if (wa.size() < nh) { wa.resize(nh); wb.resize(nh); }
-            uint32_t hist[4][2048];
-            memset(hist, 0, sizeof hist);
-            uint64_t *src = wa.data(), *dst = wb.data();
-            for (uint64_t i = 0; i < nh; ++i) {
-                const uint64_t key = ((uint64_t)(hulls[i].h0 - smin) << 1) | (hulls[i].h1 != hulls[i].h0);
-                src[i] = (key << ib) | i;
-                for (int p = 0; p < npass; ++p) ++hist[p][(key >> (11 * p)) & 0x7ff];
-            }
-            for (int p = 0; p < npass; ++p) {
-                uint32_t run = 0;
-                for (int d = 0; d < 2048; ++d) { const uint32_t c = hist[p][d]; hist[p][d] = run; run += c; }
-                const int shift = ib + 11 * p;
-                for (uint64_t i = 0; i < nh; ++i) dst[hist[p][(src[i] >> shift) & 0x7ff]++] = src[i];
-                std::swap(src, dst);
-            }
-            const uint64_t imask = ib ? ((1ull << ib) - 1) : 0;
-            order.resize(nh);
-            for (uint64_t i = 0; i < nh; ++i) order[i] = (uint32_t)(src[i] & imask);
-            ordered = true;
-        }
-    }
-    if (!ordered) {
-        if (nh > 0xffffffffull) return fail(FZ_EUNSUPPORTED, "more than 2^32 disjoint runs of matches");
-        order.resize(nh);
+        while (nb < nh && nb < (1u << 24)) nb <<= 1;
+        const uint64_t range = (uint64_t)(smax - smin);
+        int shift = 0;
+        while ((range >> shift) >= nb) ++shift;
+        cnt.assign(nb + 1, 0u);
+        for (uint64_t i = 0; i < nh; ++i) ++cnt[(((uint64_t)(hulls[i].h0 - smin)) >> shift) + 1];
+        for (uint64_t b = 1; b <= nb; ++b) cnt[b] += cnt[b - 1];                      // cnt[b] = where slice b starts
+        for (uint64_t i = 0; i < nh; ++i) order[cnt[((uint64_t)(hulls[i].h0 - smin)) >> shift]++] = (uint32_t)i;
+        // now cnt[b] = where slice b ends
+    } else {
         for (uint64_t i = 0; i < nh; ++i) order[i] = (uint32_t)i;
-        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-            const Hull &a = hulls[x], &b = hulls[y];
-            if (a.h0 != b.h0) return a.h0 < b.h0;
-            if ((a.h1 != a.h0) != (b.h1 != b.h0)) return a.h1 == a.h0;
-            return x < y;
-        });
+        std::stable_sort(order.begin(), order.end(), before);
+        cnt.assign(1, (uint32_t)nh);
     }
-    std::vector<fz_match> best;
-    int64_t h0 = 0, h1 = 0;
-    for (uint64_t vi = 0; vi < nh; ++vi) {
-        const Hull &h = hulls[order[vi]];
-        if (!best.empty() && !(h.h1 <= h0 || h.h0 >= h1)) {
-            h0 = std::min(h0, h.h0);
-            h1 = std::max(h1, h.h1);
-            if (better(h.best, best.back())) best.back() = h.best;
-        } else {
-            h0 = h.h0; h1 = h.h1;
-            best.push_back(h.best);
-        }
-    }
-    if (!std::is_sorted(best.begin(), best.end(), by_start_end_dist)) std::sort(best.begin(), best.end(), by_start_end_dist);
+    trc.mark("  hulls in slices");
+    // the survivors go straight into the caller's buffer (at most one per hull)
     void *mem = nullptr;
-    int rc = alloc_out(best.size(), sizeof(fz_match), &mem);
+    int rc = alloc_out(nh, sizeof(fz_match), &mem);
     if (rc) return rc;
-    if (!best.empty()) memcpy(mem, best.data(), best.size() * sizeof(fz_match));
-    *out = static_cast<fz_match *>(mem);
-    *n_out = best.size();
+    fz_match *best = static_cast<fz_match *>(mem);
+    uint64_t nbest = 0;
+    int64_t h0 = 0, h1 = 0;
+    uint32_t lo = 0;
+    for (uint64_t b = 0; b < nb; ++b) {
+        const uint32_t hi = cnt[b];
+        if (hi - lo > 1 && nh >= 32) {
+            if (hi - lo > 24) std::stable_sort(order.begin() + lo, order.begin() + hi, before);
+            else
+                for (uint32_t i = lo + 1; i < hi; ++i) {
+                    const uint32_t v = order[i];
+                    uint32_t j = i;
+                    while (j > lo && before(v, order[j - 1])) { order[j] = order[j - 1]; --j; }
+                    order[j] = v;
+                }
+        }
+        for (uint32_t vi = lo; vi < hi; ++vi) {
+            if (vi + 12 < nh) __builtin_prefetch(&hulls[order[vi + 12]]);    // (the hulls are gathered in random order)
+            const Hull &h = hulls[order[vi]];
+            if (nbest && !(h.h1 <= h0 || h.h0 >= h1)) {
+                h0 = std::min(h0, h.h0);
+                h1 = std::max(h1, h.h1);
+                if (better(h.best, best[nbest - 1])) best[nbest - 1] = h.best;
+            } else {
+                h0 = h.h0; h1 = h.h1;
+                best[nbest++] = h.best;
+            }
+        }
+        lo = hi;
+    }
+    trc.mark("  sweep");
+    if (!std::is_sorted(best, best + nbest, by_start_end_dist)) std::sort(best, best + nbest, by_start_end_dist);
+    trc.mark("  final order");
+    *out = best;
+    *n_out = nbest;
     return FZ_OK;
 }
 
@@ -3085,6 +3134,7 @@ int fz_consolidate(const fz_match *in, uint64_t n, fz_match **out, uint64_t *n_o
     };
     static thread_local std::vector<Hull> hulls;                // scratch kept per thread between calls
     hulls.clear();
+    Trace trc;
     for (uint64_t i = 0; i < n; ++i) {
         const fz_match &mt = in[i];
         if (!hulls.empty()) {
@@ -3098,6 +3148,7 @@ int fz_consolidate(const fz_match *in, uint64_t n, fz_match **out, uint64_t *n_o
         }
         hulls.push_back(Hull{mt.start, mt.end, mt});
     }
+    trc.mark("  runs folded");
     return consolidate_hulls(hulls, out, n_out);
 }
 
@@ -3300,6 +3351,7 @@ int fz_set_timing(fz_ctx *ctx, int on) {
 
 int fz_stats(fz_ctx *ctx, fz_stats_t *out) {
     if (!ctx || !out) return fail(FZ_EINVAL, "null argument");
+    resolve_timing(ctx);
     *out = ctx->stats;
     return FZ_OK;
 }

@@ -1,6 +1,6 @@
 """Random GPU-vs-oracle cases that also run in a SUBPROCESS (`python -m tests.gpu_cases <what> ...`): several switches
 of the library are process-wide statics read from the environment (FZ_FORCE_BIG_VERIFY, FZ_NO_SLOT_AND,
-FZ_MAX_BLOCKS), so a test that wants them set starts a fresh interpreter.  Prints "OK <n cases> <n records>"."""
+FZ_MAX_BLOCKS, FZ_NO_DIRECT), so a test that wants them set starts a fresh interpreter.  Prints "OK <n cases> <n records>"."""
 import os
 import random
 import sys
@@ -61,6 +61,37 @@ def run_lev_subs(engine, cases):
     return n_rec
 
 
+def run_pipelined(engine, cases):
+    """Two searches in flight (mixed kinds), and the folded generic search, against the oracle."""
+    import oracle
+    n_rec = 0
+    for (p, t, k) in cases:
+        h = engine.upload(t)
+        exp_s, exp_l = oracle.subs_ngrams_raw(p, t, k), oracle.lev_ngrams_raw(p, t, k)
+        engine.subs_ngrams_begin(h, p, k)
+        engine.lev_ngrams_begin(h, p, k)
+        assert engine.search_end() == exp_s, ("subs, two in flight", p, t, k)
+        assert engine.search_end() == exp_l, ("lev, two in flight", p, t, k)
+        engine.lev_ngrams_begin(h, p, k)
+        engine.lev_ngrams_begin(h, p, k)
+        assert engine.search_end() == exp_l and engine.search_end() == exp_l, ("lev twice", p, t, k)
+        n_rec += len(exp_s) + len(exp_l)
+        if k and len(t) <= 3000 and len(p) // (k + 1) >= 1:
+            try:
+                want = oracle.generic_ngrams_raw(p, t, k, k, k, k)
+                got = engine.generic_ngrams_consolidated(h, p, k, k, k, k)
+            except NotImplementedError:
+                pass
+            else:
+                assert [r[:3] for r in got] == oracle.consolidate(want), ("generic consolidated", p, t, k)
+                engine.generic_ngrams_begin(h, p, k, k, k, k, consolidated=True)
+                engine.generic_ngrams_begin(h, p, k, k, k, k)
+                assert engine.search_end() == got and engine.search_end() == want, ("generic, two in flight", p, t, k)
+                n_rec += len(want)
+        h.release()
+    return n_rec
+
+
 def main(argv):
     from fuzzysearch_amd import _native
     what = argv[0]
@@ -84,9 +115,18 @@ def main(argv):
         pat = workloads.text65(36, 2)
         workloads.plant_edits(seq, pat, 128, 4, workloads.TEXT65, lambda i: i % 4)
         cases.append((pat.tobytes(), seq.tobytes(), 3))
+    elif what == "copy":
+        # FZ_NO_DIRECT=1: counters and records through D2H copies (the path of searches with more records than the
+        # pinned staging buffer holds) — one call at a time and two in flight, where the younger search has to wait
+        # for the older one's records to leave the shared device buffer
+        cases = random_cases(rnd, n, [1, 2, 3, 4, 5], 60, 3000)
+        for sigma, nn, m, k in ((5, 300000, 5, 3), (4, 200000, 8, 1), (3, 100000, 12, 2)):
+            alpha = bytes(rnd.sample(range(1, 256), sigma))
+            cases.append((bytes(rnd.choices(alpha, k=m)), bytes(rnd.choices(alpha, k=nn)), k))   # up to 2.6e5 records per search
+        n_rec = run_pipelined(eng, cases)
     else:
         raise SystemExit("unknown case set %r" % what)
-    n_rec = run_lev_subs(eng, cases)
+    n_rec = n_rec + run_lev_subs(eng, cases) if what == "copy" else run_lev_subs(eng, cases)
     eng.close()
     print("OK %d %d" % (len(cases), n_rec))
 

@@ -39,6 +39,15 @@ def test_general_slot_form_and_multi_launch():
     assert n_cases == 202
 
 
+def test_copy_mode_one_and_two_searches_in_flight():
+    """FZ_NO_DIRECT=1: nothing is written straight into the pinned staging buffer (round 3's randomized run found the
+    younger of two searches in flight overwriting the older one's records in the shared device buffer under this switch)."""
+    n_cases, n_rec = _sub(["copy", 120, 11], {"FZ_NO_DIRECT": "1"})
+    assert n_cases == 123 and n_rec > 100000
+    n_cases, n_rec = _sub(["copy", 40, 12], {})               # the same cases in the default (direct) mode
+    assert n_cases == 43 and n_rec > 100000
+
+
 def _planted(rnd, n, p, alpha, edits_list, corrupt_blocks=None, L=None):
     """Random text over alpha with edited copies of p; corrupt_blocks = (n_blocks, L): instead of random edits, one
     substitution in each of n_blocks randomly chosen n-gram blocks (so that exactly the others hit)."""
