@@ -53,7 +53,7 @@ while time.time() < t_end:
         assert eng.search_end() == oracle.lev_ngrams_raw(p, t, k), ("lev pipelined", tag, p)
     if len(t) <= 60000:
         assert eng.search_exact(h, p[:max(1, len(p) // 3)]) == oracle.search_exact(p[:max(1, len(p) // 3)], t), ("exact", tag)
-        if k and len(t) <= 5000:
+        if k and len(t) <= 5000 and (k <= 5 or len(t) <= 500):   # (the oracle's automaton takes minutes on long texts with large budgets)
             lim = (rnd.randint(0, k), rnd.randint(0, k), rnd.randint(0, k), k)
             try:
                 got = eng.generic_ngrams(h, p, *lim)
@@ -75,7 +75,7 @@ while time.time() < t_end:
         else:
             assert got == oracle.lev_lp_raw(p, t, k), ("lev_lp", tag, p)
         assert eng.subs_lp(h, p, k) == oracle.subs_lp_raw(p, t, k), ("subs_lp", tag, p)
-        if k:
+        if k and (k <= 5 or len(t) <= 500):
             lim = (rnd.randint(0, k), rnd.randint(0, k), rnd.randint(0, k), k)
             try:
                 got = eng.generic_lp(h, p, *lim)
