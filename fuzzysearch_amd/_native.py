@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = (
     "fz_subs_ngrams_begin", "fz_generic_ngrams_begin", "fz_search_end",
     "fz_lev_lp", "fz_subs_lp", "fz_generic_lp", "fz_subs_ngrams_any", "fz_subs_lp_any", "fz_generic_ngrams_any", "fz_generic_ngrams_consolidated",
     "fz_stream_open", "fz_stream_buffer", "fz_stream_submit", "fz_stream_read_fd", "fz_stream_finish", "fz_stream_close",
-    "fz_consolidate", "fz_group_best", "fz_merge_ranks", "fz_wire_pack", "fz_wire_merge", "fz_debug_launch_plan", "fz_debug_order_records", "fz_debug_order_segments", "fz_stats", "fz_set_timing", "fz_device_ms", "fz_free",
+    "fz_consolidate", "fz_group_best", "fz_merge_ranks", "fz_wire_pack", "fz_wire_merge", "fz_debug_launch_plan", "fz_debug_order_records", "fz_debug_order_records_bounded", "fz_debug_order_segments", "fz_stats", "fz_set_timing", "fz_device_ms", "fz_free",
     "fz_comm_unique_id", "fz_comm_init_rank", "fz_comm_init_all", "fz_comm_info", "fz_comm_set_collective",
     "fz_comm_allgather", "fz_comm_max_f64", "fz_comm_barrier", "fz_comm_destroy",
 )
@@ -161,6 +161,8 @@ def load_library():
         L.fz_debug_launch_plan.argtypes = [u8p, u32, u32, ctypes.POINTER(u32), u32, ctypes.POINTER(u32)]
         L.fz_debug_order_records.restype = ci
         L.fz_debug_order_records.argtypes = [ctypes.c_void_p, u64, u32, mpp, u64p]
+        L.fz_debug_order_records_bounded.restype = ci
+        L.fz_debug_order_records_bounded.argtypes = [ctypes.c_void_p, u64, u32, u64, u32, mpp, u64p]
         L.fz_debug_order_segments.restype = ci
         L.fz_debug_order_segments.argtypes = [ctypes.c_void_p, ctypes.c_void_p, u32, u32, mpp, u64p]
         L.fz_merge_ranks.restype = ci

@@ -1288,7 +1288,11 @@ int emit_matches(const FzRec *recs, size_t cnt, uint32_t L, fz_match **out, uint
     size_t nv = 0;
     uint64_t imin = ~0ull, imax = 0;
     uint32_t gmax = 0;
-    if (idx_bound && blk_bound && !may_have_empty) {
+    // key ranges known from the search (sequence length, number of blocks): no pass over the records for them — the
+    // records sit in pinned memory the device has just written, and the first pass over them is the cold one; empty
+    // slots (slot-per-hit kernels) are then dropped while the key words are built
+    const bool bounds_known = idx_bound && blk_bound;
+    if (bounds_known) {
         nv = cnt; imin = 0; imax = idx_bound - 1; gmax = blk_bound - 1;
     } else {
         // one pass for the empty slots (slot-per-hit kernels) and the key ranges
@@ -1301,17 +1305,22 @@ int emit_matches(const FzRec *recs, size_t cnt, uint32_t L, fz_match **out, uint
         }
     }
     fz_match *mo = nullptr;
-    if (into) {
-        into->resize(nv);
-        mo = into->data();
-    } else {
+    auto make_room = [&]() -> int {                            // nv is final
+        if (into) {
+            into->resize(nv);
+            mo = into->data();
+            return FZ_OK;
+        }
         void *mem = nullptr;
         int rc = alloc_out(nv, sizeof(fz_match), &mem);
         if (rc) return rc;
         mo = static_cast<fz_match *>(mem);
         *out = mo;
         *n = nv;
-    }
+        return FZ_OK;
+    };
+    const bool count_later = bounds_known && may_have_empty && cnt > 0;   // nv = cnt is an upper bound until the key pass
+    if (!count_later) { int rc = make_room(); if (rc) return rc; }
     auto put = [&](size_t i, const FzRec &r) {
         const uint64_t idx = fz_hit_index(r.key);
         mo[i].start = (int64_t)(idx - r.l);
@@ -1319,7 +1328,7 @@ int emit_matches(const FzRec *recs, size_t cnt, uint32_t L, fz_match **out, uint
         mo[i].dist = (int32_t)r.dist;
         mo[i].block = (int32_t)fz_hit_block(r.key);
     };
-    if (nv == 0) return FZ_OK;
+    if (nv == 0) return count_later ? make_room() : FZ_OK;
     int ibits = 0, gbits = 0, pbits = 0;                       // index range, block number, record position
     while (ibits < FZ_IDX_BITS && ((imax - imin) >> ibits)) ++ibits;
     while ((gmax >> gbits)) ++gbits;
@@ -1349,6 +1358,7 @@ int emit_matches(const FzRec *recs, size_t cnt, uint32_t L, fz_match **out, uint
             a[w++] = word;
             ++hist[(shift >= 0 ? (size_t)(word >> shift) : 0) + 1];
         }
+        if (count_later) { nv = w; int rc = make_room(); if (rc) return rc; if (nv == 0) return FZ_OK; }
         for (size_t d = 0; d < nb; ++d) hist[d + 1] += hist[d];
         for (size_t i = 0; i < nv; ++i) b[hist[shift >= 0 ? (size_t)(a[i] >> shift) : 0]++] = a[i];
         // hist[d] is now the END of bucket d
@@ -1374,6 +1384,7 @@ int emit_matches(const FzRec *recs, size_t cnt, uint32_t L, fz_match **out, uint
     std::vector<FzRec> copy;
     copy.reserve(nv);
     for (size_t i = 0; i < cnt; ++i) if (recs[i].dist != FZ_REC_NONE) copy.push_back(recs[i]);
+    if (count_later) { nv = copy.size(); int rc = make_room(); if (rc) return rc; }
     sort_recs(copy);
     for (size_t i = 0; i < nv; ++i) put(i, copy[i]);
     return FZ_OK;
@@ -3239,6 +3250,12 @@ int fz_debug_order_records(const void *recs, uint64_t n, uint32_t L, fz_match **
     if ((!recs && n) || !out || !n_out) return fail(FZ_EINVAL, "null argument");
     static_assert(sizeof(FzRec) == 24, "record layout");
     return emit_matches(static_cast<const FzRec *>(recs), (size_t)n, L, out, n_out);
+}
+
+int fz_debug_order_records_bounded(const void *recs, uint64_t n, uint32_t L, uint64_t idx_bound, uint32_t blk_bound,
+                                   fz_match **out, uint64_t *n_out) {
+    if ((!recs && n) || !out || !n_out || !idx_bound || !blk_bound) return fail(FZ_EINVAL, "null argument");
+    return emit_matches(static_cast<const FzRec *>(recs), (size_t)n, L, out, n_out, idx_bound, blk_bound, /*may_have_empty=*/true);
 }
 
 int fz_debug_order_segments(const void *recs, const uint64_t *seg_ends, uint32_t n_segments, uint32_t L, fz_match **out, uint64_t *n_out) {

@@ -272,6 +272,10 @@ int fz_debug_launch_plan(const uint8_t *p, uint32_t m, uint32_t L, uint32_t *out
  * {u64 key = block << 48 | hit index, u32 left, u32 right, u32 dist (0xffffffff: empty slot), u32 aux} into fz_match
  * rows in the reference's emission order (block ascending, hit index ascending; n-gram length L). */
 int fz_debug_order_records(const void *recs, uint64_t n, uint32_t L, fz_match **out, uint64_t *n_out);
+/* ... the same with the key ranges a search knows beforehand (hit index < idx_bound, block < blk_bound): the form the
+ * searches use — no pass over the records for their ranges, empty slots dropped while the sort keys are built. */
+int fz_debug_order_records_bounded(const void *recs, uint64_t n, uint32_t L, uint64_t idx_bound, uint32_t blk_bound,
+                                   fz_match **out, uint64_t *n_out);
 /* ... and the sharded form: recs = the shards' records one shard after the other (seg_ends[i] = end of shard i), shards
  * owning ascending index ranges; every shard is ordered on its own and the rows are merged block by block. */
 int fz_debug_order_segments(const void *recs, const uint64_t *seg_ends, uint32_t n_segments, uint32_t L, fz_match **out, uint64_t *n_out);

@@ -373,16 +373,21 @@ def test_record_ordering_host_step():
         recs["dist"][empty] = 0xffffffff
         ptr = ctypes.POINTER(_native.FzMatch)()
         cnt = ctypes.c_uint64(0)
-        _native._check(lib.fz_debug_order_records(recs.ctypes.data, len(recs), L, ctypes.byref(ptr), ctypes.byref(cnt)))
-        got = _native._take_matches_array(lib, ptr, cnt.value)
         keep = recs[~empty]
         keep = keep[np.argsort(keep["key"], kind="stable")]
         kidx = (keep["key"] & np.uint64((1 << 48) - 1)).astype(np.int64)
-        assert cnt.value == len(keep)
-        assert np.array_equal(got["start"], kidx - keep["l"].astype(np.int64))
-        assert np.array_equal(got["end"], kidx + L + keep["r"].astype(np.int64))
-        assert np.array_equal(got["dist"], keep["dist"].astype(np.int32))
-        assert np.array_equal(got["block"], (keep["key"] >> np.uint64(48)).astype(np.int32))
+        for bounded in (False, True):                            # ranges found by a pass / known from the search
+            if bounded:
+                _native._check(lib.fz_debug_order_records_bounded(recs.ctypes.data, len(recs), L, max(1, span + 5000), nblocks,
+                                                                  ctypes.byref(ptr), ctypes.byref(cnt)))
+            else:
+                _native._check(lib.fz_debug_order_records(recs.ctypes.data, len(recs), L, ctypes.byref(ptr), ctypes.byref(cnt)))
+            got = _native._take_matches_array(lib, ptr, cnt.value)
+            assert cnt.value == len(keep)
+            assert np.array_equal(got["start"], kidx - keep["l"].astype(np.int64))
+            assert np.array_equal(got["end"], kidx + L + keep["r"].astype(np.int64))
+            assert np.array_equal(got["dist"], keep["dist"].astype(np.int32))
+            assert np.array_equal(got["block"], (keep["key"] >> np.uint64(48)).astype(np.int32))
 
 
 def test_no_kernel_spills_to_scratch():
