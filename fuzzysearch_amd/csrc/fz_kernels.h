@@ -727,7 +727,18 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
             const bool fire = __ballot(acc == 0) != 0;
             if (__builtin_expect(fire, 0)) {              // wave-uniform, rare: some lane, some offset
                 if (__builtin_expect(!dup_hashes, 1)) {
-#ifdef FZ_RARE_SCALAR
+#ifdef FZ_LAB_NORARE
+                    asm volatile("s_nop 0");               // (lab, timing only: the filter's compares stay, what they find is dropped)
+#elif defined(FZ_LAB_GROUPQ)
+                    // (Lab variant, timing only — the results are wrong: the firing lanes queue ONE code per 4-offset group,
+                    // offset and block left to the flush.  Upper bound of what deferring the resolution could save.)
+                    const unsigned long long fm = __ballot(acc == 0);
+                    const uint32_t gslot = qn + fz_rank(fm);
+                    uint32_t gpos = threadIdx.x;
+                    asm volatile("v_lshlrev_b32 %0, 4, %0" : "+v"(gpos));
+                    if (acc == 0 && gslot < qcap) w.queue[gslot] = fz_code(gpos + (uint32_t)(r * FZ_ROW_BYTES + GRP * j), 0u, titer);
+                    qn += (uint32_t)__popcll(fm);
+#elif defined(FZ_RARE_SCALAR)
                     // (Lab variant, measured in round 3 and NOT kept: the firing lane resolved on the scalar unit — the
                     // lane's four xor words by v_readlane, offset and table slot as scalar arithmetic, the block by one
                     // wave-uniform LDS read, the code by a wave-uniform LDS write: ~9 vector-issue slots per hit instead of
