@@ -135,8 +135,8 @@ def test_fz_consolidate_and_group_best_against_oracle_and_golden():
             raw.append((s, s + rnd.choice([0, 0, 1, 2, 3, 5, 8, 40]), rnd.randint(0, 3), rnd.randint(0, 2)))
         best, _hull = oracle.group_best(raw)
         assert [b[:3] for b in _native.group_best(raw)] == [b[:3] for b in best], (trial, n, span)
-    # Large streams: the run-folding pass followed by the radix order of the hulls (>= 2048 of them), with
-    # zero-length rows at hull edges, rows in block-major runs like the generic search emits, and shuffled.
+    # Large streams: the run-folding pass followed by the slice order of the hulls, with zero-length rows at hull
+    # edges, rows in block-major runs like the generic search emits, and shuffled.
     for n, span, run in [(3000, 60000, 1), (2600, 2000000, 1), (4000, 30000, 1), (60000, 4000000, 20), (30000, 90000, 7)]:
         raw = []
         while len(raw) < n:
@@ -148,6 +148,14 @@ def test_fz_consolidate_and_group_best_against_oracle_and_golden():
         assert [b[:3] for b in _native.consolidate(raw)] == want, (n, span, run)
         rnd.shuffle(raw)
         assert [b[:3] for b in _native.consolidate(raw)] == want, (n, span, run, "shuffled")
+    # clustered hulls: nearly all of them in a few crowded slices (the per-slice stable sort), one far outlier
+    for n, width, far in [(5000, 400, 1 << 40), (900, 3, 1 << 33), (40, 1000, 1 << 20), (31, 5, 7), (33, 5, 7)]:
+        raw = [(far, far + 3, 1, 0)]
+        for _ in range(n):
+            s0 = rnd.randint(0, width) * 50
+            raw.append((s0, s0 + rnd.choice([0, 0, 1, 7, 30, 49, 60]), rnd.randint(0, 3), rnd.randint(0, 2)))
+        rnd.shuffle(raw)
+        assert [b[:3] for b in _native.consolidate(raw)] == oracle.consolidate(raw), (n, width, far)
 
 
 def test_match_objects_from_rows_c_extension_equals_python_fill():
