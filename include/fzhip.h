@@ -280,10 +280,12 @@ int fz_debug_order_records_bounded(const void *recs, uint64_t n, uint32_t L, uin
  * owning ascending index ranges; every shard is ordered on its own and the rows are merged block by block. */
 int fz_debug_order_segments(const void *recs, const uint64_t *seg_ends, uint32_t n_segments, uint32_t L, fz_match **out, uint64_t *n_out);
 
+/* Statistics of the search collected last.  The *_ms fields are hipEvent spans read from that search's events by THIS
+ * call (and by fz_device_ms), not by the search: they describe it until the next search of the context is launched
+ * (its launch re-records the events; the fields then read 0). */
 int  fz_stats(fz_ctx *ctx, fz_stats_t *out);
 /* hipEvent timing of the kernels (filter_ms / verify_ms / device_ms of fz_stats, fz_device_ms): on by default.
- * Off, a search enqueues one packet less in front of its kernel and makes no hipEventElapsedTime calls (the *_ms
- * fields then read 0): a few microseconds per call for callers that do not look at the timings. */
+ * Off, no events are recorded around the kernels and the *_ms fields read 0. */
 int  fz_set_timing(fz_ctx *ctx, int on);
 /* hipEvent span of the filter kernel(s) of the search collected last, per device of the ctx (at most `cap` values
  * are written); returns the number of devices, or a negative FZ_E* code. */
