@@ -120,6 +120,7 @@ struct DevState {
     bool header_zeroed = false;                  // the counters were already zeroed after the last D2H copy
     bool verify_launched = false;                // the last enqueue ran fz_verify_kernel (ev[2] recorded)
     int scan_end_event = 1;                      // which event marks the end of the last scan (1 or 3)
+    int verify_end_event = 2;                    // ... and of the verification kernel behind it (2, or 3 = the completion event)
     // staging of the last closed file stream, kept for the next one (pinning 2 x 65 MiB costs ~30 ms)
     uint8_t *stream_h[2] = {nullptr, nullptr};
     uint8_t *stream_d = nullptr;
@@ -134,6 +135,7 @@ struct DevState {
     uint64_t fold_guess = 8192, fold_copied = 0; // folded generic search: pairs fetched with the counters
     bool fold_direct = true;                     // ... or written straight into h_stage by the automaton kernel (while they fit)
     bool fold_was_direct = false;                // mode of the folded search being collected
+    int lp_end_event = 2;                        // which event marks the end of the last automaton kernel (2, or 3 = the completion)
     hipStream_t stream_hi = nullptr;             // generic searches in flight: the automaton and what follows it (high priority)
     hipEvent_t ev_scan_done = nullptr;
     uint8_t *d_pat = nullptr;                    // pattern in HBM (subsequences longer than FZ_MAX_M, fz_verify_big_kernel)
@@ -157,7 +159,7 @@ struct DevState {
         hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
         uint8_t *h_stage = nullptr, *h_stage_dev = nullptr;
         bool last_direct = false, verify_launched = false, fused_used = false, timed = true;
-        int scan_end_event = 1;
+        int scan_end_event = 1, verify_end_event = 2;
         uint64_t hit_cap_used = 0, rec_cap_used = 0;
         int slot_id = 1;
     } other;
@@ -171,6 +173,7 @@ struct DevState {
         std::swap(timed, other.timed);
         std::swap(fused_used, other.fused_used);
         std::swap(scan_end_event, other.scan_end_event);
+        std::swap(verify_end_event, other.verify_end_event);
         std::swap(hit_cap_used, other.hit_cap_used);
         std::swap(rec_cap_used, other.rec_cap_used);
     }
@@ -666,7 +669,10 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     // filter_ms becomes the kernels' own span.
     static const bool no_ext = getenv("FZ_NO_EXT_LAUNCH") != nullptr;
     const bool ext_events = !no_ext && copy_back && direct && !(with_verify && !fa.fused) && ntiles > 0 && G > 0;
-    if (ctx->timing && !ext_events) HIP_TRY(hipEventRecord(d.ev[0], d.stream));
+    // ... and whenever the scan launches a kernel at all, its start / end events (ev[0], ev[1]: fz_stats' filter_ms) ride
+    // on the first / last launch as well instead of two packets of their own in front of and behind the scan
+    const bool attach = !no_ext && ntiles > 0 && G > 0;
+    if (ctx->timing && !attach) HIP_TRY(hipEventRecord(d.ev[0], d.stream));
     uint32_t launches = 0;
     for (uint32_t g0 = 0; g0 < G && ntiles > 0;) {
         // Blocks [g0, g0 + nblk) of this launch and the hash multiplier: the longest run of blocks (at
@@ -697,8 +703,8 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
         ScanKernel kern = scan_kernel(nwin, dh, fa.fused != 0, sh.geom.seg_stride != 0, fa.lut_shift == 2);
         if (!kern) return fail(FZ_EUNSUPPORTED, "this (lab) build carries no scan kernel for nwin=%d dh=%d", nwin, dh);
         static const uint32_t extra_lds = []() { const char *e = getenv("FZ_EXTRA_LDS_KB"); return e ? (uint32_t)atoi(e) * 1024u : 0u; }();
-        hipEvent_t ev_start = (ext_events && ctx->timing && g0 == 0) ? d.ev[0] : nullptr;
-        hipEvent_t ev_stop = (ext_events && g0 + nblk >= G) ? d.ev[3] : nullptr;
+        hipEvent_t ev_start = (attach && ctx->timing && g0 == 0) ? d.ev[0] : nullptr;
+        hipEvent_t ev_stop = g0 + nblk >= G ? (ext_events ? d.ev[3] : (attach && ctx->timing) ? d.ev[1] : nullptr) : nullptr;
         if (ev_start || ev_stop)
             hipExtLaunchKernelGGL(kern, grid, dim3(FZ_FILTER_THREADS), scan_lds + extra_lds, d.stream, ev_start, ev_stop, 0u, sh.d_buf, fa,
                                   ntiles, d.d_hits, recs, counters);
@@ -712,10 +718,20 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     // ev[1] = end of the scan.  When the results need no copy and no verify kernel follows, ev[3] is
     // recorded at the same point of the stream: one event packet less on the critical path.
     d.scan_end_event = (copy_back && direct && !(with_verify && !fa.fused)) ? 3 : 1;
-    if (d.scan_end_event == 1 && ctx->timing) HIP_TRY(hipEventRecord(d.ev[1], d.stream));
+    if (d.scan_end_event == 1 && ctx->timing && !attach) HIP_TRY(hipEventRecord(d.ev[1], d.stream));
     d.verify_launched = false;
+    d.verify_end_event = 2;
+    // the verification kernel is the search's last one when its records go straight to the host: then the completion
+    // event rides on its launch (no ev[2] / ev[3] packets behind it; the verify span is ev[1] .. ev[3])
+    hipEvent_t v_stop = (!no_ext && copy_back && direct && !snapshot) ? d.ev[3] : nullptr;
+#define FZ_LAUNCH_VERIFY(kernel, grid_, block_, lds_)                                                                      \
+    do {                                                                                                                   \
+        if (v_stop) hipExtLaunchKernelGGL(kernel, grid_, block_, lds_, d.stream, nullptr, v_stop, 0u, sh.d_buf, fa, d.d_hits, recs, counters); \
+        else hipLaunchKernelGGL(kernel, grid_, block_, lds_, d.stream, sh.d_buf, fa, d.d_hits, recs, counters);            \
+    } while (0)
     if (with_verify && !fa.fused && ntiles > 0 && G > 0) {
         d.verify_launched = true;
+        if (v_stop) d.verify_end_event = 3;
         fa.nblk = 0;
         fa.g0 = 0;
         fa.host_hdr = direct ? reinterpret_cast<uint64_t>(d.h_stage_dev) : 0;
@@ -727,33 +743,34 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
             if (!fa.pat_g) return fail(FZ_EDEVICE, "internal: the pattern was not staged for the big verification");
             const uint32_t cells = q.mode == FZ_MODE_LEV ? 2 * q.k + 1 : 1;
             const dim3 bgrid(d.n_cus * 32), bblock(64);
-            if (cells <= 64) hipLaunchKernelGGL(fz_verify_big_kernel<1>, bgrid, bblock, 0, d.stream, sh.d_buf, fa, d.d_hits, recs, counters);
-            else if (cells <= 128) hipLaunchKernelGGL(fz_verify_big_kernel<2>, bgrid, bblock, 0, d.stream, sh.d_buf, fa, d.d_hits, recs, counters);
-            else if (cells <= 256) hipLaunchKernelGGL(fz_verify_big_kernel<4>, bgrid, bblock, 0, d.stream, sh.d_buf, fa, d.d_hits, recs, counters);
-            else if (cells <= 512) hipLaunchKernelGGL(fz_verify_big_kernel<8>, bgrid, bblock, 0, d.stream, sh.d_buf, fa, d.d_hits, recs, counters);
-            else if (cells <= 1024) hipLaunchKernelGGL(fz_verify_big_kernel<16>, bgrid, bblock, 0, d.stream, sh.d_buf, fa, d.d_hits, recs, counters);
-            else hipLaunchKernelGGL(fz_verify_big_kernel<32>, bgrid, bblock, 0, d.stream, sh.d_buf, fa, d.d_hits, recs, counters);
+            if (cells <= 64) FZ_LAUNCH_VERIFY(fz_verify_big_kernel<1>, bgrid, bblock, 0);
+            else if (cells <= 128) FZ_LAUNCH_VERIFY(fz_verify_big_kernel<2>, bgrid, bblock, 0);
+            else if (cells <= 256) FZ_LAUNCH_VERIFY(fz_verify_big_kernel<4>, bgrid, bblock, 0);
+            else if (cells <= 512) FZ_LAUNCH_VERIFY(fz_verify_big_kernel<8>, bgrid, bblock, 0);
+            else if (cells <= 1024) FZ_LAUNCH_VERIFY(fz_verify_big_kernel<16>, bgrid, bblock, 0);
+            else FZ_LAUNCH_VERIFY(fz_verify_big_kernel<32>, bgrid, bblock, 0);
         } else if (want_wf) {
             // lane-per-cell: 64 / gw candidates per wave, one contiguous byte window per candidate
             fa.gw = (uint32_t)gw;
             // 16 waves per workgroup: few workgroups = few finish tickets (every ticket is an atomic on one word)
             const dim3 vgrid(d.n_cus * 2), vblock(1024);
-            if (gw == 16) hipLaunchKernelGGL(fz_verify_wf_kernel<16>, vgrid, vblock, wf_lds, d.stream, sh.d_buf, fa, d.d_hits, recs, counters);
-            else if (gw == 32) hipLaunchKernelGGL(fz_verify_wf_kernel<32>, vgrid, vblock, wf_lds, d.stream, sh.d_buf, fa, d.d_hits, recs, counters);
-            else hipLaunchKernelGGL(fz_verify_wf_kernel<64>, vgrid, vblock, wf_lds, d.stream, sh.d_buf, fa, d.d_hits, recs, counters);
+            if (gw == 16) FZ_LAUNCH_VERIFY(fz_verify_wf_kernel<16>, vgrid, vblock, wf_lds);
+            else if (gw == 32) FZ_LAUNCH_VERIFY(fz_verify_wf_kernel<32>, vgrid, vblock, wf_lds);
+            else FZ_LAUNCH_VERIFY(fz_verify_wf_kernel<64>, vgrid, vblock, wf_lds);
         } else {
             // LDS: pattern + per-wave window and score ring; the block was shrunk until it fits.
             fa.vlanes = 64;
             if (ring_lds > 64 * 1024)
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fz_verify_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_lds));
-            hipLaunchKernelGGL(fz_verify_kernel, dim3(d.n_cus * 4), dim3(64 * waves), ring_lds, d.stream, sh.d_buf, fa, d.d_hits, recs,
-                               counters);
+            FZ_LAUNCH_VERIFY(fz_verify_kernel, dim3(d.n_cus * 4), dim3(64 * waves), ring_lds);
         }
         HIP_TRY(hipGetLastError());
     }
+#undef FZ_LAUNCH_VERIFY
+    const bool completion_attached = ext_events || (d.verify_launched && v_stop);
     if (copy_back) {
-        if (d.verify_launched && ctx->timing) HIP_TRY(hipEventRecord(d.ev[2], d.stream));
+        if (d.verify_launched && ctx->timing && d.verify_end_event == 2) HIP_TRY(hipEventRecord(d.ev[2], d.stream));
         if (snapshot) {
             // counters to the host (overflow checks, statistics); counters + records to this slot's snapshot
             HIP_TRY(hipMemcpyAsync(d.h_stage, d.d_out, kHeaderBytes, hipMemcpyDeviceToHost, d.stream));
@@ -767,7 +784,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
             HIP_TRY(hipMemcpyAsync(d.h_stage, d.d_out, kHeaderBytes + d.first_copy * sizeof(FzRec), hipMemcpyDeviceToHost,
                                    d.stream));
         }
-        if (!ext_events) HIP_TRY(hipEventRecord(d.ev[3], d.stream));
+        if (!completion_attached) HIP_TRY(hipEventRecord(d.ev[3], d.stream));
         // the counters are zeroed for the NEXT search now, off the critical path of that call: by the
         // publishing workgroup itself in direct mode, by a memset behind the copy otherwise
         if (!direct) HIP_TRY(hipMemsetAsync(d.d_out, 0, kHeaderBytes, d.stream));
@@ -813,7 +830,7 @@ int collect_shard(fz_ctx *ctx, const Shard &sh, bool with_verify, bool view_ok, 
     if (rerun) return FZ_OK;
     d.last_filter_ms = 0;
     if (d.timed)
-        ctx->tref.push_back({&d, d.ev[0], d.ev[d.scan_end_event], d.verify_launched ? d.ev[1] : nullptr, d.ev[2], d.ev[0], d.ev[3]});
+        ctx->tref.push_back({&d, d.ev[0], d.ev[d.scan_end_event], d.verify_launched ? d.ev[1] : nullptr, d.ev[d.verify_end_event], d.ev[0], d.ev[3]});
     ctx->stats.bytes_scanned += sh.geom.buf_len;
     ctx->stats.ngram_hits += nh;
     if (with_verify && collective) {
@@ -1102,10 +1119,19 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
                 HIP_TRY(hipStreamWaitEvent(d.stream_hi, d.ev_scan_done, 0));
                 st2 = d.stream_hi;
             }
-            hipLaunchKernelGGL(lp_kernel(FZ_LP_GENERIC_HIT, scratch != 0), dim3(scratch ? kCandScratchGrid : d.n_cus * grid_per_cu), dim3(64),
-                               lds, st2, sh.d_buf, fa, d.d_hits, (uint64_t)0, recs, counters);
+            // the automaton's end event rides on its own launch; for a folded search in direct mode that event is also
+            // the search's completion (ev[3]): no event packet of its own anywhere in such a search
+            static const bool no_ext = getenv("FZ_NO_EXT_LAUNCH") != nullptr;
+            hipEvent_t lp_stop = no_ext ? nullptr : fold_direct ? d.ev[3] : ctx->timing ? d.ev[2] : nullptr;
+            d.lp_end_event = fold_direct ? 3 : 2;
+            if (lp_stop)
+                hipExtLaunchKernelGGL(lp_kernel(FZ_LP_GENERIC_HIT, scratch != 0), dim3(scratch ? kCandScratchGrid : d.n_cus * grid_per_cu),
+                                      dim3(64), lds, st2, nullptr, lp_stop, 0u, sh.d_buf, fa, d.d_hits, (uint64_t)0, recs, counters);
+            else
+                hipLaunchKernelGGL(lp_kernel(FZ_LP_GENERIC_HIT, scratch != 0), dim3(scratch ? kCandScratchGrid : d.n_cus * grid_per_cu), dim3(64),
+                                   lds, st2, sh.d_buf, fa, d.d_hits, (uint64_t)0, recs, counters);
             HIP_TRY(hipGetLastError());
-            if (ctx->timing) HIP_TRY(hipEventRecord(d.ev[2], st2));
+            if (ctx->timing && !lp_stop && !fold_direct) HIP_TRY(hipEventRecord(d.ev[2], st2));
             if (dev_order) {
                 hipLaunchKernelGGL(fz_gen_order_kernel, dim3(d.n_cus * 8), dim3(256), 0, st2, d.d_hits, fa, counters);
                 hipLaunchKernelGGL(fz_gen_scatter_kernel, dim3(d.n_cus * 8), dim3(256), 0, st2, d.d_hits, fa, recs,
@@ -1123,7 +1149,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
                     d.header_zeroed = true;
                 }
             } else {
-                HIP_TRY(hipEventRecord(d.ev[3], st2));
+                if (!lp_stop) HIP_TRY(hipEventRecord(d.ev[3], st2));
                 d.header_zeroed = true;                       // by the publishing workgroup
             }
         }
@@ -1163,7 +1189,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
                 HIP_TRY(hipMemcpy(d.h_big, d.d_out + kHeaderBytes, nr * sizeof(FzGenRec), hipMemcpyDeviceToHost));
             if (novf) { lists_overflowed = true; rerun = true; }
             if (rerun) continue;
-            if (d.timed) ctx->tref.push_back({&d, d.ev[0], d.ev[1], d.ev[1], d.ev[2], d.ev[0], d.ev[3]});
+            if (d.timed) ctx->tref.push_back({&d, d.ev[0], d.ev[1], d.ev[1], d.ev[d.lp_end_event], d.ev[0], d.ev[3]});
             ctx->stats.bytes_scanned += sh.geom.buf_len;
             ctx->stats.ngram_hits += nh;
             if (rows_ready) {                                 // finished rows, fetched by emit_generic
