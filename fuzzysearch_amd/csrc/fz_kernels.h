@@ -1329,6 +1329,10 @@ __global__ __launch_bounds__(64) void fz_verify_big_kernel(const uint8_t *__rest
 #ifndef FZ_LP_PAIR
 #define FZ_LP_PAIR 1                                       // the per-hit automaton steps two 64-candidate slices per trip
 #endif
+#ifndef FZ_LP_TRASH
+#define FZ_LP_TRASH 0                                      // lab: list / match stores unconditional, lanes without output write to a
+#endif                                                     // per-lane trash slot (an address select instead of an exec-mask round trip)
+#define FZ_LP_TRASH_BYTES (FZ_LP_TRASH ? 512u : 0u)
 #ifndef FZ_GEN_MCAP
 #define FZ_GEN_MCAP 128                                    // match-buffer entries per wave (1 KB: with 256-entry candidate lists
                                                            // 24 waves per CU are resident, every hit of configs[3b] at once)
@@ -1379,6 +1383,9 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
                              : reinterpret_cast<FzGCand *>(smem + mpad + wpad);
     FzGCand *nxt = cur + a.cand_cap;
     uint64_t *mbuf = reinterpret_cast<uint64_t *>(smem + mpad + wpad + (HBM_LISTS ? 0u : 2u * a.cand_cap * (uint32_t)sizeof(FzGCand)));
+#if FZ_LP_TRASH
+    uint64_t *trash = mbuf + FZ_GEN_MCAP + lane;           // this lane's slot behind the match buffer
+#endif
     fz_copy_pattern(pat, a, lane, 64u);
     fz_wave_lds_sync();
     auto patf = [&](uint32_t i) -> uint8_t { return pat[i]; };
@@ -1553,13 +1560,25 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
                 if (nnext + tot_s > a.cand_cap) return false;
                 if (mb + tot_m > FZ_GEN_MCAP) flush_matches();
                 uint2 *nx = reinterpret_cast<uint2 *>(nxt) + nnext + (excl & 0xffffu);
-                if (st.fa) nx[0] = make_uint2(st.a0, st.a1);
-                if (st.fb) nx[st.fa] = make_uint2(st.b0, st.b1);
-                if (st.fc) nx[st.fa + st.fb] = make_uint2(st.c0, st.c1);
                 uint64_t *mp = mbuf + mb + (excl >> 16);
                 const uint64_t stamp = (uint64_t)index << 48;
-                if (st.f1) mp[0] = (uint64_t)st.m1 | ((uint64_t)st.d1 << 32) | stamp;
-                if (st.f2) mp[st.f1] = (uint64_t)st.m2 | ((uint64_t)st.d2 << 32) | stamp;
+#if FZ_LP_TRASH
+                if constexpr (!HBM_LISTS) {
+                    uint2 *t2 = reinterpret_cast<uint2 *>(trash);
+                    *(st.fa ? nx : t2) = make_uint2(st.a0, st.a1);
+                    *(st.fb ? nx + st.fa : t2) = make_uint2(st.b0, st.b1);
+                    *(st.fc ? nx + st.fa + st.fb : t2) = make_uint2(st.c0, st.c1);
+                    *(st.f1 ? mp : trash) = (uint64_t)st.m1 | ((uint64_t)st.d1 << 32) | stamp;
+                    *(st.f2 ? mp + st.f1 : trash) = (uint64_t)st.m2 | ((uint64_t)st.d2 << 32) | stamp;
+                } else
+#endif
+                {
+                    if (st.fa) nx[0] = make_uint2(st.a0, st.a1);
+                    if (st.fb) nx[st.fa] = make_uint2(st.b0, st.b1);
+                    if (st.fc) nx[st.fa + st.fb] = make_uint2(st.c0, st.c1);
+                    if (st.f1) mp[0] = (uint64_t)st.m1 | ((uint64_t)st.d1 << 32) | stamp;
+                    if (st.f2) mp[st.f1] = (uint64_t)st.m2 | ((uint64_t)st.d2 << 32) | stamp;
+                }
                 nnext += tot_s;
                 mb += tot_m;
                 return true;
@@ -1604,18 +1623,32 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
                         const uint32_t ea = ia - pa, eb = ib - pb + ta;
                         uint2 *nxa = reinterpret_cast<uint2 *>(nxt) + nnext + (ea & 0xffffu);
                         uint2 *nxb = reinterpret_cast<uint2 *>(nxt) + nnext + (eb & 0xffffu);
+                        uint64_t *mpa = mbuf + mb + (ea >> 16), *mpb = mbuf + mb + (eb >> 16);
+                        const uint64_t stamp = (uint64_t)index << 48;
+#if FZ_LP_TRASH
+                        uint2 *t2 = reinterpret_cast<uint2 *>(trash);
+                        *(sa.fa ? nxa : t2) = make_uint2(sa.a0, sa.a1);
+                        *(sa.fb ? nxa + sa.fa : t2) = make_uint2(sa.b0, sa.b1);
+                        *(sa.fc ? nxa + sa.fa + sa.fb : t2) = make_uint2(sa.c0, sa.c1);
+                        *(sb.fa ? nxb : t2) = make_uint2(sb.a0, sb.a1);
+                        *(sb.fb ? nxb + sb.fa : t2) = make_uint2(sb.b0, sb.b1);
+                        *(sb.fc ? nxb + sb.fa + sb.fb : t2) = make_uint2(sb.c0, sb.c1);
+                        *(sa.f1 ? mpa : trash) = (uint64_t)sa.m1 | ((uint64_t)sa.d1 << 32) | stamp;
+                        *(sa.f2 ? mpa + sa.f1 : trash) = (uint64_t)sa.m2 | ((uint64_t)sa.d2 << 32) | stamp;
+                        *(sb.f1 ? mpb : trash) = (uint64_t)sb.m1 | ((uint64_t)sb.d1 << 32) | stamp;
+                        *(sb.f2 ? mpb + sb.f1 : trash) = (uint64_t)sb.m2 | ((uint64_t)sb.d2 << 32) | stamp;
+#else
                         if (sa.fa) nxa[0] = make_uint2(sa.a0, sa.a1);
                         if (sa.fb) nxa[sa.fa] = make_uint2(sa.b0, sa.b1);
                         if (sa.fc) nxa[sa.fa + sa.fb] = make_uint2(sa.c0, sa.c1);
                         if (sb.fa) nxb[0] = make_uint2(sb.a0, sb.a1);
                         if (sb.fb) nxb[sb.fa] = make_uint2(sb.b0, sb.b1);
                         if (sb.fc) nxb[sb.fa + sb.fb] = make_uint2(sb.c0, sb.c1);
-                        uint64_t *mpa = mbuf + mb + (ea >> 16), *mpb = mbuf + mb + (eb >> 16);
-                        const uint64_t stamp = (uint64_t)index << 48;
                         if (sa.f1) mpa[0] = (uint64_t)sa.m1 | ((uint64_t)sa.d1 << 32) | stamp;
                         if (sa.f2) mpa[sa.f1] = (uint64_t)sa.m2 | ((uint64_t)sa.d2 << 32) | stamp;
                         if (sb.f1) mpb[0] = (uint64_t)sb.m1 | ((uint64_t)sb.d1 << 32) | stamp;
                         if (sb.f2) mpb[sb.f1] = (uint64_t)sb.m2 | ((uint64_t)sb.d2 << 32) | stamp;
+#endif
                         nnext += tot_s;
                         mb += tot_m;
                     }
