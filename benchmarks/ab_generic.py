@@ -8,15 +8,17 @@ eng = _native.Engine([0])
 seq, pat, _ = workloads.cfg4(1 << 30, 1024)
 p = pat.tobytes()
 h = eng.upload(seq)
+cons = bool(os.environ.get("FZ_AB_CONSOLIDATED"))          # fz_generic_ngrams_consolidated instead of the raw stream
+call = (lambda: eng.generic_ngrams_consolidated(h, p, 5, 2, 2, 5, as_array=True)) if cons else (lambda: eng.generic_ngrams(h, p, 5, 2, 2, 5, as_array=True))
 t_end = time.perf_counter() + 0.3
 while time.perf_counter() < t_end:
-    r = eng.generic_ngrams(h, p, 5, 2, 2, 5, as_array=True)
+    r = call()
 f, v, dv = [], [], []
 t0 = time.perf_counter()
 for _ in range(60):
-    r = eng.generic_ngrams(h, p, 5, 2, 2, 5, as_array=True)
+    r = call()
     a, b, _d = eng.kernel_ms(); f.append(a); v.append(b); dv.append(_d)
 dt = (time.perf_counter() - t0) / 60
-print(json.dumps({"lib": os.path.basename(_native.LIB_PATH), "grid_per_cu": os.environ.get("FZ_LP_GRID_PER_CU", "16"), "ms_per_call": round(dt * 1e3, 4),
+print(json.dumps({"lib": os.path.basename(_native.LIB_PATH), "consolidated": cons, "grid_per_cu": os.environ.get("FZ_LP_GRID_PER_CU", "16"), "ms_per_call": round(dt * 1e3, 4),
                   "scan_ms": round(float(np.mean(f)), 4), "automaton_ms": round(float(np.mean(v)), 4), "device_ms": round(float(np.mean(dv)), 4),
                   "order": "host" if os.environ.get("FZ_GEN_HOST_ORDER") else "device", "sha": __import__("hashlib").sha1(r.tobytes()).hexdigest()[:12], "raw": len(r)}), flush=True)
