@@ -421,7 +421,27 @@ def test_generic_more_hits_than_the_device_orders(engine):
     for limits in ((1, 1, 1, 2), (2, 0, 1, 2)):
         got = engine.generic_ngrams(h, p, *limits)
         assert engine.stats()["ngram_hits"] > 16384
-        assert got == oracle.generic_ngrams_raw(p, t, *limits), limits
+        want = oracle.generic_ngrams_raw(p, t, *limits)
+        assert got == want, limits
+        cons = engine.generic_ngrams_consolidated(h, p, *limits)
+        assert [r[:3] for r in cons] == oracle.consolidate(want), limits
+    h.release()
+    # consolidated with more (hull, best) pairs than the pinned staging buffer holds (16 384): 2e4 copies of the
+    # pattern, three hits each — the search that overflows the buffer is run again through the device buffer, the next
+    # one stays there, and a search with few pairs returns to direct mode
+    rnd = random.Random(77)
+    p = bytes(rnd.choice(b"ACGT") for _ in range(12))
+    t = b"".join(p + bytes(rnd.choice(b"ACGT") for _ in range(8)) for _ in range(20000))
+    h = engine.upload(t)
+    want = oracle.consolidate(oracle.generic_ngrams_raw(p, t, 1, 1, 1, 2))
+    for _ in range(2):
+        cons = engine.generic_ngrams_consolidated(h, p, 1, 1, 1, 2)
+        assert engine.stats()["raw_matches"] > 16384
+        assert [r[:3] for r in cons] == want
+    q = bytes(rnd.choice(b"ACGT") for _ in range(24))
+    for _ in range(2):
+        small = engine.generic_ngrams_consolidated(h, q, 2, 1, 1, 3)
+        assert [r[:3] for r in small] == oracle.consolidate(oracle.generic_ngrams_raw(q, t, 2, 1, 1, 3))
     h.release()
 
 
