@@ -238,28 +238,45 @@ def measured_traffic(shard_bytes):
     return None, None
 
 
+def pipelined_steps(engine, handle, p, k, steps, per_dev=None, gather=None):
+    """`steps` searches with two in flight (fz_lev_ngrams_begin / _end): every one starts and completes inside the
+    call and delivers its ordered stream.  -> (seconds, last stream)."""
+    t0 = time.perf_counter()
+    engine.lev_ngrams_begin(handle, p, k)
+    matches = None
+    for i in range(steps):
+        if i + 1 < steps:
+            engine.lev_ngrams_begin(handle, p, k)
+        matches = engine.lev_ngrams_end(as_array=True)
+        if per_dev is not None:
+            per_dev.append(engine.device_ms())
+        if gather is not None:
+            gather.append(engine.comm_gather_ms())
+    return time.perf_counter() - t0, matches
+
+
 def main_multi_device(args):
-    """--gpus N > 1 launched as ONE process (no torchrun, no torch): a torch-free multi-device context.  BASELINE
+    """--gpus N launched as ONE process (no torchrun, no torch): a torch-free multi-device context.  BASELINE
     configs[4]: N shards of --mib MiB (4 GiB) each, built shard by shard (never a 4N GiB host array), one per device
     of the context (fz_seq_new / fz_seq_add_shard), (m + k)-byte halos, hits owned by index, copies of the pattern
-    planted around every shard boundary and asserted in the merged stream.  A step = one search over ALL shards:
-    every device scans its shard concurrently, the host merges the per-device record lists into the reference's
-    global order; two searches in flight (fz_lev_ngrams_begin / _end).  FZ_DEVICES="0,0" maps the N device states
-    onto the listed devices (several states on one GPU: a functional check of the code path, not a scaling number)."""
-    from fuzzysearch_amd import _native
-    from tests import workloads
+    planted around every shard boundary and asserted in the merged stream.  A step = one search over ALL shards, two
+    searches in flight.
+
+    N distinct devices (the driver's `bench.py --gpus N`): the context joins an RCCL communicator (ncclCommInitAll, one
+    rank per device) and the timed search is the COLLECTIVE one — every device scans its shard, snapshots its counters +
+    records on the device, ONE ncclAllGather per search over xGMI, every rank's block lands on the host, per-device
+    worker threads order the ranks' records, the caller merges them (`rccl_ranks`, `allgather_ms`); the same run also
+    times the form without a collective (`value_no_collective`: per-device record lists written to pinned host memory
+    and merged on the host) and ONE shard of the same size searched alone on the first device (`scaling_ref_1gpu`), so
+    that "x at N vs 1" compares like with like.
+    FZ_DEVICES="0,0" maps the N device states onto the listed devices (several states on one GPU: a functional check
+    of the code path, not a scaling number; RCCL needs one rank per GPU, so duplicates run without the collective)."""
     N = args.gpus
-    lib = _native.load_library()
-    import ctypes
-    have = ctypes.c_int(0)
-    _native._check(lib.fz_device_count(ctypes.byref(have)))
     env = os.environ.get("FZ_DEVICES", "").strip()
     devices = [int(x) for x in env.split(",") if x.strip()] if env else list(range(N))
     if len(devices) != N:
         raise SystemExit("bench.py: FZ_DEVICES lists %d devices but --gpus is %d" % (len(devices), N))
-    if max(devices) >= have.value:
-        raise SystemExit("bench.py: --gpus %d needs devices %r but only %d HIP device(s) are visible "
-                         "(launch under torch.distributed.run for one rank per GPU, or set FZ_DEVICES)" % (N, devices, have.value))
+    from tests import workloads
     k = 2
     if args.mib <= 0:
         args.mib = 4096
@@ -268,13 +285,39 @@ def main_multi_device(args):
     m = len(pattern)
     p = pattern.tobytes()
     global_n = shard_bytes * N
+
+    cpu = None
+    if not args.no_cpu_baseline:                                 # forks: before the HIP runtime exists in this process
+        sample, _pat, _pl = workloads.cfg2(min(shard_bytes, 1 << 30), 1024)
+        cpu = cpu_baseline(sample, pattern, k, args.cpu_sample_mib)
+        cpu["sample"] += " (the first GiB of a shard's workload)"
+        del sample
+
+    from fuzzysearch_amd import _native
+    lib = _native.load_library()
+    import ctypes
+    have = ctypes.c_int(0)
+    _native._check(lib.fz_device_count(ctypes.byref(have)))
+    if max(devices) >= have.value:
+        raise SystemExit("bench.py: --gpus %d needs devices %r but only %d HIP device(s) are visible "
+                         "(launch under torch.distributed.run for one rank per GPU, or set FZ_DEVICES)" % (N, devices, have.value))
+    distinct = len(set(devices)) == len(devices)
+    collective = distinct and os.environ.get("FZ_BENCH_NO_COLLECTIVE") != "1"
     engine = _native.Engine(devices)
+    ref_engine = _native.Engine([devices[0]])                    # one shard alone on the first device: the like-for-like 1-GPU figure
     t_build = time.perf_counter()
     fill, edge_plants = workloads.cfg5_fill(shard_bytes, N, pattern, k)
     handle = engine.new_sequence(global_n)
+    ref_handle = None
     for r, buf, off, lo, hi in workloads.iter_shard_buffers(N, shard_bytes, m + k, fill):
         engine.add_shard(handle, r, buf, off, lo, hi)
+        if r == 0:
+            ref_handle = ref_engine.upload(buf[:shard_bytes])
     t_build = time.perf_counter() - t_build
+    rccl_ranks = 0
+    if collective:
+        engine.comm_init_all()                                   # ncclCommInitAll: every device of the context = one rank
+        rccl_ranks = engine.comm_info()[0]
 
     first = engine.lev_ngrams(handle, p, k, as_array=True)
     t_settle = time.perf_counter()
@@ -282,26 +325,44 @@ def main_multi_device(args):
         assert np.array_equal(engine.lev_ngrams(handle, p, k, as_array=True), first), "non-deterministic result"
     for _ in range(args.warmup):
         engine.lev_ngrams(handle, p, k, as_array=True)
-    per_dev = []
-    t0 = time.perf_counter()
+    per_dev, gather = [], ([] if collective else None)
     if args.sync:
+        t0 = time.perf_counter()
         for _ in range(args.steps):
             matches = engine.lev_ngrams(handle, p, k, as_array=True)
             per_dev.append(engine.device_ms())
+            if gather is not None:
+                gather.append(engine.comm_gather_ms())
+        elapsed = time.perf_counter() - t0
     else:
-        engine.lev_ngrams_begin(handle, p, k)
-        for i in range(args.steps):
-            if i + 1 < args.steps:
-                engine.lev_ngrams_begin(handle, p, k)
-            matches = engine.lev_ngrams_end(as_array=True)
-            per_dev.append(engine.device_ms())
-    elapsed = time.perf_counter() - t0
+        elapsed, matches = pipelined_steps(engine, handle, p, k, args.steps, per_dev, gather)
     st = engine.stats()
     assert np.array_equal(matches, first), "pipelined and synchronous searches returned different streams"
     t1 = time.perf_counter()
     for _ in range(20):
         engine.lev_ngrams(handle, p, k, as_array=True)
     sync_ms = (time.perf_counter() - t1) / 20 * 1e3
+
+    # the same search without the collective (per-device records merged on the host), same run
+    no_coll = None
+    if collective:
+        engine.comm_set_collective(False)
+        for _ in range(max(3, args.warmup // 4)):
+            local = engine.lev_ngrams(handle, p, k, as_array=True)
+        assert np.array_equal(local, first), "collective and host-merged searches returned different streams"
+        dt, local = pipelined_steps(engine, handle, p, k, args.steps)
+        assert np.array_equal(local, first)
+        no_coll = {"value": round(global_n * args.steps / dt / 1e9, 2), "ms_per_step": round(dt / args.steps * 1e3, 4)}
+        engine.comm_set_collective(True)
+    # one shard of the same size alone on the first device, two in flight: the like-for-like 1-GPU reference
+    ref_first = ref_engine.lev_ngrams(ref_handle, p, k, as_array=True)
+    for _ in range(max(3, args.warmup // 4)):
+        ref_engine.lev_ngrams(ref_handle, p, k, as_array=True)
+    ref_dev = []
+    ref_dt, ref_last = pipelined_steps(ref_engine, ref_handle, p, k, args.steps, ref_dev)
+    assert np.array_equal(ref_last, ref_first)
+    ref_value = shard_bytes * args.steps / ref_dt / 1e9
+
     rows = [tuple(int(x) for x in r) for r in matches.tolist()]
     keys = [(g, s_) for (s_, e_, d_, g) in rows]
     found = {(s_, e_, d_) for (s_, e_, d_, _g) in rows}
@@ -312,9 +373,11 @@ def main_multi_device(args):
     per_dev = np.asarray(per_dev)                                # steps x devices
     f_ms = float(per_dev.mean())
     achieved = shard_bytes / (f_ms * 1e-3) / 1e9
+    value = global_n * args.steps / elapsed / 1e9
     out = {
-        "metric": "GB/s of sequence scanned at |p|=20 max_l_dist=2 (levenshtein_ngram path)",
-        "value": round(global_n * args.steps / elapsed / 1e9, 2),
+        "metric": "GB/s of sequence scanned at |p|=20 max_l_dist=2 (levenshtein_ngram path%s)"
+                  % ("" if args.sync else "; two searches in flight"),
+        "value": round(value, 2),
         "unit": "GB/s",
         "n_gpus": N,
         "steps": args.steps,
@@ -331,8 +394,23 @@ def main_multi_device(args):
                    "bytes_per_gpu": shard_bytes, "pattern_len": m, "max_l_dist": k,
                    "calls_in_flight": 1 if args.sync else 2,
                    "devices": devices,
-                   "sharding": "one process, one device state per GPU (torch-free fz_ctx): contiguous shards, (m+k)-byte halo, "
-                               "hits owned by index, per-device record lists merged on the host; no collective"},
+                   "sharding": ("one process, one device state per GPU (torch-free fz_ctx): contiguous shards, (m+k)-byte halo, "
+                                "hits owned by index; " +
+                                ("every device = one RCCL rank (ncclCommInitAll): device snapshot of counters + records, ONE "
+                                 "ncclAllGather of the ranks' record lists per search, every rank's block read on the host; the "
+                                 "all-gather of step i runs next to the scan of step i+1" if collective else
+                                 "per-device record lists merged on the host; no collective (%s)"
+                                 % ("the devices listed are not distinct: RCCL needs one rank per GPU" if not distinct
+                                    else "FZ_BENCH_NO_COLLECTIVE=1")))},
+        "rccl_ranks": rccl_ranks,
+        "allgather_ms": None if not gather else round(float(np.mean(gather)), 4),
+        "value_no_collective": round(value, 2) if no_coll is None else no_coll["value"],
+        "no_collective_ms_per_step": (round(elapsed / args.steps * 1e3, 4) if no_coll is None else no_coll["ms_per_step"]),
+        "scaling_ref_1gpu": {"value": round(ref_value, 2), "unit": "GB/s", "ms_per_step": round(ref_dt / args.steps * 1e3, 4),
+                             "scan_kernel_ms": round(float(np.mean(ref_dev)), 4),
+                             "x_vs_1gpu": round(value / ref_value, 3),
+                             "note": "shard 0 of this run (%d MiB, same bytes) searched alone on device %d by a single-device "
+                                     "context, two searches in flight, same process and run" % (args.mib, devices[0])},
         "matches_per_s": round(len(rows) * args.steps / elapsed, 1),
         "raw_matches": len(rows),
         "consolidated_matches": len(consolidated),
@@ -346,8 +424,9 @@ def main_multi_device(args):
                      "note": "per GPU: one launch scans one shard; average over devices and steps"},
         "kernel_ms": {"filter_per_device": [round(float(x), 4) for x in per_dev.mean(axis=0)]},
         "sync_ms_per_call": round(sync_ms, 4),
+        "host_threads": "one worker per device" if (N > 1 and os.environ.get("FZ_NO_DEV_THREADS") is None) else "calling thread only",
         "build_s": round(t_build, 2),
-        "cpu_baseline": None,
+        "cpu_baseline": cpu,
     }
     print(json.dumps(out), flush=True)
 
@@ -355,7 +434,8 @@ def main_multi_device(args):
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1 and args.gpus > 1 and os.environ.get("FZ_BENCH_FORCE_DIST") != "1":
+    if world == 1 and os.environ.get("FZ_BENCH_FORCE_DIST") != "1" and (args.gpus > 1 or os.environ.get("FZ_BENCH_FORCE_COLLECTIVE") == "1"):
+        # FZ_BENCH_FORCE_COLLECTIVE=1: the N-device code path (RCCL communicator over the context's devices) with N = 1 too
         return main_multi_device(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -399,8 +479,10 @@ def main():
         fill(rank, seq)
 
     cpu = None
-    if world == 1 and not use_dist and not args.no_cpu_baseline and rank == 0:
-        cpu = cpu_baseline(seq, pattern, k, args.cpu_sample_mib)      # forks: before the HIP runtime exists
+    if not args.no_cpu_baseline and rank == 0 and not use_torch:
+        # forks: before the HIP runtime exists.  N > 1: rank 0 times the first GiB of its shard while the other ranks
+        # wait for the communicator's unique id (the timed region starts behind a barrier)
+        cpu = cpu_baseline(seq[:1 << 30] if world > 1 else seq, pattern, k, args.cpu_sample_mib)
 
     engine = _native.Engine([fzd.local_device(local_rank) if use_dist else local_rank])
     if use_dist and not use_torch:
@@ -441,7 +523,8 @@ def main():
         assert np.array_equal(again, first), "non-deterministic result: two searches returned different streams"
     for _ in range(args.warmup):
         matches = step()
-    filter_ms, verify_ms, device_ms = [], [], []
+    filter_ms, verify_ms, device_ms, gather_ms = [], [], [], []
+    native_dist = use_dist and not use_torch
     sync()
     t0 = time.perf_counter()
     # Two-deep pipeline through the C-ABI (fz_lev_ngrams_begin / _end, two pinned result slots per device):
@@ -467,6 +550,8 @@ def main():
             filter_ms.append(f_)
             verify_ms.append(v_)
             device_ms.append(d_)
+            if native_dist:
+                gather_ms.append(engine.comm_gather_ms())
             matches = finish(raw)
     sync()
     elapsed = time.perf_counter() - t0
@@ -478,6 +563,26 @@ def main():
         elapsed = engine.comm_max(elapsed)
 
     st = engine.stats()
+    no_coll = ref1 = None
+    if native_dist:
+        # the same step without the exchange: every rank searches its shard and keeps its own stream (same run)
+        engine.comm_set_collective(False)
+        for _ in range(max(3, args.warmup // 4)):
+            engine.lev_ngrams(handle, p, k, as_array=True)
+        sync()
+        dt, _local = pipelined_steps(engine, handle, p, k, args.steps)
+        sync()
+        dt = engine.comm_max(dt)
+        no_coll = {"value": round(global_n * args.steps / dt / 1e9, 2), "ms_per_step": round(dt / args.steps * 1e3, 4)}
+        # ... and rank 0's shard searched while the other GPUs are idle: the like-for-like 1-GPU figure
+        if rank == 0:
+            ref_dev = []
+            dt1, _l = pipelined_steps(engine, handle, p, k, args.steps, None)
+            ref1 = {"value": round(shard_bytes * args.steps / dt1 / 1e9, 2), "unit": "GB/s", "ms_per_step": round(dt1 / args.steps * 1e3, 4),
+                    "note": "rank 0's shard (%d MiB) searched alone (the other ranks wait at a barrier), two searches in flight, "
+                            "same process and run" % args.mib}
+        sync()
+        engine.comm_set_collective(True)
     sync_ms = None
     if not use_dist and not args.sync:
         # latency of one synchronous call (one search in flight), outside the timed region
@@ -539,6 +644,15 @@ def main():
                           "device_total": round(float(np.mean(device_ms)), 4)},
             "sync_ms_per_call": None if sync_ms is None else round(sync_ms, 4),
         }
+        if use_dist:
+            out["rccl_ranks"] = world if native_dist else 0
+            out["allgather_ms"] = round(float(np.mean(gather_ms)), 4) if gather_ms else None
+            if no_coll:
+                out["value_no_collective"] = no_coll["value"]
+                out["no_collective_ms_per_step"] = no_coll["ms_per_step"]
+            if ref1:
+                ref1["x_vs_1gpu"] = round(value / ref1["value"], 3)
+                out["scaling_ref_1gpu"] = ref1
         out["cpu_baseline"] = cpu
         if world == 1 and not use_dist and not args.no_extras:
             handle.release()

@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = (
     "fz_stream_open", "fz_stream_buffer", "fz_stream_submit", "fz_stream_read_fd", "fz_stream_finish", "fz_stream_close",
     "fz_consolidate", "fz_group_best", "fz_merge_ranks", "fz_wire_pack", "fz_wire_merge", "fz_debug_launch_plan", "fz_debug_order_records", "fz_debug_order_records_bounded", "fz_debug_order_segments", "fz_stats", "fz_set_timing", "fz_device_ms", "fz_free",
     "fz_comm_unique_id", "fz_comm_init_rank", "fz_comm_init_all", "fz_comm_info", "fz_comm_set_collective",
-    "fz_comm_allgather", "fz_comm_max_f64", "fz_comm_barrier", "fz_comm_destroy",
+    "fz_comm_allgather", "fz_comm_max_f64", "fz_comm_barrier", "fz_comm_destroy", "fz_comm_gather_ms", "fz_debug_gather_merge",
 )
 
 
@@ -101,6 +101,10 @@ def load_library():
         L.fz_comm_barrier.argtypes = [vp]
         L.fz_comm_destroy.restype = None
         L.fz_comm_destroy.argtypes = [vp]
+        L.fz_comm_gather_ms.restype = ci
+        L.fz_comm_gather_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
+        L.fz_debug_gather_merge.restype = ci
+        L.fz_debug_gather_merge.argtypes = [ctypes.c_void_p, u32, u64, ctypes.c_void_p, u32, mpp, u64p, u64p]
         L.fz_seq_len.restype = u64
         L.fz_seq_len.argtypes = [vp]
         L.fz_seq_release.restype = None
@@ -540,6 +544,12 @@ class Engine(object):
         v = ctypes.c_double(value)
         with self._lock:
             _check(self._lib.fz_comm_max_f64(self._h, ctypes.byref(v)))
+        return v.value
+
+    def comm_gather_ms(self):
+        """Host milliseconds of the exchange step (all-gather + D2H + parse) of the collective search collected last."""
+        v = ctypes.c_double(0.0)
+        _check(self._lib.fz_comm_gather_ms(self._h, ctypes.byref(v)))
         return v.value
 
     def comm_barrier(self):

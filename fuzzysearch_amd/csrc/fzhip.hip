@@ -28,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <new>
 #include <string>
 #include <thread>
@@ -141,6 +142,7 @@ struct DevState {
     uint8_t *d_pat = nullptr;                    // pattern in HBM (subsequences longer than FZ_MAX_M, fz_verify_big_kernel)
     uint64_t pat_cap = 0;
     int slot_id = 0;                             // which of the two result slots is the current one
+    uint32_t launches_used = 0;                  // scan launches of the last enqueue on this device
     // RCCL (fz_comm_*): this device state is rank comm_rank of a communicator.  A search of such a context leaves
     // its counters + records in d_out; a device-to-device snapshot (d_send[slot], taken on the scan stream right
     // behind the kernels, so a younger search may reuse d_out) is what the all-gather sends.
@@ -185,6 +187,98 @@ struct Shard {
     uint8_t *d_buf = nullptr;                    // = d_alloc + FZ_PAD_FRONT
     uint64_t alloc_bytes = 0;
     FzGeom geom{};
+};
+
+}  // namespace
+
+namespace {
+
+// One host thread per device of a multi-device context (round 4).  A search over N shards used to be driven by the
+// calling thread alone: N x ~10 us of launches one after the other, N waits, and the ordering of all N record lists
+// (8 x 10^4 records at N = 8: 0.35 ms) against a 0.79 ms kernel.  Every device's worker now enqueues, waits for,
+// collects AND orders its own shard; the caller only merges the ordered rows block by block.  Workers spin for a
+// while after a job (the next one of a pipelined loop arrives within a millisecond), then sleep on a condition variable.
+// FZ_NO_DEV_THREADS=1: no workers, the calling thread does everything in shard order (A/B knob).
+struct DevWorkers {
+    struct W {
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::function<int()> job;
+        std::atomic<uint64_t> posted{0}, done{0};
+        int rc = 0;
+        std::string err;
+        bool stop = false;
+    };
+    std::vector<W *> ws;
+    long spin_us = 1500;
+
+    explicit DevWorkers(size_t n) {
+        if (const char *e = getenv("FZ_WORKER_SPIN_US")) spin_us = atol(e);
+        for (size_t i = 0; i < n; ++i) {
+            W *w = new W();
+            ws.push_back(w);
+            w->th = std::thread([this, w]() { run(w); });
+        }
+    }
+    ~DevWorkers() {
+        for (W *w : ws) {
+            { std::lock_guard<std::mutex> g(w->mu); w->stop = true; }
+            w->cv.notify_one();
+            w->th.join();
+            delete w;
+        }
+    }
+    void run(W *w) {
+        uint64_t seen = 0;
+        for (;;) {
+            const auto t0 = std::chrono::steady_clock::now();
+            unsigned spins = 0;
+            while (w->posted.load(std::memory_order_acquire) == seen) {
+                if ((++spins & 255u) == 0 &&
+                    std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us) {
+                    std::unique_lock<std::mutex> lk(w->mu);
+                    w->cv.wait(lk, [&]() { return w->stop || w->posted.load(std::memory_order_acquire) != seen; });
+                    if (w->stop) return;
+                    break;
+                }
+                __builtin_ia32_pause();
+            }
+            seen = w->posted.load(std::memory_order_acquire);
+            w->rc = w->job();
+            if (w->rc) w->err = g_err;
+            w->done.store(seen, std::memory_order_release);
+        }
+    }
+    void post(size_t i, std::function<int()> fn) {
+        W *w = ws[i];
+        w->job = std::move(fn);
+        w->posted.fetch_add(1, std::memory_order_release);
+        { std::lock_guard<std::mutex> g(w->mu); }
+        w->cv.notify_one();
+    }
+    int wait(size_t i) {
+        W *w = ws[i];
+        const uint64_t want = w->posted.load(std::memory_order_relaxed);
+        unsigned spins = 0;
+        while (w->done.load(std::memory_order_acquire) != want) {
+            if ((++spins & 1023u) == 0) std::this_thread::yield(); else __builtin_ia32_pause();
+        }
+        if (w->rc) g_err = w->err;
+        return w->rc;
+    }
+};
+
+// What collecting one shard of a multi-shard search leaves behind (one per shard, kept between searches).
+struct ShardOut {
+    std::vector<FzRec> recs;
+    std::vector<uint64_t> hits;
+    std::vector<fz_match> rows;                  // the shard's records in the reference's order (multi-shard searches)
+    bool rerun = false;
+    uint64_t nh = 0, nr = 0, bytes = 0;
+    bool has_tref = false;
+    DevState *td = nullptr;
+    hipEvent_t tev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 }  // namespace
@@ -245,12 +339,21 @@ struct fz_ctx {
     int comm_world = 0;
     bool snapshot = false;
     uint64_t gcap = 4096;                        // records per rank the all-gather carries (follows the counts, on all ranks alike)
+    double last_gather_ms = 0;                   // host time of the last search's exchange step (all-gather + D2H + parse)
+    // multi-device contexts: one host thread per device (enqueue, wait, collect and order its shard), and what the
+    // shards of the search being collected left (rows_ready: every shard's rows are ordered, emit_matches only merges)
+    DevWorkers *workers = nullptr;
+    std::vector<ShardOut> souts;
+    bool rows_ready = false;
 };
 
 struct fz_seq {
     fz_ctx *ctx = nullptr;
     uint64_t n = 0;                              // global length
     std::vector<Shard> shards;
+    // collective searches: the first index every rank of the communicator owns of THIS sequence (~0: nothing), exchanged
+    // on the sequence's first collective search; the ranks' segments are merged in that order
+    std::vector<uint64_t> rank_lo;
 };
 
 namespace {
@@ -790,20 +893,25 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
         if (!direct) HIP_TRY(hipMemsetAsync(d.d_out, 0, kHeaderBytes, d.stream));
         d.header_zeroed = true;
     }
-    ctx->stats.filter_launches += launches;
-    ctx->last_fused = fa.fused != 0;
+    d.launches_used = launches;                  // (summed by search_enqueue: this may run on the device's worker thread)
     d.fused_used = fa.fused != 0;
     d.hit_cap_used = d.hit_cap;
     d.rec_cap_used = d.rec_cap;
     return FZ_OK;
 }
 
-// Wait for a shard, handle overflow (returns 1 = capacities grown, caller must re-run), collect.
-int collect_shard(fz_ctx *ctx, const Shard &sh, bool with_verify, bool view_ok, std::vector<FzRec> &recs_out,
-                  std::vector<uint64_t> &hits_out, bool &rerun, bool collective = false) {
+// Wait for a shard, handle overflow (so.rerun = capacities grown, the caller must re-run), collect into `so`.
+// May run on the device's worker thread: touches the device state, `so` and — only for single-shard searches
+// (view_ok), which never run on a worker — the context's record view.
+int collect_shard(fz_ctx *ctx, const Shard &sh, bool with_verify, bool view_ok, ShardOut &so, bool collective = false) {
     DevState &d = ctx->devs[sh.dev];
     HIP_TRY(hipSetDevice(d.device));
     Trace tr;
+    so.recs.clear();
+    so.hits.clear();
+    so.rerun = false;
+    so.has_tref = false;
+    so.nh = so.nr = so.bytes = 0;
     // wait for the copy only: the memset that pre-zeroes the header for the next search runs behind it
     HIP_TRY(hipEventSynchronize(d.ev[3]));
     tr.mark("  sync");
@@ -812,7 +920,7 @@ int collect_shard(fz_ctx *ctx, const Shard &sh, bool with_verify, bool view_ok, 
     const uint64_t nr = cnt[1];
     const bool fused = with_verify && d.fused_used;
     if (fused) { nh = 0; for (int i = 0; i < 64; ++i) nh += cnt[8 + i]; }
-    rerun = false;
+    bool rerun = false;
     if (nh > d.hit_cap_used && !fused) {
         HIP_TRY(hipStreamSynchronize(d.stream));          // a second search in flight still uses the old buffers
         int rc = ensure_hits(d, nh + nh / 8 + 1024);
@@ -827,32 +935,35 @@ int collect_shard(fz_ctx *ctx, const Shard &sh, bool with_verify, bool view_ok, 
         rerun = true;
     }
     if (!d.last_direct && nr * 4 < kHostRecs) d.direct = true;
+    so.rerun = rerun;
     if (rerun) return FZ_OK;
     d.last_filter_ms = 0;
-    if (d.timed)
-        ctx->tref.push_back({&d, d.ev[0], d.ev[d.scan_end_event], d.verify_launched ? d.ev[1] : nullptr, d.ev[d.verify_end_event], d.ev[0], d.ev[3]});
-    ctx->stats.bytes_scanned += sh.geom.buf_len;
-    ctx->stats.ngram_hits += nh;
+    if (d.timed) {
+        so.has_tref = true;
+        so.td = &d;
+        so.tev[0] = d.ev[0]; so.tev[1] = d.ev[d.scan_end_event]; so.tev[2] = d.verify_launched ? d.ev[1] : nullptr;
+        so.tev[3] = d.ev[d.verify_end_event]; so.tev[4] = d.ev[0]; so.tev[5] = d.ev[3];
+    }
+    so.bytes = sh.geom.buf_len;
+    so.nh = nh;
     if (with_verify && collective) {
         // collective search: the records travel in the all-gather (gather_records), not through this host
     } else if (with_verify && view_ok && d.last_direct) {
-        ctx->stats.raw_matches += nr;
+        so.nr = nr;
         ctx->view = reinterpret_cast<const FzRec *>(d.h_stage + kHeaderBytes);
         ctx->view_n = nr;
     } else if (with_verify) {
-        ctx->stats.raw_matches += nr;
-        const size_t base = recs_out.size();
-        recs_out.resize(base + nr);
+        so.nr = nr;
+        so.recs.resize(nr);
         const uint64_t first = d.last_direct ? nr : std::min<uint64_t>(nr, d.first_copy);
-        if (first) memcpy(recs_out.data() + base, d.h_stage + kHeaderBytes, first * sizeof(FzRec));
+        if (first) memcpy(so.recs.data(), d.h_stage + kHeaderBytes, first * sizeof(FzRec));
         if (nr > first)
-            HIP_TRY(hipMemcpy(recs_out.data() + base + first, d.d_out + kHeaderBytes + first * sizeof(FzRec),
+            HIP_TRY(hipMemcpy(so.recs.data() + first, d.d_out + kHeaderBytes + first * sizeof(FzRec),
                               (nr - first) * sizeof(FzRec), hipMemcpyDeviceToHost));
         d.first_copy = std::max<uint64_t>(512, nr + nr / 4 + 64);      // next call: fetch about this many
     } else {
-        const size_t base = hits_out.size();
-        hits_out.resize(base + nh);
-        if (nh) HIP_TRY(hipMemcpy(hits_out.data() + base, d.d_hits, nh * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        so.hits.resize(nh);
+        if (nh) HIP_TRY(hipMemcpy(so.hits.data(), d.d_hits, nh * sizeof(uint64_t), hipMemcpyDeviceToHost));
     }
     return FZ_OK;
 }
@@ -869,6 +980,65 @@ int check_halo(const fz_seq *seq, uint64_t need) {
     return FZ_OK;
 }
 
+// fn(si) for every shard of the sequence: on the shard's device worker when the context has workers and the sequence
+// several shards (one shard per device), else on the calling thread in shard order.  -> first error.
+template <class F>
+int for_each_shard(fz_ctx *ctx, fz_seq *seq, F fn) {
+    const size_t ns = seq->shards.size();
+    if (!ctx->workers || ns < 2) {
+        for (size_t si = 0; si < ns; ++si) { int rc = fn(si); if (rc) return rc; }
+        return FZ_OK;
+    }
+    for (size_t si = 0; si < ns; ++si) ctx->workers->post((size_t)seq->shards[si].dev, [fn, si]() { return fn(si); });
+    int rc = FZ_OK;
+    std::string err;
+    for (size_t si = 0; si < ns; ++si) {
+        const int r = ctx->workers->wait((size_t)seq->shards[si].dev);
+        if (r && !rc) { rc = r; err = g_err; }
+    }
+    if (rc) g_err = err;
+    return rc;
+}
+
+int comm_rank_lows(fz_ctx *ctx, fz_seq *seq);
+int comm_gather_host(fz_ctx *ctx, const void *data, uint64_t bytes, std::vector<uint8_t> &all);
+int comm_or(fz_ctx *ctx, bool &flag);
+bool comm_multi_process(const fz_ctx *ctx);
+
+// Host half of the exchange step: `blocks` = world blocks of `bytes_per_rank` bytes, each [1 KiB of counters][records];
+// counters[1] = records the rank produced (it stored min(count, cap) of them).  -> *top = the largest count; if it is
+// above `cap` nothing else happens (the caller re-gathers with a larger capacity: every rank sees the same headers and
+// decides alike).  Else `recs` = the ranks' records rank by rank, seg_ends[r] = where rank r's end, seg_order = the
+// ranks in ascending order of the index range they own (own_lo[r]; a rank that owns nothing sorts by its number).
+void parse_gathered(const uint8_t *blocks, int world, uint64_t bytes_per_rank, uint64_t cap, const uint64_t *own_lo,
+                    std::vector<FzRec> &recs, std::vector<size_t> &seg_ends, std::vector<uint32_t> &seg_order, uint64_t *top_out,
+                    uint64_t *total_out) {
+    uint64_t top = 0, total = 0;
+    for (int r = 0; r < world; ++r) {
+        const unsigned long long *cnt = reinterpret_cast<const unsigned long long *>(blocks + (uint64_t)r * bytes_per_rank);
+        top = std::max<uint64_t>(top, cnt[1]);
+        total += cnt[1];
+    }
+    *top_out = top;
+    *total_out = total;
+    recs.clear();
+    seg_ends.clear();
+    seg_order.clear();
+    if (top > cap) return;
+    recs.resize(total);
+    uint64_t o = 0;
+    for (int r = 0; r < world; ++r) {
+        const uint8_t *blk = blocks + (uint64_t)r * bytes_per_rank;
+        const uint64_t c = reinterpret_cast<const unsigned long long *>(blk)[1];
+        if (c) memcpy(recs.data() + o, blk + kHeaderBytes, c * sizeof(FzRec));
+        o += c;
+        seg_ends.push_back(o);
+        seg_order.push_back((uint32_t)r);
+    }
+    if (own_lo)
+        std::stable_sort(seg_order.begin(), seg_order.end(), [&](uint32_t x, uint32_t y) { return own_lo[x] < own_lo[y]; });
+}
+
 #define NCCL_TRY(expr)                                                                             \
     do {                                                                                           \
         ncclResult_t r_ = (expr);                                                                  \
@@ -881,10 +1051,14 @@ int check_halo(const fz_seq *seq, uint64_t need) {
 // holds all records of the global search; the caller orders them by (block, index) as it does for one shard.
 // gcap follows the counts: the gathered headers show every rank the same numbers, so all ranks grow / shrink
 // alike; an overflow re-gathers from the same snapshots (they hold everything the search produced).
+// The ranks' segments are ordered by the index ranges they own (exchanged once per sequence: comm_rank_lows).
 int gather_records(fz_ctx *ctx, fz_seq *seq, std::vector<FzRec> &recs) {
     const int world = ctx->comm_world;
     if (world <= 0) return fail(FZ_EINVAL, "the context has not joined a communicator");
     recs.clear();
+    const auto t_start = std::chrono::steady_clock::now();
+    int rcl = comm_rank_lows(ctx, seq);
+    if (rcl) return rcl;
     for (int attempt = 0; attempt < 8; ++attempt) {
         const uint64_t bytes = kHeaderBytes + ctx->gcap * sizeof(FzRec);
         for (DevState &d : ctx->devs) {
@@ -919,35 +1093,15 @@ int gather_records(fz_ctx *ctx, fz_seq *seq, std::vector<FzRec> &recs) {
             HIP_TRY(hipStreamSynchronize(ctx->devs[i].comm_stream));
         }
         uint64_t top = 0, total = 0;
-        for (int r = 0; r < world; ++r) {
-            const unsigned long long *cnt = reinterpret_cast<const unsigned long long *>(d0.h_recv + (uint64_t)r * bytes);
-            top = std::max<uint64_t>(top, cnt[1]);
-            total += cnt[1];
-        }
+        parse_gathered(d0.h_recv, world, bytes, ctx->gcap, seq->rank_lo.data(), recs, ctx->seg_ends, ctx->seg_order, &top, &total);
         if (top > ctx->gcap) {                               // identical decision on every rank
             ctx->gcap = (top + top / 4 + 1023) / 1024 * 1024;
             continue;
         }
-        recs.resize(total);
-        uint64_t o = 0;
-        ctx->seg_ends.clear();
-        ctx->seg_order.clear();
-        for (int r = 0; r < world; ++r) {                    // ranks own ascending index ranges
-            const uint8_t *blk = d0.h_recv + (uint64_t)r * bytes;
-            const uint64_t c = reinterpret_cast<const unsigned long long *>(blk)[1];
-            if (c) memcpy(recs.data() + o, blk + kHeaderBytes, c * sizeof(FzRec));
-            o += c;
-            ctx->seg_ends.push_back(o);
-            ctx->seg_order.push_back((uint32_t)r);
-        }
-        if ((int)ctx->devs.size() == world) {                // every rank is a device of this process: order them by what they own
-            std::vector<uint64_t> lo(world, ~0ull);
-            for (const Shard &sh : seq->shards) lo[sh.dev] = sh.geom.own_lo;
-            std::stable_sort(ctx->seg_order.begin(), ctx->seg_order.end(), [&](uint32_t x, uint32_t y) { return lo[x] < lo[y]; });
-        }
         ctx->stats.raw_matches = total;
         const uint64_t want = std::max<uint64_t>(1024, (top + top / 4 + 1023) / 1024 * 1024);
         if (want * 2 <= ctx->gcap) ctx->gcap = want;         // follow the counts down as well (hysteresis: a factor of two)
+        ctx->last_gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
         return FZ_OK;
     }
     return fail(FZ_EDEVICE, "all-gather capacity kept overflowing");
@@ -957,53 +1111,92 @@ int gather_records(fz_ctx *ctx, fz_seq *seq, std::vector<FzRec> &recs) {
 int search_enqueue(fz_ctx *ctx, fz_seq *seq, const Search &q, bool with_verify) {
     ctx->view = nullptr;
     ctx->view_n = 0;
+    ctx->rows_ready = false;
     ctx->stats.filter_launches = 0;
     ctx->stats.bytes_scanned = ctx->stats.ngram_hits = ctx->stats.raw_matches = 0;
     ctx->stats.filter_ms = ctx->stats.verify_ms = ctx->stats.device_ms = 0;
-        ctx->tref.clear();
+    ctx->tref.clear();
+    int rc = for_each_shard(ctx, seq, [ctx, seq, &q, with_verify](size_t si) { return enqueue_shard(ctx, seq->shards[si], q, with_verify); });
+    if (rc) return rc;
     for (const Shard &sh : seq->shards) {
-        int rc = enqueue_shard(ctx, sh, q, with_verify);
-        if (rc) return rc;
+        const DevState &d = lane_dev(ctx, sh.dev);
+        ctx->stats.filter_launches += d.launches_used;
+        ctx->last_fused = d.fused_used;
     }
     return FZ_OK;
 }
 
+int emit_matches(const FzRec *recs, size_t cnt, uint32_t L, fz_match **out, uint64_t *n, uint64_t idx_bound, uint32_t blk_bound,
+                 bool may_have_empty, std::vector<fz_match> *into);
+
 // Wait for the search launched by search_enqueue and collect it; on an overflow the buffers have
 // been grown and the search is launched again (deterministic, at most three times).
+// One shard: the records are in `recs` (or the context's view of the staging buffer), the hits in `hits`.
+// Several shards: every shard's records are collected AND ordered on its own (ctx->souts[si].rows, by the device's
+// worker when the context has workers) and emit_matches only merges the rows (ctx->rows_ready); hits are concatenated.
 int search_collect(fz_ctx *ctx, fz_seq *seq, const Search &q, bool with_verify, std::vector<FzRec> &recs,
                    std::vector<uint64_t> &hits) {
+    const size_t ns = seq->shards.size();
+    if (ctx->souts.size() < ns) ctx->souts.resize(ns);
+    const bool order_rows = with_verify && !q.collective && ns > 1 && !q.any && seq->shards[0].geom.seg_stride == 0;
     for (int attempt = 0; attempt < 4; ++attempt) {
         recs.clear();
         hits.clear();
+        ctx->rows_ready = false;
         // the statistics describe the search being collected (a younger one may have been launched meanwhile)
         ctx->stats.bytes_scanned = ctx->stats.ngram_hits = ctx->stats.raw_matches = 0;
         ctx->stats.filter_ms = ctx->stats.verify_ms = ctx->stats.device_ms = 0;
         ctx->tref.clear();
         Trace tr;
-        bool any_rerun = false;
         ctx->seg_ends.clear();
         ctx->seg_order.clear();
-        for (const Shard &sh : seq->shards) {
-            bool rr = false;
-            int rc = collect_shard(ctx, sh, with_verify, seq->shards.size() == 1, recs, hits, rr, q.collective);
-            if (rc) return rc;
-            any_rerun |= rr;
-            ctx->seg_ends.push_back(recs.size());
-        }
-        for (uint32_t si = 0; si < seq->shards.size(); ++si) ctx->seg_order.push_back(si);
-        std::sort(ctx->seg_order.begin(), ctx->seg_order.end(), [&](uint32_t x, uint32_t y) {
-            return seq->shards[x].geom.own_lo < seq->shards[y].geom.own_lo;
+        const uint32_t L = q.plan.L, nblk = (uint32_t)q.plan.s.size();
+        const uint64_t nglob = seq->n;
+        const bool collective = q.collective;
+        int rc = for_each_shard(ctx, seq, [ctx, seq, with_verify, ns, collective, order_rows, L, nblk, nglob](size_t si) {
+            ShardOut &so = ctx->souts[si];
+            int r = collect_shard(ctx, seq->shards[si], with_verify, ns == 1, so, collective);
+            if (r || so.rerun || !order_rows) return r;
+            const bool dense = ctx->devs[seq->shards[si].dev].fused_used;
+            return emit_matches(so.recs.data(), so.recs.size(), L, nullptr, nullptr, nglob, nblk, !dense, &so.rows);
         });
+        if (rc) return rc;
+        bool any_rerun = false;
+        for (size_t si = 0; si < ns; ++si) {
+            ShardOut &so = ctx->souts[si];
+            any_rerun |= so.rerun;
+            if (so.rerun) continue;
+            ctx->stats.bytes_scanned += so.bytes;
+            ctx->stats.ngram_hits += so.nh;
+            ctx->stats.raw_matches += so.nr;
+            if (so.has_tref) ctx->tref.push_back({so.td, so.tev[0], so.tev[1], so.tev[2], so.tev[3], so.tev[4], so.tev[5]});
+        }
         tr.mark(" collect");
         if (!any_rerun) {
             if (with_verify && q.collective) {
-                int rc = gather_records(ctx, seq, recs);
-                if (rc) return rc;
+                int rc2 = gather_records(ctx, seq, recs);
+                if (rc2) return rc2;
                 tr.mark(" all-gather");
+                return FZ_OK;
+            }
+            if (ns == 1) {
+                recs.swap(ctx->souts[0].recs);
+                hits.swap(ctx->souts[0].hits);
+            } else if (order_rows) {
+                ctx->rows_ready = true;
+                for (uint32_t si = 0; si < ns; ++si) ctx->seg_order.push_back(si);
+                std::sort(ctx->seg_order.begin(), ctx->seg_order.end(), [&](uint32_t x, uint32_t y) {
+                    return seq->shards[x].geom.own_lo < seq->shards[y].geom.own_lo;
+                });
+            } else {
+                for (size_t si = 0; si < ns; ++si) {
+                    recs.insert(recs.end(), ctx->souts[si].recs.begin(), ctx->souts[si].recs.end());
+                    hits.insert(hits.end(), ctx->souts[si].hits.begin(), ctx->souts[si].hits.end());
+                }
             }
             return FZ_OK;
         }
-        int rc = search_enqueue(ctx, seq, q, with_verify);
+        rc = search_enqueue(ctx, seq, q, with_verify);
         if (rc) return rc;
     }
     return fail(FZ_EDEVICE, "result buffers kept overflowing");
@@ -1075,7 +1268,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             // keeps the host's run ordering (emit_generic), which also serves searches with more than
             // FZ_GEN_ORDER_MAX hits, several shards and the file API's segments.
             static const bool host_order = getenv("FZ_GEN_HOST_ORDER") != nullptr;
-            const bool dev_order = !gen_direct && !host_order && !q.any && !q.fold && seq->shards.size() == 1 && sh.geom.seg_stride == 0;
+            const bool dev_order = !gen_direct && !host_order && !q.any && !q.fold && seq->shards.size() == 1 && sh.geom.seg_stride == 0 && !comm_multi_process(ctx);
             if (dev_order) {
                 rc = ensure_gen_rows(d);
                 if (rc) return rc;
@@ -1182,7 +1375,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             if (!gen_direct2 && !d.fold_was_direct && nr > d.rec_cap) { int rc = ensure_recs(d, nr + nr / 8 + 1024); if (rc) return rc; rerun = true; }
             static const bool host_order2 = getenv("FZ_GEN_HOST_ORDER") != nullptr;
             const bool rows_ready = !gen_direct2 && !host_order2 && !q.fold && seq->shards.size() == 1 && sh.geom.seg_stride == 0 &&
-                                    nh <= FZ_GEN_ORDER_MAX && nr <= d.gen_rows_cap;
+                                    nh <= FZ_GEN_ORDER_MAX && nr <= d.gen_rows_cap && !comm_multi_process(ctx);
             const bool in_stage = q.fold && nr <= d.fold_copied && seq->shards.size() == 1;   // the pairs are in h_stage already
             if (q.fold) d.fold_guess = std::max<uint64_t>(4096, nr + nr / 4 + 256);
             if (!gen_direct2 && !rerun && !novf && nr && !rows_ready && !in_stage)
@@ -1449,19 +1642,11 @@ int emit_matches_seg(const FzRec *recs, size_t cnt, uint32_t L, fz_match **out, 
 // A sharded search (several devices, or the ranks of an all-gather): every shard's records are ordered on their own —
 // 10^4 records stay in the host's L2, one 8 x 10^4-record ordering does not (0.8 ms on 77 000 records) — and, shards
 // owning ascending index ranges (seg_order lists them that way), the reference's order is, block by block, the shards'
-// runs of that block one after the other.  seg_ends[i] = end of shard i's records in `recs`.
-int emit_matches_segments(const FzRec *recs, const std::vector<size_t> &seg_ends, const std::vector<uint32_t> &seg_order, uint32_t L,
-                          fz_match **out, uint64_t *n, uint64_t idx_bound, uint32_t blk_bound, bool may_have_empty) {
-    const size_t ns = seg_ends.size();
-    static thread_local std::vector<std::vector<fz_match>> rows;
-    if (rows.size() < ns) rows.resize(ns);
+// runs of that block one after the other.  merge_rows does the second half on rows that are already ordered.
+int merge_rows(const std::vector<const std::vector<fz_match> *> &rows, const std::vector<uint32_t> &seg_order, fz_match **out, uint64_t *n) {
+    const size_t ns = rows.size();
     size_t total = 0;
-    for (size_t si = 0; si < ns; ++si) {
-        const size_t b = si ? seg_ends[si - 1] : 0, e = seg_ends[si];
-        int rc = emit_matches(recs + b, e - b, L, nullptr, nullptr, idx_bound, blk_bound, may_have_empty, &rows[si]);
-        if (rc) return rc;
-        total += rows[si].size();
-    }
+    for (size_t si = 0; si < ns; ++si) total += rows[si]->size();
     void *mem = nullptr;
     int rc = alloc_out(total, sizeof(fz_match), &mem);
     if (rc) return rc;
@@ -1472,13 +1657,21 @@ int emit_matches_segments(const FzRec *recs, const std::vector<size_t> &seg_ends
         int32_t g = INT32_MAX;                             // the smallest block any shard still holds
         for (size_t k = 0; k < ns; ++k) {
             const size_t si = seg_order[k];
-            if (pos[si] < rows[si].size()) g = std::min(g, rows[si][pos[si]].block);
+            if (pos[si] < rows[si]->size()) g = std::min(g, (*rows[si])[pos[si]].block);
         }
         for (size_t k = 0; k < ns; ++k) {
             const size_t si = seg_order[k];
-            const std::vector<fz_match> &r = rows[si];
+            const std::vector<fz_match> &r = *rows[si];
             size_t q = pos[si];
-            while (q < r.size() && r[q].block == g) ++q;
+            // (a run of one block: gallop, then binary search — a shard holds thousands of rows per block)
+            if (q < r.size() && r[q].block == g) {
+                size_t step = 1, hi = q + 1;
+                while (hi < r.size() && r[hi].block == g) { q = hi; hi = std::min(r.size(), hi + step); step <<= 1; }
+                // r[q].block == g, and (hi == r.size() or r[hi].block != g): the run ends in (q, hi]
+                size_t lo2 = q + 1, hi2 = hi;
+                while (lo2 < hi2) { const size_t mid = (lo2 + hi2) / 2; if (r[mid].block == g) lo2 = mid + 1; else hi2 = mid; }
+                q = lo2;
+            }
             if (q > pos[si]) memcpy(mo + o, r.data() + pos[si], (q - pos[si]) * sizeof(fz_match));
             o += q - pos[si];
             pos[si] = q;
@@ -1489,14 +1682,43 @@ int emit_matches_segments(const FzRec *recs, const std::vector<size_t> &seg_ends
     return FZ_OK;
 }
 
-// the records of the search that just ran: the staging-buffer view or the collected vector
-int emit_matches(const fz_ctx *ctx, const std::vector<FzRec> &recs, uint32_t L, fz_match **out, uint64_t *n,
+// seg_ends[i] = end of shard i's records in `recs`.  With workers (ctx) the segments are ordered in parallel.
+int emit_matches_segments(fz_ctx *ctx, const FzRec *recs, const std::vector<size_t> &seg_ends, const std::vector<uint32_t> &seg_order, uint32_t L,
+                          fz_match **out, uint64_t *n, uint64_t idx_bound, uint32_t blk_bound, bool may_have_empty) {
+    const size_t ns = seg_ends.size();
+    static thread_local std::vector<std::vector<fz_match>> rows;
+    if (rows.size() < ns) rows.resize(ns);
+    std::vector<fz_match> *rowp = rows.data();
+    auto order_one = [recs, &seg_ends, L, idx_bound, blk_bound, may_have_empty, rowp](size_t si) {
+        const size_t b = si ? seg_ends[si - 1] : 0, e = seg_ends[si];
+        return emit_matches(recs + b, e - b, L, nullptr, nullptr, idx_bound, blk_bound, may_have_empty, &rowp[si]);
+    };
+    if (ctx && ctx->workers && ns > 1 && ns <= ctx->workers->ws.size() && seg_ends.back() >= 4096) {
+        for (size_t si = 0; si < ns; ++si) ctx->workers->post(si, [order_one, si]() { return order_one(si); });
+        int rc = FZ_OK;
+        for (size_t si = 0; si < ns; ++si) { const int r = ctx->workers->wait(si); if (r && !rc) rc = r; }
+        if (rc) return rc;
+    } else {
+        for (size_t si = 0; si < ns; ++si) { int rc = order_one(si); if (rc) return rc; }
+    }
+    std::vector<const std::vector<fz_match> *> ptrs(ns);
+    for (size_t si = 0; si < ns; ++si) ptrs[si] = &rows[si];
+    return merge_rows(ptrs, seg_order, out, n);
+}
+
+// the records of the search that just ran: the staging-buffer view, the shards' ordered rows or the collected vector
+int emit_matches(fz_ctx *ctx, const std::vector<FzRec> &recs, uint32_t L, fz_match **out, uint64_t *n,
                  uint64_t idx_bound = 0, uint32_t blk_bound = 0) {
+    if (ctx->rows_ready) {                                 // several shards: ordered by search_collect, merged here
+        std::vector<const std::vector<fz_match> *> ptrs(ctx->seg_order.size());
+        for (size_t si = 0; si < ptrs.size(); ++si) ptrs[si] = &ctx->souts[si].rows;
+        return merge_rows(ptrs, ctx->seg_order, out, n);
+    }
     // (the fused scan appends real records only; the stand-alone verifications may leave empty slots)
     bool dense = true;                                     // (of the search being collected: its slot is the current one)
     for (const DevState &d : ctx->devs) dense = dense && d.fused_used;
     if (!ctx->view && ctx->seg_ends.size() > 1 && ctx->seg_ends.back() == recs.size())
-        return emit_matches_segments(recs.data(), ctx->seg_ends, ctx->seg_order, L, out, n, idx_bound, blk_bound, !dense);
+        return emit_matches_segments(ctx, recs.data(), ctx->seg_ends, ctx->seg_order, L, out, n, idx_bound, blk_bound, !dense);
     return ctx->view ? emit_matches(ctx->view, (size_t)ctx->view_n, L, out, n, idx_bound, blk_bound, !dense)
                      : emit_matches(recs.data(), recs.size(), L, out, n, idx_bound, blk_bound, !dense);
 }
@@ -1616,12 +1838,18 @@ int fz_create(const int *device_ids, int n_devices, fz_ctx **out) {
         int rc = devstate_init(d);
         if (rc) { fz_destroy(ctx); return rc; }
     }
+    if (ctx->devs.size() > 1 && !getenv("FZ_NO_DEV_THREADS")) {
+        ctx->workers = new (std::nothrow) DevWorkers(ctx->devs.size());
+        if (!ctx->workers) { fz_destroy(ctx); return fail(FZ_ENOMEM, "out of memory"); }
+    }
     *out = ctx;
     return FZ_OK;
 }
 
 void fz_destroy(fz_ctx *ctx) {
     if (!ctx) return;
+    delete ctx->workers;
+    ctx->workers = nullptr;
     // sequences the caller never released: their device memory goes with the context (their handles die with it)
     while (!ctx->live.empty()) {
         for (DevState &d : ctx->devs) { (void)hipSetDevice(d.device); if (d.stream) (void)hipStreamSynchronize(d.stream); }
@@ -1823,6 +2051,13 @@ int fz_search_exact(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint
     std::vector<uint64_t> hits;
     rc = run_search(ctx, seq, q, /*with_verify=*/false, recs, hits);
     if (rc) return rc;
+    if (comm_multi_process(ctx)) {                         // one rank of several: every rank gets every rank's hits
+        std::vector<uint8_t> all;
+        rc = comm_gather_host(ctx, hits.data(), hits.size() * sizeof(uint64_t), all);
+        if (rc) return rc;
+        hits.resize(all.size() / sizeof(uint64_t));
+        if (!all.empty()) memcpy(hits.data(), all.data(), all.size());
+    }
     std::sort(hits.begin(), hits.end());
     void *mem = nullptr;
     rc = alloc_out(hits.size(), sizeof(uint64_t), &mem);
@@ -1878,6 +2113,7 @@ static int subs_plan(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uin
     rc = check_halo(seq, m);
     if (rc) return rc;
     q.mode = FZ_MODE_SUBS; q.m = m; q.k = k; q.p = p;
+    q.collective = ctx->snapshot;
     q.plan.L = L;
     for (uint32_t s = 0; s + L <= m; s += L) q.plan.s.push_back(s);   // template :92-101 (ranges: fz_block_range)
     if (q.plan.s.size() > FZ_MAX_BLOCKS) return fail(FZ_EUNSUPPORTED, "more than %u n-gram blocks", FZ_MAX_BLOCKS);
@@ -1905,6 +2141,22 @@ static int generic_plan(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, 
 
 static int emit_generic_result(fz_ctx *ctx, fz_seq *seq, const Search &q, const std::vector<FzGenRec> &recs_vec, bool consolidated,
                                fz_match **out, uint64_t *n);
+
+// Exchange step of a generic search in a one-process-per-GPU job: the automaton records (or folded pairs) of every rank,
+// back to back; emit_generic / consolidate_hulls order them by their (block, index) keys, which are global.
+static int generic_exchange(fz_ctx *ctx, std::vector<FzGenRec> &recs_vec) {
+    if (!comm_multi_process(ctx)) return FZ_OK;
+    const FzGenRec *mine = ctx->gen_view ? ctx->gen_view : recs_vec.data();
+    const size_t nmine = ctx->gen_view ? (size_t)ctx->gen_view_n : recs_vec.size();
+    std::vector<uint8_t> all;
+    int rc = comm_gather_host(ctx, mine, nmine * sizeof(FzGenRec), all);
+    if (rc) return rc;
+    ctx->gen_view = nullptr;
+    ctx->gen_view_n = 0;
+    recs_vec.resize(all.size() / sizeof(FzGenRec));
+    if (!all.empty()) memcpy(recs_vec.data(), all.data(), all.size());
+    return FZ_OK;
+}
 
 static int pending_plan(fz_ctx *ctx, fz_ctx::Pending &pd, Search &q) {
     const uint8_t *p = pd.pattern.data();
@@ -1988,6 +2240,7 @@ int fz_search_end(fz_ctx *ctx, fz_match **out, uint64_t *n) {
         std::vector<FzGenRec> recs_vec;
         ctx->lane = pd.lane;
         if (rc == FZ_OK) rc = run_generic(ctx, pd.seq, q, recs_vec, /*phase=*/2);
+        if (rc == FZ_OK) rc = generic_exchange(ctx, recs_vec);
         if (rc == FZ_OK) rc = emit_generic_result(ctx, pd.seq, q, recs_vec, pd.consolidated, out, n);
         ctx->lane = 0;
         if (--ctx->npend == 1) std::swap(ctx->pend[0], ctx->pend[1]);
@@ -2024,11 +2277,17 @@ static int subs_ngrams_impl(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t
     if (seq->n < m) return FZ_OK;                              // template :66-68
     const uint32_t L = q.plan.L;
     q.any = found != nullptr;
+    if (q.any) q.collective = false;                           // a flag, not a stream: exchanged below
     std::vector<FzRec> recs;
     std::vector<uint64_t> hits;
     rc = run_search(ctx, seq, q, true, recs, hits);
     if (rc) return rc;
-    if (found) { *found = (ctx->view ? ctx->view_n : (uint64_t)recs.size()) > 0 ? 1 : 0; return FZ_OK; }
+    if (found) {
+        bool any = (ctx->view ? ctx->view_n : (uint64_t)recs.size()) > 0;
+        if (comm_multi_process(ctx)) { rc = comm_or(ctx, any); if (rc) return rc; }
+        *found = any ? 1 : 0;
+        return FZ_OK;
+    }
     return emit_matches(ctx, recs, L, out, n, seq->n, (uint32_t)q.plan.s.size());
 }
 
@@ -2100,7 +2359,14 @@ static int generic_ngrams_impl(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint3
     rc = run_generic(ctx, seq, q, recs_vec);
     if (rc) return rc;
     tr.mark("generic: kernels");
-    if (found) { *found = ctx->any_found ? 1 : 0; return FZ_OK; }
+    if (found) {
+        bool any = ctx->any_found;
+        if (comm_multi_process(ctx)) { rc = comm_or(ctx, any); if (rc) return rc; }
+        *found = any ? 1 : 0;
+        return FZ_OK;
+    }
+    rc = generic_exchange(ctx, recs_vec);
+    if (rc) return rc;
     rc = emit_generic_result(ctx, seq, q, recs_vec, consolidated, out, n);
     tr.mark("generic: rows");
     return rc;
@@ -2218,6 +2484,86 @@ int comm_busy(fz_ctx *ctx) {
     return FZ_OK;
 }
 
+// One-process-per-GPU jobs: is this context one rank of several (its own results are only a part of the answer)?
+bool comm_multi_process(const fz_ctx *ctx) { return ctx->snapshot && ctx->comm_world > 0 && ctx->devs.size() == 1; }
+
+// nbytes from every rank of a one-process-per-GPU communicator, rank order, through device buffers (blocking).
+int comm_allgather_fixed(fz_ctx *ctx, const void *send, uint64_t nbytes, void *recv) {
+    DevState &d = ctx->devs[0];
+    HIP_TRY(hipSetDevice(d.device));
+    const uint64_t world = (uint64_t)ctx->comm_world;
+    uint8_t *tmp = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), (world + 1) * nbytes));
+    auto body = [&]() -> int {
+        HIP_TRY(hipMemcpyAsync(tmp, send, nbytes, hipMemcpyHostToDevice, d.comm_stream));
+        NCCL_TRY(ncclAllGather(tmp, tmp + nbytes, nbytes, ncclChar, d.comm, d.comm_stream));
+        HIP_TRY(hipMemcpyAsync(recv, tmp + nbytes, world * nbytes, hipMemcpyDeviceToHost, d.comm_stream));
+        HIP_TRY(hipStreamSynchronize(d.comm_stream));
+        return FZ_OK;
+    };
+    int rc = body();
+    (void)hipFree(tmp);
+    return rc;
+}
+
+// The exchange step of the searches whose results reach the host before they are exchanged (exact search: hit
+// indices; generic search: automaton records / folded pairs; the linear-programming routes): every rank contributes
+// `bytes` bytes of `elem`-byte items, `all` receives the ranks' contributions back to back in rank order.  Two
+// all-gathers (sizes, then the payload padded to the largest contribution).  The callers order what they get by keys
+// that are global (hit index, block), so the rank order itself carries no meaning.
+int comm_gather_host(fz_ctx *ctx, const void *data, uint64_t bytes, std::vector<uint8_t> &all) {
+    const auto t_start = std::chrono::steady_clock::now();
+    const uint64_t world = (uint64_t)ctx->comm_world;
+    std::vector<uint64_t> sizes(world, 0);
+    int rc = comm_allgather_fixed(ctx, &bytes, sizeof bytes, sizes.data());
+    if (rc) return rc;
+    uint64_t top = 0, total = 0;
+    for (uint64_t v : sizes) { top = std::max(top, v); total += v; }
+    all.clear();
+    if (top == 0) return FZ_OK;
+    const uint64_t cap = (top + 255) / 256 * 256;
+    std::vector<uint8_t> mine(cap, 0), got(world * cap);
+    if (bytes) memcpy(mine.data(), data, bytes);
+    rc = comm_allgather_fixed(ctx, mine.data(), cap, got.data());
+    if (rc) return rc;
+    all.resize(total);
+    uint64_t o = 0;
+    for (uint64_t r = 0; r < world; ++r) {
+        if (sizes[r]) memcpy(all.data() + o, got.data() + r * cap, sizes[r]);
+        o += sizes[r];
+    }
+    ctx->last_gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    return FZ_OK;
+}
+
+// has_near_match_* of a one-process-per-GPU job: true on every rank if any rank found something
+int comm_or(fz_ctx *ctx, bool &flag) {
+    uint64_t mine = flag ? 1 : 0;
+    std::vector<uint64_t> all((size_t)ctx->comm_world, 0);
+    int rc = comm_allgather_fixed(ctx, &mine, sizeof mine, all.data());
+    if (rc) return rc;
+    for (uint64_t v : all) flag = flag || v != 0;
+    return FZ_OK;
+}
+
+// seq->rank_lo: the first index every rank owns of this sequence.  A multi-device context knows them; the ranks of a
+// one-process-per-GPU job exchange them on the sequence's first collective search (every rank is in that search).
+int comm_rank_lows(fz_ctx *ctx, fz_seq *seq) {
+    const size_t world = (size_t)ctx->comm_world;
+    if (seq->rank_lo.size() == world) return FZ_OK;
+    seq->rank_lo.assign(world, ~0ull);
+    if (ctx->devs.size() == world && world > 1) {
+        for (const Shard &sh : seq->shards)
+            if (sh.geom.own_hi > sh.geom.own_lo) seq->rank_lo[(size_t)ctx->devs[sh.dev].comm_rank] = sh.geom.own_lo;
+        return FZ_OK;
+    }
+    uint64_t mine = ~0ull;
+    for (const Shard &sh : seq->shards) if (sh.geom.own_hi > sh.geom.own_lo) mine = std::min(mine, sh.geom.own_lo);
+    int rc = comm_allgather_fixed(ctx, &mine, sizeof mine, seq->rank_lo.data());
+    if (rc) seq->rank_lo.clear();
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -2297,21 +2643,7 @@ int fz_comm_allgather(fz_ctx *ctx, const void *send, uint64_t nbytes, void *recv
     if (ctx->devs.size() != 1) return fail(FZ_EINVAL, "fz_comm_allgather is for one-process-per-GPU jobs (a multi-device context holds every rank's data itself)");
     if (!nbytes) return FZ_OK;
     if (!send || !recv) return fail(FZ_EINVAL, "null argument");
-    DevState &d = ctx->devs[0];
-    HIP_TRY(hipSetDevice(d.device));
-    const uint64_t world = (uint64_t)ctx->comm_world;
-    uint8_t *tmp = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), (world + 1) * nbytes));
-    auto body = [&]() -> int {
-        HIP_TRY(hipMemcpyAsync(tmp, send, nbytes, hipMemcpyHostToDevice, d.comm_stream));
-        NCCL_TRY(ncclAllGather(tmp, tmp + nbytes, nbytes, ncclChar, d.comm, d.comm_stream));
-        HIP_TRY(hipMemcpyAsync(recv, tmp + nbytes, world * nbytes, hipMemcpyDeviceToHost, d.comm_stream));
-        HIP_TRY(hipStreamSynchronize(d.comm_stream));
-        return FZ_OK;
-    };
-    rc = body();
-    (void)hipFree(tmp);
-    return rc;
+    return comm_allgather_fixed(ctx, send, nbytes, recv);
 }
 
 // max over the ranks of one double per rank (the job's step time); doubles as a barrier
@@ -2340,6 +2672,26 @@ int fz_comm_barrier(fz_ctx *ctx) {
     if (ctx) for (DevState &d : ctx->devs) { (void)hipSetDevice(d.device); (void)hipStreamSynchronize(d.stream); }
     double one = 1.0;
     return fz_comm_max_f64(ctx, &one);
+}
+
+int fz_comm_gather_ms(fz_ctx *ctx, double *ms) {
+    if (!ctx || !ms) return fail(FZ_EINVAL, "null argument");
+    *ms = ctx->last_gather_ms;
+    return FZ_OK;
+}
+
+int fz_debug_gather_merge(const void *blocks, uint32_t world, uint64_t cap, const uint64_t *own_lo, uint32_t L, fz_match **out,
+                          uint64_t *n_out, uint64_t *need_cap) {
+    if (!blocks || !out || !n_out || !need_cap || world == 0) return fail(FZ_EINVAL, "null argument");
+    *out = nullptr; *n_out = 0; *need_cap = 0;
+    std::vector<FzRec> recs;
+    std::vector<size_t> seg_ends;
+    std::vector<uint32_t> seg_order;
+    uint64_t top = 0, total = 0;
+    parse_gathered(static_cast<const uint8_t *>(blocks), (int)world, kHeaderBytes + cap * sizeof(FzRec), cap, own_lo, recs, seg_ends,
+                   seg_order, &top, &total);
+    if (top > cap) { *need_cap = (top + top / 4 + 1023) / 1024 * 1024; return FZ_OK; }
+    return emit_matches_segments(nullptr, recs.data(), seg_ends, seg_order, L, out, n_out, 0, 0, true);
 }
 
 }  // extern "C"
@@ -2440,6 +2792,19 @@ int run_lp(fz_ctx *ctx, fz_seq *seq, const Search &q, uint32_t lp_kind, std::vec
     return fail(FZ_EUNSUPPORTED, "automaton candidate lists / result buffers kept overflowing");
 }
 
+// one-process-per-GPU jobs: the ranks' records back to back (emit_lp orders them by step / tile / list position,
+// all of which are global)
+int lp_exchange(fz_ctx *ctx, std::vector<LpRec> &recs) {
+    if (!comm_multi_process(ctx)) return FZ_OK;
+    std::vector<uint8_t> all;
+    int rc = comm_gather_host(ctx, recs.data(), recs.size() * sizeof(LpRec), all);
+    if (rc) return rc;
+    recs.resize(all.size() / sizeof(LpRec));
+    if (!all.empty()) memcpy(static_cast<void *>(recs.data()), all.data(), all.size());
+    ctx->stats.raw_matches = recs.size();
+    return FZ_OK;
+}
+
 int emit_lp(std::vector<LpRec> &recs, bool newest_first, fz_match **out, uint64_t *n) {
     // reference emission order: by sequence step; within a step by candidate-list order, i.e. by
     // start ascending (generic: fresh candidates are appended) or descending (Levenshtein: the fresh
@@ -2485,6 +2850,7 @@ extern "C" int fz_lev_lp(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m,
     q.mode = FZ_MODE_LEV; q.m = m; q.k = k; q.p = p;
     std::vector<LpRec> recs;
     rc = run_lp(ctx, seq, q, FZ_LP_LEV_SEQ, recs);
+    if (rc == FZ_OK) rc = lp_exchange(ctx, recs);
     if (rc) return rc;
     return emit_lp(recs, /*newest_first=*/true, out, n);
 }
@@ -2503,6 +2869,7 @@ extern "C" int fz_generic_lp(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_
     q.max_subs = std::min(max_subs, 255u); q.max_ins = std::min(max_ins, 255u); q.max_dels = std::min(max_dels, 255u);
     std::vector<LpRec> recs;
     rc = run_lp(ctx, seq, q, FZ_LP_GENERIC_SEQ, recs);
+    if (rc == FZ_OK) rc = lp_exchange(ctx, recs);
     if (rc) return rc;
     return emit_lp(recs, /*newest_first=*/false, out, n);
 }
@@ -2573,7 +2940,19 @@ static int subs_lp_impl(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, 
         if (!rerun) break;
         if (attempt == 3) return fail(FZ_EDEVICE, "result buffers kept overflowing");
     }
-    if (found) return FZ_OK;
+    if (found) {
+        bool any = *found != 0;
+        if (comm_multi_process(ctx)) { rc = comm_or(ctx, any); if (rc) return rc; }
+        *found = any ? 1 : 0;
+        return FZ_OK;
+    }
+    if (comm_multi_process(ctx)) {
+        std::vector<uint8_t> all;
+        rc = comm_gather_host(ctx, recs.data(), recs.size() * sizeof(FzRec), all);
+        if (rc) return rc;
+        recs.resize(all.size() / sizeof(FzRec));
+        if (!all.empty()) memcpy(static_cast<void *>(recs.data()), all.data(), all.size());
+    }
     sort_recs(recs);
     void *mem = nullptr;
     rc = alloc_out(recs.size(), sizeof(fz_match), &mem);
@@ -3289,7 +3668,7 @@ int fz_debug_order_segments(const void *recs, const uint64_t *seg_ends, uint32_t
     std::vector<size_t> ends(seg_ends, seg_ends + n_segments);
     std::vector<uint32_t> order(n_segments);
     for (uint32_t i = 0; i < n_segments; ++i) order[i] = i;
-    return emit_matches_segments(static_cast<const FzRec *>(recs), ends, order, L, out, n_out, 0, 0, true);
+    return emit_matches_segments(nullptr, static_cast<const FzRec *>(recs), ends, order, L, out, n_out, 0, 0, true);
 }
 
 int fz_debug_launch_plan(const uint8_t *p, uint32_t m, uint32_t L, uint32_t *out, uint32_t cap, uint32_t *n_launches) {

@@ -204,6 +204,9 @@ int  fz_comm_allgather(fz_ctx *ctx, const void *send, uint64_t nbytes, void *rec
 int  fz_comm_max_f64(fz_ctx *ctx, double *value);
 int  fz_comm_barrier(fz_ctx *ctx);
 void fz_comm_destroy(fz_ctx *ctx);
+/* Host time (ms) of the exchange step of the collective search collected last on this context: from "every local
+ * shard has finished" to "every rank's records are on this host" (all-gather + D2H copy + parsing the ranks' blocks). */
+int  fz_comm_gather_ms(fz_ctx *ctx, double *ms);
 
 /* consolidate_overlapping_matches: overlap groups -> best (dist, -len) per group -> sorted by
  * (start, end, dist).  Ties inside a group (the reference breaks them by set iteration order, i.e.
@@ -279,6 +282,16 @@ int fz_debug_order_records_bounded(const void *recs, uint64_t n, uint32_t L, uin
 /* ... and the sharded form: recs = the shards' records one shard after the other (seg_ends[i] = end of shard i), shards
  * owning ascending index ranges; every shard is ordered on its own and the rows are merged block by block. */
 int fz_debug_order_segments(const void *recs, const uint64_t *seg_ends, uint32_t n_segments, uint32_t L, fz_match **out, uint64_t *n_out);
+
+/* Test hook (no device needed): the host half of the exchange step of a collective search (what follows the
+ * ncclAllGather).  `blocks` = `world` blocks of 1024 + cap * 24 bytes, block r = what rank r contributed: 128 64-bit
+ * counters (word 1 = records the rank produced) followed by min(count, cap) device records (see fz_debug_order_records);
+ * own_lo[r] = first hit index rank r owns (NULL: ranks own ascending ranges in rank order), L = n-gram length.
+ * Some rank produced more than `cap` records: *need_cap = the capacity the re-gather uses (every rank computes the same
+ * value from the same headers) and no stream.  Else *need_cap = 0 and *out = the merged stream in the reference's order:
+ * every rank's records ordered by (block, index), then block by block the ranks' runs in ascending order of own_lo. */
+int fz_debug_gather_merge(const void *blocks, uint32_t world, uint64_t cap, const uint64_t *own_lo, uint32_t L, fz_match **out,
+                          uint64_t *n_out, uint64_t *need_cap);
 
 /* Statistics of the search collected last.  The *_ms fields are hipEvent spans read from that search's events by THIS
  * call (and by fz_device_ms), not by the search: they describe it until the next search of the context is launched

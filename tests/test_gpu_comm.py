@@ -49,13 +49,64 @@ def test_collective_search_of_one_rank_equals_the_oracle(comm_engine):
     # wide budget: the slot-per-hit wavefront kernel's records (with empty slots) travel the same way
     p3 = workloads.dna(48, 11).tobytes()
     assert _rows(eng.lev_ngrams(h, p3, 6, as_array=True)) == oracle.lev_ngrams_raw(p3, t, 6)
-    # the other searches of a communicator's context stay local
-    assert _rows(eng.subs_ngrams(h, p, 2, as_array=True)) == oracle.subs_ngrams_raw(p, t, 2)
-    assert eng.search_exact(h, p[:8]) == oracle.search_exact(p[:8], t)
+    assert eng.comm_gather_ms() > 0
     eng.comm_set_collective(False)
     assert eng.comm_info() == (1, 0, False)
     assert _rows(eng.lev_ngrams(h, p, 2, as_array=True)) == exp
     h.release()
+
+
+def test_every_search_kind_is_collective_in_a_communicator(comm_engine):
+    """Round 4: no search of a context that joined a communicator returns a silent local answer.  Substitutions-only
+    n-gram searches travel like the Levenshtein ones (device snapshot + ncclAllGather of records); exact searches (hit
+    indices), generic searches (automaton records / folded pairs), the linear-programming routes and the has_* flags
+    exchange what reached the host (two all-gathers: sizes, payload).  With one rank the merged stream is the rank's
+    own — what is checked here is that every kind goes through its exchange step and comes out in the reference's
+    order; the parsing / merging of 2..8 ranks' blocks is checked on the CPU (tests/test_host_logic.py)."""
+    eng = comm_engine
+    seq = workloads.dna(4 << 20, 78)
+    pattern = workloads.dna(20, 1)
+    workloads.plant_variants(seq, pattern, 256, 5)
+    p, t = pattern.tobytes(), seq.tobytes()
+    h = eng.upload(seq)
+
+    def exchanged():
+        ms = eng.comm_gather_ms()
+        return ms
+
+    want_subs = oracle.subs_ngrams_raw(p, t, 2)
+    g0 = exchanged()
+    assert _rows(eng.subs_ngrams(h, p, 2, as_array=True)) == want_subs and len(want_subs) > 50
+    assert exchanged() != g0
+    g0 = exchanged()
+    assert eng.search_exact(h, p[:8]) == oracle.search_exact(p[:8], t)
+    assert exchanged() != g0
+    gen = oracle.generic_ngrams_raw(p, t, 2, 1, 1, 2)
+    g0 = exchanged()
+    assert eng.generic_ngrams(h, p, 2, 1, 1, 2) == gen and len(gen) > 100
+    assert exchanged() != g0
+    assert [r[:3] for r in eng.generic_ngrams_consolidated(h, p, 2, 1, 1, 2)] == oracle.consolidate(gen)
+    assert eng.generic_ngrams_any(h, p, 2, 1, 1, 2) is True
+    assert eng.subs_ngrams_any(h, p, 2) is True
+    assert eng.subs_ngrams_any(h, b"T" * 20, 1) is False
+    # two in flight, every kind
+    eng.subs_ngrams_begin(h, p, 2)
+    eng.lev_ngrams_begin(h, p, 2)
+    assert eng.search_end() == want_subs and eng.search_end() == oracle.lev_ngrams_raw(p, t, 2)
+    eng.generic_ngrams_begin(h, p, 2, 1, 1, 2)
+    eng.generic_ngrams_begin(h, p, 2, 1, 1, 2, consolidated=True)
+    assert eng.search_end() == gen
+    assert [r[:3] for r in eng.search_end()] == oracle.consolidate(gen)
+    h.release()
+    # the linear-programming routes (short patterns) on a smaller sequence
+    small = t[: 1 << 16]
+    hs = eng.upload(small)
+    ps = p[:5]
+    assert eng.lev_lp(hs, ps, 2) == oracle.lev_lp_raw(ps, small, 2)
+    assert eng.subs_lp(hs, ps, 2) == oracle.subs_lp_raw(ps, small, 2)
+    assert eng.generic_lp(hs, ps, 1, 1, 1, 2) == oracle.generic_lp_raw(ps, small, 1, 1, 1, 2)
+    assert eng.subs_lp_any(hs, ps, 2) is True
+    hs.release()
 
 
 def test_gather_capacity_follows_the_counts(comm_engine):

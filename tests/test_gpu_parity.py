@@ -464,10 +464,15 @@ def test_generic_public_api(engine):
     assert n == 200
 
 
-def test_multi_device_context_on_one_gpu():
+@pytest.mark.parametrize("dev_threads", [True, False])
+def test_multi_device_context_on_one_gpu(dev_threads, monkeypatch):
     """fz_create([0, 0, 0]): three device states on the same GPU exercise the single-process
-    multi-device path (shard + halo + concurrent launches + host merge) end to end."""
+    multi-device path (shard + halo + concurrent launches + host merge) end to end — with one host worker thread per
+    device (round 4: every worker enqueues, collects and orders its own shard, the caller merges the ordered rows)
+    and with the calling thread doing everything (FZ_NO_DEV_THREADS=1)."""
     from fuzzysearch_amd import _native
+    if not dev_threads:
+        monkeypatch.setenv("FZ_NO_DEV_THREADS", "1")
     eng = _native.Engine([0, 0, 0])
     rnd = random.Random(51)
     for n in (0, 5, 100, 5000, 1 << 20):
@@ -497,6 +502,13 @@ def test_multi_device_context_on_one_gpu():
         if n >= 4096:
             p6 = (p + p[:5])[:25]
             assert eng.lev_ngrams(h, p6, 6) == oracle.lev_ngrams_raw(p6, t, 6), n
+            # many records per shard (beyond the pinned staging buffer on the dense one): the copy mode per worker
+            dense = np.frombuffer(b"ACGT" * (n // 4), dtype=np.uint8)
+            hd = eng.upload(dense)
+            pd_ = b"ACGTACGTACGTAC"
+            assert eng.lev_ngrams(hd, pd_, 2) == oracle.lev_ngrams_raw(pd_, dense.tobytes(), 2)
+            assert eng.lev_ngrams(h, p, 2) == oracle.lev_ngrams_raw(p, t, 2), n
+            hd.release()
         h.release()
     assert eng.stats()["n_devices"] == 3
     eng.close()

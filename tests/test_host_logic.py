@@ -507,3 +507,81 @@ def test_sharded_record_ordering_equals_the_global_one():
         whole = call(lib.fz_debug_order_records, recs.ctypes.data, len(recs), 6)
         seg = call(lib.fz_debug_order_segments, recs.ctypes.data, ends_a.ctypes.data, nshards, 6)
         assert np.array_equal(whole, seg), (nshards, per, nblocks)
+
+
+def test_gathered_blocks_parse_regrow_and_merge():
+    """fz_debug_gather_merge = the host half of gather_records (what follows the ncclAllGather of a collective search):
+    2..8 ranks' [counters][records] blocks -> one stream in the reference's order.  Covered: empty ranks, a rank whose
+    count exceeds the capacity (the re-gather decision and its capacity, identical on every rank because it only
+    depends on the gathered headers), ranks that are NOT in ownership order (merged by own_lo), empty record slots,
+    garbage behind a rank's last record."""
+    import ctypes
+    import numpy as np
+    lib = _native.load_library()
+    rec_dt = np.dtype([("key", "<u8"), ("l", "<u4"), ("r", "<u4"), ("dist", "<u4"), ("aux", "<u4")])
+    rng = np.random.default_rng(41)
+    HDR = 1024
+    L = 6
+
+    def run(blocks, world, cap, own_lo):
+        ptr = ctypes.POINTER(_native.FzMatch)()
+        cnt, need = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        lo = None if own_lo is None else np.asarray(own_lo, dtype=np.uint64)
+        _native._check(lib.fz_debug_gather_merge(blocks.ctypes.data, world, cap, None if lo is None else lo.ctypes.data, L,
+                                                 ctypes.byref(ptr), ctypes.byref(cnt), ctypes.byref(need)))
+        if need.value:
+            assert not ptr
+            return None, need.value
+        return _native._take_matches_array(lib, ptr, cnt.value), 0
+
+    def expected(parts):
+        allr = np.concatenate(parts) if parts else np.zeros(0, dtype=rec_dt)
+        allr = allr[allr["dist"] != 0xffffffff]
+        allr = allr[np.argsort(allr["key"], kind="stable")]            # (block << 48 | idx): the reference's order
+        idx = (allr["key"] & np.uint64((1 << 48) - 1)).astype(np.int64)
+        out = np.zeros(len(allr), dtype=_native._match_dtype())
+        out["start"] = idx - allr["l"].astype(np.int64)
+        out["end"] = idx + L + allr["r"].astype(np.int64)
+        out["dist"] = allr["dist"].astype(np.int32)
+        out["block"] = (allr["key"] >> np.uint64(48)).astype(np.int32)
+        return out
+
+    cases = 0
+    for world in (1, 2, 3, 5, 8):
+        for trial in range(12):
+            nblocks = int(rng.integers(1, 9))
+            span = 1 << 30
+            # rank r owns [perm[r] * span, (perm[r] + 1) * span): in rank order for half the trials, shuffled otherwise
+            perm = np.arange(world) if trial % 2 == 0 else rng.permutation(world)
+            counts = [int(rng.integers(0, 3000)) if rng.random() > 0.25 else 0 for _ in range(world)]
+            parts = []
+            for r in range(world):
+                n = counts[r]
+                idx = (int(perm[r]) * span + rng.choice(span, n, replace=False)).astype(np.uint64)
+                key = (rng.integers(0, nblocks, n).astype(np.uint64) << np.uint64(48)) | idx
+                rec = np.zeros(n, dtype=rec_dt)
+                rec["key"] = key[rng.permutation(n)]
+                rec["l"] = rng.integers(0, 4, n); rec["r"] = rng.integers(0, 7, n); rec["dist"] = rng.integers(0, 3, n)
+                if trial % 3 == 1 and n:
+                    rec["dist"][rng.random(n) < 0.15] = 0xffffffff      # slot-per-hit verification: empty slots
+                parts.append(rec)
+            top = max(counts)
+            for cap in sorted({max(1, top // 2), top, top + 17, 4096}):
+                blocks = np.zeros((world, HDR + cap * 24), dtype=np.uint8)
+                for r in range(world):
+                    hdr = blocks[r, :HDR].view("<u8")
+                    hdr[1] = counts[r]
+                    hdr[0] = 12345                                      # other counters are not the parser's business
+                    body = blocks[r, HDR:].view(rec_dt)
+                    body[:] = np.frombuffer(rng.bytes(cap * 24), dtype=rec_dt)   # garbage behind the rank's records
+                    body[:min(cap, counts[r])] = parts[r][:cap]
+                own_lo = [int(perm[r]) * span if counts[r] or trial % 4 else (1 << 64) - 1 for r in range(world)]
+                in_order = bool(np.all(perm == np.arange(world)))
+                got, need = run(blocks, world, cap, own_lo if not in_order or trial % 4 == 2 else None)
+                if top > cap:
+                    assert got is None and need == (top + top // 4 + 1023) // 1024 * 1024 and need >= top, (world, cap, top, need)
+                else:
+                    want = expected(parts)
+                    assert need == 0 and np.array_equal(got, want), (world, trial, cap)
+                cases += 1
+    assert cases > 150
