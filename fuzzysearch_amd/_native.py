@@ -493,7 +493,8 @@ class Engine(object):
         """Scan-kernel hipEvent span of the search collected last, one value per device of the engine."""
         n = len(self.devices)
         out = (ctypes.c_double * n)()
-        rc = self._lib.fz_device_ms(self._h, out, n)
+        with self._lock:                           # resolves the event spans: mutates the context
+            rc = self._lib.fz_device_ms(self._h, out, n)
         if rc < 0:
             _raise(rc)
         return list(out)
@@ -685,14 +686,16 @@ class Engine(object):
 
     def stats(self):
         st = FzStats()
-        _check(self._lib.fz_stats(self._h, ctypes.byref(st)))
+        with self._lock:                           # fz_stats resolves the event spans: it mutates the context
+            _check(self._lib.fz_stats(self._h, ctypes.byref(st)))
         return {f: getattr(st, f) for f, _ in FzStats._fields_}
 
     def kernel_ms(self):
         """(filter_ms, verify_ms, device_ms) of the last call: the cheap subset of stats()."""
-        st = self._st
-        _check(self._lib.fz_stats(self._h, self._st_ref))
-        return st.filter_ms, st.verify_ms, st.device_ms
+        with self._lock:
+            st = self._st
+            _check(self._lib.fz_stats(self._h, self._st_ref))
+            return st.filter_ms, st.verify_ms, st.device_ms
 
 
 _default_engine = None

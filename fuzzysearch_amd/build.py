@@ -39,9 +39,10 @@ def build(force=False, report=False):
     # the library, checked by tests/test_host_logic.py (a kernel that silently starts using scratch memory is a bug)
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wall", "-Wno-unused-function", "-Wno-pass-failed", "-Rpass-analysis=kernel-resource-usage"]
-    # RCCL (the all-gather of match lists, fz_comm_*): linked, not dlopen-ed, so a missing librccl fails at load time
+    # RCCL (the all-gather of match lists, fz_comm_*) is dlopen-ed on first use (fzhip.hip: rccl_api), not linked: the
+    # library loads and searches on an install without librccl; the run path lets that dlopen find ROCm's copy
     rocm_lib = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-L" + rocm_lib, "-lrccl", "-Wl,-rpath," + rocm_lib, "-o", LIB + ".tmp"]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl", "-Wl,-rpath," + rocm_lib, "-o", LIB + ".tmp"]
     res = subprocess.run(cmd, cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     err = res.stderr.decode("utf-8", "replace")
     remarks = [ln for ln in err.splitlines() if "-Rpass-analysis=kernel-resource-usage" in ln]

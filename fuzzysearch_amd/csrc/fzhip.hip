@@ -18,7 +18,8 @@
 // in flight on the sequence.  Buffers that turn out too small are grown and the search re-runs.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>                             // types only: the library is dlopen-ed on first use (rccl_api)
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <atomic>
@@ -1039,10 +1040,66 @@ void parse_gathered(const uint8_t *blocks, int world, uint64_t bytes_per_rank, u
         std::stable_sort(seg_order.begin(), seg_order.end(), [&](uint32_t x, uint32_t y) { return own_lo[x] < own_lo[y]; });
 }
 
+// RCCL is loaded on first use (dlopen), not linked: a single-GPU install without librccl — or with ROCM_PATH pointing
+// somewhere that lacks it — still loads libfzhip.so and searches; only fz_comm_* then return FZ_EUNSUPPORTED.
+struct RcclApi {
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+    bool ok = false;
+};
+
+const RcclApi *rccl_api() {
+    static const RcclApi api = []() {
+        RcclApi a;
+        if (getenv("FZ_NO_RCCL")) { a.error = "disabled by FZ_NO_RCCL"; return a; }      // test knob: an install without librccl
+        std::vector<std::string> names;
+        if (const char *e = getenv("FZ_RCCL_LIB")) names.push_back(e);
+        names.push_back("librccl.so.1");
+        names.push_back("librccl.so");
+        const char *rocm = getenv("ROCM_PATH");
+        names.push_back(std::string(rocm ? rocm : "/opt/rocm") + "/lib/librccl.so.1");
+        void *h = nullptr;
+        for (const std::string &n : names) {
+            h = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+            const char *de = dlerror();
+            a.error += (a.error.empty() ? "" : "; ") + std::string(de ? de : n.c_str());
+        }
+        if (!h) return a;
+        bool all = true;
+        auto sym = [&](const char *name) { void *p = dlsym(h, name); if (!p) { all = false; a.error = std::string("librccl lacks ") + name; } return p; };
+        a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(sym("ncclGetUniqueId"));
+        a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(sym("ncclCommInitRank"));
+        a.CommInitAll = reinterpret_cast<decltype(a.CommInitAll)>(sym("ncclCommInitAll"));
+        a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+        a.AllGather = reinterpret_cast<decltype(a.AllGather)>(sym("ncclAllGather"));
+        a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
+        a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(sym("ncclGroupStart"));
+        a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(sym("ncclGroupEnd"));
+        a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+        a.ok = all;
+        return a;
+    }();
+    return &api;
+}
+
+#define RCCL_NEED()                                                                                \
+    do {                                                                                           \
+        if (!rccl_api()->ok) return fail(FZ_EUNSUPPORTED, "RCCL is not available (%s)", rccl_api()->error.c_str()); \
+    } while (0)
+
 #define NCCL_TRY(expr)                                                                             \
     do {                                                                                           \
         ncclResult_t r_ = (expr);                                                                  \
-        if (r_ != ncclSuccess) return fail(FZ_EDEVICE, "%s failed: %s", #expr, ncclGetErrorString(r_)); \
+        if (r_ != ncclSuccess) return fail(FZ_EDEVICE, "%s failed: %s", #expr, rccl_api()->GetErrorString(r_)); \
     } while (0)
 
 // The exchange step of a sharded search: every rank of the communicator contributes the
@@ -1079,10 +1136,10 @@ int gather_records(fz_ctx *ctx, fz_seq *seq, std::vector<FzRec> &recs) {
             if (has_shard && d.snap_taken[d.slot_id]) HIP_TRY(hipStreamWaitEvent(d.comm_stream, d.ev_snap[d.slot_id], 0));
             else HIP_TRY(hipMemsetAsync(d.d_send[d.slot_id], 0, kHeaderBytes, d.comm_stream));   // this rank holds nothing of the sequence
         }
-        NCCL_TRY(ncclGroupStart());
+        NCCL_TRY(rccl_api()->GroupStart());
         for (DevState &d : ctx->devs)
-            NCCL_TRY(ncclAllGather(d.d_send[d.slot_id], d.d_recv, bytes, ncclChar, d.comm, d.comm_stream));
-        NCCL_TRY(ncclGroupEnd());
+            NCCL_TRY(rccl_api()->AllGather(d.d_send[d.slot_id], d.d_recv, bytes, ncclChar, d.comm, d.comm_stream));
+        NCCL_TRY(rccl_api()->GroupEnd());
         DevState &d0 = ctx->devs[0];
         HIP_TRY(hipSetDevice(d0.device));
         HIP_TRY(hipMemcpyAsync(d0.h_recv, d0.d_recv, (uint64_t)world * bytes, hipMemcpyDeviceToHost, d0.comm_stream));
@@ -1791,14 +1848,21 @@ static void devstate_destroy(DevState &d) {
 // the second lane (generic searches in flight): created on first use, hit lists as large as lane 0's
 static int ensure_lane2(fz_ctx *ctx) {
     if (ctx->devs2.size() != ctx->devs.size()) {
-        ctx->devs2.clear();
-        ctx->devs2.resize(ctx->devs.size());
+        // built aside and only installed once EVERY device initialised: a half-built lane (out of memory part-way) must
+        // not be mistaken for a usable one by the next call
+        std::vector<DevState> lane(ctx->devs.size());
         for (size_t i = 0; i < ctx->devs.size(); ++i) {
-            ctx->devs2[i].device = ctx->devs[i].device;
-            ctx->devs2[i].n_cus = ctx->devs[i].n_cus;
-            int rc = devstate_init(ctx->devs2[i]);
-            if (rc) return rc;
+            lane[i].device = ctx->devs[i].device;
+            lane[i].n_cus = ctx->devs[i].n_cus;
+            int rc = devstate_init(lane[i]);
+            if (rc) {
+                const std::string keep = g_err;
+                for (size_t j = 0; j <= i; ++j) devstate_destroy(lane[j]);
+                g_err = keep;
+                return rc;
+            }
         }
+        ctx->devs2.swap(lane);
     }
     for (size_t i = 0; i < ctx->devs.size(); ++i) {
         int rc = ensure_hits(ctx->devs2[i], ctx->devs[i].hit_cap);
@@ -2129,6 +2193,10 @@ static int generic_plan(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, 
     if (k > FZ_MAX_K) return fail(FZ_EUNSUPPORTED, "max_l_dist above %d is not supported by the verify kernels", FZ_MAX_K);
     const uint32_t L = m / (k + 1);
     if (L == 0) return fail(FZ_EINVAL, "the subsequence length must be greater than max_l_dist");
+    // the automaton's records carry window-relative start / end in 16 bits each: the window (m + 2k bytes) must fit
+    if ((uint64_t)m + 2ull * k > 65535ull)
+        return fail(FZ_EUNSUPPORTED, "generic search: len(subsequence) + 2 * max_l_dist = %llu exceeds 65535 (16-bit window coordinates)",
+                    (unsigned long long)m + 2ull * k);
     rc = check_halo(seq, (uint64_t)m + k);
     if (rc) return rc;
     q.mode = FZ_MODE_GENERIC; q.m = m; q.k = k; q.p = p;
@@ -2462,7 +2530,7 @@ void comm_teardown(fz_ctx *ctx) {
     for (DevState &d : ctx->devs) {
         (void)hipSetDevice(d.device);
         if (d.comm_stream) (void)hipStreamSynchronize(d.comm_stream);
-        if (d.comm) { (void)ncclCommDestroy(d.comm); d.comm = nullptr; }
+        if (d.comm) { if (rccl_api()->ok) (void)rccl_api()->CommDestroy(d.comm); d.comm = nullptr; }
         for (auto &b : d.d_send) if (b) { (void)hipFree(b); b = nullptr; }
         d.send_cap = 0;
         if (d.d_recv) { (void)hipFree(d.d_recv); d.d_recv = nullptr; }
@@ -2496,7 +2564,7 @@ int comm_allgather_fixed(fz_ctx *ctx, const void *send, uint64_t nbytes, void *r
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), (world + 1) * nbytes));
     auto body = [&]() -> int {
         HIP_TRY(hipMemcpyAsync(tmp, send, nbytes, hipMemcpyHostToDevice, d.comm_stream));
-        NCCL_TRY(ncclAllGather(tmp, tmp + nbytes, nbytes, ncclChar, d.comm, d.comm_stream));
+        NCCL_TRY(rccl_api()->AllGather(tmp, tmp + nbytes, nbytes, ncclChar, d.comm, d.comm_stream));
         HIP_TRY(hipMemcpyAsync(recv, tmp + nbytes, world * nbytes, hipMemcpyDeviceToHost, d.comm_stream));
         HIP_TRY(hipStreamSynchronize(d.comm_stream));
         return FZ_OK;
@@ -2571,8 +2639,9 @@ extern "C" {
 int fz_comm_unique_id(void *id, uint64_t id_bytes) {
     static_assert(FZ_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
     if (!id || id_bytes < FZ_COMM_ID_BYTES) return fail(FZ_EINVAL, "the id buffer must hold %d bytes", FZ_COMM_ID_BYTES);
+    RCCL_NEED();
     ncclUniqueId u;
-    NCCL_TRY(ncclGetUniqueId(&u));
+    NCCL_TRY(rccl_api()->GetUniqueId(&u));
     memcpy(id, u.internal, FZ_COMM_ID_BYTES);
     return FZ_OK;
 }
@@ -2583,12 +2652,13 @@ int fz_comm_init_rank(fz_ctx *ctx, const void *id, int world, int rank) {
     if (!id || world < 1 || rank < 0 || rank >= world) return fail(FZ_EINVAL, "bad communicator arguments");
     if (ctx->devs.size() != 1) return fail(FZ_EINVAL, "fz_comm_init_rank needs a single-device context (one process per GPU); use fz_comm_init_all");
     if (ctx->comm_world) return fail(FZ_EINVAL, "the context already joined a communicator");
+    RCCL_NEED();
     DevState &d = ctx->devs[0];
     rc = comm_setup_dev(d);
     if (rc) return rc;
     ncclUniqueId u;
     memcpy(u.internal, id, FZ_COMM_ID_BYTES);
-    NCCL_TRY(ncclCommInitRank(&d.comm, world, u, rank));
+    NCCL_TRY(rccl_api()->CommInitRank(&d.comm, world, u, rank));
     d.comm_rank = rank;
     ctx->comm_world = world;
     ctx->snapshot = true;
@@ -2599,6 +2669,7 @@ int fz_comm_init_all(fz_ctx *ctx) {
     int rc = comm_busy(ctx);
     if (rc) return rc;
     if (ctx->comm_world) return fail(FZ_EINVAL, "the context already joined a communicator");
+    RCCL_NEED();
     const int nd = (int)ctx->devs.size();
     std::vector<int> ids(nd);
     for (int i = 0; i < nd; ++i) {
@@ -2608,7 +2679,7 @@ int fz_comm_init_all(fz_ctx *ctx) {
     }
     for (DevState &d : ctx->devs) { rc = comm_setup_dev(d); if (rc) return rc; }
     std::vector<ncclComm_t> comms(nd, nullptr);
-    NCCL_TRY(ncclCommInitAll(comms.data(), nd, ids.data()));
+    NCCL_TRY(rccl_api()->CommInitAll(comms.data(), nd, ids.data()));
     for (int i = 0; i < nd; ++i) { ctx->devs[i].comm = comms[i]; ctx->devs[i].comm_rank = i; }
     ctx->comm_world = nd;
     ctx->snapshot = true;
@@ -2658,7 +2729,7 @@ int fz_comm_max_f64(fz_ctx *ctx, double *value) {
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), sizeof(double)));
     auto body = [&]() -> int {
         HIP_TRY(hipMemcpyAsync(tmp, value, sizeof(double), hipMemcpyHostToDevice, d.comm_stream));
-        NCCL_TRY(ncclAllReduce(tmp, tmp, 1, ncclDouble, ncclMax, d.comm, d.comm_stream));
+        NCCL_TRY(rccl_api()->AllReduce(tmp, tmp, 1, ncclDouble, ncclMax, d.comm, d.comm_stream));
         HIP_TRY(hipMemcpyAsync(value, tmp, sizeof(double), hipMemcpyDeviceToHost, d.comm_stream));
         HIP_TRY(hipStreamSynchronize(d.comm_stream));
         return FZ_OK;
@@ -2708,6 +2779,10 @@ constexpr uint32_t kLpStarts = 256;      // start positions owned by one window 
 // at most m - 1 + k characters, so tiles are independent; only the tile reaching the sequence end
 // performs the reference's end-of-sequence flush.
 int run_lp(fz_ctx *ctx, fz_seq *seq, const Search &q, uint32_t lp_kind, std::vector<LpRec> &out) {
+    // tile-relative start / end travel in 16 bits each: a tile's window is m + 2k + kLpStarts bytes
+    if ((uint64_t)q.m + 2ull * q.k + kLpStarts > 65535ull)
+        return fail(FZ_EUNSUPPORTED, "linear-programming route: len(subsequence) + 2 * max_l_dist + %u = %llu exceeds 65535 (16-bit window coordinates)",
+                    kLpStarts, (unsigned long long)q.m + 2ull * q.k + kLpStarts);
     memset(&ctx->stats, 0, sizeof ctx->stats); ctx->tref.clear();
     ctx->stats.n_devices = (uint32_t)ctx->devs.size();
     uint32_t cand_cap = 1024;
@@ -3147,6 +3222,8 @@ int fz_stream_open(fz_ctx *ctx, uint32_t mode, const uint8_t *p, uint32_t m, uin
     if (!p || m == 0) return fail(FZ_EINVAL, "subsequence must not be empty");
     if (m > FZ_MAX_M_ANY) return fail(FZ_EUNSUPPORTED, "subsequence longer than %u bytes", FZ_MAX_M_ANY);
     if (mode > FZ_MODE_GENERIC) return fail(FZ_EINVAL, "bad mode");
+    if (mode == FZ_MODE_GENERIC && (uint64_t)m + 2ull * k > 65535ull)
+        return fail(FZ_EUNSUPPORTED, "generic search: len(subsequence) + 2 * max_l_dist exceeds 65535 (16-bit window coordinates)");
     if (k > (mode == FZ_MODE_GENERIC ? (uint32_t)FZ_MAX_K : FZ_MAX_K_ANY)) return fail(FZ_EUNSUPPORTED, "distance limit %u is not supported", k);
     if (seg_stride == 0 || (seg_pre && seg_post)) return fail(FZ_EINVAL, "bad segment geometry");
     // a position may lie in at most two segments, and a chunk must hold a whole pattern window with its reach
@@ -3606,7 +3683,9 @@ int fz_wire_pack(const fz_match *in, uint64_t n, uint64_t cap_rows, void *dst) {
         const int32_t b = in[i].block;
         if (b < 0 || b > 255 || in[i].end < in[i].start || in[i].end - in[i].start > 0xffffffffll || in[i].dist < 0 ||
             in[i].dist > 0xffff)
-            return fail(FZ_EUNSUPPORTED, "record %llu does not fit the wire format", (unsigned long long)i);
+            return fail(FZ_EUNSUPPORTED, "record %llu does not fit the torch glue's wire format (at most 256 n-gram blocks, i.e. max_l_dist "
+                        "< 256, 32-bit lengths, 16-bit distances): use the native collective (fz_comm_*), which has no such limit",
+                        (unsigned long long)i);
         ++h->per_block[b];
         nb = std::max(nb, (uint32_t)b + 1);
         if (i < fit) rows[i] = WireRow{in[i].start, (uint32_t)(in[i].end - in[i].start), (uint16_t)in[i].dist, (uint16_t)b};

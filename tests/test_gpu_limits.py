@@ -167,9 +167,43 @@ def test_refusals_through_the_c_abi(engine):
         engine.lev_ngrams(h, t[:40000], 1024)                    # budget above 1023
     with pytest.raises(_native.UnsupportedSearch):
         engine.generic_ngrams(h, t[:1000], 256, 256, 256, 256)   # the automaton's counters are 8 bits wide
+    # the automaton's records carry window-relative coordinates in 16 bits: m + 2k (generic n-gram route) and
+    # m + 2k + 256 (linear-programming tiles) must fit, else the search is refused (round 3 silently wrapped)
+    with pytest.raises(_native.UnsupportedSearch):
+        engine.generic_ngrams(h, t[:65500], 20, 20, 20, 20)
+    with pytest.raises(_native.UnsupportedSearch):
+        engine.generic_ngrams_consolidated(h, t[:65500], 20, 20, 20, 20)
+    with pytest.raises(_native.UnsupportedSearch):
+        engine.generic_ngrams_any(h, t[:65500], 20, 20, 20, 20)
+    with pytest.raises(_native.UnsupportedSearch):
+        engine.lev_lp(h, t[:65300], 2)
+    with pytest.raises(_native.UnsupportedSearch):
+        engine.generic_lp(h, t[:65300], 2, 2, 2, 2)
     with pytest.raises(ValueError):
         engine.lev_ngrams(h, t[:5], 5)                           # n-gram length 0 (levenshtein_ngram.py:164-165)
     assert engine.lev_ngrams(h, t[:65535], 2)[0][:3] == (0, 65535, 0)
+    h.release()
+
+
+def test_generic_route_at_the_16_bit_window_limit(engine):
+    """m + 2k = 65 408 <= 65 535: the largest windows the generic n-gram route accepts; start / end offsets close to 2^16."""
+    rnd = random.Random(79)
+    alpha = bytes(rnd.sample(range(1, 256), 4))
+    m = 65400
+    p = bytes(rnd.choices(alpha, k=m))
+    t = bytearray(rnd.choices(alpha, k=3 * m))
+    v = bytearray(p)
+    v[100] = next(c for c in alpha if c != v[100])               # one substitution near the start
+    del v[40000]                                                 # one deletion
+    v.insert(65000, alpha[0])                                    # one insertion near the end
+    t[70000:70000 + len(v)] = v
+    t = bytes(t)
+    h = engine.upload(t)
+    limits = (3, 2, 2, 4)
+    exp = oracle.generic_ngrams_raw(p, t, *limits)
+    assert engine.generic_ngrams(h, p, *limits) == exp and len(exp) > 0
+    assert max(e - s for (s, e, _d, _g) in exp) > 65000
+    assert [r[:3] for r in engine.generic_ngrams_consolidated(h, p, *limits)] == oracle.consolidate(exp)
     h.release()
 
 

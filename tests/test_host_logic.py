@@ -585,3 +585,24 @@ def test_gathered_blocks_parse_regrow_and_merge():
                     assert need == 0 and np.array_equal(got, want), (world, trial, cap)
                 cases += 1
     assert cases > 150
+
+
+def test_rccl_is_loaded_lazily_and_its_absence_only_disables_the_collectives():
+    """libfzhip.so does not link librccl (an install without RCCL must still load and search); fz_comm_* dlopen it on first
+    use and return FZ_EUNSUPPORTED when it cannot be had (FZ_NO_RCCL=1 stands in for a missing library)."""
+    import os
+    import subprocess
+    import sys
+    out = subprocess.run(["ldd", _native.LIB_PATH], capture_output=True, text=True)
+    assert out.returncode == 0 and "librccl" not in out.stdout and "libamdhip64" in out.stdout
+    code = ("import ctypes\n"
+            "from fuzzysearch_amd import _native\n"
+            "L = _native.load_library()\n"
+            "buf = ctypes.create_string_buffer(128)\n"
+            "rc = L.fz_comm_unique_id(buf, 128)\n"
+            "print(rc, L.fz_last_error().decode())\n")
+    env = dict(os.environ, FZ_NO_RCCL="1")
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert res.returncode == 0, res.stderr
+    assert res.stdout.startswith("%d RCCL is not available" % _native.FZ_EUNSUPPORTED), res.stdout
