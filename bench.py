@@ -116,6 +116,8 @@ def cpu_baseline(seq, pattern, k, sample_mib, one_core_mib=1024):
         out["all_cores"] = {"error": repr(exc), "cores": cores}
     finally:
         _CPU_SHARD.clear()
+    out["_rows"] = [tuple(r[:3]) for r in res1]          # (popped by the caller: compared with the GPU stream, not printed)
+    out["_rows_bytes"] = n1
     return out
 
 
@@ -291,7 +293,7 @@ def main_multi_device(args):
         sample, _pat, _pl = workloads.cfg2(min(shard_bytes, 1 << 30), 1024)
         cpu = cpu_baseline(sample, pattern, k, args.cpu_sample_mib)
         cpu["sample"] += " (the first GiB of a shard's workload)"
-        del sample
+        cpu_rows, cpu_rows_bytes = cpu.pop("_rows"), cpu.pop("_rows_bytes")
 
     from fuzzysearch_amd import _native
     lib = _native.load_library()
@@ -305,6 +307,14 @@ def main_multi_device(args):
     collective = distinct and os.environ.get("FZ_BENCH_NO_COLLECTIVE") != "1"
     engine = _native.Engine(devices)
     ref_engine = _native.Engine([devices[0]])                    # one shard alone on the first device: the like-for-like 1-GPU figure
+    if cpu is not None:
+        # the CPU leg and the GPU agree row by row on the CPU leg's sample (ordered raw streams), before anything is timed
+        hs = ref_engine.upload(sample[:cpu_rows_bytes])
+        gpu_rows = [tuple(int(x) for x in r)[:3] for r in ref_engine.lev_ngrams(hs, p, k, as_array=True).tolist()]
+        assert gpu_rows == cpu_rows, "the CPU baseline and the GPU returned different raw streams on the CPU leg's sample"
+        cpu["rows_equal_gpu"] = len(cpu_rows)
+        hs.release()
+        del sample, cpu_rows, gpu_rows
     t_build = time.perf_counter()
     fill, edge_plants = workloads.cfg5_fill(shard_bytes, N, pattern, k)
     handle = engine.new_sequence(global_n)
@@ -483,6 +493,8 @@ def main():
         # forks: before the HIP runtime exists.  N > 1: rank 0 times the first GiB of its shard while the other ranks
         # wait for the communicator's unique id (the timed region starts behind a barrier)
         cpu = cpu_baseline(seq[:1 << 30] if world > 1 else seq, pattern, k, args.cpu_sample_mib)
+    cpu_rows = cpu.pop("_rows") if cpu else None
+    cpu_rows_bytes = cpu.pop("_rows_bytes") if cpu else 0
 
     engine = _native.Engine([fzd.local_device(local_rank) if use_dist else local_rank])
     if use_dist and not use_torch:
@@ -515,6 +527,14 @@ def main():
         # C-ABI's fz_match array; no per-record Python objects inside the timed region)
         return finish(engine.lev_ngrams(handle, p, k, as_array=True))
 
+    if cpu_rows is not None and not use_dist and cpu_rows_bytes == len(seq):
+        # the CPU leg (the reference's natives on the whole input) and the GPU agree row by row — ordered raw streams,
+        # not just counts — before anything is timed
+        gpu_rows = [tuple(int(x) for x in r)[:3] for r in engine.lev_ngrams(handle, p, k, as_array=True).tolist()]
+        assert gpu_rows == cpu_rows, "the CPU baseline and the GPU returned different raw streams"
+        cpu["rows_equal_gpu"] = len(cpu_rows)
+        del gpu_rows
+    cpu_rows = None
     # setup self-check + clock settle (untimed): repeated searches must return the identical stream
     t_settle = time.perf_counter()
     first = step()
