@@ -155,9 +155,32 @@ def time_pipelined(engine, handle, p, k, reps, want):
     return dt * 1e3
 
 
+def time_api(fn, reps, warm_s=0.2):
+    """Mean ms of a public-API call (find_near_matches on a resident sequence: search + consolidation + Match objects)."""
+    t_end = time.perf_counter() + warm_s
+    res = fn()
+    while time.perf_counter() < t_end:
+        res = fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = fn()
+    return (time.perf_counter() - t0) / reps * 1e3, res
+
+
+def api_block(fa, engine, seq, kwargs, pattern, c_abi_ms, reps):
+    """find_near_matches(pattern, resident(bytes), **kwargs) next to the C-ABI call it wraps: the sequence handed over as
+    `bytes`, as the reference is called (Match.matched slices are bytes objects)."""
+    data = seq.tobytes()
+    res = fa.resident(data, engine=engine)
+    ms, out = time_api(lambda: fa.find_near_matches(pattern, res, **kwargs), reps)
+    res.release()
+    return {"find_near_matches_ms": round(ms, 4), "api_over_c_abi": round(ms / c_abi_ms, 3), "api_matches": len(out)}
+
+
 def extra_blocks(engine, workloads, reps):
     """Driver-visible numbers for the north-star target (4 GiB DNA) and the other BASELINE configs, measured
     in the same run as the headline (N = 1 only): C-ABI GB/s, kernel ms, raw match counts."""
+    import fuzzysearch_amd as fa
     out = {}
     pattern = workloads.dna(20, 1)
     p = pattern.tobytes()
@@ -187,6 +210,8 @@ def extra_blocks(engine, workloads, reps):
     h.release()
     cfgs["configs[2] ASCII m=32 subs<=3 (substitutions_only)"] = {
         "ms_per_call": round(ms, 4), "GB_per_s": round(gib / ms / 1e6, 1), "scan_kernel_ms": round(f_ms, 4), "raw_matches": int(len(res))}
+    cfgs["configs[2] ASCII m=32 subs<=3 (substitutions_only)"].update(
+        api_block(fa, engine, seq, dict(max_substitutions=3, max_insertions=0, max_deletions=0), p2, ms, reps))
     seq, pat, _ = workloads.cfg4(gib, 1024)
     p3 = pat.tobytes()
     h = engine.upload(seq)
@@ -197,6 +222,8 @@ def extra_blocks(engine, workloads, reps):
         "two_in_flight_ms_per_call": round(pipe_ms, 4), "two_in_flight_GB_per_s": round(gib / pipe_ms / 1e6, 1),
         "scan_kernel_ms": round(f_ms, 4),
         "verify_kernel_ms": round(v_ms, 4), "raw_matches": int(len(res))}
+    cfgs["configs[3a] UTF-8 m=64 max_l_dist=5 (levenshtein_ngram, wavefront verify)"].update(
+        api_block(fa, engine, seq, dict(max_l_dist=5), p3, ms, reps))
     ms, f_ms, v_ms, res = time_call(engine, lambda: engine.generic_ngrams(h, p3, 5, 2, 2, 5, as_array=True), max(20, reps // 4))
     cms, _f, cv_ms, cres = time_call(engine, lambda: engine.generic_ngrams_consolidated(h, p3, 5, 2, 2, 5, as_array=True), max(20, reps // 4))
     # two generic searches in flight (two lanes: the scan of one next to the automaton kernel of the other)
@@ -213,6 +240,7 @@ def extra_blocks(engine, workloads, reps):
     glast = engine.search_end(as_array=True)
     assert np.array_equal(graw, res) and np.array_equal(glast, res), "pipelined generic search returned a different stream"
     h.release()
+    api3b = api_block(fa, engine, seq, dict(max_substitutions=5, max_insertions=2, max_deletions=2, max_l_dist=5), p3, ms, max(20, reps // 4))
     cfgs["configs[3b] UTF-8 m=64 limits (5,2,2,5) (generic_search)"] = {
         "ms_per_call": round(ms, 4), "GB_per_s": round(gib / ms / 1e6, 1), "scan_kernel_ms": round(f_ms, 4),
         "automaton_kernel_ms": round(v_ms, 4), "raw_matches": int(len(res)),
@@ -220,6 +248,17 @@ def extra_blocks(engine, workloads, reps):
         "consolidated_ms_per_call": round(cms, 4), "consolidated_GB_per_s": round(gib / cms / 1e6, 1),
         "consolidated_automaton_kernel_ms": round(cv_ms, 4), "consolidated_matches": int(len(cres)),
         "note": "consolidated = fz_generic_ngrams_consolidated: search + consolidate_overlapping_matches, first stage on the device"}
+    cfgs["configs[3b] UTF-8 m=64 limits (5,2,2,5) (generic_search)"].update(api3b)
+    # configs[1] through the public API (the headline workload): find_near_matches on a resident bytes sequence
+    seq, pat, _ = workloads.cfg2(gib, 1024)
+    p1 = pat.tobytes()
+    h = engine.upload(seq)
+    ms, f_ms, v_ms, res = time_call(engine, lambda: engine.lev_ngrams(h, p1, 2, as_array=True), reps)
+    h.release()
+    cfgs["configs[1] DNA m=20 max_l_dist=2 (levenshtein_ngram) through find_near_matches"] = {
+        "ms_per_call": round(ms, 4), "GB_per_s": round(gib / ms / 1e6, 1), "scan_kernel_ms": round(f_ms, 4), "raw_matches": int(len(res))}
+    cfgs["configs[1] DNA m=20 max_l_dist=2 (levenshtein_ngram) through find_near_matches"].update(
+        api_block(fa, engine, seq, dict(max_l_dist=2), p1, ms, reps))
     out["configs"] = cfgs
     return out
 

@@ -21,6 +21,7 @@ EXPORTED_SYMBOLS = (
     "fz_search_exact", "fz_lev_ngrams", "fz_lev_ngrams_begin", "fz_lev_ngrams_end", "fz_subs_ngrams", "fz_generic_ngrams",
     "fz_subs_ngrams_begin", "fz_generic_ngrams_begin", "fz_search_end",
     "fz_lev_lp", "fz_subs_lp", "fz_generic_lp", "fz_subs_ngrams_any", "fz_subs_lp_any", "fz_generic_ngrams_any", "fz_generic_ngrams_consolidated",
+    "fz_lev_ngrams_consolidated", "fz_subs_ngrams_best",
     "fz_stream_open", "fz_stream_buffer", "fz_stream_submit", "fz_stream_read_fd", "fz_stream_finish", "fz_stream_close",
     "fz_consolidate", "fz_group_best", "fz_merge_ranks", "fz_wire_pack", "fz_wire_merge", "fz_debug_launch_plan", "fz_debug_order_records", "fz_debug_order_records_bounded", "fz_debug_order_segments", "fz_stats", "fz_set_timing", "fz_device_ms", "fz_free",
     "fz_comm_unique_id", "fz_comm_init_rank", "fz_comm_init_all", "fz_comm_info", "fz_comm_set_collective",
@@ -133,6 +134,10 @@ def load_library():
         L.fz_subs_lp.argtypes = [vp, vp, u8p, u32, u32, mpp, u64p]
         L.fz_generic_lp.restype = ci
         L.fz_generic_lp.argtypes = [vp, vp, u8p, u32, u32, u32, u32, u32, mpp, u64p]
+        L.fz_lev_ngrams_consolidated.restype = ci
+        L.fz_lev_ngrams_consolidated.argtypes = [vp, vp, u8p, u32, u32, mpp, u64p]
+        L.fz_subs_ngrams_best.restype = ci
+        L.fz_subs_ngrams_best.argtypes = [vp, vp, u8p, u32, u32, mpp, u64p]
         L.fz_generic_ngrams_consolidated.restype = ci
         L.fz_generic_ngrams_consolidated.argtypes = [vp, vp, u8p, u32, u32, u32, u32, u32, mpp, u64p]
         L.fz_subs_ngrams_any.restype = ci
@@ -332,6 +337,33 @@ def consolidate(raw):
 
 def group_best(raw):
     return group_best_array(raw).tolist()
+
+
+class OwnedRows(object):
+    """A C-ABI result buffer (fz_match rows) that has not been copied anywhere: address, n, and fz_free on release."""
+    __slots__ = ('_lib', '_ptr', 'n')
+
+    def __init__(self, lib, ptr, n):
+        self._lib, self._ptr, self.n = lib, ptr, n
+
+    @property
+    def address(self):
+        return ctypes.cast(self._ptr, ctypes.c_void_p).value or 0
+
+    def to_array(self):
+        ptr, self._ptr = self._ptr, None
+        return _take_matches_array(self._lib, ptr, self.n)
+
+    def release(self):
+        ptr, self._ptr = self._ptr, None
+        if ptr is not None:
+            self._lib.fz_free(ptr)
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
 
 
 class FileStream(object):
@@ -592,6 +624,27 @@ class Engine(object):
         if kw.get("as_array"):
             return _take_matches_array(self._lib, ptr, cnt.value)
         return _take_matches(self._lib, ptr, cnt.value)
+
+    def rows_call(self, fn, seq, pattern, *ints):
+        """One C-ABI search -> OwnedRows: the library's result buffer itself (address + row count), for callers that turn
+        the rows into Match objects in C (common.matches_from_rows) — no numpy array, no second copy."""
+        if type(pattern) is bytes:
+            paddr, m, keep = pattern, len(pattern), None
+        else:
+            paddr, m, keep = _buffer_address(pattern)
+        ptr = ctypes.POINTER(FzMatch)()
+        cnt = ctypes.c_uint64(0)
+        with self._lock:
+            _check(fn(self._h, seq._h, paddr, m, *ints, ctypes.byref(ptr), ctypes.byref(cnt)))
+        return OwnedRows(self._lib, ptr, cnt.value)
+
+    def lev_ngrams_consolidated(self, seq, pattern, k, as_array=False):
+        """consolidate_overlapping_matches(find_near_matches_levenshtein_ngrams(...)) in one call (fz_lev_ngrams_consolidated)."""
+        return self._match_call(self._lib.fz_lev_ngrams_consolidated, seq, pattern, k, as_array=as_array)
+
+    def subs_ngrams_best(self, seq, pattern, k, as_array=False):
+        """Best match of every overlap group of the substitutions-only n-gram stream, group-list order (fz_subs_ngrams_best)."""
+        return self._match_call(self._lib.fz_subs_ngrams_best, seq, pattern, k, as_array=as_array)
 
     def lev_ngrams(self, seq, pattern, k, as_array=False):
         """Raw stream of find_near_matches_levenshtein_ngrams: list of (start, end, dist, block)

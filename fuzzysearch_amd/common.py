@@ -17,7 +17,7 @@ import attr
 from . import _native
 
 __all__ = [
-    'Match', 'RawMatches', 'LevenshteinSearchParams', 'FuzzySearchBase',
+    'Match', 'RawMatches', 'matches_from_rows', 'LevenshteinSearchParams', 'FuzzySearchBase',
     'group_matches', 'get_best_match_in_group', 'consolidate_overlapping_matches',
     'count_differences_with_maximum',
 ]
@@ -176,6 +176,19 @@ class RawMatches(object):
 
     def __repr__(self):
         return 'RawMatches(%r)' % (self.materialize(),)
+
+
+def matches_from_rows(rows, sequence):
+    """_native.OwnedRows (the result buffer of a C-ABI call) -> list of Match over `sequence`, built in C straight from
+    the buffer (csrc/_fzmatch.c: make_matches_at); the buffer is released.  Falls back to the array path without the
+    extension."""
+    try:
+        if _fzmatch is not None and hasattr(_fzmatch, 'make_matches_at'):
+            return _fzmatch.make_matches_at(Match, rows.address, rows.n, sequence, 0, Match.start, Match.end, Match.dist,
+                                            Match.matched)
+        return RawMatches(rows.to_array(), sequence).materialize()
+    finally:
+        rows.release()
 
 
 def _rows_of(matches):

@@ -2168,6 +2168,20 @@ int fz_lev_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32
     return rc;
 }
 
+// find_near_matches_levenshtein_ngrams + consolidate_overlapping_matches in one call (what LevenshteinSearch.search followed
+// by consolidate_matches computes): no second call, no array round trip through the caller in between.
+int fz_lev_ngrams_consolidated(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, fz_match **out, uint64_t *n) {
+    if (!out || !n) return fail(FZ_EINVAL, "null argument");
+    *out = nullptr; *n = 0;
+    fz_match *raw = nullptr;
+    uint64_t nraw = 0;
+    int rc = fz_lev_ngrams(ctx, seq, p, m, k, &raw, &nraw);
+    if (rc) return rc;
+    rc = fz_consolidate(raw, nraw, out, n);
+    release_out(raw);
+    return rc;
+}
+
 // Argument checks and the block plan of the substitutions-only n-gram search (template :92-101).
 static int subs_plan(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, Search &q, bool in_pipeline = false) {
     int rc = validate(ctx, seq, p, m, in_pipeline);
@@ -2363,6 +2377,20 @@ int fz_subs_ngrams(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint3
     if (!out || !n) return fail(FZ_EINVAL, "null argument");
     *out = nullptr; *n = 0;
     return subs_ngrams_impl(ctx, seq, p, m, k, out, n, nullptr);
+}
+
+// The substitutions-only n-gram search as the reference's wrapper returns it for bytes-like input (substitutions_only.py:
+// 258-282): the best match of every overlap group in group-list order — fz_group_best of fz_subs_ngrams in one call.
+int fz_subs_ngrams_best(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, fz_match **out, uint64_t *n) {
+    if (!out || !n) return fail(FZ_EINVAL, "null argument");
+    *out = nullptr; *n = 0;
+    fz_match *raw = nullptr;
+    uint64_t nraw = 0;
+    int rc = subs_ngrams_impl(ctx, seq, p, m, k, &raw, &nraw, nullptr);
+    if (rc) return rc;
+    rc = fz_group_best(raw, nraw, out, n);
+    release_out(raw);
+    return rc;
 }
 
 int fz_subs_ngrams_any(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, int *found) {
@@ -3776,9 +3804,146 @@ int fz_debug_launch_plan(const uint8_t *p, uint32_t m, uint32_t L, uint32_t *out
 // zero-length group is a point that is never strictly inside another hull), so the groups are kept ordered by
 // (hull start, hull end) and the groups a match overlaps are a contiguous run found by one search; the list
 // position of a group is a sequence number handed out on creation and on merges.
+static int group_best_exact(const fz_match *in, uint64_t n, fz_match **out, uint64_t *n_out);
+
+// Fast form for what the searches produce (round 4: the std::map walk below cost 0.39 ms on the 2.8e3 rows of configs[2],
+// more than the search it follows): thousands of matches in a few hundred to a few thousand SMALL groups.  The partition
+// into groups is order independent (connected components of the overlap relation: sort + sweep, as fz_consolidate);
+// what depends on the input order is only WHERE in the list a group ends up, and that is decided inside the group: a
+// group's position is the moment (input index) of the last event that gave it a new list entry — its creation, or the
+// last merge of two or more groups into one (the union is appended at the end, common.py:169-175); extensions in place
+// keep the entry.  So every component replays its own members in input order on a handful of sub-groups, and the
+// components are emitted in the order of those moments.  Components with many members (dense repeats) or anything the
+// sweep and the replay disagree on take the exact walk.
 int fz_group_best(const fz_match *in, uint64_t n, fz_match **out, uint64_t *n_out) {
     if (!out || !n_out || (!in && n)) return fail(FZ_EINVAL, "null argument");
     *out = nullptr; *n_out = 0;
+    static const bool no_fast = getenv("FZ_GROUP_BEST_EXACT") != nullptr;      // test knob
+    if (n < 32 || n > 0x7fffffffull || no_fast) return group_best_exact(in, n, out, n_out);
+    auto better = [](const fz_match &a, const fz_match &b) {
+        const int64_t la = a.end - a.start, lb = b.end - b.start;
+        return a.dist < b.dist || (a.dist == b.dist && (la > lb || (la == lb && a.start < b.start)));
+    };
+    static thread_local std::vector<uint32_t> order, cnt, comp, first, members, slot;
+    // (1) sweep order = (start, zero-length first, input order): one counting pass over ~n slices of the start range,
+    //     then the few crowded slices are fixed (as consolidate_hulls does)
+    order.resize(n);
+    int64_t smin = in[0].start, smax = smin;
+    for (uint64_t i = 0; i < n; ++i) { smin = std::min(smin, in[i].start); smax = std::max(smax, in[i].start); }
+    uint64_t nb = 1;
+    while (nb < n && nb < (1u << 24)) nb <<= 1;
+    const uint64_t range = (uint64_t)(smax - smin);
+    int shift = 0;
+    while ((range >> shift) >= nb) ++shift;
+    cnt.assign(nb + 1, 0u);
+    for (uint64_t i = 0; i < n; ++i) ++cnt[(((uint64_t)(in[i].start - smin)) >> shift) + 1];
+    for (uint64_t b = 1; b <= nb; ++b) cnt[b] += cnt[b - 1];
+    for (uint64_t i = 0; i < n; ++i) order[cnt[((uint64_t)(in[i].start - smin)) >> shift]++] = (uint32_t)i;
+    auto before = [&](uint32_t x, uint32_t y) {
+        const fz_match &a = in[x], &b = in[y];
+        if (a.start != b.start) return a.start < b.start;
+        const bool pa = a.end == a.start, pb = b.end == b.start;
+        if (pa != pb) return pa;
+        return x < y;
+    };
+    // (2) components
+    comp.resize(n);
+    uint32_t ncomp = 0, lo = 0, biggest = 0, cur = 0;
+    int64_t h0 = 0, h1 = 0;
+    for (uint64_t b = 0; b < nb; ++b) {
+        const uint32_t hi = cnt[b];
+        if (hi - lo > 1) {
+            if (hi - lo > 24) std::sort(order.begin() + lo, order.begin() + hi, before);
+            else
+                for (uint32_t i = lo + 1; i < hi; ++i) {
+                    const uint32_t v = order[i];
+                    uint32_t j = i;
+                    while (j > lo && before(v, order[j - 1])) { order[j] = order[j - 1]; --j; }
+                    order[j] = v;
+                }
+        }
+        for (uint32_t vi = lo; vi < hi; ++vi) {
+            const fz_match &mt = in[order[vi]];
+            if (ncomp && !(mt.end <= h0 || mt.start >= h1)) {
+                h0 = std::min(h0, mt.start);
+                h1 = std::max(h1, mt.end);
+                biggest = std::max(biggest, ++cur);
+            } else {
+                h0 = mt.start; h1 = mt.end;
+                ++ncomp;
+                cur = 1;
+            }
+            comp[order[vi]] = ncomp - 1;
+        }
+        lo = hi;
+    }
+    if (biggest > 256) return group_best_exact(in, n, out, n_out);
+    // (3) members of every component in input order
+    first.assign((size_t)ncomp + 1, 0u);
+    for (uint64_t i = 0; i < n; ++i) ++first[comp[i] + 1];
+    for (uint32_t c = 0; c < ncomp; ++c) first[c + 1] += first[c];
+    members.resize(n);
+    {
+        static thread_local std::vector<uint32_t> fill;
+        fill.assign(first.begin(), first.end() - 1);
+        for (uint64_t i = 0; i < n; ++i) members[fill[comp[i]]++] = (uint32_t)i;
+    }
+    // (4) replay every component; slot[moment] = component + 1
+    slot.assign(n, 0u);
+    struct Sub { int64_t s, e; uint32_t when; };
+    Sub subs[260];
+    for (uint32_t c = 0; c < ncomp; ++c) {
+        const uint32_t b0 = first[c], b1 = first[c + 1];
+        if (b1 - b0 == 1) { slot[members[b0]] = c + 1; continue; }
+        uint32_t ns = 0;
+        for (uint32_t q = b0; q < b1; ++q) {
+            const uint32_t i = members[q];
+            const fz_match &mt = in[i];
+            uint32_t nov = 0, firstov = 0;
+            for (uint32_t g = 0; g < ns; ++g)
+                if (!(mt.end <= subs[g].s || mt.start >= subs[g].e)) { if (!nov) firstov = g; ++nov; }
+            if (nov == 0) {
+                subs[ns++] = Sub{mt.start, mt.end, i};
+            } else if (nov == 1) {
+                subs[firstov].s = std::min(subs[firstov].s, mt.start);
+                subs[firstov].e = std::max(subs[firstov].e, mt.end);
+            } else {
+                Sub u{mt.start, mt.end, i};
+                uint32_t w = 0;
+                for (uint32_t g = 0; g < ns; ++g) {
+                    if (!(mt.end <= subs[g].s || mt.start >= subs[g].e)) {
+                        u.s = std::min(u.s, subs[g].s);
+                        u.e = std::max(u.e, subs[g].e);
+                    } else {
+                        subs[w++] = subs[g];
+                    }
+                }
+                subs[w++] = u;
+                ns = w;
+            }
+        }
+        if (ns != 1) return group_best_exact(in, n, out, n_out);     // the sweep saw one component, the replay did not
+        slot[subs[0].when] = c + 1;
+    }
+    void *mem = nullptr;
+    int rc = alloc_out(ncomp, sizeof(fz_match), &mem);
+    if (rc) return rc;
+    fz_match *o = static_cast<fz_match *>(mem);
+    uint64_t w = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (!slot[i]) continue;
+        const uint32_t c = slot[i] - 1;
+        fz_match best = in[members[first[c]]];
+        for (uint32_t q = first[c] + 1; q < first[c + 1]; ++q)
+            if (better(in[members[q]], best)) best = in[members[q]];
+        o[w++] = best;
+    }
+    *out = o;
+    *n_out = w;
+    return FZ_OK;
+}
+
+static int group_best_exact(const fz_match *in, uint64_t n, fz_match **out, uint64_t *n_out) {
     struct Key {
         int64_t s, e; uint64_t seq;
         bool operator<(const Key &o) const { return s != o.s ? s < o.s : (e != o.e ? e < o.e : seq < o.seq); }

@@ -2,7 +2,7 @@
 
 Mirrors src/fuzzysearch/generic_search.py:25-54, :198-237, :256-273.
 """
-from .common import FuzzySearchBase, Match, RawMatches, consolidate_overlapping_matches
+from .common import FuzzySearchBase, Match, RawMatches, consolidate_overlapping_matches, matches_from_rows
 from .engine import prepare
 from .search_exact import exact_raw
 
@@ -100,10 +100,11 @@ class GenericSearch(FuzzySearchBase):
             return None
         pr = prepare(subsequence, sequence)
         try:
-            rows = pr.engine.generic_ngrams_consolidated(pr.handle, pr.pattern, max_subs, max_ins, max_dels, max_l, as_array=True)
+            rows = pr.engine.rows_call(pr.engine._lib.fz_generic_ngrams_consolidated, pr.handle, pr.pattern, max_subs, max_ins,
+                                       max_dels, max_l)
         finally:
             pr.release()
-        return RawMatches(rows, pr.original).materialize()
+        return matches_from_rows(rows, pr.original)
 
     @classmethod
     def consolidate_matches(cls, matches):

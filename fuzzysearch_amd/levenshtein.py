@@ -1,5 +1,5 @@
 """Levenshtein search dispatcher (mirrors src/fuzzysearch/levenshtein.py:9-38, :151-164)."""
-from .common import FuzzySearchBase, Match, RawMatches, consolidate_overlapping_matches
+from .common import FuzzySearchBase, Match, RawMatches, consolidate_overlapping_matches, matches_from_rows
 from .engine import prepare
 from .levenshtein_ngram import raw_levenshtein_ngrams
 from .search_exact import exact_raw
@@ -47,6 +47,23 @@ class LevenshteinSearch(FuzzySearchBase):
     @classmethod
     def search(cls, subsequence, sequence, search_params):
         return raw_levenshtein(subsequence, sequence, search_params.max_l_dist)
+
+    @classmethod
+    def search_consolidated(cls, subsequence, sequence, search_params):
+        """search() + consolidate_matches() in ONE C-ABI call for the n-gram route (fz_lev_ngrams_consolidated: the
+        consolidation runs on the rows where they are) and Match objects built in C straight from the result buffer.
+        -> list of Match, or None when the call takes another route (exact, linear programming)."""
+        if not len(subsequence):
+            raise ValueError('Given subsequence is empty!')
+        k = search_params.max_l_dist
+        if k == 0 or len(subsequence) // (k + 1) < 3:
+            return None
+        pr = prepare(subsequence, sequence)
+        try:
+            rows = pr.engine.rows_call(pr.engine._lib.fz_lev_ngrams_consolidated, pr.handle, pr.pattern, k)
+        finally:
+            pr.release()
+        return matches_from_rows(rows, pr.original)
 
     @classmethod
     def consolidate_matches(cls, matches):

@@ -5,8 +5,8 @@ group in group-creation order (C path + group_matches, :258-282); for ``str`` it
 Hamming <= k window sorted by start (pure-Python path, :160-167).  Both are reproduced from the
 same GPU raw stream (fz_subs_ngrams).
 """
-from .common import FuzzySearchBase, Match, RawMatches, best_of_groups_in_discovery_order
-from .engine import prepare
+from .common import FuzzySearchBase, Match, RawMatches, best_of_groups_in_discovery_order, matches_from_rows
+from .engine import DeviceSequence, is_byteslike, prepare
 from .search_exact import exact_raw, search_exact
 
 __all__ = ['find_near_matches_substitutions', 'find_near_matches_substitutions_ngrams',
@@ -116,6 +116,28 @@ class SubstitutionsOnlySearch(FuzzySearchBase):
     def search(cls, subsequence, sequence, search_params):
         k = min(x for x in (search_params.max_l_dist, search_params.max_substitutions) if x is not None)
         return find_near_matches_substitutions(subsequence, sequence, k)
+
+    @classmethod
+    def search_consolidated(cls, subsequence, sequence, search_params):
+        """The n-gram route on bytes-like input in ONE C-ABI call (fz_subs_ngrams_best: search + best of every overlap
+        group in group-list order, substitutions_only.py:258-282), Match objects built in C straight from the result
+        buffer.  -> list of Match, or None for every other route (str input: every window sorted by start; exact;
+        linear programming; n-gram length 0)."""
+        k = min(x for x in (search_params.max_l_dist, search_params.max_substitutions) if x is not None)
+        _check_arguments(subsequence, sequence, k)
+        if k == 0 or len(subsequence) // (k + 1) < 3:
+            return None
+        if isinstance(sequence, DeviceSequence):
+            if not sequence.byteslike:
+                return None
+        elif not (is_byteslike(sequence) and is_byteslike(subsequence)):
+            return None                                    # (decided before anything is uploaded)
+        pr = prepare(subsequence, sequence)
+        try:
+            rows = pr.engine.rows_call(pr.engine._lib.fz_subs_ngrams_best, pr.handle, pr.pattern, k)
+        finally:
+            pr.release()
+        return matches_from_rows(rows, pr.original)
 
     @classmethod
     def extra_items_for_chunked_search(cls, subsequence, search_params):

@@ -161,6 +161,16 @@ int fz_generic_ngrams_consolidated(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, u
                                    uint32_t max_subs, uint32_t max_ins, uint32_t max_dels, uint32_t max_l,
                                    fz_match **out, uint64_t *n);
 
+/* Search + the reduction the reference's strategy class applies to its result, in one call (round 4: find_near_matches
+ * on a resident sequence paid a second C-ABI call and an array round trip through Python for it):
+ *   fz_lev_ngrams_consolidated = fz_consolidate(fz_lev_ngrams(...))   LevenshteinSearch.search + consolidate_matches,
+ *                                                                      levenshtein.py:151-164, common.py:185-189
+ *   fz_subs_ngrams_best        = fz_group_best(fz_subs_ngrams(...))   what find_near_matches_substitutions_ngrams returns
+ *                                                                      for bytes-like input, substitutions_only.py:258-282
+ * (in a communicator: collective like the searches they start with). */
+int fz_lev_ngrams_consolidated(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, fz_match **out, uint64_t *n);
+int fz_subs_ngrams_best(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, fz_match **out, uint64_t *n);
+
 /* has_near_match_* (substitutions_only.py:139-145, :218-233; generic_search.py:240-253): *found = 1 iff the
  * corresponding search would return at least one record.  Nothing is ordered or copied, and device work that starts
  * after the first record has been counted is skipped (workgroups of the scan, hits of the automaton kernel). */

@@ -359,6 +359,55 @@ def test_public_api_matches_oracle(engine):
     assert fa.find_near_matches('PATTERN', '---PATERN---', max_l_dist=1) == [fa.Match(3, 9, 1, 'PATERN')]
 
 
+def test_fused_search_and_reduction_entry_points(engine):
+    """Round 4: fz_lev_ngrams_consolidated / fz_subs_ngrams_best (search + the strategy class's reduction in one C-ABI
+    call) against fz_consolidate / fz_group_best of the raw streams and against the oracle; find_near_matches takes
+    them and builds the Match objects in C straight from the result buffer — for bytes, bytearray, str and resident
+    sequences, `matched` has the type the sequence's own slicing gives."""
+    import fuzzysearch_amd as fa
+    rnd = random.Random(47)
+    n_lev = n_subs = 0
+    for _ in range(400):
+        p, t, k = _rand_case(rnd, max_n=400)
+        if len(p) // (k + 1) < 1:
+            continue
+        h = engine.upload(t)
+        raw = oracle.lev_ngrams_raw(p, t, k)
+        assert [r[:3] for r in engine.lev_ngrams_consolidated(h, p, k)] == oracle.consolidate(raw), (p, t, k)
+        rs = oracle.subs_ngrams_raw(p, t, k)
+        best, _hull = oracle.group_best(rs)
+        assert [r[:3] for r in engine.subs_ngrams_best(h, p, k)] == [b[:3] for b in best], (p, t, k)
+        h.release()
+        n_lev += bool(raw)
+        n_subs += bool(rs)
+        if len(p) // (k + 1) >= 3:
+            got = fa.find_near_matches(p, t, max_substitutions=k, max_insertions=0, max_deletions=0)
+            assert [(x.start, x.end, x.dist) for x in got] == [b[:3] for b in best], (p, t, k)
+            assert all(type(x.matched) is bytes and x.matched == t[x.start:x.end] for x in got)
+    assert n_lev > 150 and n_subs > 100
+    # sequence types: the slices are what sequence[start:end] gives
+    t = workloads.dna(1 << 16, 8).tobytes()
+    p = t[5000:5020]
+    want = oracle.consolidate(oracle.lev_ngrams_raw(p, t, 2))
+    for seq, typ in ((t, bytes), (bytearray(t), bytearray), (t.decode('latin-1'), str), (np.frombuffer(t, dtype=np.uint8), np.ndarray),
+                     (memoryview(t), memoryview)):
+        pat = p.decode('latin-1') if typ is str else p
+        got = fa.find_near_matches(pat, seq, max_l_dist=2)
+        assert [(x.start, x.end, x.dist) for x in got] == want
+        assert all(type(x.matched) is typ and bytes(x.matched if typ is not str else x.matched.encode('latin-1')) == t[x.start:x.end] for x in got)
+    res = fa.resident(t)
+    got = fa.find_near_matches(p, res, max_l_dist=2)
+    assert [(x.start, x.end, x.dist) for x in got] == want and all(x.matched == t[x.start:x.end] for x in got)
+    got = fa.find_near_matches(p, res, max_substitutions=2, max_insertions=0, max_deletions=0)
+    best, _hull = oracle.group_best(oracle.subs_ngrams_raw(p, t, 2))
+    assert [(x.start, x.end, x.dist) for x in got] == [b[:3] for b in best]
+    res.release()
+    # str input on the substitutions route: every window sorted by start (the reference's pure-Python form), not fused
+    ts = t.decode('latin-1')
+    got = fa.find_near_matches(p.decode('latin-1'), ts, max_substitutions=2, max_insertions=0, max_deletions=0)
+    assert [x.start for x in got] == sorted({r[0] for r in oracle.subs_ngrams_raw(p, t, 2)})
+
+
 def test_generic_ngrams_raw_random(engine):
     """a11: the candidate-set automaton, ordered raw stream == oracle (App. A.3)."""
     rnd = random.Random(41)

@@ -135,6 +135,25 @@ def test_fz_consolidate_and_group_best_against_oracle_and_golden():
             raw.append((s, s + rnd.choice([0, 0, 1, 2, 3, 5, 8, 40]), rnd.randint(0, 3), rnd.randint(0, 2)))
         best, _hull = oracle.group_best(raw)
         assert [b[:3] for b in _native.group_best(raw)] == [b[:3] for b in best], (trial, n, span)
+    # round 4: the fast form of fz_group_best (components by sort + sweep, every component replays its own members) on
+    # what the substitutions-only search emits — block-major runs of equal-length windows with cross-block duplicates —
+    # plus mixed lengths, zero-length rows, chains that merge several groups, and streams with one crowded component
+    # (> 256 members: the exact walk)
+    for trial in range(400):
+        n = rnd.choice([32, 40, 200, 2800, 6000])
+        span = rnd.choice([300, 5000, 200000, 1 << 34])
+        m = rnd.choice([1, 5, 20, 32])
+        raw = []
+        if trial % 2:
+            starts = sorted(rnd.randint(0, span) for _ in range(n // 3))
+            for g in range(rnd.randint(1, 6)):                       # block-major: every block finds most windows again
+                raw += [(s, s + m, rnd.randint(0, 3), g) for s in starts if rnd.random() < 0.8]
+        else:
+            for _ in range(n):
+                s = rnd.randint(0, span)
+                raw.append((s, s + rnd.choice([0, 0, 1, 2, 3, 5, 8, 40]), rnd.randint(0, 3), rnd.randint(0, 2)))
+        best, _hull = oracle.group_best(raw)
+        assert [b[:3] for b in _native.group_best(raw)] == [b[:3] for b in best], (trial, n, span, m)
     # Large streams: the run-folding pass followed by the slice order of the hulls, with zero-length rows at hull
     # edges, rows in block-major runs like the generic search emits, and shuffled.
     for n, span, run in [(3000, 60000, 1), (2600, 2000000, 1), (4000, 30000, 1), (60000, 4000000, 20), (30000, 90000, 7)]:
