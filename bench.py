@@ -279,6 +279,28 @@ def measured_traffic(shard_bytes):
     return None, None
 
 
+class stdout_to_stderr(object):
+    """RCCL prints a version banner on the process's C stdout when a communicator is created; this line-oriented
+    program owes its stdout ONE JSON line.  Inside the block file descriptor 1 points at stderr (C stdio flushed on both
+    sides)."""
+
+    def __enter__(self):
+        import ctypes
+        self._libc = ctypes.CDLL(None)
+        sys.stdout.flush()
+        self._libc.fflush(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        self._libc.fflush(None)
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def pipelined_steps(engine, handle, p, k, steps, per_dev=None, gather=None):
     """`steps` searches with two in flight (fz_lev_ngrams_begin / _end): every one starts and completes inside the
     call and delivers its ordered stream.  -> (seconds, last stream)."""
@@ -365,7 +387,9 @@ def main_multi_device(args):
     t_build = time.perf_counter() - t_build
     rccl_ranks = 0
     if collective:
-        engine.comm_init_all()                                   # ncclCommInitAll: every device of the context = one rank
+        with stdout_to_stderr():
+            engine.comm_init_all()                               # ncclCommInitAll: every device of the context = one rank
+            first_coll = engine.lev_ngrams(handle, p, k, as_array=True)      # (RCCL sets its channels up on first use)
         rccl_ranks = engine.comm_info()[0]
 
     first = engine.lev_ngrams(handle, p, k, as_array=True)
@@ -478,6 +502,7 @@ def main_multi_device(args):
         "cpu_baseline": cpu,
     }
     print(json.dumps(out), flush=True)
+    os.dup2(2, 1)                                                # whatever the libraries print while shutting down is not stdout's business
 
 
 def main():
@@ -537,7 +562,8 @@ def main():
 
     engine = _native.Engine([fzd.local_device(local_rank) if use_dist else local_rank])
     if use_dist and not use_torch:
-        fzd.init_engine_from_env(engine)          # joins the job's RCCL communicator: searches are collective from here on
+        with stdout_to_stderr():
+            fzd.init_engine_from_env(engine)      # joins the job's RCCL communicator: searches are collective from here on
     if not use_dist:
         handle = engine.upload(seq)
     else:
@@ -718,11 +744,15 @@ def main():
             del seq
             out.update(extra_blocks(engine, workloads, max(20, args.steps // 2)))
         print(json.dumps(out), flush=True)
+    if use_dist:
+        sys.stdout.flush()
+        os.dup2(2, 1)                                            # (RCCL's shutdown messages)
     if use_torch:
         dist.destroy_process_group()
     elif use_dist:
-        engine.comm_barrier()
-        engine.comm_destroy()
+        with stdout_to_stderr():
+            engine.comm_barrier()
+            engine.comm_destroy()
 
 
 if __name__ == "__main__":
