@@ -13,6 +13,8 @@
       every comparison.
 * ``DeviceSequence`` keeps a sequence resident in HBM across queries (upload once, search often).
 """
+import sys
+
 import numpy as np
 
 from . import _native
@@ -21,13 +23,21 @@ from ._native import UnsupportedSearch
 __all__ = ['DeviceSequence', 'resident', 'encode_pair', 'is_byteslike']
 
 
+_BIO_SEQ = []                                    # [Seq class or None] once looked up
+
+
 def _bio_seq():
-    """Bio.Seq.Seq when Biopython is installed (search_exact.py:13-19 registers it as a sequence type), else None."""
-    try:
-        from Bio.Seq import Seq
-        return Seq
-    except ImportError:
-        return None
+    """Bio.Seq.Seq when Biopython is installed (search_exact.py:13-19 registers it as a sequence type), else None.
+    Looked up once: a failing import walks sys.path every time (0.15 ms — more than the Match objects of a search)."""
+    if _BIO_SEQ and _BIO_SEQ[0] is None and 'Bio.Seq' in sys.modules:
+        del _BIO_SEQ[:]                              # Biopython was imported (or installed) after the first look
+    if not _BIO_SEQ:
+        try:
+            from Bio.Seq import Seq
+            _BIO_SEQ.append(Seq)
+        except ImportError:
+            _BIO_SEQ.append(None)
+    return _BIO_SEQ[0]
 
 
 def _unwrap_bio(x):

@@ -483,6 +483,8 @@ def test_biopython_seq_inputs_are_unwrapped(monkeypatch):
     bio.Seq = bio_seq
     monkeypatch.setitem(sys.modules, "Bio", bio)
     monkeypatch.setitem(sys.modules, "Bio.Seq", bio_seq)
+    monkeypatch.setattr(engine, "_BIO_SEQ", [])              # (the lookup is cached; dropped again when the test ends)
+    assert engine.encode_pair(b"AC", b"ACAC")[2] is True and engine._bio_seq() is Seq
     p, t, byteslike = engine.encode_pair("ACGT", Seq(b"TTACGTTT"))
     assert (bytes(p), bytes(t), byteslike) == (b"ACGT", b"TTACGTTT", False)
     p, t, byteslike = engine.encode_pair(Seq(b"ACGT"), Seq(b"TTACGTTT"))
