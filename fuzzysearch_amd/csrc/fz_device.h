@@ -137,6 +137,9 @@ struct FzScanArgs {
     uint64_t rec_cap;                           // capacity of the record list
     uint64_t gen_order;                         // generic search, one shard, no segments: device address of the ordering
                                                 // area (FZ_GEN_ORDER_MAX x {u64 first row, u32 row count}); 0: the host orders
+    uint64_t gen_dedup;                         // generic search: device address of the window table (FzGenDedup layout below);
+                                                // 0: every n-gram hit runs the automaton on its own
+    uint64_t rows_cap;                          // generic search ordered on the device: rows the row buffer holds
     uint64_t host_hdr;                          // device-visible address of the host copy of the counters
                                                 // (0: none); the last workgroup of the launch fills it
     uint64_t pat_g;                             // m > FZ_MAX_M: device address of the pattern (pat[] unused); else 0
@@ -614,6 +617,41 @@ struct FzGenRec {
     uint32_t dist;
     uint32_t win;        // tiled modes: window (tile) number; per-hit mode: segment number, or (no segments) the
                          // hit's slot in the hit list
+};
+
+// Window table of the generic search (round 4).  The automaton's input is the window [idx - s - k, idx - s + m + k) of
+// an n-gram hit (generic_search.py:229-231): it depends on idx - s only, and the hits that the different n-gram blocks of
+// ONE occurrence produce share it (a planted copy with e edits is found by up to G - e blocks: BASELINE configs[3b] has
+// 3x as many hits as distinct windows).  The reference runs its automaton once per hit and emits the same matches each
+// time; here a hit runs the automaton only if, when its wave arrives, no hit of a SMALLER block has claimed the window
+// (atomicMax on the inverted (block, slot) word: the hit of the smallest block always runs, and — hits being listed in scan
+// order — nearly always arrives first); the window's matches are those of its smallest-block hit, the "leader":
+//   ordered form: every hit of the window registers as a member, fz_gen_order_kernel counts the leader's rows for each
+//     of them and fz_gen_scatter_kernel writes every row of the leader once per member, with the member's block number
+//     (records of hits that ran before a smaller block arrived are skipped);
+//   folded / flag-only form: the other hits emit nothing, or (hull, best) pairs that repeat the leader's with a larger
+//     block number — a consolidation keeps the smallest.
+// Layout at FzScanArgs.gen_dedup: u64 keys[T] (idx + k - s + 1; 0 = free), u64 best[T] (~((block << 32) | hit-list slot),
+// maximum = smallest block), u32 nmem[T], u32 mem[T][FZ_GEN_DEDUP_MEMBERS], u32 wslot[FZ_GEN_ORDER_MAX] (table slot of
+// every hit, or FZ_GEN_DEDUP_NONE: the hit keeps its own rows).  keys, best and nmem must be zero when a search starts.
+#define FZ_GEN_DEDUP_SLOTS 32768u
+#define FZ_GEN_DEDUP_MEMBERS 7u
+#define FZ_GEN_DEDUP_NONE 0xffffffffu
+#define FZ_GEN_DEDUP_ZERO_BYTES ((size_t)FZ_GEN_DEDUP_SLOTS * 20u)
+#define FZ_GEN_DEDUP_BYTES ((size_t)FZ_GEN_DEDUP_SLOTS * (8u + 8u + 4u + 4u * FZ_GEN_DEDUP_MEMBERS) + (size_t)16384u * 4u)
+#define FZ_HDR_GEN_ROWS 4                              // counters[4]: rows of the ordered generic search (hits x their window's matches)
+
+struct FzGenDedup {
+    unsigned long long *keys, *best;
+    uint32_t *nmem, *mem, *wslot;
+    FZ_HD explicit FzGenDedup(uint64_t base) {
+        keys = reinterpret_cast<unsigned long long *>(base);
+        best = keys + FZ_GEN_DEDUP_SLOTS;
+        nmem = reinterpret_cast<uint32_t *>(best + FZ_GEN_DEDUP_SLOTS);
+        mem = nmem + FZ_GEN_DEDUP_SLOTS;
+        wslot = mem + (size_t)FZ_GEN_DEDUP_SLOTS * FZ_GEN_DEDUP_MEMBERS;
+    }
+    FZ_HD uint32_t leader(uint32_t slot) const { return (uint32_t)~best[slot]; }     // hit-list slot of the smallest block's hit
 };
 
 // The generic search's records are ordered on the device when one shard without segments produced at most this

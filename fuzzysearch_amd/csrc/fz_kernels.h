@@ -1399,6 +1399,9 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
     const bool order = per_hit && a.gen_order != 0;
     unsigned long long *order_first = reinterpret_cast<unsigned long long *>(a.gen_order);
     uint32_t *order_count = reinterpret_cast<uint32_t *>(order_first + FZ_GEN_ORDER_MAX);
+    // window table (FzGenDedup, fz_device.h): hits that share a window run the automaton once
+    const bool dedup = per_hit && a.gen_dedup != 0 && nitems <= FZ_GEN_ORDER_MAX && ncand == 1u;
+    const FzGenDedup dd(a.gen_dedup);
     for (uint64_t qc = blockIdx.x; qc < nitems * ncand; qc += gridDim.x) {
         if ((a.flags & FZ_FLAG_ANY) && __hip_atomic_load(&counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;   // has_near_match_*
         const uint64_t q = qc / ncand;
@@ -1411,8 +1414,34 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
             const uint64_t idx = fz_hit_index(hit);
             const FzSeg sg = fz_segment(a.geom, idx, (uint32_t)(qc % ncand));
             if (!fz_hit_in_range_s(a, s, idx, sg)) {                   // wave-uniform: one hit per wave
-                if (order && q < FZ_GEN_ORDER_MAX && lane == 0) { order_first[q] = 0; order_count[q] = 0; }
+                if (order && q < FZ_GEN_ORDER_MAX && lane == 0) { order_first[q] = 0; order_count[q] = 0; if (dedup) dd.wslot[q] = FZ_GEN_DEDUP_NONE; }
                 continue;
+            }
+            if (dedup) {
+                // find the window's slot, register (ordered form), and run only as the smallest block seen so far
+                uint32_t run = 1u;
+                if (lane == 0) {
+                    const unsigned long long wk = idx + a.k - s + 1ull;
+                    uint32_t slot = (uint32_t)((wk * 0x9E3779B97F4A7C15ull) >> 40) & (FZ_GEN_DEDUP_SLOTS - 1u);
+                    uint32_t at = FZ_GEN_DEDUP_NONE;
+                    for (uint32_t probe = 0; probe < 32u; ++probe) {
+                        const unsigned long long old = atomicCAS(&dd.keys[slot], 0ull, wk);
+                        if (old == 0ull || old == wk) { at = slot; break; }
+                        slot = (slot + 1u) & (FZ_GEN_DEDUP_SLOTS - 1u);
+                    }
+                    if (at != FZ_GEN_DEDUP_NONE && order) {            // (a crowded table or a full member list: the hit stays on its own)
+                        const uint32_t pos = atomicAdd(&dd.nmem[at], 1u);
+                        if (pos < FZ_GEN_DEDUP_MEMBERS) dd.mem[at * FZ_GEN_DEDUP_MEMBERS + pos] = (uint32_t)q;
+                        else at = FZ_GEN_DEDUP_NONE;
+                    }
+                    if (at != FZ_GEN_DEDUP_NONE) {
+                        const unsigned long long mine = ~(((unsigned long long)fz_hit_block(hit) << 32) | (unsigned long long)q);
+                        run = atomicMax(&dd.best[at], mine) < mine ? 1u : 0u;
+                    }
+                    if (order) { dd.wslot[q] = at; if (!run) { order_first[q] = 0; order_count[q] = 0; } }
+                }
+                run = (uint32_t)__builtin_amdgcn_readfirstlane((int)run);
+                if (!run) continue;
             }
             const uint64_t reach = (uint64_t)s + a.k;
             w0 = idx - sg.sa > reach ? idx - reach : sg.sa;            // generic_search.py:231
@@ -1704,8 +1733,10 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
 // index, the matches of a hit in emission order) restored on the device.  A hit's first row = the rows of all hits
 // with a smaller key (block << 56 | index).  Quadratic, tiled 256 x 64 over (hit, other hit) pairs with partial
 // sums added atomically (6e3 hits = 2304 tiles); the host orders searches with more than FZ_GEN_ORDER_MAX hits.
+__device__ __forceinline__ unsigned long long *counters_rw(const unsigned long long *c) { return const_cast<unsigned long long *>(c); }
+
 __global__ __launch_bounds__(256) void fz_gen_order_kernel(const uint64_t *__restrict__ hits, const FzScanArgs a,
-                                                           const unsigned long long *__restrict__ counters) {
+                                                           const unsigned long long *counters) {
     constexpr uint32_t TJ = 64;                                 // other hits per tile: the length of a thread's serial chain
     __shared__ uint64_t skey[TJ];
     __shared__ uint32_t scnt[TJ];
@@ -1713,15 +1744,28 @@ __global__ __launch_bounds__(256) void fz_gen_order_kernel(const uint64_t *__res
     if (n > a.hit_cap || n > FZ_GEN_ORDER_MAX || counters[2]) return;
     unsigned long long *first = reinterpret_cast<unsigned long long *>(a.gen_order);
     const uint32_t *count = reinterpret_cast<const uint32_t *>(first + FZ_GEN_ORDER_MAX);
+    // rows of hit j: its own, or — window table — those of its window's leader (the hit of the smallest block)
+    const bool dedup = a.gen_dedup != 0;
+    const FzGenDedup dd(a.gen_dedup);
+    auto rows_of = [&](uint32_t j) -> uint32_t {
+        if (!dedup) return count[j];
+        const uint32_t sl = dd.wslot[j];
+        return count[sl == FZ_GEN_DEDUP_NONE ? j : dd.leader(sl)];
+    };
     const uint32_t nti = ((uint32_t)n + 255u) / 256u, ntj = ((uint32_t)n + TJ - 1u) / TJ;
     for (uint32_t p = blockIdx.x; p < nti * ntj; p += gridDim.x) {
         const uint32_t i = (p / ntj) * 256u + threadIdx.x, j = (p % ntj) * TJ + threadIdx.x;
         __syncthreads();
         if (threadIdx.x < TJ) {
             skey[threadIdx.x] = j < n ? hits[j] : ~0ull;
-            scnt[threadIdx.x] = j < n ? count[j] : 0u;
+            scnt[threadIdx.x] = j < n ? rows_of(j) : 0u;
         }
         __syncthreads();
+        if (p % ntj == 0 && threadIdx.x < TJ) {                 // the search's row count: every hit once (tile column 0 of its row)
+            uint32_t mine = 0;
+            for (uint32_t ii = (p / ntj) * 256u + threadIdx.x; ii < (p / ntj) * 256u + 256u && ii < n; ii += TJ) mine += rows_of(ii);
+            if (mine) atomicAdd(&counters_rw(counters)[FZ_HDR_GEN_ROWS], (unsigned long long)mine);
+        }
         if (i < n) {
             const uint64_t me = hits[i];
             uint32_t sum = 0;                                   // <= TJ * rows of one hit
@@ -1739,9 +1783,24 @@ __global__ __launch_bounds__(256) void fz_gen_scatter_kernel(const uint64_t *__r
     const unsigned long long n = counters[0], nr = counters[1];
     if (n > a.hit_cap || n > FZ_GEN_ORDER_MAX || counters[2] || nr > a.rec_cap) return;
     const unsigned long long *first = reinterpret_cast<const unsigned long long *>(a.gen_order);
+    const bool dedup = a.gen_dedup != 0;
+    const FzGenDedup dd(a.gen_dedup);
     for (unsigned long long r = (unsigned long long)blockIdx.x * 256u + threadIdx.x; r < nr; r += (unsigned long long)gridDim.x * 256u) {
         const FzGenRec rec = recs[r];
-        rows[first[rec.win] + rec.seq] = fz_gen_row(hits[rec.win], a.L, a.k, 0, rec.se, rec.dist);
+        const uint32_t sl = dedup ? dd.wslot[rec.win] : FZ_GEN_DEDUP_NONE;
+        if (sl == FZ_GEN_DEDUP_NONE) {                          // a hit on its own
+            const unsigned long long at = first[rec.win] + rec.seq;
+            if (at < a.rows_cap) rows[at] = fz_gen_row(hits[rec.win], a.L, a.k, 0, rec.se, rec.dist);
+            continue;
+        }
+        if (dd.leader(sl) != rec.win) continue;                 // ran before a hit of a smaller block arrived: that one's records count
+        uint32_t nm = dd.nmem[sl];
+        nm = nm < FZ_GEN_DEDUP_MEMBERS ? nm : FZ_GEN_DEDUP_MEMBERS;
+        for (uint32_t i = 0; i < nm; ++i) {                     // the same match for every hit of the window (the leader is a member too)
+            const uint32_t h = dd.mem[sl * FZ_GEN_DEDUP_MEMBERS + i];
+            const unsigned long long at = first[h] + rec.seq;
+            if (at < a.rows_cap) rows[at] = fz_gen_row(hits[h], a.L, a.k, 0, rec.se, rec.dist);
+        }
     }
 }
 

@@ -111,6 +111,9 @@ struct DevState {
     // generic search ordered on the device: per-hit {first row, row count} and the finished fz_match rows
     uint8_t *d_gen_order = nullptr;
     uint8_t *d_gen_rows = nullptr;
+    uint8_t *d_gen_dedup = nullptr;               // window table of the generic search (FzGenDedup, fz_device.h)
+    bool dedup_zeroed = false;                   // ... zeroed behind the last search that used it
+    bool dedup_used = false;                     // the search being collected ran with it (row count = counters[FZ_HDR_GEN_ROWS])
     uint64_t gen_rows_cap = 0;                   // rows
     uint8_t *h_big = nullptr, *h_big_dev = nullptr;
     uint64_t big_cap = 0;                        // records
@@ -1330,6 +1333,22 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
                 rc = ensure_gen_rows(d);
                 if (rc) return rc;
                 fa.gen_order = reinterpret_cast<uint64_t>(d.d_gen_order);
+                fa.rows_cap = d.gen_rows_cap;
+            }
+            // Window table: the hits that the n-gram blocks of one occurrence produce share their window, the automaton runs
+            // once per window (fz_device.h: FzGenDedup).  Where the rows are finished on the device, where only (hull, best)
+            // pairs leave it, and for the flag-only search; FZ_GEN_NO_DEDUP=1: every hit on its own (A/B, tests).
+            static const bool no_dedup = getenv("FZ_GEN_NO_DEDUP") != nullptr;
+            const bool dedup = !no_dedup && sh.geom.seg_stride == 0 && (dev_order || q.fold || q.any);
+            d.dedup_used = dedup;
+            if (dedup) {
+                if (!d.d_gen_dedup) {
+                    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d.d_gen_dedup), FZ_GEN_DEDUP_BYTES));
+                    d.dedup_zeroed = false;
+                }
+                if (!d.dedup_zeroed) HIP_TRY(hipMemsetAsync(d.d_gen_dedup, 0, FZ_GEN_DEDUP_ZERO_BYTES, d.stream));
+                d.dedup_zeroed = false;
+                fa.gen_dedup = reinterpret_cast<uint64_t>(d.d_gen_dedup);
             }
             // Folded search (a few thousand pairs): the automaton kernel writes them straight into the pinned staging
             // buffer and its last workgroup publishes the counters there, as the fused scan does for its records — no
@@ -1402,6 +1421,10 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
                 if (!lp_stop) HIP_TRY(hipEventRecord(d.ev[3], st2));
                 d.header_zeroed = true;                       // by the publishing workgroup
             }
+            if (dedup && st2 == d.stream) {                   // the window table is cleared for the next search, behind this one
+                HIP_TRY(hipMemsetAsync(d.d_gen_dedup, 0, FZ_GEN_DEDUP_ZERO_BYTES, d.stream));
+                d.dedup_zeroed = true;
+            }
         }
         if (phase == 1) return FZ_OK;
         bool lists_overflowed = false;
@@ -1414,6 +1437,8 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             trg.mark(" generic sync");
             const unsigned long long *cnt = reinterpret_cast<const unsigned long long *>(d.h_stage);
             const uint64_t nh = cnt[0], nr = cnt[1], novf = cnt[2];
+            // rows of the ordered search: with the window table every hit takes its window's matches, computed once
+            const uint64_t nrows = d.dedup_used && !q.fold && !q.any && nh <= FZ_GEN_ORDER_MAX ? cnt[FZ_HDR_GEN_ROWS] : nr;
             if (q.any) {                                      // has_near_match_generic_ngrams: a record anywhere settles it
                 ctx->any_found |= nr > 0;
                 if (nr > 0) continue;
@@ -1429,10 +1454,10 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             if (d.fold_was_direct) {                          // pairs beyond the staging buffer were dropped: again, through d_out
                 if (nr > kHostRecs) { d.fold_direct = false; rerun = true; }
             } else if (q.fold && nr * 4 < kHostRecs) d.fold_direct = true;
-            if (!gen_direct2 && !d.fold_was_direct && nr > d.rec_cap) { int rc = ensure_recs(d, nr + nr / 8 + 1024); if (rc) return rc; rerun = true; }
+            if (!gen_direct2 && !d.fold_was_direct && std::max(nr, nrows) > d.rec_cap) { int rc = ensure_recs(d, std::max(nr, nrows) + nrows / 8 + 1024); if (rc) return rc; rerun = true; }
             static const bool host_order2 = getenv("FZ_GEN_HOST_ORDER") != nullptr;
             const bool rows_ready = !gen_direct2 && !host_order2 && !q.fold && seq->shards.size() == 1 && sh.geom.seg_stride == 0 &&
-                                    nh <= FZ_GEN_ORDER_MAX && nr <= d.gen_rows_cap && !comm_multi_process(ctx);
+                                    nh <= FZ_GEN_ORDER_MAX && nrows <= d.gen_rows_cap && !comm_multi_process(ctx);
             const bool in_stage = q.fold && nr <= d.fold_copied && seq->shards.size() == 1;   // the pairs are in h_stage already
             if (q.fold) d.fold_guess = std::max<uint64_t>(4096, nr + nr / 4 + 256);
             if (!gen_direct2 && !rerun && !novf && nr && !rows_ready && !in_stage)
@@ -1444,7 +1469,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             ctx->stats.ngram_hits += nh;
             if (rows_ready) {                                 // finished rows, fetched by emit_generic
                 ctx->gen_rows_dev = d.d_gen_rows;
-                ctx->gen_rows_n = nr;
+                ctx->gen_rows_n = nrows;
                 ctx->gen_rows_device = d.device;
             } else if (seq->shards.size() == 1) {             // read in place (valid until the next search)
                 ctx->gen_view = reinterpret_cast<const FzGenRec *>(in_stage ? d.h_stage + kHeaderBytes : d.h_big);
@@ -1837,6 +1862,7 @@ static void devstate_destroy(DevState &d) {
     if (d.d_pat) (void)hipFree(d.d_pat);
     if (d.d_gen_order) (void)hipFree(d.d_gen_order);
     if (d.d_gen_rows) (void)hipFree(d.d_gen_rows);
+    if (d.d_gen_dedup) (void)hipFree(d.d_gen_dedup);
     for (int i = 0; i < 2; ++i) if (d.stream_h[i]) (void)hipHostFree(d.stream_h[i]);
     if (d.stream_d) (void)hipFree(d.stream_d);
     for (auto &ev : d.ev) if (ev) (void)hipEventDestroy(ev);

@@ -92,6 +92,56 @@ def run_pipelined(engine, cases):
     return n_rec
 
 
+def run_generic_windows(engine, rnd, n_cases):
+    """Generic searches whose n-gram hits share windows (the window table, fz_device.h: FzGenDedup): exact and lightly
+    edited copies of patterns with 2 .. 14 blocks (more hits per window than a slot lists members), copies at both ends
+    of the text, dense repeats — raw stream, consolidated rows (block included: the smallest), the flag and the two-deep
+    pipeline against the oracle."""
+    import oracle
+    n_rec = cases = 0
+    while cases < n_cases:
+        alpha = bytes(rnd.sample(range(1, 256), rnd.choice([3, 4, 8, 60])))
+        k = rnd.choice([1, 2, 3, 4, 6, 9, 13])
+        L = rnd.choice([2, 3, 4, 6])
+        m = (k + 1) * L + rnd.randint(0, L - 1)
+        p = bytes(rnd.choice(alpha) for _ in range(m))
+        n = rnd.randint(m, 4000)
+        t = bytearray(rnd.choice(alpha) for _ in range(n))
+        for _rep in range(rnd.randint(1, 6)):
+            v = edited(rnd, p, rnd.choice([0, 0, 0, 1, 2]), alpha)
+            st = max(0, min(rnd.choice([0, n - len(v), rnd.randint(0, max(0, n - len(v)))]), n - len(v)))
+            t[st:st + len(v)] = v
+        if rnd.random() < 0.15:
+            t = bytearray((p * (n // m + 1))[:n])                   # dense repeats: every window shared, long member lists
+        t = bytes(t)
+        lim = (rnd.randint(0, k), rnd.randint(0, min(k, 3)), rnd.randint(0, min(k, 3)), k)
+        try:
+            want = oracle.generic_ngrams_raw(p, t, *lim)
+        except Exception:
+            continue
+        if len(want) > 200000:
+            continue
+        h = engine.upload(t)
+        try:
+            got = engine.generic_ngrams(h, p, *lim)
+        except NotImplementedError:
+            h.release()
+            continue
+        assert got == want, ("generic raw", p, t, lim)
+        cons = engine.generic_ngrams_consolidated(h, p, *lim)
+        assert [r[:3] for r in cons] == oracle.consolidate(want), ("generic consolidated", p, t, lim)
+        from fuzzysearch_amd import _native
+        assert cons == [tuple(r) for r in _native.consolidate(got)], ("consolidated rows incl. block", p, t, lim)
+        assert engine.generic_ngrams_any(h, p, *lim) == (len(want) > 0)
+        engine.generic_ngrams_begin(h, p, *lim)
+        engine.generic_ngrams_begin(h, p, *lim, consolidated=True)
+        assert engine.search_end() == want and engine.search_end() == cons, ("generic, two in flight", p, t, lim)
+        h.release()
+        n_rec += len(want)
+        cases += 1
+    return cases, n_rec
+
+
 def main(argv):
     from fuzzysearch_amd import _native
     what = argv[0]
@@ -124,6 +174,12 @@ def main(argv):
             alpha = bytes(rnd.sample(range(1, 256), sigma))
             cases.append((bytes(rnd.choices(alpha, k=m)), bytes(rnd.choices(alpha, k=nn)), k))   # up to 2.6e5 records per search
         n_rec = run_pipelined(eng, cases)
+    elif what == "windows":
+        # the generic search's window table, on (default) and off (FZ_GEN_NO_DEDUP=1: every hit runs the automaton)
+        n_cases, n_rec = run_generic_windows(eng, rnd, n)
+        eng.close()
+        print("OK %d %d" % (n_cases, n_rec))
+        return
     else:
         raise SystemExit("unknown case set %r" % what)
     n_rec = n_rec + run_lev_subs(eng, cases) if what == "copy" else run_lev_subs(eng, cases)

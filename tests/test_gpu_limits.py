@@ -39,6 +39,16 @@ def test_general_slot_form_and_multi_launch():
     assert n_cases == 202
 
 
+def test_generic_window_table_on_and_off():
+    """Round 4: hits that share their window run the automaton once (smallest block = leader, the others take its rows).
+    The same random cases with the table (default) and without (FZ_GEN_NO_DEDUP=1) against the oracle: identical
+    streams either way."""
+    n_cases, n_rec = _sub(["windows", 250, 21], {})
+    assert n_cases == 250 and n_rec > 5000
+    n_cases2, n_rec2 = _sub(["windows", 250, 21], {"FZ_GEN_NO_DEDUP": "1"})
+    assert (n_cases2, n_rec2) == (n_cases, n_rec)
+
+
 def test_copy_mode_one_and_two_searches_in_flight():
     """FZ_NO_DIRECT=1: nothing is written straight into the pinned staging buffer (round 3's randomized run found the
     younger of two searches in flight overwriting the older one's records in the shared device buffer under this switch)."""
