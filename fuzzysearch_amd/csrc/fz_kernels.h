@@ -1729,6 +1729,265 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
     fz_finish_launch(a, counters, reinterpret_cast<volatile uint32_t *>(smem));
 }
 
+// ---- the generic search's automaton, one WORKGROUP of four waves per n-gram hit (round 4) --------------------------
+// fz_lp_kernel runs a hit on ONE wave: ~74 window characters one after the other, every character 2-3 slices of 64
+// candidates, every slice a dependent chain of ~220 instructions and three LDS round trips — a hit's time is that chain
+// (0.15 ms for BASELINE configs[3b], however few hits there are: the kernel lasts as long as its slowest hit, and with
+// the window table a third of the waves is left, on a machine that is then mostly idle).  But the candidates of
+// different START positions never interact: a candidate's successors keep its start, the list is grouped by start in
+// ascending order (fresh candidates are appended, generic_search.py:80), and a match's place in the emission order is
+// (window character, start, order among the matches of that start).  So the starts are dealt out to the four waves of
+// a workgroup (start mod W, W = 2 or 4 — neighbouring starts carry the large trees of a true occurrence), every wave runs the whole
+// window over its own quarter of the list with NO synchronisation, buffers its matches, and at the end the four sorted
+// buffers are merged by rank (binary searches on (character, start): no ties across waves).  One slice per character
+// instead of 2-3.  A hit whose wave outgrows its list quarter or its match buffer is counted in counters[FZ_HDR_GEN_FAIL]
+// and the host runs the search again with fz_lp_kernel (which also keeps the lists-in-HBM form, the file API's segments
+// and the tiled whole-sequence automata).
+#define FZ_GH_MAX_WAVES 4u                                  // waves per hit: template parameter W in {2, 4}
+#define FZ_GH_MCAP 256u                                     // matches a wave buffers for one hit
+#define FZ_HDR_GEN_FAIL 5                                   // counters[5]: hits fz_gen_hit_kernel could not finish
+#define FZ_GH_CTL_BYTES 64u
+
+__device__ __forceinline__ uint32_t fz_gh_lower_bound(const uint64_t *mb, uint32_t n, uint32_t key) {
+    uint32_t lo = 0, hi = n;                                // first entry whose (character << 16 | start) is >= key
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint64_t v = mb[mid];
+        const uint32_t kv = ((uint32_t)(v >> 48) << 16) | ((uint32_t)v & 0xffffu);
+        if (kv < key) lo = mid + 1u; else hi = mid;
+    }
+    return lo;
+}
+
+template <uint32_t W>
+__global__ __launch_bounds__(64 * W) void fz_gen_hit_kernel(const uint8_t *__restrict__ buf, const FzScanArgs a,
+                                                                      const uint64_t *__restrict__ hits, FzGenRec *__restrict__ recs,
+                                                                      unsigned long long *__restrict__ counters) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t mpad = (a.m + 15u) & ~15u;
+    const uint32_t wpad = (a.m + 2u * a.k + 15u) & ~15u;
+    const uint32_t capw = a.cand_cap;                       // candidate slots per list of ONE wave
+    uint8_t *pat = smem;
+    uint8_t *win = smem + mpad;
+    volatile uint32_t *ctl = reinterpret_cast<volatile uint32_t *>(smem + mpad + wpad);   // [0] run [1] fail [2..5] matches per wave [6,7] record base [8] stop
+    FzGCand *lists = reinterpret_cast<FzGCand *>(smem + mpad + wpad + FZ_GH_CTL_BYTES);
+    FzGCand *cur = lists + (size_t)wave * 2u * capw, *nxt = cur + capw;
+    uint64_t *mball = reinterpret_cast<uint64_t *>(lists + (size_t)W * 2u * capw);
+    uint64_t *mbuf = mball + (size_t)wave * FZ_GH_MCAP;
+    fz_copy_pattern(pat, a, tid, 64u * W);
+    auto patf = [&](uint32_t i) -> uint8_t { return pat[i]; };
+    unsigned long long nitems = counters[0];
+    if (nitems > a.hit_cap) nitems = a.hit_cap;
+    const bool order = a.gen_order != 0;
+    unsigned long long *order_first = reinterpret_cast<unsigned long long *>(a.gen_order);
+    uint32_t *order_count = reinterpret_cast<uint32_t *>(order_first + FZ_GEN_ORDER_MAX);
+    const bool dedup = a.gen_dedup != 0 && nitems <= FZ_GEN_ORDER_MAX;
+    const FzGenDedup dd(a.gen_dedup);
+    const bool fold = (a.flags & FZ_FLAG_FOLD) != 0;
+    for (uint64_t q = blockIdx.x; q < nitems; q += gridDim.x) {
+        __syncthreads();                                    // the previous hit's LDS (window, lists, buffers, ctl) is free
+        const uint64_t hit = hits[q];
+        const uint32_t s = fz_hit_block(hit) * a.L;
+        const uint64_t idx = fz_hit_index(hit);
+        const FzSeg sg = fz_segment(a.geom, idx, 0u);
+        if (!fz_hit_in_range_s(a, s, idx, sg)) {             // the same for every thread
+            if (order && q < FZ_GEN_ORDER_MAX && tid == 0) { order_first[q] = 0; order_count[q] = 0; if (dedup) dd.wslot[q] = FZ_GEN_DEDUP_NONE; }
+            continue;
+        }
+        const uint64_t reach = (uint64_t)s + a.k;
+        const uint64_t w0 = idx - sg.sa > reach ? idx - reach : sg.sa;               // generic_search.py:231
+        uint64_t w1 = idx - s + a.m + a.k;
+        if (w1 > sg.se) w1 = sg.se;
+        const uint32_t wlen = (uint32_t)(w1 - w0);
+        if (tid == 0) {
+            uint32_t run = 1u, stop = 0u;
+            if ((a.flags & FZ_FLAG_ANY) && __hip_atomic_load(&counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) { stop = 1u; run = 0u; }
+            if (dedup && !stop) {                           // the window table (fz_device.h: FzGenDedup), as in fz_lp_kernel
+                const unsigned long long wk = idx + a.k - s + 1ull;
+                uint32_t slot = (uint32_t)((wk * 0x9E3779B97F4A7C15ull) >> 40) & (FZ_GEN_DEDUP_SLOTS - 1u);
+                uint32_t at = FZ_GEN_DEDUP_NONE;
+                for (uint32_t probe = 0; probe < 32u; ++probe) {
+                    const unsigned long long old = atomicCAS(&dd.keys[slot], 0ull, wk);
+                    if (old == 0ull || old == wk) { at = slot; break; }
+                    slot = (slot + 1u) & (FZ_GEN_DEDUP_SLOTS - 1u);
+                }
+                if (at != FZ_GEN_DEDUP_NONE && order) {
+                    const uint32_t pos = atomicAdd(&dd.nmem[at], 1u);
+                    if (pos < FZ_GEN_DEDUP_MEMBERS) dd.mem[at * FZ_GEN_DEDUP_MEMBERS + pos] = (uint32_t)q;
+                    else at = FZ_GEN_DEDUP_NONE;
+                }
+                if (at != FZ_GEN_DEDUP_NONE) {
+                    const unsigned long long mine = ~(((unsigned long long)fz_hit_block(hit) << 32) | (unsigned long long)q);
+                    run = atomicMax(&dd.best[at], mine) < mine ? 1u : 0u;
+                }
+                if (order) { dd.wslot[q] = at; if (!run) { order_first[q] = 0; order_count[q] = 0; } }
+            }
+            ctl[0] = run; ctl[1] = 0u; ctl[8] = stop;
+        }
+        for (uint32_t i = tid; i < wlen; i += 64u * W) win[i] = buf[(w0 - a.geom.buf_off) + i];
+        __syncthreads();
+        if (ctl[8]) break;                                  // has_near_match_*: a record exists somewhere
+        if (!ctl[0]) continue;                              // a hit of a smaller block runs this window
+
+        // ---- this wave's quarter of the candidate list over the whole window; no synchronisation with the other waves ----
+        uint32_t ncur = 0, mb = 0;
+        bool fail = false;
+        FzGCand *lc = cur, *ln = nxt;
+        for (uint32_t index = 0; index <= wlen && !fail; ++index) {
+            uint32_t nnext = 0;
+            if (index < wlen) {
+                const uint8_t ch = win[index];
+                uint32_t fresh_at = 0xffffffffu;
+                if ((index & (W - 1u)) == wave) {   // this start is ours: the fresh candidate (py:80), taken from registers
+                    if (ncur >= capw) { fail = true; break; }
+                    fresh_at = ncur;
+                    ++ncur;
+                }
+                for (uint32_t c0 = 0; c0 < ncur; c0 += 64u) {
+                    const bool valid = c0 + lane < ncur;
+                    uint2 cw = reinterpret_cast<const uint2 *>(lc)[c0 + lane];      // (up to 63 slots past the list: still this workgroup's LDS)
+                    const bool fresh = c0 + lane == fresh_at;
+                    cw.x = valid ? (fresh ? index : cw.x) : 0u;
+                    cw.y = valid && !fresh ? cw.y : 0u;
+                    FzGStep st;
+                    fz_generic_step_packed(cw.x, cw.y, ch, index, a.m, patf, a.max_subs, a.max_ins, a.max_dels, a.k, st);
+                    const uint32_t vm = valid ? 1u : 0u;
+                    st.fa &= vm; st.fb &= vm; st.fc &= vm; st.f1 &= vm; st.f2 &= vm;
+                    const uint32_t packed = (st.fa + st.fb + st.fc) | ((st.f1 + st.f2) << 16);
+                    const uint32_t incl = fz_wave_incl_scan(packed);
+                    const uint32_t tot = __builtin_amdgcn_readlane(incl, 63);
+                    const uint32_t excl = incl - packed;
+                    const uint32_t tot_s = tot & 0xffffu, tot_m = tot >> 16;
+                    if (nnext + tot_s > capw || mb + tot_m > FZ_GH_MCAP) { fail = true; break; }
+                    uint2 *nx = reinterpret_cast<uint2 *>(ln) + nnext + (excl & 0xffffu);
+                    uint64_t *mp = mbuf + mb + (excl >> 16);
+                    const uint64_t stamp = (uint64_t)index << 48;
+                    if (st.fa) nx[0] = make_uint2(st.a0, st.a1);
+                    if (st.fb) nx[st.fa] = make_uint2(st.b0, st.b1);
+                    if (st.fc) nx[st.fa + st.fb] = make_uint2(st.c0, st.c1);
+                    if (st.f1) mp[0] = (uint64_t)st.m1 | ((uint64_t)st.d1 << 32) | stamp;
+                    if (st.f2) mp[st.f1] = (uint64_t)st.m2 | ((uint64_t)st.d2 << 32) | stamp;
+                    nnext += tot_s;
+                    mb += tot_m;
+                }
+            } else {
+                // end of the window (py:172-177): the survivors that reach the pattern's end by deletions
+                for (uint32_t c0 = 0; c0 < ncur; c0 += 64u) {
+                    const bool valid = c0 + lane < ncur;
+                    const uint2 cw = reinterpret_cast<const uint2 *>(lc)[c0 + lane];
+                    const FzGCand c = fz_gcand_of(cw.x, cw.y);
+                    uint32_t d = 0;
+                    const bool hit_end = valid && fz_generic_final(c, a.m, a.max_dels, a.k, d);
+                    const unsigned long long mask = __ballot(hit_end);
+                    const uint32_t tot_m = (uint32_t)__popcll(mask);
+                    if (mb + tot_m > FZ_GH_MCAP) { fail = true; break; }
+                    if (hit_end) mbuf[mb + fz_rank(mask)] = (uint64_t)((uint32_t)c.start | (wlen << 16)) | ((uint64_t)d << 32) | ((uint64_t)index << 48);
+                    mb += tot_m;
+                }
+            }
+            // the next character reads what this one stored: a wave's LDS operations are performed in issue order
+            asm volatile("" ::: "memory");
+            FzGCand *tmp = lc; lc = ln; ln = tmp;
+            ncur = nnext;
+        }
+        if (lane == 0) { ctl[2u + wave] = mb; if (fail) ctl[1] = 1u; }
+        __syncthreads();
+        if (ctl[1]) {                                       // outgrew a list quarter or a match buffer: the host re-runs with fz_lp_kernel
+            if (tid == 0) atomicAdd(&counters[FZ_HDR_GEN_FAIL], 1ull);
+            continue;
+        }
+        uint32_t mbw[W];
+        uint32_t total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < W; ++w) { mbw[w] = ctl[2u + w]; total += mbw[w]; }
+        if (order && q < FZ_GEN_ORDER_MAX && tid == 0) { order_first[q] = 0; order_count[q] = total; }
+        if (total == 0) continue;
+        if (fold) {
+            // first stage of consolidate_overlapping_matches (common.py:150-159), as in fz_lp_kernel: every match that overlaps
+            // the running hull is folded into it; the order of the matches does not matter (best = a total order), so wave 0
+            // takes the four buffers one after the other
+            if (wave == 0) {
+                bool f_have = false;
+                uint32_t f_lo = 0, f_hi = 0, f_k1 = 0, f_k2 = 0, f_pairs = 0;
+                auto emit_pair = [&]() {
+                    if (lane == 0) {
+                        const unsigned long long slot = atomicAdd(&counters[1], 1ull);
+                        if (slot < a.rec_cap) {
+                            const uint32_t len = 0xffffu - (f_k1 & 0xffffu);
+                            FzGenRec r;
+                            r.key = hit; r.seq = f_pairs; r.se = f_k2 | ((f_k2 + len) << 16); r.dist = f_k1 >> 16; r.win = f_lo | (f_hi << 16);
+                            recs[slot] = r;
+                        }
+                    }
+                    ++f_pairs;
+                    f_have = false;
+                };
+                auto wave_min = [&](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)fz_wave_incl_min(v), 63); };
+                for (uint32_t w = 0; w < W; ++w) {
+                    const uint64_t *mbx = mball + (size_t)w * FZ_GH_MCAP;
+                    const uint32_t nw = ctl[2u + w];
+                    for (uint32_t e0 = 0; e0 < nw; e0 += 64u) {
+                        const bool have_row = e0 + lane < nw;
+                        const uint64_t v = have_row ? mbx[e0 + lane] : 0ull;
+                        const uint32_t rs = (uint32_t)v & 0xffffu, re = ((uint32_t)v >> 16) & 0xffffu, rd = (uint32_t)(v >> 32) & 0xffffu;
+                        const uint32_t k1 = (rd << 16) | (0xffffu - (re - rs));
+                        unsigned long long pending = __ballot(have_row);
+                        while (pending) {
+                            if (!f_have) {
+                                const uint32_t l0 = (uint32_t)__builtin_ctzll(pending);
+                                f_lo = (uint32_t)__builtin_amdgcn_readlane((int)rs, (int)l0);
+                                f_hi = (uint32_t)__builtin_amdgcn_readlane((int)re, (int)l0);
+                                f_k1 = (uint32_t)__builtin_amdgcn_readlane((int)k1, (int)l0);
+                                f_k2 = f_lo;
+                                f_have = true;
+                                pending &= pending - 1ull;
+                                continue;
+                            }
+                            const bool mine = ((pending >> lane) & 1ull) && !(re <= f_lo || rs >= f_hi);
+                            const unsigned long long ov = __ballot(mine);
+                            if (!ov) { emit_pair(); continue; }
+                            const uint32_t mlo = wave_min(mine ? rs : 0xffffffffu), mhi = ~wave_min(mine ? ~re : 0xffffffffu);
+                            const uint32_t mk1 = wave_min(mine ? k1 : 0xffffffffu);
+                            const uint32_t mk2 = wave_min((mine && k1 == mk1) ? rs : 0xffffffffu);
+                            f_lo = mlo < f_lo ? mlo : f_lo;
+                            f_hi = mhi > f_hi ? mhi : f_hi;
+                            if (mk1 < f_k1 || (mk1 == f_k1 && mk2 < f_k2)) { f_k1 = mk1; f_k2 = mk2; }
+                            pending &= ~ov;
+                        }
+                    }
+                }
+                if (f_have) emit_pair();
+            }
+            continue;
+        }
+        // the hit's records, contiguous and in emission order: record (base + rank), rank = the match's place among the four
+        // sorted buffers (its own position + the entries of the other waves with a smaller (character, start))
+        if (tid == 0) {
+            const unsigned long long base = atomicAdd(&counters[1], (unsigned long long)total);
+            ctl[6] = (uint32_t)base; ctl[7] = (uint32_t)(base >> 32);
+        }
+        __syncthreads();
+        const unsigned long long base = (unsigned long long)ctl[6] | ((unsigned long long)ctl[7] << 32);
+        for (uint32_t e = lane; e < mb; e += 64u) {
+            const uint64_t v = mbuf[e];
+            const uint32_t key = ((uint32_t)(v >> 48) << 16) | ((uint32_t)v & 0xffffu);
+            uint32_t rank = e;
+#pragma unroll
+            for (uint32_t w = 0; w < W; ++w)
+                if (w != wave) rank += fz_gh_lower_bound(mball + (size_t)w * FZ_GH_MCAP, mbw[w], key);
+            if (base + rank < a.rec_cap) {
+                FzGenRec r;
+                r.key = hit; r.seq = rank; r.se = (uint32_t)v; r.dist = (uint32_t)(v >> 32) & 0xffffu; r.win = order ? (uint32_t)q : sg.j;
+                recs[base + rank] = r;
+            }
+        }
+    }
+    // folded search whose pairs went straight into the host's staging buffer: the last workgroup publishes the counters
+    __syncthreads();
+    fz_finish_launch(a, counters, reinterpret_cast<volatile uint32_t *>(smem + mpad + wpad + 60u));
+}
+
 // Reference order of the generic search's rows (generic_search.py:221-237: blocks in order, the hits of a block by
 // index, the matches of a hit in emission order) restored on the device.  A hit's first row = the rows of all hits
 // with a smaller key (block << 56 | index).  Quadratic, tiled 256 x 64 over (hit, other hit) pairs with partial

@@ -114,6 +114,7 @@ struct DevState {
     uint8_t *d_gen_dedup = nullptr;               // window table of the generic search (FzGenDedup, fz_device.h)
     bool dedup_zeroed = false;                   // ... zeroed behind the last search that used it
     bool dedup_used = false;                     // the search being collected ran with it (row count = counters[FZ_HDR_GEN_ROWS])
+    bool gen_multi_used = false;                 // ... and its automaton as fz_gen_hit_kernel (counters[FZ_HDR_GEN_FAIL]: hits it gave up on)
     uint64_t gen_rows_cap = 0;                   // rows
     uint8_t *h_big = nullptr, *h_big_dev = nullptr;
     uint64_t big_cap = 0;                        // records
@@ -295,6 +296,12 @@ struct fz_ctx {
     // be resident at once (256 slots: 8 KB of LDS per wave, 19 waves per CU; 1024: 7 per CU); a search
     // that overflows them re-runs with 4x the slots and the context remembers.
     uint32_t gen_cand_cap = 256;
+    // The per-hit automaton runs as fz_gen_hit_kernel (a workgroup of 2 or 4 waves per hit).  A search in which a hit
+    // outgrows a wave's share of the candidate list or its match buffer is run again with fz_lp_kernel (one wave per hit),
+    // and so are the next gen_multi_skip searches of the context (1, 2, 4 .. 64 after consecutive failures; a success
+    // resets the back-off): inputs that always fail (dense repeats) pay a wasted launch now and then, not every time.
+    bool gen_multi = getenv("FZ_GEN_LEGACY") == nullptr;
+    uint32_t gen_multi_skip = 0, gen_multi_backoff = 0;
     // Single-shard searches in direct mode leave their records in the pinned staging buffer and only
     // publish a view of them (valid until the next search of this context): saves a 24 B x nr memcpy.
     const FzRec *view = nullptr;
@@ -1284,7 +1291,8 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
     ctx->stats.n_devices = (uint32_t)ctx->devs.size();
     static_assert(sizeof(FzGenRec) == sizeof(FzRec), "record buffers are shared");
     uint32_t cand_cap = ctx->gen_cand_cap;
-    for (int attempt = 0; attempt < 9; ++attempt) {
+    bool legacy_rest = false;                                  // the remaining attempts of this search use fz_lp_kernel
+    for (int attempt = 0; attempt < 10; ++attempt) {
         recs_out.clear();
         ctx->any_found = false;
         ctx->gen_view = nullptr;
@@ -1292,6 +1300,9 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
         ctx->gen_rows_dev = nullptr;
         ctx->gen_rows_n = 0;
         bool rerun = false;
+        bool multi_failed = false, multi_ok = false;
+        const bool legacy_now = legacy_rest || (attempt == 0 && phase != 2 && ctx->gen_multi_skip > 0);
+        if (attempt == 0 && phase != 2 && ctx->gen_multi_skip > 0) { --ctx->gen_multi_skip; legacy_rest = true; }
         ctx->stats.filter_launches = 0;
         ctx->stats.bytes_scanned = ctx->stats.ngram_hits = ctx->stats.raw_matches = 0;
         ctx->stats.filter_ms = ctx->stats.verify_ms = ctx->stats.device_ms = 0;
@@ -1363,6 +1374,19 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
                            : fold_direct ? reinterpret_cast<FzGenRec *>(d.h_stage_dev + kHeaderBytes)
                                          : reinterpret_cast<FzGenRec *>(d.d_out + kHeaderBytes);
             static_assert(sizeof(FzGenRec) == sizeof(FzRec), "the generic records share the record buffer");
+            // fz_gen_hit_kernel: four waves per hit, every wave a quarter of the list (in-memory searches with the lists in LDS)
+            static const uint32_t gh_waves = []() { const char *e = getenv("FZ_GH_WAVES"); return e && atoi(e) == 4 ? 4u : 2u; }();
+            const uint32_t capw = std::max<uint32_t>(64u, cand_cap / 2u);
+            const size_t lds_multi = (size_t)mpad + wpad + FZ_GH_CTL_BYTES + (size_t)gh_waves * 2u * capw * sizeof(FzGCand) +
+                                     (size_t)gh_waves * FZ_GH_MCAP * 8u;
+            const bool multi = ctx->gen_multi && !legacy_now && scratch == 0 && sh.geom.seg_stride == 0 && lds_multi <= 160 * 1024;
+            d.gen_multi_used = multi;
+            if (multi) {
+                fa.cand_cap = capw;
+                if (lds_multi > 64 * 1024)
+                    HIP_TRY(hipFuncSetAttribute(gh_waves == 4 ? reinterpret_cast<const void *>(fz_gen_hit_kernel<4>) : reinterpret_cast<const void *>(fz_gen_hit_kernel<2>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi));
+            }
             if (lds > 64 * 1024)
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(lp_kernel(FZ_LP_GENERIC_HIT, scratch != 0)),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1393,7 +1417,16 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             static const bool no_ext = getenv("FZ_NO_EXT_LAUNCH") != nullptr;
             hipEvent_t lp_stop = no_ext ? nullptr : fold_direct ? d.ev[3] : ctx->timing ? d.ev[2] : nullptr;
             d.lp_end_event = fold_direct ? 3 : 2;
-            if (lp_stop)
+            static const unsigned multi_per_cu = getenv("FZ_GH_GRID_PER_CU") ? (unsigned)atoi(getenv("FZ_GH_GRID_PER_CU")) : 16u;   // lab knob
+            using GhKernel = void (*)(const uint8_t *, const FzScanArgs, const uint64_t *, FzGenRec *, unsigned long long *);
+            const GhKernel gh = gh_waves == 4 ? fz_gen_hit_kernel<4> : fz_gen_hit_kernel<2>;
+            if (multi && lp_stop)
+                hipExtLaunchKernelGGL(gh, dim3(d.n_cus * multi_per_cu), dim3(64 * gh_waves), lds_multi, st2, nullptr, lp_stop, 0u,
+                                      sh.d_buf, fa, d.d_hits, recs, counters);
+            else if (multi)
+                hipLaunchKernelGGL(gh, dim3(d.n_cus * multi_per_cu), dim3(64 * gh_waves), lds_multi, st2, sh.d_buf, fa, d.d_hits,
+                                   recs, counters);
+            else if (lp_stop)
                 hipExtLaunchKernelGGL(lp_kernel(FZ_LP_GENERIC_HIT, scratch != 0), dim3(scratch ? kCandScratchGrid : d.n_cus * grid_per_cu),
                                       dim3(64), lds, st2, nullptr, lp_stop, 0u, sh.d_buf, fa, d.d_hits, (uint64_t)0, recs, counters);
             else
@@ -1436,7 +1469,15 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             HIP_TRY(hipEventSynchronize(d.ev[3]));            // (recorded behind the last command of the search, on whichever stream)
             trg.mark(" generic sync");
             const unsigned long long *cnt = reinterpret_cast<const unsigned long long *>(d.h_stage);
-            const uint64_t nh = cnt[0], nr = cnt[1], novf = cnt[2];
+            const uint64_t nh = cnt[0], nr = cnt[1];
+            uint64_t novf = cnt[2];
+            if (d.gen_multi_used && cnt[FZ_HDR_GEN_FAIL]) {   // a hit outgrew a wave's share of the list / its match buffer: one wave per hit
+                multi_failed = true;
+                if (q.any && nr > 0) { ctx->any_found = true; continue; }
+                rerun = true;
+                continue;
+            }
+            if (d.gen_multi_used) multi_ok = true;
             // rows of the ordered search: with the window table every hit takes its window's matches, computed once
             const uint64_t nrows = d.dedup_used && !q.fold && !q.any && nh <= FZ_GEN_ORDER_MAX ? cnt[FZ_HDR_GEN_ROWS] : nr;
             if (q.any) {                                      // has_near_match_generic_ngrams: a record anywhere settles it
@@ -1479,6 +1520,13 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
                 recs_out.resize(base + nr);
                 if (nr) memcpy(recs_out.data() + base, d.h_big, nr * sizeof(FzGenRec));
             }
+        }
+        if (multi_failed) {
+            legacy_rest = true;
+            ctx->gen_multi_backoff = ctx->gen_multi_backoff ? std::min<uint32_t>(64u, ctx->gen_multi_backoff * 2u) : 1u;
+            ctx->gen_multi_skip = ctx->gen_multi_backoff;
+        } else if (multi_ok && !rerun) {
+            ctx->gen_multi_backoff = 0;
         }
         if (lists_overflowed) cand_cap *= 4;
         if (q.any && ctx->any_found) return FZ_OK;

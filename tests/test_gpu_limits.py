@@ -49,6 +49,18 @@ def test_generic_window_table_on_and_off():
     assert (n_cases2, n_rec2) == (n_cases, n_rec)
 
 
+def test_generic_automaton_kernel_forms():
+    """The per-hit automaton as a workgroup of 2 waves (default) or 4 waves per hit (fz_gen_hit_kernel: the window's start
+    positions dealt out to the waves, the sorted match buffers merged by rank) and as one wave per hit (fz_lp_kernel,
+    FZ_GEN_LEGACY=1) — the same random cases (dense repeats among them: hits that outgrow a wave's match buffer make the
+    search run again on fz_lp_kernel, with a back-off for the searches that follow) against the oracle."""
+    base = _sub(["windows", 200, 23], {})
+    assert base[0] == 200 and base[1] > 4000
+    assert _sub(["windows", 200, 23], {"FZ_GH_WAVES": "4"}) == base
+    assert _sub(["windows", 200, 23], {"FZ_GEN_LEGACY": "1"}) == base
+    assert _sub(["windows", 120, 24], {"FZ_GH_WAVES": "4", "FZ_GEN_NO_DEDUP": "1"})[0] == 120
+
+
 def test_copy_mode_one_and_two_searches_in_flight():
     """FZ_NO_DIRECT=1: nothing is written straight into the pinned staging buffer (round 3's randomized run found the
     younger of two searches in flight overwriting the older one's records in the shared device buffer under this switch)."""
