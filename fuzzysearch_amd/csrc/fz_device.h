@@ -623,14 +623,12 @@ struct FzGenRec {
 // an n-gram hit (generic_search.py:229-231): it depends on idx - s only, and the hits that the different n-gram blocks of
 // ONE occurrence produce share it (a planted copy with e edits is found by up to G - e blocks: BASELINE configs[3b] has
 // 3x as many hits as distinct windows).  The reference runs its automaton once per hit and emits the same matches each
-// time; here a hit runs the automaton only if, when its wave arrives, no hit of a SMALLER block has claimed the window
-// (atomicMax on the inverted (block, slot) word: the hit of the smallest block always runs, and — hits being listed in scan
-// order — nearly always arrives first); the window's matches are those of its smallest-block hit, the "leader":
-//   ordered form: every hit of the window registers as a member, fz_gen_order_kernel counts the leader's rows for each
-//     of them and fz_gen_scatter_kernel writes every row of the leader once per member, with the member's block number
-//     (records of hits that ran before a smaller block arrived are skipped);
-//   folded / flag-only form: the other hits emit nothing, or (hull, best) pairs that repeat the leader's with a larger
-//     block number — a consolidation keeps the smallest.
+// time; here the scan enters every hit it lists into a table of windows (fz_gen_claim: the window's slot by atomicCAS, the
+// hit as a member, the window's LEADER = its hit of the smallest block by atomicMax on the inverted (block, slot) word),
+// and the automaton kernel runs the leaders only:
+//   ordered form: fz_gen_order_kernel counts the leader's rows for every member and fz_gen_scatter_kernel writes every row
+//     of the leader once per member, with the member's block number;
+//   folded / flag-only form: the other hits emit nothing (a consolidation of equal matches keeps the smallest block).
 // Layout at FzScanArgs.gen_dedup: u64 keys[T] (idx + k - s + 1; 0 = free), u64 best[T] (~((block << 32) | hit-list slot),
 // maximum = smallest block), u32 nmem[T], u32 mem[T][FZ_GEN_DEDUP_MEMBERS], u32 wslot[FZ_GEN_ORDER_MAX] (table slot of
 // every hit, or FZ_GEN_DEDUP_NONE: the hit keeps its own rows).  keys, best and nmem must be zero when a search starts.

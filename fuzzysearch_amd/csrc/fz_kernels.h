@@ -499,6 +499,30 @@ __device__ __forceinline__ void fz_prefetch_tile(const uint8_t *__restrict__ buf
 // separately because the in-memory search (one segment, the whole sequence) must not pay for it in
 // registers.  FUSED && !SEG: the windows were prefetched (entry e -> slot e).  Returns the number of
 // confirmed n-gram hits.
+// Generic search, window table (fz_device.h: FzGenDedup): the scan enters every n-gram hit it lists — its window's slot
+// (claimed by atomicCAS), the hit as a member of the window, and the window's leader = the hit of the smallest block
+// (atomicMax on the inverted word) — so that when the automaton kernel starts, every hit knows whether it runs.
+__device__ __forceinline__ void fz_gen_claim(const FzScanArgs &a, uint64_t hit, unsigned long long q) {
+    if (q >= FZ_GEN_ORDER_MAX) return;
+    const FzGenDedup dd(a.gen_dedup);
+    const uint32_t blk = fz_hit_block(hit);
+    const unsigned long long wk = fz_hit_index(hit) + a.k - (unsigned long long)blk * a.L + 1ull;
+    uint32_t slot = (uint32_t)((wk * 0x9E3779B97F4A7C15ull) >> 40) & (FZ_GEN_DEDUP_SLOTS - 1u);
+    uint32_t at = FZ_GEN_DEDUP_NONE;
+    for (uint32_t probe = 0; probe < 32u; ++probe) {
+        const unsigned long long old = atomicCAS(&dd.keys[slot], 0ull, wk);
+        if (old == 0ull || old == wk) { at = slot; break; }
+        slot = (slot + 1u) & (FZ_GEN_DEDUP_SLOTS - 1u);
+    }
+    if (at != FZ_GEN_DEDUP_NONE) {                            // (a crowded table or a full member list: the hit stays on its own)
+        const uint32_t pos = atomicAdd(&dd.nmem[at], 1u);
+        if (pos < FZ_GEN_DEDUP_MEMBERS) dd.mem[at * FZ_GEN_DEDUP_MEMBERS + pos] = (uint32_t)q;
+        else at = FZ_GEN_DEDUP_NONE;
+    }
+    if (at != FZ_GEN_DEDUP_NONE) atomicMax(&dd.best[at], ~(((unsigned long long)blk << 32) | q));
+    dd.wslot[q] = at;
+}
+
 template <bool FUSED, bool SEG>
 __device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ buf, const FzScanArgs &a,
                                                    const uint8_t *pat_lds, const FzWaveLds &w, uint32_t qn,
@@ -553,7 +577,10 @@ __device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ b
                     if (lane == 0) base = atomicAdd(&counters[0], (unsigned long long)__popcll(mask));
                     base = fz_bcast64(base);
                     const unsigned long long slot = base + fz_rank(mask);
-                    if (valid && slot < a.hit_cap) hits[slot] = hit;
+                    if (valid && slot < a.hit_cap) {
+                        hits[slot] = hit;
+                        if (!SEG && a.gen_dedup) fz_gen_claim(a, hit, slot);
+                    }
                 }
             }
         }
@@ -1362,6 +1389,14 @@ __device__ __forceinline__ uint32_t fz_wave_incl_scan(uint32_t v) {
 #endif
 }
 
+#ifdef FZ_LAB_LPTIME
+// lab build: per n-gram hit {shader clock at start, after the window is staged, at the end, slice steps << 32 | characters}
+static __device__ unsigned long long fz_lab_lp[16384 * 4];
+#define FZ_LAB_LP(q, i, v) do { if ((q) < 16384u && (threadIdx.x & 63u) == 0 && (threadIdx.x >> 6) == 0) fz_lab_lp[(q) * 4u + (i)] = (v); } while (0)
+#else
+#define FZ_LAB_LP(q, i, v) do { } while (0)
+#endif
+
 // KIND (FzLpKind) and HBM_LISTS are compile-time: the per-hit instance carries none of the tiled Levenshtein
 // automaton's code, and with the lists in LDS their accesses are ds_ instructions instead of flat ones.
 template <int KIND, bool HBM_LISTS>
@@ -1414,34 +1449,17 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
             const uint64_t idx = fz_hit_index(hit);
             const FzSeg sg = fz_segment(a.geom, idx, (uint32_t)(qc % ncand));
             if (!fz_hit_in_range_s(a, s, idx, sg)) {                   // wave-uniform: one hit per wave
-                if (order && q < FZ_GEN_ORDER_MAX && lane == 0) { order_first[q] = 0; order_count[q] = 0; if (dedup) dd.wslot[q] = FZ_GEN_DEDUP_NONE; }
+                if (order && q < FZ_GEN_ORDER_MAX && lane == 0) { order_first[q] = 0; order_count[q] = 0; }
                 continue;
             }
             if (dedup) {
-                // find the window's slot, register (ordered form), and run only as the smallest block seen so far
-                uint32_t run = 1u;
-                if (lane == 0) {
-                    const unsigned long long wk = idx + a.k - s + 1ull;
-                    uint32_t slot = (uint32_t)((wk * 0x9E3779B97F4A7C15ull) >> 40) & (FZ_GEN_DEDUP_SLOTS - 1u);
-                    uint32_t at = FZ_GEN_DEDUP_NONE;
-                    for (uint32_t probe = 0; probe < 32u; ++probe) {
-                        const unsigned long long old = atomicCAS(&dd.keys[slot], 0ull, wk);
-                        if (old == 0ull || old == wk) { at = slot; break; }
-                        slot = (slot + 1u) & (FZ_GEN_DEDUP_SLOTS - 1u);
-                    }
-                    if (at != FZ_GEN_DEDUP_NONE && order) {            // (a crowded table or a full member list: the hit stays on its own)
-                        const uint32_t pos = atomicAdd(&dd.nmem[at], 1u);
-                        if (pos < FZ_GEN_DEDUP_MEMBERS) dd.mem[at * FZ_GEN_DEDUP_MEMBERS + pos] = (uint32_t)q;
-                        else at = FZ_GEN_DEDUP_NONE;
-                    }
-                    if (at != FZ_GEN_DEDUP_NONE) {
-                        const unsigned long long mine = ~(((unsigned long long)fz_hit_block(hit) << 32) | (unsigned long long)q);
-                        run = atomicMax(&dd.best[at], mine) < mine ? 1u : 0u;
-                    }
-                    if (order) { dd.wslot[q] = at; if (!run) { order_first[q] = 0; order_count[q] = 0; } }
+                // the scan entered the hit into the window table: only the window's leader (smallest block) runs
+                const uint32_t sl = dd.wslot[q];
+                if (sl != FZ_GEN_DEDUP_NONE && dd.leader(sl) != (uint32_t)q) {
+                    if (order && lane == 0) { order_first[q] = 0; order_count[q] = 0; }
+                    FZ_LAB_LP(q, 2, 0ull);
+                    continue;
                 }
-                run = (uint32_t)__builtin_amdgcn_readfirstlane((int)run);
-                if (!run) continue;
             }
             const uint64_t reach = (uint64_t)s + a.k;
             w0 = idx - sg.sa > reach ? idx - reach : sg.sa;            // generic_search.py:231
@@ -1461,8 +1479,11 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
             key_base = w0;                  // elsewhere every candidate of this tile has died by w1
         }
         const uint32_t wlen = (uint32_t)(w1 - w0);
+        FZ_LAB_LP(q, 0, __builtin_readcyclecounter());
         for (uint32_t i = lane; i < wlen; i += 64u) win[i] = buf[(w0 - a.geom.buf_off) + i];
         fz_wave_lds_sync();
+        FZ_LAB_LP(q, 1, __builtin_readcyclecounter());
+        uint32_t lab_slices = 0;
 
         uint32_t ncur = 0, mb = 0, mseq = 0;
         bool overflow = false;
@@ -1478,12 +1499,22 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
             if (lane == 0) {
                 // (measured: without this atomic — slot = hit number — the kernel takes the same 0.164 ms: the slot counter is
                 //  not what the automaton waits for)
-                const unsigned long long slot = atomicAdd(&counters[1], 1ull);
-                if (slot < a.rec_cap) {
-                    const uint32_t len = 0xffffu - (f_k1 & 0xffffu);
-                    FzGenRec r;
-                    r.key = key_base; r.seq = f_pairs; r.se = f_k2 | ((f_k2 + len) << 16); r.dist = f_k1 >> 16; r.win = f_lo | (f_hi << 16);
-                    recs[slot] = r;
+                // Window table: this hit stands for every hit of its window.  Their equal matches fall into one overlap group
+                // (the smallest block — this hit's — is the one a consolidation keeps) EXCEPT zero-length matches, which
+                // overlap nothing, not even their own copies (common.py:152-153): a pair with an empty hull is emitted once
+                // per member of the window, under that member's key.
+                const uint32_t sl = dedup ? dd.wslot[q] : FZ_GEN_DEDUP_NONE;
+                uint32_t copies = 1u;
+                if (sl != FZ_GEN_DEDUP_NONE && f_lo == f_hi) { copies = dd.nmem[sl]; copies = copies < FZ_GEN_DEDUP_MEMBERS ? copies : FZ_GEN_DEDUP_MEMBERS; }
+                for (uint32_t cpy = 0; cpy < copies; ++cpy) {
+                    const unsigned long long slot = atomicAdd(&counters[1], 1ull);
+                    if (slot < a.rec_cap) {
+                        const uint32_t len = 0xffffu - (f_k1 & 0xffffu);
+                        FzGenRec r;
+                        r.key = copies > 1u ? hits[dd.mem[sl * FZ_GEN_DEDUP_MEMBERS + cpy]] : key_base;
+                        r.seq = f_pairs; r.se = f_k2 | ((f_k2 + len) << 16); r.dist = f_k1 >> 16; r.win = f_lo | (f_hi << 16);
+                        recs[slot] = r;
+                    }
                 }
             }
             ++f_pairs;
@@ -1688,6 +1719,7 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
                     load_step(c0, st);
                     if (!emit(st)) { overflow = true; break; }
                 }
+                lab_slices += (ncur + 63u) / 64u;
             } else {
                 for (uint32_t c0 = 0; c0 < ncur; c0 += 64u) {
                     FzGStep st;
@@ -1722,6 +1754,8 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
             if (fold && f_have) emit_pair();
         }
         if (order && q < FZ_GEN_ORDER_MAX && lane == 0) { order_first[q] = 0; order_count[q] = overflow ? 0u : mseq; }
+        FZ_LAB_LP(q, 2, __builtin_readcyclecounter());
+        FZ_LAB_LP(q, 3, ((unsigned long long)lab_slices << 32) | wlen);
         fz_wave_lds_sync();
     }
     // folded search whose pairs went straight into the host's staging buffer: the last workgroup publishes the counters
@@ -1792,7 +1826,7 @@ __global__ __launch_bounds__(64 * W) void fz_gen_hit_kernel(const uint8_t *__res
         const uint64_t idx = fz_hit_index(hit);
         const FzSeg sg = fz_segment(a.geom, idx, 0u);
         if (!fz_hit_in_range_s(a, s, idx, sg)) {             // the same for every thread
-            if (order && q < FZ_GEN_ORDER_MAX && tid == 0) { order_first[q] = 0; order_count[q] = 0; if (dedup) dd.wslot[q] = FZ_GEN_DEDUP_NONE; }
+            if (order && q < FZ_GEN_ORDER_MAX && tid == 0) { order_first[q] = 0; order_count[q] = 0; }
             continue;
         }
         const uint64_t reach = (uint64_t)s + a.k;
@@ -1803,32 +1837,21 @@ __global__ __launch_bounds__(64 * W) void fz_gen_hit_kernel(const uint8_t *__res
         if (tid == 0) {
             uint32_t run = 1u, stop = 0u;
             if ((a.flags & FZ_FLAG_ANY) && __hip_atomic_load(&counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) { stop = 1u; run = 0u; }
-            if (dedup && !stop) {                           // the window table (fz_device.h: FzGenDedup), as in fz_lp_kernel
-                const unsigned long long wk = idx + a.k - s + 1ull;
-                uint32_t slot = (uint32_t)((wk * 0x9E3779B97F4A7C15ull) >> 40) & (FZ_GEN_DEDUP_SLOTS - 1u);
-                uint32_t at = FZ_GEN_DEDUP_NONE;
-                for (uint32_t probe = 0; probe < 32u; ++probe) {
-                    const unsigned long long old = atomicCAS(&dd.keys[slot], 0ull, wk);
-                    if (old == 0ull || old == wk) { at = slot; break; }
-                    slot = (slot + 1u) & (FZ_GEN_DEDUP_SLOTS - 1u);
+            if (dedup && !stop) {                           // the window table (fz_device.h: FzGenDedup): only the window's leader runs
+                const uint32_t sl = dd.wslot[q];
+                if (sl != FZ_GEN_DEDUP_NONE && dd.leader(sl) != (uint32_t)q) {
+                    run = 0u;
+                    if (order) { order_first[q] = 0; order_count[q] = 0; }
                 }
-                if (at != FZ_GEN_DEDUP_NONE && order) {
-                    const uint32_t pos = atomicAdd(&dd.nmem[at], 1u);
-                    if (pos < FZ_GEN_DEDUP_MEMBERS) dd.mem[at * FZ_GEN_DEDUP_MEMBERS + pos] = (uint32_t)q;
-                    else at = FZ_GEN_DEDUP_NONE;
-                }
-                if (at != FZ_GEN_DEDUP_NONE) {
-                    const unsigned long long mine = ~(((unsigned long long)fz_hit_block(hit) << 32) | (unsigned long long)q);
-                    run = atomicMax(&dd.best[at], mine) < mine ? 1u : 0u;
-                }
-                if (order) { dd.wslot[q] = at; if (!run) { order_first[q] = 0; order_count[q] = 0; } }
             }
             ctl[0] = run; ctl[1] = 0u; ctl[8] = stop;
         }
+        FZ_LAB_LP(q, 0, __builtin_readcyclecounter());
         for (uint32_t i = tid; i < wlen; i += 64u * W) win[i] = buf[(w0 - a.geom.buf_off) + i];
         __syncthreads();
+        FZ_LAB_LP(q, 1, __builtin_readcyclecounter());
         if (ctl[8]) break;                                  // has_near_match_*: a record exists somewhere
-        if (!ctl[0]) continue;                              // a hit of a smaller block runs this window
+        if (!ctl[0]) { FZ_LAB_LP(q, 2, 0ull); continue; }     // a hit of a smaller block runs this window
 
         // ---- this wave's quarter of the candidate list over the whole window; no synchronisation with the other waves ----
         uint32_t ncur = 0, mb = 0;
@@ -1893,6 +1916,8 @@ __global__ __launch_bounds__(64 * W) void fz_gen_hit_kernel(const uint8_t *__res
         }
         if (lane == 0) { ctl[2u + wave] = mb; if (fail) ctl[1] = 1u; }
         __syncthreads();
+        FZ_LAB_LP(q, 2, __builtin_readcyclecounter());
+        FZ_LAB_LP(q, 3, (unsigned long long)wlen);
         if (ctl[1]) {                                       // outgrew a list quarter or a match buffer: the host re-runs with fz_lp_kernel
             if (tid == 0) atomicAdd(&counters[FZ_HDR_GEN_FAIL], 1ull);
             continue;
@@ -1912,12 +1937,19 @@ __global__ __launch_bounds__(64 * W) void fz_gen_hit_kernel(const uint8_t *__res
                 uint32_t f_lo = 0, f_hi = 0, f_k1 = 0, f_k2 = 0, f_pairs = 0;
                 auto emit_pair = [&]() {
                     if (lane == 0) {
-                        const unsigned long long slot = atomicAdd(&counters[1], 1ull);
-                        if (slot < a.rec_cap) {
-                            const uint32_t len = 0xffffu - (f_k1 & 0xffffu);
-                            FzGenRec r;
-                            r.key = hit; r.seq = f_pairs; r.se = f_k2 | ((f_k2 + len) << 16); r.dist = f_k1 >> 16; r.win = f_lo | (f_hi << 16);
-                            recs[slot] = r;
+                        // (window table: a pair with an empty hull once per member of the window — see fz_lp_kernel)
+                        const uint32_t sl = dedup ? dd.wslot[q] : FZ_GEN_DEDUP_NONE;
+                        uint32_t copies = 1u;
+                        if (sl != FZ_GEN_DEDUP_NONE && f_lo == f_hi) { copies = dd.nmem[sl]; copies = copies < FZ_GEN_DEDUP_MEMBERS ? copies : FZ_GEN_DEDUP_MEMBERS; }
+                        for (uint32_t cpy = 0; cpy < copies; ++cpy) {
+                            const unsigned long long slot = atomicAdd(&counters[1], 1ull);
+                            if (slot < a.rec_cap) {
+                                const uint32_t len = 0xffffu - (f_k1 & 0xffffu);
+                                FzGenRec r;
+                                r.key = copies > 1u ? hits[dd.mem[sl * FZ_GEN_DEDUP_MEMBERS + cpy]] : hit;
+                                r.seq = f_pairs; r.se = f_k2 | ((f_k2 + len) << 16); r.dist = f_k1 >> 16; r.win = f_lo | (f_hi << 16);
+                                recs[slot] = r;
+                            }
                         }
                     }
                     ++f_pairs;

@@ -113,6 +113,7 @@ struct DevState {
     uint8_t *d_gen_rows = nullptr;
     uint8_t *d_gen_dedup = nullptr;               // window table of the generic search (FzGenDedup, fz_device.h)
     bool dedup_zeroed = false;                   // ... zeroed behind the last search that used it
+    uint64_t gen_dedup_arg = 0;                  // ... its address for the kernels of the search being launched (0: no table)
     bool dedup_used = false;                     // the search being collected ran with it (row count = counters[FZ_HDR_GEN_ROWS])
     bool gen_multi_used = false;                 // ... and its automaton as fz_gen_hit_kernel (counters[FZ_HDR_GEN_FAIL]: hits it gave up on)
     uint64_t gen_rows_cap = 0;                   // rows
@@ -628,6 +629,7 @@ void fill_common_args(FzScanArgs &fa, const Shard &sh, const Search &q) {
     if (q.m <= FZ_MAX_M) memcpy(fa.pat, q.p, q.m);
 }
 
+
 // The pattern in HBM, for kernels that do not (or cannot) take it from the kernel-argument block.  The copy is
 // ordered on the device's stream like the kernels that read it (searches of one context run one after the other
 // on that stream, so two searches in flight can share the buffer).
@@ -734,6 +736,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
 
     FzScanArgs fa;
     fill_common_args(fa, sh, q);
+    if (q.mode == FZ_MODE_GENERIC && !with_verify) fa.gen_dedup = d.gen_dedup_arg;      // the scan fills the window table (run_generic)
     static const bool force_big = getenv("FZ_FORCE_BIG_VERIFY") != nullptr;
     const VerifyPlan vp = plan_verify(q);
     {
@@ -1310,9 +1313,30 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
         const uint32_t mpad = (q.m + 15u) & ~15u, wpad = (q.m + 2 * q.k + 15u) & ~15u;
         for (const Shard &sh : seq->shards) {
             if (phase == 2 && attempt == 0) break;            // launched by fz_generic_ngrams_begin
+            DevState &d = lane_dev(ctx, sh.dev);
+            // Window table: the hits that the n-gram blocks of one occurrence produce share their window, the automaton runs
+            // once per window (fz_device.h: FzGenDedup; the scan fills the table as it lists the hits).  Where the rows are
+            // finished on the device, where only (hull, best) pairs leave it, and for the flag-only search;
+            // FZ_GEN_NO_DEDUP=1: every hit on its own (A/B, tests).
+            static const bool no_dedup = getenv("FZ_GEN_NO_DEDUP") != nullptr;
+            static const bool gen_direct0 = getenv("FZ_GEN_DIRECT") != nullptr, host_order0 = getenv("FZ_GEN_HOST_ORDER") != nullptr;
+            const bool dev_order0 = !gen_direct0 && !host_order0 && !q.any && !q.fold && seq->shards.size() == 1 && sh.geom.seg_stride == 0 &&
+                                    !comm_multi_process(ctx);
+            const bool dedup = !no_dedup && sh.geom.seg_stride == 0 && (dev_order0 || q.fold || q.any);
+            d.dedup_used = dedup;
+            d.gen_dedup_arg = 0;
+            if (dedup) {
+                HIP_TRY(hipSetDevice(d.device));
+                if (!d.d_gen_dedup) {
+                    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d.d_gen_dedup), FZ_GEN_DEDUP_BYTES));
+                    d.dedup_zeroed = false;
+                }
+                if (!d.dedup_zeroed) HIP_TRY(hipMemsetAsync(d.d_gen_dedup, 0, FZ_GEN_DEDUP_ZERO_BYTES, d.stream));
+                d.dedup_zeroed = false;
+                d.gen_dedup_arg = reinterpret_cast<uint64_t>(d.d_gen_dedup);
+            }
             int rc = enqueue_shard(ctx, sh, q, /*with_verify=*/false, /*copy_back=*/false);
             if (rc) return rc;
-            DevState &d = lane_dev(ctx, sh.dev);
             size_t lds = 0;
             uint64_t scratch = 0;
             rc = cand_lists(d, cand_cap, mpad + wpad + FZ_GEN_MCAP * 8 + FZ_LP_TRASH_BYTES, lds, scratch);
@@ -1346,21 +1370,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
                 fa.gen_order = reinterpret_cast<uint64_t>(d.d_gen_order);
                 fa.rows_cap = d.gen_rows_cap;
             }
-            // Window table: the hits that the n-gram blocks of one occurrence produce share their window, the automaton runs
-            // once per window (fz_device.h: FzGenDedup).  Where the rows are finished on the device, where only (hull, best)
-            // pairs leave it, and for the flag-only search; FZ_GEN_NO_DEDUP=1: every hit on its own (A/B, tests).
-            static const bool no_dedup = getenv("FZ_GEN_NO_DEDUP") != nullptr;
-            const bool dedup = !no_dedup && sh.geom.seg_stride == 0 && (dev_order || q.fold || q.any);
-            d.dedup_used = dedup;
-            if (dedup) {
-                if (!d.d_gen_dedup) {
-                    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d.d_gen_dedup), FZ_GEN_DEDUP_BYTES));
-                    d.dedup_zeroed = false;
-                }
-                if (!d.dedup_zeroed) HIP_TRY(hipMemsetAsync(d.d_gen_dedup, 0, FZ_GEN_DEDUP_ZERO_BYTES, d.stream));
-                d.dedup_zeroed = false;
-                fa.gen_dedup = reinterpret_cast<uint64_t>(d.d_gen_dedup);
-            }
+            fa.gen_dedup = d.gen_dedup_arg;
             // Folded search (a few thousand pairs): the automaton kernel writes them straight into the pinned staging
             // buffer and its last workgroup publishes the counters there, as the fused scan does for its records — no
             // copy command between the kernel and the host (FZ_NO_DIRECT=1, or more pairs than the buffer holds: the copy).
@@ -1417,7 +1427,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             static const bool no_ext = getenv("FZ_NO_EXT_LAUNCH") != nullptr;
             hipEvent_t lp_stop = no_ext ? nullptr : fold_direct ? d.ev[3] : ctx->timing ? d.ev[2] : nullptr;
             d.lp_end_event = fold_direct ? 3 : 2;
-            static const unsigned multi_per_cu = getenv("FZ_GH_GRID_PER_CU") ? (unsigned)atoi(getenv("FZ_GH_GRID_PER_CU")) : 16u;   // lab knob
+            static const unsigned multi_per_cu = getenv("FZ_GH_GRID_PER_CU") ? (unsigned)atoi(getenv("FZ_GH_GRID_PER_CU")) : 32u;   // lab knob (configs[3b]: 16 -> 0.130 ms, 32 -> 0.104: every hit of the search needs a workgroup of its own)
             using GhKernel = void (*)(const uint8_t *, const FzScanArgs, const uint64_t *, FzGenRec *, unsigned long long *);
             const GhKernel gh = gh_waves == 4 ? fz_gen_hit_kernel<4> : fz_gen_hit_kernel<2>;
             if (multi && lp_stop)
@@ -1454,7 +1464,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
                 if (!lp_stop) HIP_TRY(hipEventRecord(d.ev[3], st2));
                 d.header_zeroed = true;                       // by the publishing workgroup
             }
-            if (dedup && st2 == d.stream) {                   // the window table is cleared for the next search, behind this one
+            if (d.dedup_used && st2 == d.stream) {            // the window table is cleared for the next search, behind this one
                 HIP_TRY(hipMemsetAsync(d.d_gen_dedup, 0, FZ_GEN_DEDUP_ZERO_BYTES, d.stream));
                 d.dedup_zeroed = true;
             }
@@ -4097,5 +4107,13 @@ int fz_stats(fz_ctx *ctx, fz_stats_t *out) {
 }
 
 void fz_free(void *p) { release_out(p); }
+
+#ifdef FZ_LAB_LPTIME
+// lab builds only (benchmarks/lab_build.sh ... -DFZ_LAB_LPTIME; not part of the C-ABI): the per-hit time stamps of the
+// automaton kernels of the last generic search
+int fz_lab_lp_read(unsigned long long *out, uint64_t n_words) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(fz_lab_lp), std::min<uint64_t>(n_words, 16384ull * 4) * 8, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+}
+#endif
 
 }  // extern "C"
