@@ -754,41 +754,6 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
             const bool fire = __ballot(acc == 0) != 0;
             if (__builtin_expect(fire, 0)) {              // wave-uniform, rare: some lane, some offset
                 if (__builtin_expect(!dup_hashes, 1)) {
-#ifdef FZ_LAB_NORARE
-                    asm volatile("s_nop 0");               // (lab, timing only: the filter's compares stay, what they find is dropped)
-#elif defined(FZ_LAB_GROUPQ)
-                    // (Lab variant, timing only — the results are wrong: the firing lanes queue ONE code per 4-offset group,
-                    // offset and block left to the flush.  Upper bound of what deferring the resolution could save.)
-                    const unsigned long long fm = __ballot(acc == 0);
-                    const uint32_t gslot = qn + fz_rank(fm);
-                    uint32_t gpos = threadIdx.x;
-                    asm volatile("v_lshlrev_b32 %0, 4, %0" : "+v"(gpos));
-                    if (acc == 0 && gslot < qcap) w.queue[gslot] = fz_code(gpos + (uint32_t)(r * FZ_ROW_BYTES + GRP * j), 0u, titer);
-                    qn += (uint32_t)__popcll(fm);
-#elif defined(FZ_RARE_SCALAR)
-                    // (Lab variant, measured in round 3 and NOT kept: the firing lane resolved on the scalar unit — the
-                    // lane's four xor words by v_readlane, offset and table slot as scalar arithmetic, the block by one
-                    // wave-uniform LDS read, the code by a wave-uniform LDS write: ~9 vector-issue slots per hit instead of
-                    // ~16, 6M fewer VALU wave-instructions per GiB — and 0.2205 instead of 0.2150 ms: the dependent
-                    // readlane -> compare -> branch chain per hit costs more than the issue slots it frees, and the
-                    // SGPR spills grow from 71 to 119.)
-                    unsigned long long fm = __ballot(acc == 0);
-                    do {
-                        const uint32_t fl = (uint32_t)__builtin_ctzll(fm);
-                        fm &= fm - 1ull;
-#pragma unroll
-                        for (int i = 0; i < GRP; ++i) {
-                            if (__builtin_amdgcn_readlane((int)am[i], (int)fl) == 0) {
-                                const uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)hv[i], (int)fl);
-                                const uint32_t sl = (SA ? (h >> 2) : (h >> a.lut_shift)) & (FZ_LUT_SLOTS - 1u);
-                                const uint32_t g = lut[FZ_LUT_SLOTS + sl];                    // the same word in every lane
-                                const uint32_t off = ((wave * 64u + fl) << 4) + (uint32_t)(r * FZ_ROW_BYTES + GRP * j + i);
-                                if (qn < qcap) w.queue[qn] = fz_code(off, g, titer);
-                                ++qn;
-                            }
-                        }
-                    } while (fm);
-#else
 #pragma unroll
                     for (int i = 0; i < GRP; ++i) {
                         const unsigned long long mi = __ballot(hv[i] == lv[i]);      // which offset (scalar branch)
@@ -809,7 +774,6 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                             qn += (uint32_t)__popcll(mi);
                         }
                     }
-#endif
                 } else {
                     // equal n-grams share a slot: compare with every block of the launch
 #pragma unroll 1
@@ -941,7 +905,7 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
 // Verification of a hit list in HBM, one lane per candidate (parameter ranges whose LDS footprint does
 // not fit beside the filter, substitutions with large budgets, Levenshtein budgets above 31).  One wave
 // verifies 64 hits at a time.  Dynamic LDS: pattern + per-wave window/score areas.
-__global__ void fz_verify_kernel(const uint8_t *__restrict__ buf, const FzScanArgs a,
+__global__ __launch_bounds__(256) void fz_verify_kernel(const uint8_t *__restrict__ buf, const FzScanArgs a,
                                  const uint64_t *__restrict__ hits, FzRec *__restrict__ recs,
                                  unsigned long long *__restrict__ counters) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1356,10 +1320,6 @@ __global__ __launch_bounds__(64) void fz_verify_big_kernel(const uint8_t *__rest
 #ifndef FZ_LP_PAIR
 #define FZ_LP_PAIR 1                                       // the per-hit automaton steps two 64-candidate slices per trip
 #endif
-#ifndef FZ_LP_TRASH
-#define FZ_LP_TRASH 0                                      // lab: list / match stores unconditional, lanes without output write to a
-#endif                                                     // per-lane trash slot (an address select instead of an exec-mask round trip)
-#define FZ_LP_TRASH_BYTES (FZ_LP_TRASH ? 512u : 0u)
 #ifndef FZ_GEN_MCAP
 #define FZ_GEN_MCAP 128                                    // match-buffer entries per wave (1 KB: with 256-entry candidate lists
                                                            // 24 waves per CU are resident, every hit of configs[3b] at once)
@@ -1418,9 +1378,6 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
                              : reinterpret_cast<FzGCand *>(smem + mpad + wpad);
     FzGCand *nxt = cur + a.cand_cap;
     uint64_t *mbuf = reinterpret_cast<uint64_t *>(smem + mpad + wpad + (HBM_LISTS ? 0u : 2u * a.cand_cap * (uint32_t)sizeof(FzGCand)));
-#if FZ_LP_TRASH
-    uint64_t *trash = mbuf + FZ_GEN_MCAP + lane;           // this lane's slot behind the match buffer
-#endif
     fz_copy_pattern(pat, a, lane, 64u);
     fz_wave_lds_sync();
     auto patf = [&](uint32_t i) -> uint8_t { return pat[i]; };
@@ -1622,16 +1579,6 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
                 uint2 *nx = reinterpret_cast<uint2 *>(nxt) + nnext + (excl & 0xffffu);
                 uint64_t *mp = mbuf + mb + (excl >> 16);
                 const uint64_t stamp = (uint64_t)index << 48;
-#if FZ_LP_TRASH
-                if constexpr (!HBM_LISTS) {
-                    uint2 *t2 = reinterpret_cast<uint2 *>(trash);
-                    *(st.fa ? nx : t2) = make_uint2(st.a0, st.a1);
-                    *(st.fb ? nx + st.fa : t2) = make_uint2(st.b0, st.b1);
-                    *(st.fc ? nx + st.fa + st.fb : t2) = make_uint2(st.c0, st.c1);
-                    *(st.f1 ? mp : trash) = (uint64_t)st.m1 | ((uint64_t)st.d1 << 32) | stamp;
-                    *(st.f2 ? mp + st.f1 : trash) = (uint64_t)st.m2 | ((uint64_t)st.d2 << 32) | stamp;
-                } else
-#endif
                 {
                     if (st.fa) nx[0] = make_uint2(st.a0, st.a1);
                     if (st.fb) nx[st.fa] = make_uint2(st.b0, st.b1);
@@ -1685,19 +1632,6 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
                         uint2 *nxb = reinterpret_cast<uint2 *>(nxt) + nnext + (eb & 0xffffu);
                         uint64_t *mpa = mbuf + mb + (ea >> 16), *mpb = mbuf + mb + (eb >> 16);
                         const uint64_t stamp = (uint64_t)index << 48;
-#if FZ_LP_TRASH
-                        uint2 *t2 = reinterpret_cast<uint2 *>(trash);
-                        *(sa.fa ? nxa : t2) = make_uint2(sa.a0, sa.a1);
-                        *(sa.fb ? nxa + sa.fa : t2) = make_uint2(sa.b0, sa.b1);
-                        *(sa.fc ? nxa + sa.fa + sa.fb : t2) = make_uint2(sa.c0, sa.c1);
-                        *(sb.fa ? nxb : t2) = make_uint2(sb.a0, sb.a1);
-                        *(sb.fb ? nxb + sb.fa : t2) = make_uint2(sb.b0, sb.b1);
-                        *(sb.fc ? nxb + sb.fa + sb.fb : t2) = make_uint2(sb.c0, sb.c1);
-                        *(sa.f1 ? mpa : trash) = (uint64_t)sa.m1 | ((uint64_t)sa.d1 << 32) | stamp;
-                        *(sa.f2 ? mpa + sa.f1 : trash) = (uint64_t)sa.m2 | ((uint64_t)sa.d2 << 32) | stamp;
-                        *(sb.f1 ? mpb : trash) = (uint64_t)sb.m1 | ((uint64_t)sb.d1 << 32) | stamp;
-                        *(sb.f2 ? mpb + sb.f1 : trash) = (uint64_t)sb.m2 | ((uint64_t)sb.d2 << 32) | stamp;
-#else
                         if (sa.fa) nxa[0] = make_uint2(sa.a0, sa.a1);
                         if (sa.fb) nxa[sa.fa] = make_uint2(sa.b0, sa.b1);
                         if (sa.fc) nxa[sa.fa + sa.fb] = make_uint2(sa.c0, sa.c1);
@@ -1708,7 +1642,6 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
                         if (sa.f2) mpa[sa.f1] = (uint64_t)sa.m2 | ((uint64_t)sa.d2 << 32) | stamp;
                         if (sb.f1) mpb[0] = (uint64_t)sb.m1 | ((uint64_t)sb.d1 << 32) | stamp;
                         if (sb.f2) mpb[sb.f1] = (uint64_t)sb.m2 | ((uint64_t)sb.d2 << 32) | stamp;
-#endif
                         nnext += tot_s;
                         mb += tot_m;
                     }
@@ -1727,16 +1660,13 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
                     if (c0 + lane < ncur) {
                         const uint2 cw = reinterpret_cast<const uint2 *>(cur)[c0 + lane];
                         const FzGCand c = fz_gcand_of(cw.x, cw.y);
-                        FzGOut o;
-                        o.nsucc = 0; o.nmatch = 0;
                         if (!last) {
-                            fz_levlp_step(c, ch, index, more_seq, a.m, patf, a.k, o);
+                            fz_levlp_step_slots(c, ch, index, more_seq, a.m, patf, a.k, st);
                         } else {
                             uint32_t d;
                             const bool hit_end = lev ? fz_levlp_final(c, a.m, a.k, d) : fz_generic_final(c, a.m, a.max_dels, a.k, d);
-                            if (hit_end) { o.mstart[0] = c.start; o.mend[0] = wlen; o.mdist[0] = d; o.nmatch = 1; }
+                            if (hit_end) { st.f1 = 1; st.m1 = (uint32_t)c.start | (wlen << 16); st.d1 = d; }
                         }
-                        fz_gstep_from_out(o, st);
                     }
                     if (!emit(st)) { overflow = true; break; }
                 }

@@ -1339,7 +1339,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             if (rc) return rc;
             size_t lds = 0;
             uint64_t scratch = 0;
-            rc = cand_lists(d, cand_cap, mpad + wpad + FZ_GEN_MCAP * 8 + FZ_LP_TRASH_BYTES, lds, scratch);
+            rc = cand_lists(d, cand_cap, mpad + wpad + FZ_GEN_MCAP * 8, lds, scratch);
             if (rc) return rc;
             FzScanArgs fa;
             fill_common_args(fa, sh, q);
@@ -2907,7 +2907,7 @@ int run_lp(fz_ctx *ctx, fz_seq *seq, const Search &q, uint32_t lp_kind, std::vec
             HIP_TRY(hipSetDevice(d.device));
             size_t lds = 0;
             uint64_t scratch = 0;
-            int rc_lists = cand_lists(d, cand_cap, mpad + wpad + FZ_GEN_MCAP * 8 + FZ_LP_TRASH_BYTES, lds, scratch);
+            int rc_lists = cand_lists(d, cand_cap, mpad + wpad + FZ_GEN_MCAP * 8, lds, scratch);
             if (rc_lists) return rc_lists;
             unsigned long long *counters = reinterpret_cast<unsigned long long *>(d.d_out);
             FzGenRec *recs = reinterpret_cast<FzGenRec *>(d.d_out + kHeaderBytes);

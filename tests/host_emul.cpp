@@ -199,8 +199,15 @@ int64_t emul_generic_lp_packed(const uint8_t *p, uint32_t m, const uint8_t *t, u
 // row count; a hit's first row is the sum of the counts of all hits with a smaller key; every record lands at
 // first row + emission number as fz_gen_row makes it.  -> rows, or -1 if packed and struct steps ever disagreed.
 int64_t emul_generic_ngrams_ordered(const uint8_t *p, uint32_t m, const uint8_t *t, uint64_t n, uint32_t max_subs,
-                                    uint32_t max_ins, uint32_t max_dels, uint32_t max_l, uint32_t scramble,
+                                    uint32_t max_ins, uint32_t max_dels, uint32_t max_l, uint32_t scramble, uint32_t mode,
                                     OutRec *out, int64_t cap) {
+    // mode: bit 0 = the window table (fz_device.h: FzGenDedup — the scan enters every hit, the smallest block of a window
+    // leads, members take the leader's rows); bits 1..2 = waves per hit (0: one wave, fz_lp_kernel; 1: two, 2: four —
+    // fz_gen_hit_kernel: starts dealt out to the waves, match buffers merged by rank); bits 8.. = member-list length to
+    // model (0: the real one), so that windows with more hits than a slot lists are reached with few blocks
+    const bool dedup = mode & 1u;
+    const uint32_t W = 1u << ((mode >> 1) & 3u);
+    const uint32_t members_cap = (mode >> 8) ? std::min<uint32_t>(mode >> 8, FZ_GEN_DEDUP_MEMBERS) : FZ_GEN_DEDUP_MEMBERS;
     const uint32_t k = max_l, L = m / (k + 1);
     if (L == 0) return -2;
     FzScanArgs a;
@@ -211,12 +218,41 @@ int64_t emul_generic_ngrams_ordered(const uint8_t *p, uint32_t m, const uint8_t 
     uint32_t g = 0;
     for (uint32_t s = 0; s + L <= m; s += L, ++g)
         for (uint64_t idx = 0; idx + L <= n; ++idx)
-            if (memcmp(t + idx, p + s, L) == 0) hits.push_back(fz_hit_pack(g, idx));
+            if (memcmp(t + idx, p + s, L) == 0) {
+                const FzSeg sg = fz_segment(a.geom, idx, 0);
+                if (fz_hit_in_range_s(a, s, idx, sg)) hits.push_back(fz_hit_pack(g, idx));   // (the scan lists hits in range only)
+            }
     // the scan kernel appends hits with atomics: any order
     uint64_t x = 0x9E3779B97F4A7C15ull * (scramble + 1);
     for (size_t i = hits.size(); i > 1; --i) {
         x ^= x << 13; x ^= x >> 7; x ^= x << 17;
         std::swap(hits[i - 1], hits[x % i]);
+    }
+    if (hits.size() > FZ_GEN_ORDER_MAX) return -4;
+    // fz_gen_claim, hit by hit in list order (the scan does it with atomics as it lists the hits)
+    std::vector<uint8_t> table(dedup ? FZ_GEN_DEDUP_BYTES : 8, 0);
+    const FzGenDedup dd(reinterpret_cast<uint64_t>(table.data()));
+    if (dedup) {
+        for (size_t q = 0; q < hits.size(); ++q) {
+            const uint32_t blk = fz_hit_block(hits[q]);
+            const unsigned long long wk = fz_hit_index(hits[q]) + k - (unsigned long long)blk * L + 1ull;
+            uint32_t slot = (uint32_t)((wk * 0x9E3779B97F4A7C15ull) >> 40) & (FZ_GEN_DEDUP_SLOTS - 1u);
+            uint32_t at = FZ_GEN_DEDUP_NONE;
+            for (uint32_t probe = 0; probe < 32u; ++probe) {
+                if (dd.keys[slot] == 0ull || dd.keys[slot] == wk) { dd.keys[slot] = wk; at = slot; break; }
+                slot = (slot + 1u) & (FZ_GEN_DEDUP_SLOTS - 1u);
+            }
+            if (at != FZ_GEN_DEDUP_NONE) {
+                const uint32_t pos = dd.nmem[at]++;
+                if (pos < members_cap) dd.mem[at * FZ_GEN_DEDUP_MEMBERS + pos] = (uint32_t)q;
+                else at = FZ_GEN_DEDUP_NONE;
+            }
+            if (at != FZ_GEN_DEDUP_NONE) {
+                const unsigned long long mine = ~(((unsigned long long)blk << 32) | (unsigned long long)q);
+                if (dd.best[at] < mine) dd.best[at] = mine;
+            }
+            dd.wslot[q] = at;
+        }
     }
     struct Rec { uint32_t slot, seq, se, dist; };
     std::vector<Rec> recs;
@@ -228,51 +264,146 @@ int64_t emul_generic_ngrams_ordered(const uint8_t *p, uint32_t m, const uint8_t 
         const uint64_t idx = fz_hit_index(hit);
         const FzSeg sg = fz_segment(a.geom, idx, 0);
         if (!fz_hit_in_range_s(a, s, idx, sg)) continue;
+        if (dedup && dd.wslot[q] != FZ_GEN_DEDUP_NONE && dd.leader(dd.wslot[q]) != (uint32_t)q) continue;   // its window's leader runs
         const uint64_t reach = (uint64_t)s + k;
         const uint64_t w0 = idx - sg.sa > reach ? idx - reach : sg.sa;
         uint64_t w1 = idx - s + m + k;
         if (w1 > sg.se) w1 = sg.se;
         const uint32_t wlen = (uint32_t)(w1 - w0);
-        std::vector<uint64_t> cur, nxt;
-        uint32_t mseq = 0;
-        for (uint32_t index = 0; index < wlen; ++index) {
-            cur.push_back((uint64_t)index);
-            nxt.clear();
-            for (uint64_t cw : cur) {
-                FzGStep st;
-                fz_generic_step_packed((uint32_t)cw, (uint32_t)(cw >> 32), t[w0 + index], index, m, pat, max_subs, max_ins, max_dels,
-                                       max_l, st);
-                if (st.fa) nxt.push_back(st.a0 | ((uint64_t)st.a1 << 32));
-                if (st.fb) nxt.push_back(st.b0 | ((uint64_t)st.b1 << 32));
-                if (st.fc) nxt.push_back(st.c0 | ((uint64_t)st.c1 << 32));
-                if (st.f1) recs.push_back(Rec{(uint32_t)q, mseq++, st.m1, st.d1});
-                if (st.f2) recs.push_back(Rec{(uint32_t)q, mseq++, st.m2, st.d2});
+        // every wave: its share of the starts over the whole window, matches buffered as (step << 48 | dist << 32 | se)
+        std::vector<std::vector<uint64_t>> mbuf(W);
+        for (uint32_t wave = 0; wave < W; ++wave) {
+            std::vector<uint64_t> cur, nxt;
+            for (uint32_t index = 0; index < wlen; ++index) {
+                if ((index & (W - 1u)) == wave) cur.push_back((uint64_t)index);
+                nxt.clear();
+                for (uint64_t cw : cur) {
+                    FzGStep st;
+                    fz_generic_step_packed((uint32_t)cw, (uint32_t)(cw >> 32), t[w0 + index], index, m, pat, max_subs, max_ins, max_dels,
+                                           max_l, st);
+                    if (st.fa) nxt.push_back(st.a0 | ((uint64_t)st.a1 << 32));
+                    if (st.fb) nxt.push_back(st.b0 | ((uint64_t)st.b1 << 32));
+                    if (st.fc) nxt.push_back(st.c0 | ((uint64_t)st.c1 << 32));
+                    if (st.f1) mbuf[wave].push_back((uint64_t)st.m1 | ((uint64_t)st.d1 << 32) | ((uint64_t)index << 48));
+                    if (st.f2) mbuf[wave].push_back((uint64_t)st.m2 | ((uint64_t)st.d2 << 32) | ((uint64_t)index << 48));
+                }
+                cur.swap(nxt);
             }
-            cur.swap(nxt);
+            for (uint64_t cw : cur) {                            // end-of-window flush
+                uint32_t d;
+                const FzGCand c = fz_gcand_of((uint32_t)cw, (uint32_t)(cw >> 32));
+                if (fz_generic_final(c, m, max_dels, max_l, d))
+                    mbuf[wave].push_back((uint64_t)((uint32_t)c.start | (wlen << 16)) | ((uint64_t)d << 32) | ((uint64_t)wlen << 48));
+            }
         }
-        for (uint64_t cw : cur) {                                // end-of-window flush
-            uint32_t d;
-            const FzGCand c = fz_gcand_of((uint32_t)cw, (uint32_t)(cw >> 32));
-            if (fz_generic_final(c, m, max_dels, max_l, d)) recs.push_back(Rec{(uint32_t)q, mseq++, (uint32_t)c.start | (wlen << 16), d});
-        }
-        count[q] = mseq;
+        // merge by rank: own position + the entries of the other waves with a smaller (step, start)
+        auto key_of = [](uint64_t v) { return ((uint32_t)(v >> 48) << 16) | ((uint32_t)v & 0xffffu); };
+        uint32_t total = 0;
+        for (uint32_t wave = 0; wave < W; ++wave) total += (uint32_t)mbuf[wave].size();
+        for (uint32_t wave = 0; wave < W; ++wave)
+            for (uint32_t e = 0; e < mbuf[wave].size(); ++e) {
+                const uint64_t v = mbuf[wave][e];
+                uint32_t rank = e;
+                for (uint32_t w2 = 0; w2 < W; ++w2) {
+                    if (w2 == wave) continue;
+                    uint32_t lo = 0, hi = (uint32_t)mbuf[w2].size();
+                    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (key_of(mbuf[w2][mid]) < key_of(v)) lo = mid + 1; else hi = mid; }
+                    rank += lo;
+                }
+                recs.push_back(Rec{(uint32_t)q, rank, (uint32_t)v, (uint32_t)(v >> 32) & 0xffffu});
+            }
+        count[q] = total;
     }
+    auto rows_of = [&](size_t j) -> uint32_t {
+        if (!dedup) return count[j];
+        const uint32_t sl = dd.wslot[j];
+        return count[sl == FZ_GEN_DEDUP_NONE ? j : dd.leader(sl)];
+    };
     std::vector<uint64_t> first(hits.size(), 0);                 // fz_gen_order_kernel
-    for (size_t i = 0; i < hits.size(); ++i)
+    uint64_t nrows = 0;
+    for (size_t i = 0; i < hits.size(); ++i) {
+        nrows += rows_of(i);
         for (size_t j = 0; j < hits.size(); ++j)
-            if (hits[j] < hits[i]) first[i] += count[j];
-    std::vector<FzOutRow> rows(recs.size());                     // fz_gen_scatter_kernel
-    std::vector<uint8_t> written(recs.size(), 0);
-    for (const Rec &r : recs) {
-        const uint64_t pos = first[r.slot] + r.seq;
-        if (pos >= rows.size() || written[pos]) return -3;
-        written[pos] = 1;
-        rows[pos] = fz_gen_row(hits[r.slot], L, k, 0, r.se, r.dist);
+            if (hits[j] < hits[i]) first[i] += rows_of(j);
     }
+    std::vector<FzOutRow> rows(nrows);                           // fz_gen_scatter_kernel
+    std::vector<uint8_t> written(nrows, 0);
+    auto put = [&](uint32_t h, const Rec &r) -> bool {
+        const uint64_t pos = first[h] + r.seq;
+        if (pos >= rows.size() || written[pos]) return false;
+        written[pos] = 1;
+        rows[pos] = fz_gen_row(hits[h], L, k, 0, r.se, r.dist);
+        return true;
+    };
+    for (const Rec &r : recs) {
+        const uint32_t sl = dedup ? dd.wslot[r.slot] : FZ_GEN_DEDUP_NONE;
+        if (sl == FZ_GEN_DEDUP_NONE) { if (!put(r.slot, r)) return -3; continue; }
+        if (dd.leader(sl) != r.slot) continue;
+        const uint32_t nm = std::min<uint32_t>(dd.nmem[sl], members_cap);
+        for (uint32_t i = 0; i < nm; ++i)
+            if (!put(dd.mem[sl * FZ_GEN_DEDUP_MEMBERS + i], r)) return -3;
+    }
+    for (size_t i = 0; i < rows.size(); ++i) if (!written[i]) return -5;
     for (size_t i = 0; i < rows.size() && (int64_t)i < cap; ++i) {
         out[i].start = rows[i].start; out[i].end = rows[i].end; out[i].dist = rows[i].dist; out[i].block = rows[i].block;
     }
     return (int64_t)rows.size();
+}
+
+// find_near_matches_levenshtein_linear_programming over a whole sequence through the struct form of the step
+// (fz_levlp_step, the statement of levenshtein.py:52-148) and through the slot form the kernel stores from
+// (fz_levlp_step_slots): both must emit the same list; -> -1 if the two forms ever disagree.
+int64_t emul_lev_lp(const uint8_t *p, uint32_t m, const uint8_t *t, uint32_t n, uint32_t k, OutRec *out, int64_t cap) {
+    std::vector<uint64_t> cur, nxt;
+    int64_t cnt = 0;
+    bool agree = true;
+    auto pat = [&](uint32_t i) -> uint8_t { return p[i]; };
+    auto emit = [&](uint32_t se, uint32_t d) {
+        if (cnt < cap) { out[cnt].start = se & 0xffffu; out[cnt].end = se >> 16; out[cnt].dist = (int32_t)d; out[cnt].block = -1; }
+        ++cnt;
+    };
+    for (uint32_t index = 0; index < n; ++index) {
+        nxt.clear();
+        const uint8_t ch = t[index];
+        // levenshtein.py:75-80: a fresh candidate for the first pattern char (within the budget) equal to ch goes FIRST
+        uint32_t f = 0xffffffffu;
+        const uint32_t lim = k + 1 < m ? k + 1 : m;
+        for (uint32_t i = 0; i < lim; ++i) if (p[i] == ch) { f = i; break; }
+        if (f != 0xffffffffu) {
+            if (f + 1 == m) emit(index | ((index + 1) << 16), f);
+            else { FzGCand c; c.start = (uint16_t)index; c.j = (uint16_t)(f + 1); c.l = (uint8_t)f; c.ns = c.ni = c.nd = 0; uint32_t w0, w1; fz_gcand_words(c, w0, w1); nxt.push_back(w0 | ((uint64_t)w1 << 32)); }
+        }
+        const bool more_seq = index + 1 < n;
+        for (uint64_t cw : cur) {
+            const FzGCand c = fz_gcand_of((uint32_t)cw, (uint32_t)(cw >> 32));
+            FzGStep st;
+            fz_levlp_step_slots(c, ch, index, more_seq, m, pat, k, st);
+            FzGOut o;
+            fz_levlp_step(c, ch, index, more_seq, m, pat, k, o);
+            FzGStep ref;
+            fz_gstep_from_out(o, ref);
+            uint64_t got[3], want[3];
+            uint32_t ng = 0, nw = 0;
+            if (st.fa) got[ng++] = st.a0 | ((uint64_t)st.a1 << 32);
+            if (st.fb) got[ng++] = st.b0 | ((uint64_t)st.b1 << 32);
+            if (st.fc) got[ng++] = st.c0 | ((uint64_t)st.c1 << 32);
+            if (ref.fa) want[nw++] = ref.a0 | ((uint64_t)ref.a1 << 32);
+            if (ref.fb) want[nw++] = ref.b0 | ((uint64_t)ref.b1 << 32);
+            if (ref.fc) want[nw++] = ref.c0 | ((uint64_t)ref.c1 << 32);
+            agree &= ng == nw && st.f2 == 0 && ref.f2 == 0 && st.f1 == ref.f1;
+            for (uint32_t i = 0; i < ng && i < nw; ++i) agree &= got[i] == want[i];
+            if (st.f1) agree &= st.m1 == ref.m1 && st.d1 == ref.d1;
+            for (uint32_t i = 0; i < ng; ++i) nxt.push_back(got[i]);
+            if (st.f1) emit(st.m1, st.d1);
+        }
+        cur.swap(nxt);
+    }
+    for (uint64_t cw : cur) {
+        uint32_t d;
+        const FzGCand c = fz_gcand_of((uint32_t)cw, (uint32_t)(cw >> 32));
+        if (fz_levlp_final(c, m, k, d)) emit((uint32_t)c.start | (n << 16), d);
+    }
+    return agree ? cnt : -1;
 }
 
 int emul_expand(const uint8_t *sub, uint32_t sublen, const uint8_t *win, uint32_t winlen, uint32_t budget,

@@ -151,26 +151,58 @@ def test_generic_automaton_struct_and_packed_steps_equal_oracle(emul):
 def test_generic_ngram_search_as_ordered_on_the_device_equals_oracle(emul):
     """The whole generic n-gram pipeline in the form the GPU runs it with device-side ordering — hits in a scrambled
     order, packed automaton per hit window, row counts, first rows by key, scatter through fz_gen_row — emits the
-    oracle's list (blocks in order, hits by index, matches in emission order, duplicates included)."""
+    oracle's list (blocks in order, hits by index, matches in emission order, duplicates included).  Round 4: with the
+    window table (the scan enters every hit; only the smallest block of a window runs, the others take its rows; member
+    lists shortened to 2 so that windows with more hits than a slot lists occur) and with the starts of a window dealt
+    out to 2 or 4 waves whose sorted match buffers are merged by rank (fz_gen_hit_kernel)."""
     fn = emul.emul_generic_ngrams_ordered
     fn.restype = ctypes.c_int64
     fn.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
-                   ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(OutRec), ctypes.c_int64]
+                   ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(OutRec), ctypes.c_int64]
     rnd = random.Random(12)
     cap = 1 << 17
     out = (OutRec * cap)()
     done = total = 0
+    modes = [0, 1, 1 | (1 << 1), 1 | (2 << 1), (1 << 1), 1 | (1 << 1) | (2 << 8), 1 | (2 << 8)]
     while done < 1500:
         p, t, k = _case(rnd, max_n=120, max_m=24, max_k=4)
+        if done % 3 == 0 and len(t) > 3 * len(p):                   # exact copies: every block hits, the windows are shared
+            at = rnd.randint(0, len(t) - len(p))
+            t = t[:at] + p + t[at + len(p):]
         limits = (rnd.randint(0, k), rnd.randint(0, k), rnd.randint(0, k))
         max_l = min(k, sum(limits))
         if max_l == 0 or len(p) // (max_l + 1) == 0:
             continue
         want = oracle.generic_ngrams_raw(p, t, limits[0], limits[1], limits[2], max_l)
-        c = fn(p, len(p), t, len(t), limits[0], limits[1], limits[2], max_l, done, out, cap)
-        assert 0 <= c <= cap, (c, p, t, limits, max_l)
-        got = [(out[i].start, out[i].end, out[i].dist, out[i].block) for i in range(c)]
-        assert got == [tuple(r) for r in want], (p, t, limits, max_l)
+        for mode in (modes if done % 4 == 0 else [modes[done % len(modes)]]):
+            c = fn(p, len(p), t, len(t), limits[0], limits[1], limits[2], max_l, done, mode, out, cap)
+            assert 0 <= c <= cap, (c, mode, p, t, limits, max_l)
+            got = [(out[i].start, out[i].end, out[i].dist, out[i].block) for i in range(c)]
+            assert got == [tuple(r) for r in want], (mode, p, t, limits, max_l)
         done += 1
         total += c
     assert total > 20000
+
+
+def test_levenshtein_lp_struct_and_slot_steps_equal_oracle(emul):
+    """fz_levlp_step (the statement of levenshtein.py:52-148) and fz_levlp_step_slots (what fz_lp_kernel stores from since
+    round 4: no arrays, no scratch memory) driven over whole sequences: the oracle's list, and the two forms agree
+    candidate by candidate."""
+    fn = emul.emul_lev_lp
+    fn.restype = ctypes.c_int64
+    fn.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(OutRec), ctypes.c_int64]
+    rnd = random.Random(14)
+    cap = 1 << 16
+    out = (OutRec * cap)()
+    done = nonempty = 0
+    while done < 3000:
+        p, t, k = _case(rnd, max_n=70, max_m=12, max_k=4)
+        if k >= len(p):
+            continue
+        want = [r[:3] for r in oracle.lev_lp_raw(p, t, k)]
+        c = fn(p, len(p), t, len(t), k, out, cap)
+        assert 0 <= c <= cap, (c, p, t, k)
+        assert [(out[i].start, out[i].end, out[i].dist) for i in range(c)] == want, (p, t, k)
+        done += 1
+        nonempty += bool(want)
+    assert nonempty > 1500

@@ -418,8 +418,7 @@ def test_record_ordering_host_step():
 
 
 def test_no_kernel_spills_to_scratch():
-    """Compiler resource remarks collected by fuzzysearch_amd/build.py: the streaming and automaton kernels must not
-    use scratch memory (round 3 caught a 1.5 KB-per-lane copy of the argument struct in every hit-emitting scan
+    """Compiler resource remarks collected by fuzzysearch_amd/build.py: no kernel may use scratch memory (round 3 caught a 1.5 KB-per-lane copy of the argument struct in every hit-emitting scan
     instance — exact search 3.4x slower, every parity test green)."""
     import os
     import pytest
@@ -433,11 +432,9 @@ def test_no_kernel_spills_to_scratch():
             rows[parts[0]] = dict(kv.split("=") for kv in parts[1:])
     scan = {k: v for k, v in rows.items() if "fz_scan_kernel" in k}
     assert len(scan) == 40
-    for name, r in rows.items():
-        hot = ("fz_scan_kernel" in name or "fz_verify_wf_kernel" in name or "fz_verify_big_kernel" in name or
-               "fz_lp_kernelILi0E" in name or "fz_gen_" in name or "fz_hamming" in name)
-        if hot:
-            assert int(r["scratch"]) == 0 and int(r["vgpr_spill"]) == 0, (name, r)
+    assert len(rows) >= 60 and any("fz_gen_hit_kernel" in k for k in rows) and any("fz_verify_kernel" in k for k in rows)
+    for name, r in rows.items():                                  # round 4: EVERY kernel (fz_verify_kernel had 232 B / 57 spilled VGPRs, the tiled
+        assert int(r["scratch"]) == 0 and int(r["vgpr_spill"]) == 0, (name, r)   # Levenshtein automaton 20 B)
     headline = [v for k, v in scan.items() if "ILi2ELi3ELb1ELb0ELb1EE" in k]
     assert len(headline) == 1 and int(headline[0]["occupancy"]) == 7 and int(headline[0]["vgprs"]) <= 72
 
