@@ -8,5 +8,5 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1; shift
 mkdir -p $ROOT/benchmarks/lab
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-function -Wno-pass-failed \
-  -DFZ_LAB_ONLY "$@" $ROOT/fuzzysearch_amd/csrc/fzhip.hip -ldl -Wl,-rpath,/opt/rocm/lib -o $ROOT/benchmarks/lab/libfzhip_$NAME.so
+  "$@" $ROOT/fuzzysearch_amd/csrc/fzhip.hip -ldl -Wl,-rpath,/opt/rocm/lib -o $ROOT/benchmarks/lab/libfzhip_$NAME.so
 echo built benchmarks/lab/libfzhip_$NAME.so

@@ -600,23 +600,22 @@ FZ_HD void fz_levlp_step(const FzGCand &c, uint8_t ch, uint32_t index, bool more
 // successors in list order a (:103), b (:105-111), c (:114-137), at most one match.  No arrays: the struct form's
 // succ[] was indexed dynamically here and lived in scratch memory (20 bytes per lane in the tiled Levenshtein automaton).
 template <class PatF>
-FZ_HD void fz_levlp_step_slots(const FzGCand &c, uint8_t ch, uint32_t index, bool more_seq, uint32_t m, PatF pat,
+FZ_HD void fz_levlp_step_slots(uint32_t w0, uint32_t w1, uint8_t ch, uint32_t index, bool more_seq, uint32_t m, PatF pat,
                                uint32_t k, FzGStep &o) {
     fz_gstep_clear(o);
-    uint32_t w0, w1;
-    fz_gcand_words(c, w0, w1);
-    if (pat(c.j) == ch) {                                              // :84-92
-        if (c.j + 1u == m) { o.f1 = 1; o.m1 = (uint32_t)c.start | ((index + 1u) << 16); o.d1 = c.l; }
+    const uint32_t start = w0 & 0xffffu, j = w0 >> 16, l = w1 & 0xffu;
+    if (pat(j) == ch) {                                                // :84-92
+        if (j + 1u == m) { o.f1 = 1; o.m1 = start | ((index + 1u) << 16); o.d1 = l; }
         else { o.fa = 1; o.a0 = w0 + 0x10000u; o.a1 = w1; }
         return;
     }
-    if (c.l == k) return;                                              // :99-100
+    if (l == k) return;                                                // :99-100
     o.fa = 1; o.a0 = w0; o.a1 = w1 + 1u;                               // :103 skip a sequence char (l++)
-    if (more_seq && c.j + 1u < m) { o.fb = 1; o.b0 = w0 + 0x10000u; o.b1 = w1 + 1u; }   // :105-111 skip both
-    for (uint32_t sk = 1; sk <= k - c.l; ++sk) {                       // :114-137 skip pattern chars
-        const bool at_end = c.j + sk == m;
-        if (at_end || pat(c.j + sk) == ch) {
-            if (at_end || c.j + sk + 1u == m) { o.f1 = 1; o.m1 = (uint32_t)c.start | ((index + 1u) << 16); o.d1 = c.l + sk; }
+    if (more_seq && j + 1u < m) { o.fb = 1; o.b0 = w0 + 0x10000u; o.b1 = w1 + 1u; }   // :105-111 skip both
+    for (uint32_t sk = 1; sk <= k - l; ++sk) {                         // :114-137 skip pattern chars
+        const bool at_end = j + sk == m;
+        if (at_end || pat(j + sk) == ch) {
+            if (at_end || j + sk + 1u == m) { o.f1 = 1; o.m1 = start | ((index + 1u) << 16); o.d1 = l + sk; }
             else { o.fc = 1; o.c0 = w0 + ((1u + sk) << 16); o.c1 = w1 + sk; }
             break;
         }

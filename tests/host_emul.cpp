@@ -377,7 +377,7 @@ int64_t emul_lev_lp(const uint8_t *p, uint32_t m, const uint8_t *t, uint32_t n, 
         for (uint64_t cw : cur) {
             const FzGCand c = fz_gcand_of((uint32_t)cw, (uint32_t)(cw >> 32));
             FzGStep st;
-            fz_levlp_step_slots(c, ch, index, more_seq, m, pat, k, st);
+            fz_levlp_step_slots((uint32_t)cw, (uint32_t)(cw >> 32), ch, index, more_seq, m, pat, k, st);
             FzGOut o;
             fz_levlp_step(c, ch, index, more_seq, m, pat, k, o);
             FzGStep ref;
