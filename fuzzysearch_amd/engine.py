@@ -78,14 +78,36 @@ def _remap_str(subsequence, sequence):
 
 
 def _remap_items(subsequence, sequence):
+    """list / tuple inputs: every distinct subsequence item -> a code 1..255, every other sequence item -> 0 (all the
+    algorithms on this path only compare a subsequence item with a sequence item).  Integer items (the common case of
+    non-text sequences) are coded by one vectorised numpy pass; anything else by a dict lookup per item that runs inside
+    `map` (no Python-level loop body)."""
+    try:
+        p = np.asarray(subsequence)
+        t = np.asarray(sequence)
+        if p.dtype.kind in 'iub' and t.dtype.kind in 'iub' and p.ndim == 1 and t.ndim == 1:
+            p = p.astype(np.int64, copy=False) if p.dtype.kind != 'u' or p.dtype.itemsize < 8 else p
+            t = t.astype(p.dtype, copy=False)
+            symbols = np.unique(p)
+            if len(symbols) > 255:
+                raise UnsupportedSearch('subsequences with more than 255 distinct symbols are not supported')
+
+            def code(a):
+                if len(a) == 0:
+                    return b''
+                pos = np.minimum(np.searchsorted(symbols, a), len(symbols) - 1)
+                return np.where(symbols[pos] == a, pos + 1, 0).astype(np.uint8).tobytes()
+            return code(p), code(t)
+    except (ValueError, TypeError, OverflowError):
+        pass                                             # ragged / mixed items: the general form below
     table = {}
     for item in subsequence:
         if item not in table:
             if len(table) == 255:
                 raise UnsupportedSearch('subsequences with more than 255 distinct symbols are not supported')
             table[item] = len(table) + 1
-    get = table.get
-    return bytes(table[item] for item in subsequence), bytes(bytearray(get(item, 0) for item in sequence))
+    from itertools import repeat
+    return bytes(map(table.__getitem__, subsequence)), bytes(map(table.get, sequence, repeat(0)))
 
 
 def encode_pair(subsequence, sequence):
