@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = (
     "fz_lev_lp", "fz_subs_lp", "fz_generic_lp", "fz_subs_ngrams_any", "fz_subs_lp_any", "fz_generic_ngrams_any", "fz_generic_ngrams_consolidated",
     "fz_lev_ngrams_consolidated", "fz_subs_ngrams_best",
     "fz_stream_open", "fz_stream_buffer", "fz_stream_submit", "fz_stream_read_fd", "fz_stream_finish", "fz_stream_close",
-    "fz_consolidate", "fz_group_best", "fz_merge_ranks", "fz_wire_pack", "fz_wire_merge", "fz_debug_launch_plan", "fz_debug_order_records", "fz_debug_order_records_bounded", "fz_debug_order_segments", "fz_stats", "fz_set_timing", "fz_device_ms", "fz_free",
+    "fz_consolidate", "fz_group_best", "fz_merge_ranks", "fz_wire_pack", "fz_wire_merge", "fz_debug_launch_plan", "fz_debug_order_records", "fz_debug_order_records_bounded", "fz_debug_order_segments", "fz_stats", "fz_set_timing", "fz_set_streams", "fz_device_ms", "fz_free",
     "fz_comm_unique_id", "fz_comm_init_rank", "fz_comm_init_all", "fz_comm_info", "fz_comm_set_collective",
     "fz_comm_allgather", "fz_comm_max_f64", "fz_comm_barrier", "fz_comm_destroy", "fz_comm_gather_ms", "fz_debug_gather_merge",
 )
@@ -180,6 +180,8 @@ def load_library():
         L.fz_stats.argtypes = [vp, ctypes.POINTER(FzStats)]
         L.fz_set_timing.restype = ci
         L.fz_set_timing.argtypes = [vp, ci]
+        L.fz_set_streams.restype = ci
+        L.fz_set_streams.argtypes = [vp, ci]
         L.fz_free.restype = None
         L.fz_free.argtypes = [vp]
         if L.fz_abi_version() != 1:
@@ -736,6 +738,11 @@ class Engine(object):
         """hipEvent timing of the kernels (stats()["filter_ms"] ...): on by default; off saves a few us per call."""
         with self._lock:
             _check(self._lib.fz_set_timing(self._h, 1 if on else 0))
+
+    def set_streams(self, n):
+        """1 (default) or 2 streams for the two-deep pipeline of fused searches (fz_set_streams)."""
+        with self._lock:
+            _check(self._lib.fz_set_streams(self._h, n))
 
     def stats(self):
         st = FzStats()

@@ -149,6 +149,10 @@ struct DevState {
     uint64_t pat_cap = 0;
     int slot_id = 0;                             // which of the two result slots is the current one
     uint32_t launches_used = 0;                  // scan launches of the last enqueue on this device
+    // Two fused searches in flight (result slot 1): the younger one's scan on a stream and a counter block of its own, so
+    // that it starts while the older scan drains instead of behind it (FZ_DUAL_STREAM=0: one stream, as before)
+    hipStream_t stream_alt = nullptr;
+    uint8_t *d_hdr_alt = nullptr;
     // RCCL (fz_comm_*): this device state is rank comm_rank of a communicator.  A search of such a context leaves
     // its counters + records in d_out; a device-to-device snapshot (d_send[slot], taken on the scan stream right
     // behind the kernels, so a younger search may reuse d_out) is what the all-gather sends.
@@ -351,6 +355,8 @@ struct fz_ctx {
     int comm_world = 0;
     bool snapshot = false;
     uint64_t gcap = 4096;                        // records per rank the all-gather carries (follows the counts, on all ranks alike)
+    // fz_set_streams: 2 = the younger of two fused searches in flight scans on a stream of its own (FZ_DUAL_STREAM=1 presets it)
+    int streams = []() { const char *e = getenv("FZ_DUAL_STREAM"); return e && atoi(e) != 0 ? 2 : 1; }();
     double last_gather_ms = 0;                   // host time of the last search's exchange step (all-gather + D2H + parse)
     // multi-device contexts: one host thread per device (enqueue, wait, collect and order its shard), and what the
     // shards of the search being collected left (rows_ready: every shard's rows are ordered, emit_matches only merges)
@@ -693,8 +699,6 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     const bool direct = copy_back && d.direct && !no_direct && !snapshot && sh.geom.buf_len > 0 && !q.plan.s.empty();
     if (direct && with_verify) recs = reinterpret_cast<FzRec *>(d.h_stage_dev + kHeaderBytes);
     d.last_direct = direct;
-    if (!d.header_zeroed) HIP_TRY(hipMemsetAsync(d.d_out, 0, kHeaderBytes, d.stream));
-    d.header_zeroed = false;
     d.timed = ctx->timing;
 
     const uint32_t L = q.plan.L;
@@ -779,6 +783,14 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
                 (q.mode != FZ_MODE_LEV || q.k <= 4)) ? 1u : 0u;
     // (the hit-emitting form keeps no pattern in LDS: fz_confirm reads it from the argument block / HBM)
     const uint32_t scan_lds = fa.fused ? fused_lds : FZ_TABLE_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(0, 0, 64, true);
+    // the stream and the counter block of this search (see DevState::stream_alt)
+    const bool alt = ctx->streams == 2 && d.slot_id == 1 && fa.fused && direct && copy_back && !fa.pat_g && sh.geom.seg_stride == 0;
+    const hipStream_t st = alt ? d.stream_alt : d.stream;
+    if (alt) counters = reinterpret_cast<unsigned long long *>(d.d_hdr_alt);
+    else {
+        if (!d.header_zeroed) HIP_TRY(hipMemsetAsync(d.d_out, 0, kHeaderBytes, d.stream));
+        d.header_zeroed = false;
+    }
 
     // When the scan's last launch is also the search's last kernel (fused verification, results written straight to
     // the host), the start / completion events ride on the kernels' own dispatch packets (hipExtLaunchKernelGGL)
@@ -789,7 +801,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     // ... and whenever the scan launches a kernel at all, its start / end events (ev[0], ev[1]: fz_stats' filter_ms) ride
     // on the first / last launch as well instead of two packets of their own in front of and behind the scan
     const bool attach = !no_ext && ntiles > 0 && G > 0;
-    if (ctx->timing && !attach) HIP_TRY(hipEventRecord(d.ev[0], d.stream));
+    if (ctx->timing && !attach) HIP_TRY(hipEventRecord(d.ev[0], st));
     uint32_t launches = 0;
     for (uint32_t g0 = 0; g0 < G && ntiles > 0;) {
         // Blocks [g0, g0 + nblk) of this launch and the hash multiplier: the longest run of blocks (at
@@ -823,10 +835,10 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
         hipEvent_t ev_start = (attach && ctx->timing && g0 == 0) ? d.ev[0] : nullptr;
         hipEvent_t ev_stop = g0 + nblk >= G ? (ext_events ? d.ev[3] : (attach && ctx->timing) ? d.ev[1] : nullptr) : nullptr;
         if (ev_start || ev_stop)
-            hipExtLaunchKernelGGL(kern, grid, dim3(FZ_FILTER_THREADS), scan_lds + extra_lds, d.stream, ev_start, ev_stop, 0u, sh.d_buf, fa,
+            hipExtLaunchKernelGGL(kern, grid, dim3(FZ_FILTER_THREADS), scan_lds + extra_lds, st, ev_start, ev_stop, 0u, sh.d_buf, fa,
                                   ntiles, d.d_hits, recs, counters);
         else
-            hipLaunchKernelGGL(kern, grid, dim3(FZ_FILTER_THREADS), scan_lds + extra_lds, d.stream, sh.d_buf, fa, ntiles, d.d_hits, recs,
+            hipLaunchKernelGGL(kern, grid, dim3(FZ_FILTER_THREADS), scan_lds + extra_lds, st, sh.d_buf, fa, ntiles, d.d_hits, recs,
                                counters);
         HIP_TRY(hipGetLastError());
         ++launches;
@@ -835,7 +847,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     // ev[1] = end of the scan.  When the results need no copy and no verify kernel follows, ev[3] is
     // recorded at the same point of the stream: one event packet less on the critical path.
     d.scan_end_event = (copy_back && direct && !(with_verify && !fa.fused)) ? 3 : 1;
-    if (d.scan_end_event == 1 && ctx->timing && !attach) HIP_TRY(hipEventRecord(d.ev[1], d.stream));
+    if (d.scan_end_event == 1 && ctx->timing && !attach) HIP_TRY(hipEventRecord(d.ev[1], st));
     d.verify_launched = false;
     d.verify_end_event = 2;
     // the verification kernel is the search's last one when its records go straight to the host: then the completion
@@ -901,11 +913,11 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
             HIP_TRY(hipMemcpyAsync(d.h_stage, d.d_out, kHeaderBytes + d.first_copy * sizeof(FzRec), hipMemcpyDeviceToHost,
                                    d.stream));
         }
-        if (!completion_attached) HIP_TRY(hipEventRecord(d.ev[3], d.stream));
+        if (!completion_attached) HIP_TRY(hipEventRecord(d.ev[3], st));
         // the counters are zeroed for the NEXT search now, off the critical path of that call: by the
         // publishing workgroup itself in direct mode, by a memset behind the copy otherwise
         if (!direct) HIP_TRY(hipMemsetAsync(d.d_out, 0, kHeaderBytes, d.stream));
-        d.header_zeroed = true;
+        if (!alt) d.header_zeroed = true;
     }
     d.launches_used = launches;                  // (summed by search_enqueue: this may run on the device's worker thread)
     d.fused_used = fa.fused != 0;
@@ -937,6 +949,7 @@ int collect_shard(fz_ctx *ctx, const Shard &sh, bool with_verify, bool view_ok, 
     bool rerun = false;
     if (nh > d.hit_cap_used && !fused) {
         HIP_TRY(hipStreamSynchronize(d.stream));          // a second search in flight still uses the old buffers
+        HIP_TRY(hipStreamSynchronize(d.stream_alt));
         int rc = ensure_hits(d, nh + nh / 8 + 1024);
         if (rc) return rc;
         rerun = true;
@@ -944,6 +957,7 @@ int collect_shard(fz_ctx *ctx, const Shard &sh, bool with_verify, bool view_ok, 
     if (d.last_direct && with_verify && nr > kHostRecs) d.direct = false;   // too many for the staging buffer
     if (nr > (d.last_direct ? kHostRecs : d.rec_cap_used)) {
         HIP_TRY(hipStreamSynchronize(d.stream));
+        HIP_TRY(hipStreamSynchronize(d.stream_alt));
         int rc = ensure_recs(d, nr + nr / 8 + 1024);
         if (rc) return rc;
         rerun = true;
@@ -1894,6 +1908,9 @@ static int devstate_init(DevState &d) {
     HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
     static const bool default_prio = getenv("FZ_STREAM_DEFAULT_PRIORITY") != nullptr;
     HIP_TRY(hipStreamCreateWithPriority(&d.stream, hipStreamNonBlocking, default_prio ? 0 : prio_least));
+    HIP_TRY(hipStreamCreateWithPriority(&d.stream_alt, hipStreamNonBlocking, default_prio ? 0 : prio_least));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d.d_hdr_alt), kHeaderBytes));
+    HIP_TRY(hipMemset(d.d_hdr_alt, 0, kHeaderBytes));
     for (auto &ev : d.ev) HIP_TRY(hipEventCreate(&ev));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&d.h_stage), kHeaderBytes + kHostRecs * sizeof(FzRec), hipHostMallocMapped));
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&d.h_stage_dev), d.h_stage, 0));
@@ -1908,6 +1925,8 @@ static int devstate_init(DevState &d) {
 static void devstate_destroy(DevState &d) {
     (void)hipSetDevice(d.device);
     if (d.stream) (void)hipStreamSynchronize(d.stream);
+    if (d.stream_alt) { (void)hipStreamSynchronize(d.stream_alt); (void)hipStreamDestroy(d.stream_alt); }
+    if (d.d_hdr_alt) (void)hipFree(d.d_hdr_alt);
     if (d.stream_hi) (void)hipStreamSynchronize(d.stream_hi);
     if (d.d_hits) (void)hipFree(d.d_hits);
     if (d.d_out) (void)hipFree(d.d_out);
@@ -2852,7 +2871,7 @@ int fz_comm_max_f64(fz_ctx *ctx, double *value) {
 }
 
 int fz_comm_barrier(fz_ctx *ctx) {
-    if (ctx) for (DevState &d : ctx->devs) { (void)hipSetDevice(d.device); (void)hipStreamSynchronize(d.stream); }
+    if (ctx) for (DevState &d : ctx->devs) { (void)hipSetDevice(d.device); (void)hipStreamSynchronize(d.stream); (void)hipStreamSynchronize(d.stream_alt); }
     double one = 1.0;
     return fz_comm_max_f64(ctx, &one);
 }
@@ -4096,6 +4115,13 @@ int fz_set_timing(fz_ctx *ctx, int on) {
     if (!ctx) return fail(FZ_EINVAL, "null argument");
     if (ctx->npend || ctx->stream_inflight) return fail(FZ_EINVAL, "a search of this context is in flight");
     ctx->timing = on != 0;
+    return FZ_OK;
+}
+
+int fz_set_streams(fz_ctx *ctx, int n) {
+    if (!ctx || (n != 1 && n != 2)) return fail(FZ_EINVAL, "streams must be 1 or 2");
+    if (ctx->npend || ctx->stream_inflight) return fail(FZ_EINVAL, "a search of this context is in flight");
+    ctx->streams = n;
     return FZ_OK;
 }
 

@@ -408,6 +408,60 @@ def test_fused_search_and_reduction_entry_points(engine):
     assert [x.start for x in got] == sorted({r[0] for r in oracle.subs_ngrams_raw(p, t, 2)})
 
 
+def test_two_streams_pipeline_equals_the_synchronous_calls():
+    """fz_set_streams(2): the younger of two fused searches in flight scans on a stream and a counter block of its own.
+    Same streams as the synchronous calls for Levenshtein / substitutions searches in any mix, different patterns and
+    sequences, across a result-buffer overflow (the search leaves direct mode: back on the one stream) and back."""
+    from fuzzysearch_amd import _native
+    eng = _native.Engine([0])
+    try:
+        eng.set_streams(2)
+        with pytest.raises(ValueError):
+            eng.set_streams(3)
+        t = workloads.dna(8 << 20, 33).tobytes()
+        t2 = workloads.text65(4 << 20, 34).tobytes()
+        pats = [(t[5000:5020], 2), (t[70000:70024], 3), (t[123456:123470], 1), (t[999:1031], 4)]
+        for q, (p, k) in enumerate(pats):
+            t = t[:200000 * (q + 1)] + p + t[200000 * (q + 1) + len(p):]
+        h, h2 = eng.upload(t), eng.upload(t2)
+        want = {(p, k): (oracle.lev_ngrams_raw(p, t, k), oracle.subs_ngrams_raw(p, t, k)) for p, k in pats}
+        p2 = t2[777:809]
+        want2 = oracle.subs_ngrams_raw(p2, t2, 3)
+        rnd = random.Random(5)
+        inflight = []
+        for step in range(120):
+            p, k = rnd.choice(pats)
+            kind = rnd.choice(["lev", "subs", "other"])
+            if kind == "lev":
+                eng.lev_ngrams_begin(h, p, k); inflight.append(want[(p, k)][0])
+            elif kind == "subs":
+                eng.subs_ngrams_begin(h, p, k); inflight.append(want[(p, k)][1])
+            else:
+                eng.subs_ngrams_begin(h2, p2, 3); inflight.append(want2)
+            if len(inflight) == 2:
+                assert eng.search_end() == inflight.pop(0), step
+        while inflight:
+            assert eng.search_end() == inflight.pop(0)
+        # more records than the pinned staging buffer holds: the search falls back to the device buffer (one stream), a
+        # small one afterwards returns to direct mode and to the second stream
+        dense = b"ACGT" * 30000
+        pd_, hd = b"ACGTACGTACGTAC", eng.upload(b"ACGT" * 30000)
+        wd = oracle.lev_ngrams_raw(pd_, dense, 2)
+        assert len(wd) > 20000
+        p, k = pats[0]
+        for _ in range(3):
+            eng.lev_ngrams_begin(hd, pd_, 2)
+            eng.lev_ngrams_begin(h, p, k)
+            assert eng.search_end() == wd and eng.search_end() == want[(p, k)][0]
+            eng.lev_ngrams_begin(h, p, k)
+            eng.lev_ngrams_begin(h, p, k)
+            assert eng.search_end() == want[(p, k)][0] and eng.search_end() == want[(p, k)][0]
+        eng.set_streams(1)
+        assert eng.lev_ngrams(h, p, k) == want[(p, k)][0]
+    finally:
+        eng.close()
+
+
 def test_generic_ngrams_raw_random(engine):
     """a11: the candidate-set automaton, ordered raw stream == oracle (App. A.3)."""
     rnd = random.Random(41)
