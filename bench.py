@@ -46,6 +46,10 @@ def parse():
     ap.add_argument("--cpu-sample-mib", type=int, default=1024)
     ap.add_argument("--no-extras", action="store_true", help="skip the 4 GiB target and the other BASELINE configs (N = 1 extras)")
     ap.add_argument("--sync", action="store_true", help="time synchronous fz_lev_ngrams calls (one search in flight) instead of the two-deep pipeline")
+    ap.add_argument("--two-streams", action="store_true",
+                    help="after the timed region, also time the two-deep pipeline with the younger scan on a second stream "
+                         "(fz_set_streams(2)) and report it as `two_streams` beside `value`.  Not part of the default run: the "
+                         "scans then overlap, and a kernel trace of the run would average overlapped launches of the headline kernel")
     return ap.parse_args()
 
 
@@ -678,7 +682,7 @@ def main():
             step()
         sync_ms = (time.perf_counter() - t1) / 100 * 1e3
     two_streams = None
-    if not use_dist and not args.sync:
+    if not use_dist and not args.sync and args.two_streams:
         # the same two-deep pipeline with the younger scan on a second stream (fz_set_streams(2)): it starts while the older
         # scan drains.  Reported beside `value`, not as `value`: the scans then overlap, so a kernel's own hipEvent span no
         # longer measures the kernel alone (the roofline block above stays on the one-stream loop)
