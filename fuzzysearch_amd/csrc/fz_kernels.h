@@ -1734,10 +1734,13 @@ __global__ __launch_bounds__(64 * W) void fz_gen_hit_kernel(const uint8_t *__res
                                                                       const uint64_t *__restrict__ hits, FzGenRec *__restrict__ recs,
                                                                       unsigned long long *__restrict__ counters) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    // (the wave number through v_readfirstlane: the compiler must know it is the same in every lane, or the list lengths
+    //  that depend on it — and every loop over them — turn into per-lane values and exec-mask loops)
+    const uint32_t wave = fz_uniform(tid >> 6);
     const uint32_t mpad = (a.m + 15u) & ~15u;
     const uint32_t wpad = (a.m + 2u * a.k + 15u) & ~15u;
-    const uint32_t capw = a.cand_cap;                       // candidate slots per list of ONE wave
+    const uint32_t capw = fz_uniform(a.cand_cap);           // candidate slots per list of ONE wave
     uint8_t *pat = smem;
     uint8_t *win = smem + mpad;
     volatile uint32_t *ctl = reinterpret_cast<volatile uint32_t *>(smem + mpad + wpad);   // [0] run [1] fail [2..5] matches per wave [6,7] record base [8] stop
@@ -1747,7 +1750,10 @@ __global__ __launch_bounds__(64 * W) void fz_gen_hit_kernel(const uint8_t *__res
     uint64_t *mbuf = mball + (size_t)wave * FZ_GH_MCAP;
     fz_copy_pattern(pat, a, tid, 64u * W);
     auto patf = [&](uint32_t i) -> uint8_t { return pat[i]; };
-    unsigned long long nitems = counters[0];
+    // (everything that is the same in all lanes goes through v_readfirstlane: values loaded from memory are per-lane values
+    //  to the compiler, and list lengths, loop bounds and branch conditions derived from them would become vector registers
+    //  and exec-mask loops — the first build of this kernel ran its slice loop that way)
+    unsigned long long nitems = fz_bcast64(counters[0]);
     if (nitems > a.hit_cap) nitems = a.hit_cap;
     const bool order = a.gen_order != 0;
     unsigned long long *order_first = reinterpret_cast<unsigned long long *>(a.gen_order);
@@ -1757,7 +1763,7 @@ __global__ __launch_bounds__(64 * W) void fz_gen_hit_kernel(const uint8_t *__res
     const bool fold = (a.flags & FZ_FLAG_FOLD) != 0;
     for (uint64_t q = blockIdx.x; q < nitems; q += gridDim.x) {
         __syncthreads();                                    // the previous hit's LDS (window, lists, buffers, ctl) is free
-        const uint64_t hit = hits[q];
+        const uint64_t hit = fz_bcast64(hits[q]);
         const uint32_t s = fz_hit_block(hit) * a.L;
         const uint64_t idx = fz_hit_index(hit);
         const FzSeg sg = fz_segment(a.geom, idx, 0u);
@@ -1786,8 +1792,8 @@ __global__ __launch_bounds__(64 * W) void fz_gen_hit_kernel(const uint8_t *__res
         for (uint32_t i = tid; i < wlen; i += 64u * W) win[i] = buf[(w0 - a.geom.buf_off) + i];
         __syncthreads();
         FZ_LAB_LP(q, 1, __builtin_readcyclecounter());
-        if (ctl[8]) break;                                  // has_near_match_*: a record exists somewhere
-        if (!ctl[0]) { FZ_LAB_LP(q, 2, 0ull); continue; }     // a hit of a smaller block runs this window
+        if (fz_uniform(ctl[8])) break;                      // has_near_match_*: a record exists somewhere
+        if (!fz_uniform(ctl[0])) { FZ_LAB_LP(q, 2, 0ull); continue; }   // a hit of a smaller block runs this window
 
         // ---- this wave's quarter of the candidate list over the whole window; no synchronisation with the other waves ----
         uint32_t ncur = 0, mb = 0;
@@ -1796,12 +1802,12 @@ __global__ __launch_bounds__(64 * W) void fz_gen_hit_kernel(const uint8_t *__res
         for (uint32_t index = 0; index <= wlen && !fail; ++index) {
             uint32_t nnext = 0;
             if (index < wlen) {
-                const uint8_t ch = win[index];
+                const uint8_t ch = (uint8_t)fz_uniform(win[index]);
                 uint32_t fresh_at = 0xffffffffu;
                 if ((index & (W - 1u)) == wave) {   // this start is ours: the fresh candidate (py:80), taken from registers
                     if (ncur >= capw) { fail = true; break; }
                     fresh_at = ncur;
-                    ++ncur;
+                    ncur = fz_uniform(ncur + 1u);
                 }
                 for (uint32_t c0 = 0; c0 < ncur; c0 += 64u) {
                     const bool valid = c0 + lane < ncur;
@@ -1827,8 +1833,8 @@ __global__ __launch_bounds__(64 * W) void fz_gen_hit_kernel(const uint8_t *__res
                     if (st.fc) nx[st.fa + st.fb] = make_uint2(st.c0, st.c1);
                     if (st.f1) mp[0] = (uint64_t)st.m1 | ((uint64_t)st.d1 << 32) | stamp;
                     if (st.f2) mp[st.f1] = (uint64_t)st.m2 | ((uint64_t)st.d2 << 32) | stamp;
-                    nnext += tot_s;
-                    mb += tot_m;
+                    nnext = fz_uniform(nnext + tot_s);
+                    mb = fz_uniform(mb + tot_m);
                 }
             } else {
                 // end of the window (py:172-177): the survivors that reach the pattern's end by deletions
@@ -1842,26 +1848,26 @@ __global__ __launch_bounds__(64 * W) void fz_gen_hit_kernel(const uint8_t *__res
                     const uint32_t tot_m = (uint32_t)__popcll(mask);
                     if (mb + tot_m > FZ_GH_MCAP) { fail = true; break; }
                     if (hit_end) mbuf[mb + fz_rank(mask)] = (uint64_t)((uint32_t)c.start | (wlen << 16)) | ((uint64_t)d << 32) | ((uint64_t)index << 48);
-                    mb += tot_m;
+                    mb = fz_uniform(mb + tot_m);
                 }
             }
             // the next character reads what this one stored: a wave's LDS operations are performed in issue order
             asm volatile("" ::: "memory");
             FzGCand *tmp = lc; lc = ln; ln = tmp;
-            ncur = nnext;
+            ncur = fz_uniform(nnext);
         }
         if (lane == 0) { ctl[2u + wave] = mb; if (fail) ctl[1] = 1u; }
         __syncthreads();
         FZ_LAB_LP(q, 2, __builtin_readcyclecounter());
         FZ_LAB_LP(q, 3, (unsigned long long)wlen);
-        if (ctl[1]) {                                       // outgrew a list quarter or a match buffer: the host re-runs with fz_lp_kernel
+        if (fz_uniform(ctl[1])) {                           // outgrew a list quarter or a match buffer: the host re-runs with fz_lp_kernel
             if (tid == 0) atomicAdd(&counters[FZ_HDR_GEN_FAIL], 1ull);
             continue;
         }
         uint32_t mbw[W];
         uint32_t total = 0;
 #pragma unroll
-        for (uint32_t w = 0; w < W; ++w) { mbw[w] = ctl[2u + w]; total += mbw[w]; }
+        for (uint32_t w = 0; w < W; ++w) { mbw[w] = fz_uniform(ctl[2u + w]); total += mbw[w]; }
         if (order && q < FZ_GEN_ORDER_MAX && tid == 0) { order_first[q] = 0; order_count[q] = total; }
         if (total == 0) continue;
         if (fold) {
@@ -1894,7 +1900,7 @@ __global__ __launch_bounds__(64 * W) void fz_gen_hit_kernel(const uint8_t *__res
                 auto wave_min = [&](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)fz_wave_incl_min(v), 63); };
                 for (uint32_t w = 0; w < W; ++w) {
                     const uint64_t *mbx = mball + (size_t)w * FZ_GH_MCAP;
-                    const uint32_t nw = ctl[2u + w];
+                    const uint32_t nw = fz_uniform(ctl[2u + w]);
                     for (uint32_t e0 = 0; e0 < nw; e0 += 64u) {
                         const bool have_row = e0 + lane < nw;
                         const uint64_t v = have_row ? mbx[e0 + lane] : 0ull;
