@@ -118,9 +118,16 @@ __device__ __forceinline__ uint32_t fz_load_win(const uint8_t *__restrict__ buf,
 // a few workgroups' phases (printf), FZ_LAB_NOVERIFY / FZ_LAB_NODP / FZ_LAB_NOEXACT / FZ_LAB_NOPREFETCH /
 // FZ_LAB_NOPOOL leave a part of the candidate handling out (DESIGN.md §4 quotes the A/B runs), FZ_GROUP forces the
 // number of offsets per branch.
-#ifdef FZ_LAB_TIMING
-static __device__ unsigned long long fz_lab_t[64];
-#define FZ_LAB_STAMP(i) do { if ((blockIdx.x & 1023u) == 512u && threadIdx.x == 0) fz_lab_t[(blockIdx.x >> 10) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#ifdef FZ_LAB_LPTIME
+// lab build (read back by fz_lab_lp_read): time stamps of the automaton kernels' hits, or — FZ_LAB_SCANTIME — of the scan
+// kernel's workgroups: stamp i of workgroup b (its wave 0) at [b * 8 + i], constant-rate clock (100 MHz)
+static __device__ unsigned long long fz_lab_lp[16384 * 4];
+#endif
+#if defined(FZ_LAB_SCANTIME)
+#define FZ_LAB_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192u) fz_lab_lp[blockIdx.x * 8u + (i)] = wall_clock64(); } while (0)
+#elif defined(FZ_LAB_TIMING)
+static __device__ unsigned long long fz_lab_t[256];
+#define FZ_LAB_STAMP(i) do { if ((blockIdx.x & 127u) == 64u && threadIdx.x == 0) fz_lab_t[((blockIdx.x >> 7) & 31u) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define FZ_LAB_STAMP(i) do { } while (0)
 #endif
@@ -142,6 +149,9 @@ __host__ __device__ inline uint32_t fz_wave_lds_bytes(uint32_t win_dwords, uint3
     b += ((band_w * vlanes * 2) + 15u) & ~15u;
     return b;
 }
+
+// Fused lane-per-cell verification: 64 / gw contiguous byte windows per wave (window + 16 bytes of slack each), in dwords.
+__host__ __device__ inline uint32_t fz_wf_fused_dwords(uint32_t win_dwords, uint32_t gw) { return (64u / gw) * (win_dwords + 4u); }
 
 __device__ __forceinline__ FzWaveLds fz_wave_lds(uint8_t *base, uint32_t wave, uint32_t win_dwords, uint32_t band_w,
                                                  uint32_t vlanes, bool with_queue) {
@@ -523,6 +533,12 @@ __device__ __forceinline__ void fz_gen_claim(const FzScanArgs &a, uint64_t hit, 
     dd.wslot[q] = at;
 }
 
+template <int GW>
+__device__ __forceinline__ uint32_t fz_flush_wf(const uint8_t *__restrict__ buf, const FzScanArgs &a, const uint8_t *lds0,
+                                                const uint8_t *pat_lds, const FzWaveLds &w, const uint8_t *area, uint32_t per_wave,
+                                                volatile uint32_t *fills, uint32_t wave, uint32_t qn, bool pooled,
+                                                FzRec *__restrict__ recs, unsigned long long *__restrict__ counters);
+
 template <bool FUSED, bool SEG>
 __device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ buf, const FzScanArgs &a,
                                                    const uint8_t *pat_lds, const FzWaveLds &w, uint32_t qn,
@@ -665,11 +681,12 @@ __device__ __forceinline__ uint32_t fz_pooled_flush(const uint8_t *__restrict__ 
 //     by LDS-DMA now (fz_prefetch_windows).
 // 7 waves per SIMD (72 VGPRs): measured 2-3 % faster than the natural 79-VGPR / 6-wave allocation;
 // 8 waves (64 VGPRs) spills 27 VGPRs in the verify path and is 50 % slower.
-template <int NWIN, int DH, bool FUSED, bool SEG, bool SA>
+template <int NWIN, int DH, bool FUSED, bool SEG, bool SA, bool WF = false>
 __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_eu(7, 7))) void fz_scan_kernel(
     const uint8_t *__restrict__ buf, const FzScanArgs a, uint64_t ntiles,
     uint64_t *__restrict__ hits, FzRec *__restrict__ recs, unsigned long long *__restrict__ counters) {
-    constexpr bool PREF = FUSED && !SEG;              // candidate windows are prefetched by LDS-DMA
+    static_assert(!WF || (FUSED && !SEG), "the lane-per-cell form is a fused form of the in-memory search");
+    constexpr bool PREF = FUSED && !SEG && !WF;       // candidate windows are prefetched by LDS-DMA
     FZ_LAB_STAMP(0);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t mpad = FUSED ? (a.m + 15u) & ~15u : 0u;   // only the fused verification reads the pattern from LDS (m <= FZ_MAX_M there)
@@ -696,9 +713,11 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
         if (fz_lane() == g) hvec = a.H[g];
     const bool dup_hashes = (a.flags & FZ_FLAG_DUP_HASHES) != 0;
     __syncthreads();
+    FZ_LAB_STAMP(2);
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t qcap = PREF ? a.qcap : (uint32_t)FZ_QCAP;   // queue entries per wave
     const FzWaveLds w = PREF ? fz_wave_lds_pref(smem + FZ_TABLE_BYTES + mpad, FZ_TABLE_BYTES + mpad, wave, qcap, a.win_pieces)
+                        : WF ? fz_wave_lds(smem + FZ_TABLE_BYTES + mpad, wave, fz_wf_fused_dwords(a.win_dwords, 16), 0u, 1u, true)
                              : fz_wave_lds(smem + FZ_TABLE_BYTES + mpad, wave, FUSED ? a.win_dwords : 0u,
                                            FUSED ? a.band_w : 0u, a.vlanes, true);
     const uint32_t hash_k = a.hash_k;
@@ -870,7 +889,12 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
 #ifndef FZ_LAB_NOPOOL
         if (PREF && done) break;                      // what is queued now is verified by the pooled flush below
 #endif
-        if (qn) {
+        if constexpr (WF) {
+            // lane-per-cell verification (Levenshtein budgets 5 .. 7): own queue in mid-scan, the workgroup's pool at the end
+            confirmed += fz_flush_wf<16>(buf, a, smem, pat_lds, w, smem + FZ_TABLE_BYTES + mpad,
+                                         fz_wave_lds_bytes(fz_wf_fused_dwords(a.win_dwords, 16), 0u, 1u, true),
+                                         reinterpret_cast<volatile uint32_t *>(smem + 2u * FZ_LUT_BYTES), wave, qn, done, recs, counters);
+        } else if (qn) {
 #ifndef FZ_LAB_NOPREFETCH
             if (PREF && qn > qf) fz_prefetch_windows(buf, a, w, qf, qn);
 #endif
@@ -890,8 +914,8 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
 
 #ifdef FZ_LAB_TIMING
     FZ_LAB_STAMP(4);
-    if ((blockIdx.x & 1023u) == 512u && threadIdx.x == 0) {
-        const unsigned long long *t = fz_lab_t + (blockIdx.x >> 10) * 8;
+    if ((blockIdx.x & 127u) == 64u && threadIdx.x == 0) {
+        const unsigned long long *t = fz_lab_t + ((blockIdx.x >> 7) & 31u) * 8;
         printf("wg %u: life %llu cyc; scan %llu, wait-dma %llu, decode+range+exact %llu, dp %llu, append %llu, tail %llu; confirmed %u\n", blockIdx.x,
                t[4] - t[0], t[1] - t[0], t[2] - t[1], t[5] - t[2], t[6] - t[5], t[3] - t[6], t[4] - t[3], confirmed);
     }
@@ -900,6 +924,7 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
     // workgroup polling for the others instead of every workgroup waiting for its ticket: 0.2172 vs 0.2183 ms, within noise)
     if (FUSED && lane == 0 && confirmed) atomicAdd(&counters[8 + (blockIdx.x & 63u)], (unsigned long long)confirmed);
     fz_finish_launch(a, counters, lut);
+    FZ_LAB_STAMP(7);
 }
 
 // Verification of a hit list in HBM, one lane per candidate (parameter ranges whose LDS footprint does
@@ -1035,6 +1060,146 @@ __device__ __forceinline__ bool fz_wf_pick(uint32_t cell, uint32_t gl, uint32_t 
     dist = best;
     consumed = arg;
     return valid && best <= budget;
+}
+
+// The same verification inside the scan kernel (fz_scan_kernel<..., WF = true>, in-memory searches): queued candidates,
+// 64 / GW at a time on GW lanes each, straight from the queue — no hit list, no second kernel and no gap between the two.
+// One pass = one memory round trip (the candidates' windows into LDS), the exact n-gram test out of LDS (the scan's filter
+// compared a hash), the two expansions, one atomic for the records of the pass.
+// (Measured and not kept: right and left expansion of a candidate side by side on two lane groups, the left one with the
+// full budget and the pick narrowed afterwards — the rows of a pass drop from max(right) + max(left) over its candidates
+// to max(right, left), but a pass takes half the candidates: 0.2128 vs 0.2141 ms where candidates are rare (configs[3a]),
+// 0.847 vs 0.605 ms where they are dense and leave after a few rows (1 GiB DNA, m = 40).)
+// `have` / `code` are uniform inside a lane group.  Returns the number of confirmed, in-range n-gram hits of the pass.
+template <int GW>
+__device__ __forceinline__ uint32_t fz_wf_pass(const uint8_t *__restrict__ buf, const FzScanArgs &a, const uint8_t *lds0,
+                                               const uint8_t *pat_lds, uint8_t *gwin, bool have, uint32_t code,
+                                               FzRec *__restrict__ recs, unsigned long long *__restrict__ counters) {
+    static_assert(GW < 64, "one ballot word holds several lane groups");
+    const uint32_t lane = fz_lane();
+    const uint32_t grp = lane / (uint32_t)GW, gl = lane % (uint32_t)GW;
+    uint32_t blk = 0;
+    const uint64_t local = fz_code_local(code, blk);
+    const uint64_t idx = a.geom.buf_off + local;
+    const uint32_t s = (a.g0 + blk) * a.L;
+    FzSeg sg;
+    sg.sa = 0; sg.se = a.geom.n; sg.j = 0; sg.ok = 1;
+    bool valid = have && fz_hit_in_range(a, blk, idx, sg);
+    if (!__ballot(valid)) return 0;
+    // the candidate's window [wlo, whi), staged as plain bytes: byte g of the sequence at gwin[g - wbase]
+    uint64_t whi = 0, wbase = 0;
+    if (valid) {
+        whi = idx - s + a.m + a.k;
+        const uint64_t lim = a.geom.buf_off + a.geom.buf_len;
+        if (whi > lim) whi = lim;
+        if (whi > sg.se) whi = sg.se;
+        wbase = fz_window_base(a, fz_window_lo(a, idx, s, sg.sa));
+    }
+    const uint32_t nd = valid ? (uint32_t)((whi - wbase + 3) >> 2) : 0u;
+    const uint8_t *src = buf + (int64_t)(wbase - a.geom.buf_off);
+    for (uint32_t d0 = 0; d0 < a.win_dwords; d0 += 4u * (uint32_t)GW) {       // four loads in flight per lane, then four stores
+        uint32_t v[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t dd = d0 + j * (uint32_t)GW + gl;
+            v[j] = dd < nd ? *reinterpret_cast<const uint32_t *>(src + (size_t)dd * 4) : 0u;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t dd = d0 + j * (uint32_t)GW + gl;
+            if (dd < nd) reinterpret_cast<uint32_t *>(gwin)[dd] = v[j];
+        }
+    }
+    fz_wave_lds_sync();
+    FZ_LAB_STAMP(5);
+    // exact n-gram test: lane gl compares the bytes gl, gl + GW, ...
+    bool differs = false;
+    if (valid) {
+        const uint8_t *tn = gwin + (uint32_t)(idx - wbase), *pn = pat_lds + s;
+        for (uint32_t b = gl; b < a.L; b += (uint32_t)GW) differs = differs || tn[b] != pn[b];
+    }
+    const unsigned long long group_bits = (((1ull << GW) - 1ull) << (grp * (uint32_t)GW));
+    if (__ballot(differs) & group_bits) valid = false;
+    const unsigned long long vm = __ballot(valid && gl == 0);
+    if (!vm) { fz_wave_lds_sync(); return 0; }
+    const int prel = (int)(pat_lds - lds0), wrel = (int)(gwin - lds0);
+    auto lds_of = [&](uint64_t gidx) -> int { return valid ? wrel + (int)(int64_t)(gidx - wbase) : 0; };
+    // right: p[s+L:] vs t[idx+L : min(se, idx-s+m+k)]
+    uint64_t rbeg = idx + a.L, rend = idx + a.m + a.k - s;
+    if (rend > sg.se) rend = sg.se;
+    if (rbeg > sg.se) rbeg = sg.se;
+    if (rend < rbeg) rend = rbeg;
+    const uint32_t rwin = (uint32_t)(rend - rbeg), rlen = a.m - s - a.L;
+    uint32_t dR = 0, r = 0, dL = 0, l = 0;
+    const uint32_t cellr = fz_wf_rows<GW>(lds0, gl, a.k, prel + (int)(s + a.L), 1, rlen, lds_of(rbeg), 1, rwin, a.k, valid);
+    const bool ok1 = fz_wf_pick<GW>(cellr, gl, a.k, rlen, rwin, a.k, valid, dR, r);
+    // left: reversed p[:s] vs reversed t[max(sa, idx-s-(k-dR)) : idx], budget k - dR
+    const uint32_t bl = ok1 ? a.k - dR : 0u;
+    const uint64_t want = (uint64_t)s + bl;
+    const uint64_t lbeg = (idx - sg.sa > want) ? idx - want : sg.sa;
+    const uint32_t lwin = ok1 ? (uint32_t)(idx - lbeg) : 0u;
+    const uint32_t celll = fz_wf_rows<GW>(lds0, gl, a.k, prel + (int)s - 1, -1, s, lds_of(idx) - 1, -1, lwin, bl, ok1);
+    const bool ok = fz_wf_pick<GW>(celll, gl, a.k, s, lwin, bl, ok1, dL, l) && gl == 0;
+    FZ_LAB_STAMP(6);
+    const unsigned long long mask = __ballot(ok);
+    if (mask) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&counters[1], (unsigned long long)__popcll(mask));
+        base = fz_bcast64(base);
+        const unsigned long long slot = base + fz_rank(mask);
+        if (ok && slot < a.rec_cap) {
+            FzRec rec;
+            rec.key = fz_hit_pack(a.g0 + blk, idx); rec.l = l; rec.r = r; rec.dist = dL + dR; rec.aux = sg.j;
+            recs[slot] = rec;
+        }
+    }
+    fz_wave_lds_sync();
+    return (uint32_t)__popcll(vm);
+}
+
+// The flush of the fused lane-per-cell form — ONE call site in the scan kernel (a second inlined copy of the pass costs the
+// hot loop its registers).  In the middle of the scan (`pooled` = false: this wave's queue filled up) the wave works through
+// its own queue.  At the end of the workgroup's life (`pooled` = true, every wave gets here exactly once) what the four waves
+// still hold is pooled, as fz_pooled_flush does for the lane-per-candidate form, and dealt out 64 / GW candidates at a time,
+// pass p to wave p mod 4: the n-gram hits of one near match sit a few bytes apart, i.e. in ONE wave's queue, and would take
+// that wave several passes while the other three have none.
+// `area` = first wave's area (queue first), `per_wave` = bytes per wave area, `fills` = four LDS dwords.
+template <int GW>
+__device__ __forceinline__ uint32_t fz_flush_wf(const uint8_t *__restrict__ buf, const FzScanArgs &a, const uint8_t *lds0,
+                                                const uint8_t *pat_lds, const FzWaveLds &w, const uint8_t *area, uint32_t per_wave,
+                                                volatile uint32_t *fills, uint32_t wave, uint32_t qn, bool pooled,
+                                                FzRec *__restrict__ recs, unsigned long long *__restrict__ counters) {
+    constexpr uint32_t NH = 64u / (uint32_t)GW;                         // candidates per pass
+    const uint32_t lane = fz_lane();
+    const uint32_t grp = lane / (uint32_t)GW;
+    uint32_t n0 = qn, n1 = 0, n2 = 0, n3 = 0, first = 0, step = NH;
+    const uint8_t *q0 = reinterpret_cast<const uint8_t *>(w.queue);
+    if (pooled) {
+        if (lane == 0) fills[wave] = qn;
+        __syncthreads();
+        n0 = fills[0]; n1 = fills[1]; n2 = fills[2]; n3 = fills[3];
+        first = wave * NH;
+        step = FZ_WAVES_PER_BLOCK * NH;
+        q0 = area;
+    } else {
+        fz_wave_lds_sync();
+    }
+    const uint32_t total = n0 + n1 + n2 + n3;
+    uint8_t *gwin = reinterpret_cast<uint8_t *>(w.win) + grp * (a.win_dwords * 4u + 16u);
+    uint32_t confirmed = 0;
+    FZ_LAB_STAMP(1);
+    // (Measured: a pass with the hits of one near match — different blocks, so max(right) + max(left) ~ 100 rows of a
+    // 64-byte pattern — takes 17 - 23 us, ~400 cycles per row, next to six streaming waves per SIMD; s_setprio(3)
+    // around the passes changed nothing: the rows wait for their own dependent instructions, not for issue slots.)
+    for (uint32_t e0 = first; e0 < total; e0 += step) {
+        uint32_t li = e0 + grp, ow = 0;
+        const bool have = li < total;
+        if (li >= n0) { li -= n0; ow = 1; if (li >= n1) { li -= n1; ow = 2; if (li >= n2) { li -= n2; ow = 3; } } }
+        const uint32_t code = have ? reinterpret_cast<const uint32_t *>(q0 + ow * per_wave)[li] : 0u;
+        confirmed += fz_wf_pass<GW>(buf, a, lds0, pat_lds, gwin, have, code, recs, counters);
+    }
+    FZ_LAB_STAMP(3);
+    return confirmed;
 }
 
 // Levenshtein verification of a hit list, GW lanes per hit (64 / GW hits per wave at a time): right
@@ -1351,7 +1516,6 @@ __device__ __forceinline__ uint32_t fz_wave_incl_scan(uint32_t v) {
 
 #ifdef FZ_LAB_LPTIME
 // lab build: per n-gram hit {shader clock at start, after the window is staged, at the end, slice steps << 32 | characters}
-static __device__ unsigned long long fz_lab_lp[16384 * 4];
 #define FZ_LAB_LP(q, i, v) do { if ((q) < 16384u && (threadIdx.x & 63u) == 0 && (threadIdx.x >> 6) == 0) fz_lab_lp[(q) * 4u + (i)] = (v); } while (0)
 #else
 #define FZ_LAB_LP(q, i, v) do { } while (0)

@@ -528,12 +528,25 @@ ScanKernel scan_kernel_s(int nwin, int dh, bool sa) {
 // The segmented variants (file API) only exist where a segment changes the outcome: Levenshtein /
 // generic clamps.  Exact and substitutions-only windows fit exactly one chunk (the host assigns it).
 // sa: the launch's blocks are told apart by hash bits 2..6 (slot address = one v_and).
-ScanKernel scan_kernel(int nwin, int dh, bool fused, bool seg, bool sa) {
+// The fused lane-per-cell form (Levenshtein budgets 5 .. 7, fz_queue_flush_wf).
+template <bool SEG, bool SA>
+ScanKernel scan_kernel_wf(int nwin, int dh) {
+    if (nwin == 1) return fz_scan_kernel<1, 0, true, SEG, SA, true>;
+    switch (dh) {
+        case 2: return fz_scan_kernel<2, 2, true, SEG, SA, true>;
+        case 3: return fz_scan_kernel<2, 3, true, SEG, SA, true>;
+        case 4: return fz_scan_kernel<2, 4, true, SEG, SA, true>;
+        default: return fz_scan_kernel<2, 5, true, SEG, SA, true>;
+    }
+}
+
+ScanKernel scan_kernel(int nwin, int dh, bool fused, bool seg, bool sa, bool wf = false) {
 #ifdef FZ_LAB_ONLY      // lab builds (benchmarks/lab_build.sh): only the instances of the headline and exact-search workloads
     if (nwin == 2 && dh == 3 && fused && !seg) return sa ? fz_scan_kernel<2, 3, true, false, true> : fz_scan_kernel<2, 3, true, false, false>;
     if (nwin == 2 && dh == 5 && !fused && !seg) return sa ? fz_scan_kernel<2, 5, false, false, true> : fz_scan_kernel<2, 5, false, false, false>;
     return nullptr;
 #else
+    if (wf) return seg ? nullptr : (sa ? scan_kernel_wf<false, true>(nwin, dh) : scan_kernel_wf<false, false>(nwin, dh));
     if (seg) return fused ? scan_kernel_s<true, true>(nwin, dh, sa) : scan_kernel_s<false, true>(nwin, dh, sa);
     return fused ? scan_kernel_s<true, false>(nwin, dh, sa) : scan_kernel_s<false, false>(nwin, dh, sa);
 #endif
@@ -778,9 +791,17 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
             fa.vlanes >>= 1;
         fused_lds = mpad + FZ_TABLE_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, fa.vlanes, true);
     }
-    // k > 4 (register band too wide for the scan kernel's VGPR budget) -> verify in a kernel of its own
+    // k > 4 (register band too wide for the scan kernel's VGPR budget) -> lane-per-cell: inside the scan as well while 16
+    // lanes hold the band (budgets 5 .. 7: the candidates of a wave's queue, four at a time, at the end of the wave's
+    // life), in a kernel of its own beyond that
     fa.fused = (with_verify && !force_big && q.m <= FZ_MAX_M && q.k <= FZ_MAX_K && fused_lds <= kFusedLdsBudget &&
                 (q.mode != FZ_MODE_LEV || q.k <= 4)) ? 1u : 0u;
+    static const bool no_wf_fuse = getenv("FZ_NO_WF_FUSE") != nullptr;          // test / measurement knob: the stand-alone kernel
+    const uint32_t wf_fused_lds = mpad + FZ_TABLE_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fz_wf_fused_dwords(fa.win_dwords, 16), 0, 1, true);
+    // (in-memory searches only: the segmented instances of this form spill registers — the file API keeps the kernel of its own)
+    const bool wf_fused = !fa.fused && sh.geom.seg_stride == 0 && with_verify && !force_big && !no_wf_fuse && vp.want_wf && !vp.big && vp.gw == 16 &&
+                          q.m <= FZ_MAX_M && wf_fused_lds <= target + 4096;
+    if (wf_fused) { fa.fused = 1u; fused_lds = wf_fused_lds; fa.vlanes = 64; }
     // (the hit-emitting form keeps no pattern in LDS: fz_confirm reads it from the argument block / HBM)
     const uint32_t scan_lds = fa.fused ? fused_lds : FZ_TABLE_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(0, 0, 64, true);
     // the stream and the counter block of this search (see DevState::stream_alt)
@@ -829,7 +850,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
         for (uint32_t b = 1; b < nblk; ++b)
             for (uint32_t c = 0; c < b; ++c)
                 if (fa.H[b] == fa.H[c]) fa.flags |= FZ_FLAG_DUP_HASHES;
-        ScanKernel kern = scan_kernel(nwin, dh, fa.fused != 0, sh.geom.seg_stride != 0, fa.lut_shift == 2);
+        ScanKernel kern = scan_kernel(nwin, dh, fa.fused != 0, sh.geom.seg_stride != 0, fa.lut_shift == 2, wf_fused);
         if (!kern) return fail(FZ_EUNSUPPORTED, "this (lab) build carries no scan kernel for nwin=%d dh=%d", nwin, dh);
         static const uint32_t extra_lds = []() { const char *e = getenv("FZ_EXTRA_LDS_KB"); return e ? (uint32_t)atoi(e) * 1024u : 0u; }();
         hipEvent_t ev_start = (attach && ctx->timing && g0 == 0) ? d.ev[0] : nullptr;

@@ -174,6 +174,35 @@ def main(argv):
             alpha = bytes(rnd.sample(range(1, 256), sigma))
             cases.append((bytes(rnd.choices(alpha, k=m)), bytes(rnd.choices(alpha, k=nn)), k))   # up to 2.6e5 records per search
         n_rec = run_pipelined(eng, cases)
+    elif what == "wf":
+        # Levenshtein budgets 5 .. 7: lane-per-cell verification inside the scan kernel (default) or in the kernel of its
+        # own (FZ_NO_WF_FUSE=1) — ragged ends, patterns up to the argument block, queues that fill up (tiny alphabets)
+        cases = random_cases(rnd, n, [5, 6, 7], 300, 6000)
+        from tests import workloads
+        for sigma, nn, m, k in ((2, 60000, 40, 5), (4, 400000, 30, 5), (3, 150000, 56, 7), (20, 1 << 20, 64, 6)):
+            alpha = bytes(rnd.sample(range(1, 256), sigma))
+            pp = bytes(rnd.choices(alpha, k=m))
+            tt = bytearray(rnd.choices(alpha, k=nn))
+            for _ in range(40):
+                v = edited(rnd, pp, rnd.randint(0, k), alpha)
+                st = rnd.randint(0, nn - len(v))
+                tt[st:st + len(v)] = v
+            cases.append((pp, bytes(tt), k))
+        seq = workloads.text65(4 << 20, 41)
+        pat = workloads.text65(64, 3)
+        workloads.plant_edits(seq, pat, 200, 5, workloads.TEXT65, lambda i: i % 6)
+        cases.append((pat.tobytes(), seq.tobytes(), 5))
+        n_rec = 0
+        import oracle
+        for (pp, tt, k) in cases:                               # (Levenshtein only: the substitutions form has no such path)
+            h = eng.upload(tt)
+            got = eng.lev_ngrams(h, pp, k)
+            assert got == oracle.lev_ngrams_raw(pp, tt, k), ("lev", pp, tt[:200], k)
+            n_rec += len(got)
+            h.release()
+        eng.close()
+        print("OK %d %d" % (len(cases), n_rec))
+        return
     elif what == "windows":
         # the generic search's window table, on (default) and off (FZ_GEN_NO_DEDUP=1: every hit runs the automaton)
         n_cases, n_rec = run_generic_windows(eng, rnd, n)

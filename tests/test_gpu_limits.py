@@ -61,6 +61,16 @@ def test_generic_automaton_kernel_forms():
     assert _sub(["windows", 120, 24], {"FZ_GH_WAVES": "4", "FZ_GEN_NO_DEDUP": "1"})[0] == 120
 
 
+def test_lane_per_cell_verification_fused_and_stand_alone():
+    """Levenshtein budgets 5 .. 7 of an in-memory search verify inside the scan kernel (fz_queue_flush_wf: the wave's queued
+    candidates, four at a time on 16 lanes each); FZ_NO_WF_FUSE=1 sends the same searches through the hit list and
+    fz_verify_wf_kernel.  The same random cases — ragged ends, long patterns, alphabets small enough to fill the queues —
+    against the oracle either way."""
+    base = _sub(["wf", 300, 31], {})
+    assert base[0] == 305 and base[1] > 1000
+    assert _sub(["wf", 300, 31], {"FZ_NO_WF_FUSE": "1"}) == base
+
+
 def test_copy_mode_one_and_two_searches_in_flight():
     """FZ_NO_DIRECT=1: nothing is written straight into the pinned staging buffer (round 3's randomized run found the
     younger of two searches in flight overwriting the older one's records in the shared device buffer under this switch)."""
