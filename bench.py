@@ -221,12 +221,12 @@ def extra_blocks(engine, workloads, reps):
     h = engine.upload(seq)
     ms, f_ms, v_ms, res = time_call(engine, lambda: engine.lev_ngrams(h, p3, 5, as_array=True), reps)
     pipe_ms = time_pipelined(engine, h, p3, 5, reps, res)
-    cfgs["configs[3a] UTF-8 m=64 max_l_dist=5 (levenshtein_ngram, wavefront verify)"] = {
+    cfgs["configs[3a] UTF-8 m=64 max_l_dist=5 (levenshtein_ngram, lane-per-cell verify fused into the scan)"] = {
         "ms_per_call": round(ms, 4), "GB_per_s": round(gib / ms / 1e6, 1),
         "two_in_flight_ms_per_call": round(pipe_ms, 4), "two_in_flight_GB_per_s": round(gib / pipe_ms / 1e6, 1),
         "scan_kernel_ms": round(f_ms, 4),
         "verify_kernel_ms": round(v_ms, 4), "raw_matches": int(len(res))}
-    cfgs["configs[3a] UTF-8 m=64 max_l_dist=5 (levenshtein_ngram, wavefront verify)"].update(
+    cfgs["configs[3a] UTF-8 m=64 max_l_dist=5 (levenshtein_ngram, lane-per-cell verify fused into the scan)"].update(
         api_block(fa, engine, seq, dict(max_l_dist=5), p3, ms, reps))
     ms, f_ms, v_ms, res = time_call(engine, lambda: engine.generic_ngrams(h, p3, 5, 2, 2, 5, as_array=True), max(20, reps // 4))
     cms, _f, cv_ms, cres = time_call(engine, lambda: engine.generic_ngrams_consolidated(h, p3, 5, 2, 2, 5, as_array=True), max(20, reps // 4))
