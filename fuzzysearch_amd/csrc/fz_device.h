@@ -27,6 +27,7 @@
 #endif
 
 #define FZ_MAX_BLOCKS_PER_LAUNCH 8     // n-gram blocks tested by one filter launch
+#define FZ_MAX_REGIONS 8               // regions of a scan grid (FzScanArgs.reg_*)
 #define FZ_MAX_M 1024                  // pattern bytes carried in the kernel argument block (longer patterns: FzScanArgs.pat_g)
 #define FZ_MAX_K 255                   // largest budget of the LDS-ring verification and of the candidate automata (8-bit counters)
 #define FZ_MAX_M_ANY 65535u            // longest subsequence any path accepts (16-bit window-relative coordinates)
@@ -144,6 +145,12 @@ struct FzScanArgs {
                                                 // (0: none); the last workgroup of the launch fills it
     uint64_t pat_g;                             // m > FZ_MAX_M: device address of the pattern (pat[] unused); else 0
     uint8_t  pat[FZ_MAX_M];                     // whole pattern (m <= FZ_MAX_M)
+    // Scan grid in regions (nreg = 0: one region, every workgroup strides over all tiles): workgroups [reg_wg0[r],
+    // reg_wg0[r] + reg_nwg[r]) stride over the tiles [reg_tile0[r], reg_end[r]) — the last resident round of a launch gets
+    // fewer and fewer tiles per workgroup so that the machine does not drain one long workgroup life at a time
+    uint32_t nreg;
+    uint32_t reg_wg0[FZ_MAX_REGIONS], reg_nwg[FZ_MAX_REGIONS];
+    uint64_t reg_tile0[FZ_MAX_REGIONS], reg_end[FZ_MAX_REGIONS];
 };
 
 // A hit: (block g << FZ_IDX_BITS) | global idx (48-bit index: sequences below 256 TiB; 16-bit block number).

@@ -56,7 +56,10 @@
 #endif
 #define FZ_LUT_SLOTS (1u << FZ_LUT_BITS)                   // slots of the block-hash table
 #define FZ_LUT_BYTES (FZ_LUT_SLOTS * 4u)
-#define FZ_TABLE_BYTES (2u * FZ_LUT_BYTES + 16u)           // the hash table + one dword per slot: the block that lives there
+#define FZ_TABLE_BYTES (2u * FZ_LUT_BYTES + 32u)           // the hash table + one dword per slot: the block that lives there,
+                                                           // four dwords of the pooled flush, the workgroup's tile walk (below)
+#define FZ_WALK_LDS (2u * FZ_LUT_BYTES + 16u)              // LDS address of {first tile lo, hi, tile stride}: the scan kernel's
+                                                           // dynamic LDS starts at address 0
                                                            // + the four waves' final queue fills (pooled last flush)
                                                            // (same byte offset as the hash: no address arithmetic in the rare path)
 #define FZ_FLAG_DUP_HASHES 1u                              // FzScanArgs.flags: two blocks of the launch have the same hash
@@ -124,12 +127,18 @@ __device__ __forceinline__ uint32_t fz_load_win(const uint8_t *__restrict__ buf,
 static __device__ unsigned long long fz_lab_lp[16384 * 4];
 #endif
 #if defined(FZ_LAB_SCANTIME)
-#define FZ_LAB_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192u) fz_lab_lp[blockIdx.x * 8u + (i)] = wall_clock64(); } while (0)
+// phases of a scan workgroup: 0 entry, 1 tables ready, 2 tiles done, 3 end-of-life flush done, 4 end (after the finish
+// protocol), 5 / 6 the pooled lane-per-cell flush (after its barrier / done)
+#define FZ_LAB_PHASE(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192u) fz_lab_lp[blockIdx.x * 8u + (i)] = wall_clock64(); } while (0)
+#define FZ_LAB_STAMP(i) do { } while (0)
 #elif defined(FZ_LAB_TIMING)
 static __device__ unsigned long long fz_lab_t[256];
 #define FZ_LAB_STAMP(i) do { if ((blockIdx.x & 127u) == 64u && threadIdx.x == 0) fz_lab_t[((blockIdx.x >> 7) & 31u) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define FZ_LAB_STAMP(i) do { } while (0)
+#endif
+#ifndef FZ_LAB_PHASE
+#define FZ_LAB_PHASE(i) do { } while (0)
 #endif
 
 // Per-wave LDS areas, carved from dynamic LDS by fz_wave_lds() / fz_wave_lds_pref().
@@ -444,7 +453,10 @@ __device__ __forceinline__ uint32_t fz_code(uint32_t off, uint32_t blk, uint32_t
 // Queue entry -> (block of this launch, local byte position in the buffer).
 __device__ __forceinline__ uint64_t fz_code_local(uint32_t code, uint32_t &blk) {
     blk = (code >> FZ_TILE_BITS) & 7u;
-    const uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)(code >> (FZ_TILE_BITS + 3)) * gridDim.x;
+    // the workgroup's tile walk (first tile, stride) as the scan kernel left it in LDS
+    FzLdsU32 *walk = (FzLdsU32 *)(uintptr_t)FZ_WALK_LDS;
+    const uint64_t first = ((uint64_t)walk[1] << 32) | walk[0];
+    const uint64_t tile = first + (uint64_t)(code >> (FZ_TILE_BITS + 3)) * walk[2];
     return tile * (uint64_t)FZ_TILE_BYTES + (code & (FZ_TILE_BYTES - 1u));
 }
 
@@ -688,6 +700,12 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
     static_assert(!WF || (FUSED && !SEG), "the lane-per-cell form is a fused form of the in-memory search");
     constexpr bool PREF = FUSED && !SEG && !WF;       // candidate windows are prefetched by LDS-DMA
     FZ_LAB_STAMP(0);
+    FZ_LAB_PHASE(0);
+#ifdef FZ_LAB_SCANTIME
+    // where the workgroup runs: HW_ID (wave / SIMD / CU / SH / SE fields) and XCC_ID
+    if (threadIdx.x == 0 && blockIdx.x < 8192u)
+        fz_lab_lp[blockIdx.x * 8u + 7u] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t mpad = FUSED ? (a.m + 15u) & ~15u : 0u;   // only the fused verification reads the pattern from LDS (m <= FZ_MAX_M there)
     // [32] hash living in the slot.  The kernel has no static LDS, so the dynamic area, and with it this
@@ -712,8 +730,20 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
     for (uint32_t g = 0; g < FZ_MAX_BLOCKS_PER_LAUNCH; ++g)
         if (fz_lane() == g) hvec = a.H[g];
     const bool dup_hashes = (a.flags & FZ_FLAG_DUP_HASHES) != 0;
+    // this workgroup's walk over the tiles: first_tile, first_tile + stride, .. below limit (scalar values); the flushes
+    // decode queue entries with the copy in LDS (fz_code_local)
+    uint32_t wg0 = 0, stride = gridDim.x;
+    uint64_t tile0 = 0, limit = ntiles;
+#pragma unroll
+    for (uint32_t r = 0; r < FZ_MAX_REGIONS; ++r)
+        if (r < a.nreg && blockIdx.x >= a.reg_wg0[r]) { wg0 = a.reg_wg0[r]; stride = a.reg_nwg[r]; tile0 = a.reg_tile0[r]; limit = a.reg_end[r]; }
+    const uint64_t first_tile = tile0 + (blockIdx.x - wg0);
+    if (threadIdx.x == 0) {
+        uint32_t *walk = reinterpret_cast<uint32_t *>(smem + FZ_WALK_LDS);
+        walk[0] = (uint32_t)first_tile; walk[1] = (uint32_t)(first_tile >> 32); walk[2] = stride;
+    }
     __syncthreads();
-    FZ_LAB_STAMP(2);
+    FZ_LAB_PHASE(1);
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t qcap = PREF ? a.qcap : (uint32_t)FZ_QCAP;   // queue entries per wave
     const FzWaveLds w = PREF ? fz_wave_lds_pref(smem + FZ_TABLE_BYTES + mpad, FZ_TABLE_BYTES + mpad, wave, qcap, a.win_pieces)
@@ -732,10 +762,10 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
     uint32_t qf = 0;                                  // PREF: entries [0, qf) have their windows requested
     uint32_t confirmed = 0;                           // wave-uniform statistics
     uint32_t titer = 0;                               // tile iteration of this workgroup
-    uint64_t tile = blockIdx.x;
+    uint64_t tile = first_tile;
     // has_near_match_* (substitutions_only.py:218-233 stops at the first match): a workgroup that starts after a record
     // has been counted skips its tiles (thousands of short workgroups per launch: the ones not yet started are the saving)
-    if ((a.flags & FZ_FLAG_ANY) && __hip_atomic_load(&counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) tile = ntiles;
+    if ((a.flags & FZ_FLAG_ANY) && __hip_atomic_load(&counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) tile = limit;
     bool slow = false;                                // a tile is being re-scanned by enumeration
     uint32_t slow_pos = 0;
 
@@ -830,8 +860,8 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                 qn += 64u;
                 ++slow_pos;
             }
-            if (slow_pos >= steps) { slow = false; tile += gridDim.x; ++titer; }
-        } else if (tile < ntiles && qn <= qcap / 2) {
+            if (slow_pos >= steps) { slow = false; tile += stride; ++titer; }
+        } else if (tile < limit && qn <= qcap / 2) {
             uint4 va[2], vb[2];
             uint2 ha[2], hb[2];
             bool pre;                                 // va / ha hold rows 0-1 of the next tile
@@ -854,8 +884,8 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                 const uint32_t q_tile = qn;
                 test_row(va[0], ha[0], std::integral_constant<int, 0>{});
                 test_row(va[1], ha[1], std::integral_constant<int, 1>{});
-                const uint64_t next = tile + gridDim.x;
-                pre = next < ntiles && qn <= qcap / 2;
+                const uint64_t next = tile + stride;
+                pre = next < limit && qn <= qcap / 2;
                 {   // unconditional (a branch here would make the compiler wait for the prefetch at the join):
                     // without a next tile the loads re-read this one (L2 hits, results unused)
                     const uint8_t *nsrc = buf + fz_bcast64((pre ? next : tile) * (uint64_t)FZ_TILE_BYTES);
@@ -885,7 +915,7 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                 ++titer;
             } while (pre);                            // else: the end of the sequence, or a flush is due
         }
-        const bool done = !slow && tile >= ntiles;
+        const bool done = !slow && tile >= limit;
 #ifndef FZ_LAB_NOPOOL
         if (PREF && done) break;                      // what is queued now is verified by the pooled flush below
 #endif
@@ -904,6 +934,7 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
         qf = 0;
         if (done) break;
     }
+    FZ_LAB_PHASE(2);
 #ifndef FZ_LAB_NOPOOL
     if constexpr (PREF) {
         if (qn > qf) fz_prefetch_windows(buf, a, w, qf, qn);
@@ -923,8 +954,9 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
     // (measured and not kept: one no-return atomic per workgroup — ticket and tallies in one word — with the last-indexed
     // workgroup polling for the others instead of every workgroup waiting for its ticket: 0.2172 vs 0.2183 ms, within noise)
     if (FUSED && lane == 0 && confirmed) atomicAdd(&counters[8 + (blockIdx.x & 63u)], (unsigned long long)confirmed);
+    FZ_LAB_PHASE(3);
     fz_finish_launch(a, counters, lut);
-    FZ_LAB_STAMP(7);
+    FZ_LAB_PHASE(4);
 }
 
 // Verification of a hit list in HBM, one lane per candidate (parameter ranges whose LDS footprint does
@@ -1188,6 +1220,7 @@ __device__ __forceinline__ uint32_t fz_flush_wf(const uint8_t *__restrict__ buf,
     uint8_t *gwin = reinterpret_cast<uint8_t *>(w.win) + grp * (a.win_dwords * 4u + 16u);
     uint32_t confirmed = 0;
     FZ_LAB_STAMP(1);
+    if (pooled) FZ_LAB_PHASE(5);
     // (Measured: a pass with the hits of one near match — different blocks, so max(right) + max(left) ~ 100 rows of a
     // 64-byte pattern — takes 17 - 23 us, ~400 cycles per row, next to six streaming waves per SIMD; s_setprio(3)
     // around the passes changed nothing: the rows wait for their own dependent instructions, not for issue slots.)
@@ -1199,6 +1232,7 @@ __device__ __forceinline__ uint32_t fz_flush_wf(const uint8_t *__restrict__ buf,
         confirmed += fz_wf_pass<GW>(buf, a, lds0, pat_lds, gwin, have, code, recs, counters);
     }
     FZ_LAB_STAMP(3);
+    if (pooled) FZ_LAB_PHASE(6);
     return confirmed;
 }
 

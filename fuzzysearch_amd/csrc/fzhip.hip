@@ -753,6 +753,45 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
 
     FzScanArgs fa;
     fill_common_args(fa, sh, q);
+    // Tapered last round: workgroups start in blockIdx order, so the last resident round of a launch starts while the
+    // machine is still full and — with equal shares — ends one workgroup life (~60 us) after the grid ran dry, the chip
+    // draining all the while (device stamps of every workgroup, benchmarks/lab_scan_phases.py: residency falls linearly from
+    // 1 792 to 0 over the last 60 us of a 1 GiB launch).  The last `resident` workgroups therefore take shrinking shares
+    // (kTaperSteps groups, down to kTaperMin of a full share) of their own tile range at the end of the buffer, the others
+    // correspondingly more.
+    fa.nreg = 0;
+    {
+        static const int steps = []() { const char *e = getenv("FZ_TAPER_STEPS"); int v = e ? atoi(e) : 4; return std::min(v, FZ_MAX_REGIONS - 1); }();
+        static const double fmin = []() { const char *e = getenv("FZ_TAPER_MIN"); double v = e ? atof(e) : 0.25; return std::min(1.0, std::max(0.02, v)); }();
+        static const int t_per_cu = []() { const char *e = getenv("FZ_TAPER_WG_PER_CU"); int v = e ? atoi(e) : 7; return std::max(1, v); }();
+        const uint64_t Gw = grid.x, T = (uint64_t)d.n_cus * t_per_cu;
+        if (steps > 0 && Gw >= 2 * T && ntiles >= 4 * Gw) {
+            const uint64_t per = T / steps;                            // workgroups per taper group (the last group takes the rest)
+            double weight = (double)(Gw - T);
+            std::vector<double> f(steps);
+            std::vector<uint64_t> nw(steps);
+            for (int j = 0; j < steps; ++j) {
+                f[j] = 1.0 - (1.0 - fmin) * (j + 1) / steps;
+                nw[j] = j + 1 < steps ? per : T - per * (steps - 1);
+                weight += f[j] * (double)nw[j];
+            }
+            const double share = (double)ntiles / weight;              // tiles of a full workgroup
+            uint64_t at = 0, wg = 0;
+            auto add = [&](uint64_t nwg, uint64_t tiles) {
+                fa.reg_wg0[fa.nreg] = (uint32_t)wg; fa.reg_nwg[fa.nreg] = (uint32_t)nwg;
+                fa.reg_tile0[fa.nreg] = at; fa.reg_end[fa.nreg] = at + tiles;
+                ++fa.nreg; wg += nwg; at += tiles;
+            };
+            add(Gw - T, std::min<uint64_t>(ntiles, (uint64_t)(share * (double)(Gw - T) + 0.5)));
+            for (int j = 0; j < steps; ++j) {
+                const uint64_t left = ntiles - at;
+                add(nw[j], j + 1 < steps ? std::min<uint64_t>(left, (uint64_t)(share * f[j] * (double)nw[j] + 0.5)) : left);
+            }
+            // the queue codes carry a bounded per-workgroup tile iteration
+            for (uint32_t r = 0; r < fa.nreg; ++r)
+                if ((fa.reg_end[r] - fa.reg_tile0[r] + fa.reg_nwg[r] - 1) / fa.reg_nwg[r] >= FZ_TITER_MAX) fa.nreg = 0;
+        }
+    }
     if (q.mode == FZ_MODE_GENERIC && !with_verify) fa.gen_dedup = d.gen_dedup_arg;      // the scan fills the window table (run_generic)
     static const bool force_big = getenv("FZ_FORCE_BIG_VERIFY") != nullptr;
     const VerifyPlan vp = plan_verify(q);

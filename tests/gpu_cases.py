@@ -174,6 +174,24 @@ def main(argv):
             alpha = bytes(rnd.sample(range(1, 256), sigma))
             cases.append((bytes(rnd.choices(alpha, k=m)), bytes(rnd.choices(alpha, k=nn)), k))   # up to 2.6e5 records per search
         n_rec = run_pipelined(eng, cases)
+    elif what == "taper":
+        # the scan grid's regions (FZ_TAPER_STEPS / FZ_TAPER_MIN / FZ_TAPER_WG_PER_CU): a launch big enough to taper its
+        # last resident round must return the same streams however the tiles are dealt out
+        import hashlib
+        from tests import workloads
+        seq, pat, _ = workloads.cfg2(n << 20, n)
+        p = pat.tobytes()
+        h = eng.upload(seq)
+        dig = hashlib.sha1()
+        n_rec = 0
+        for rows in (eng.lev_ngrams(h, p, 2, as_array=True), eng.search_exact(h, p, as_array=True),
+                     eng.subs_ngrams(h, p, 2, as_array=True), eng.lev_ngrams(h, workloads.dna(36, 9).tobytes(), 5, as_array=True)):
+            dig.update(rows.tobytes())
+            n_rec += len(rows)
+        h.release()
+        eng.close()
+        print("OK %d %d %d" % (n, n_rec, int(dig.hexdigest()[:12], 16)))
+        return
     elif what == "wf":
         # Levenshtein budgets 5 .. 7: lane-per-cell verification inside the scan kernel (default) or in the kernel of its
         # own (FZ_NO_WF_FUSE=1) — ragged ends, patterns up to the argument block, queues that fill up (tiny alphabets)

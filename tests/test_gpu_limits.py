@@ -61,6 +61,16 @@ def test_generic_automaton_kernel_forms():
     assert _sub(["windows", 120, 24], {"FZ_GH_WAVES": "4", "FZ_GEN_NO_DEDUP": "1"})[0] == 120
 
 
+def test_scan_grid_regions_leave_the_streams_alone():
+    """Round 4: the last resident round of a big scan launch takes shrinking tile shares (FzScanArgs.reg_*).  768 MiB of DNA
+    — Levenshtein k = 2 (fused), exact (hit list), substitutions, k = 5 with 36 bytes (six-byte n-grams, lane-per-cell
+    verification in the scan: a million candidates) — without regions, with the default taper and with a steep one: the same digests."""
+    base = _sub(["taper", 768], {"FZ_TAPER_STEPS": "0"})
+    assert base[0] == 768 and base[1] > 1500
+    assert _sub(["taper", 768], {}) == base
+    assert _sub(["taper", 768], {"FZ_TAPER_STEPS": "7", "FZ_TAPER_MIN": "0.05", "FZ_TAPER_WG_PER_CU": "10"}) == base
+
+
 def test_lane_per_cell_verification_fused_and_stand_alone():
     """Levenshtein budgets 5 .. 7 of an in-memory search verify inside the scan kernel (fz_queue_flush_wf: the wave's queued
     candidates, four at a time on 16 lanes each); FZ_NO_WF_FUSE=1 sends the same searches through the hit list and
