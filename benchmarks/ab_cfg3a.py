@@ -28,7 +28,7 @@ def run(tag, h, p, k, reps=200):
         eng.lev_ngrams_begin(h, p, k); eng.lev_ngrams_end(as_array=True)
     pipe = (time.perf_counter() - t0) / reps
     eng.lev_ngrams_end(as_array=True)
-    print(json.dumps({"case": tag, "fused_wf": "FZ_NO_WF_FUSE" not in os.environ, "k": k, "ms_per_call": round(dt * 1e3, 4),
+    print(json.dumps({"case": tag, "fused_wf": "FZ_NO_WF_FUSE" not in os.environ, "wf32": os.environ.get("FZ_WF32", "adaptive"), "k": k, "ms_per_call": round(dt * 1e3, 4),
                       "two_in_flight_ms": round(pipe * 1e3, 4), "scan_ms": round(float(np.mean(f)), 4),
                       "verify_ms": round(float(np.mean(v)), 4), "raw": len(r), "hits": hits,
                       "sha": hashlib.sha1(r.tobytes()).hexdigest()[:12]}), flush=True)
@@ -36,7 +36,7 @@ def run(tag, h, p, k, reps=200):
 
 seq, pat, _ = workloads.cfg4(1 << 30, 1024)
 h = eng.upload(seq)
-for k in (5, 6, 7, 8):
+for k in (5, 6, 7, 8, 12):
     run("utf8 m=64", h, pat.tobytes(), k)
 run("utf8 m=64, pattern of bytes the text does not hold", h, bytes(range(1, 65)), 5)
 h.release()
@@ -46,3 +46,5 @@ workloads.plant_variants(seq, pat, 1024, 9)
 h = eng.upload(seq)
 run("dna m=40", h, pat.tobytes(), 5, reps=30)
 run("dna m=48", h, workloads.dna(48, 6).tobytes(), 5, reps=50)
+run("dna m=54", h, workloads.dna(54, 7).tobytes(), 8, reps=20)
+run("dna m=100", h, workloads.dna(100, 8).tobytes(), 10, reps=50)

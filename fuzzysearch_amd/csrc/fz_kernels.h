@@ -693,10 +693,12 @@ __device__ __forceinline__ uint32_t fz_pooled_flush(const uint8_t *__restrict__ 
 //     by LDS-DMA now (fz_prefetch_windows).
 // 7 waves per SIMD (72 VGPRs): measured 2-3 % faster than the natural 79-VGPR / 6-wave allocation;
 // 8 waves (64 VGPRs) spills 27 VGPRs in the verify path and is 50 % slower.
-template <int NWIN, int DH, bool FUSED, bool SEG, bool SA, bool WF = false>
+template <int NWIN, int DH, bool FUSED, bool SEG, bool SA, int WFG = 0>
 __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_eu(7, 7))) void fz_scan_kernel(
     const uint8_t *__restrict__ buf, const FzScanArgs a, uint64_t ntiles,
     uint64_t *__restrict__ hits, FzRec *__restrict__ recs, unsigned long long *__restrict__ counters) {
+    constexpr bool WF = WFG != 0;                     // lane-per-cell verification inside the scan, WFG lanes per candidate
+    static_assert(WFG == 0 || WFG == 16 || WFG == 32, "lanes per candidate of the fused lane-per-cell form");
     static_assert(!WF || (FUSED && !SEG), "the lane-per-cell form is a fused form of the in-memory search");
     constexpr bool PREF = FUSED && !SEG && !WF;       // candidate windows are prefetched by LDS-DMA
     FZ_LAB_STAMP(0);
@@ -747,7 +749,7 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t qcap = PREF ? a.qcap : (uint32_t)FZ_QCAP;   // queue entries per wave
     const FzWaveLds w = PREF ? fz_wave_lds_pref(smem + FZ_TABLE_BYTES + mpad, FZ_TABLE_BYTES + mpad, wave, qcap, a.win_pieces)
-                        : WF ? fz_wave_lds(smem + FZ_TABLE_BYTES + mpad, wave, fz_wf_fused_dwords(a.win_dwords, 16), 0u, 1u, true)
+                        : WF ? fz_wave_lds(smem + FZ_TABLE_BYTES + mpad, wave, fz_wf_fused_dwords(a.win_dwords, WF ? WFG : 16), 0u, 1u, true)
                              : fz_wave_lds(smem + FZ_TABLE_BYTES + mpad, wave, FUSED ? a.win_dwords : 0u,
                                            FUSED ? a.band_w : 0u, a.vlanes, true);
     const uint32_t hash_k = a.hash_k;
@@ -920,10 +922,10 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
         if (PREF && done) break;                      // what is queued now is verified by the pooled flush below
 #endif
         if constexpr (WF) {
-            // lane-per-cell verification (Levenshtein budgets 5 .. 7): own queue in mid-scan, the workgroup's pool at the end
-            confirmed += fz_flush_wf<16>(buf, a, smem, pat_lds, w, smem + FZ_TABLE_BYTES + mpad,
-                                         fz_wave_lds_bytes(fz_wf_fused_dwords(a.win_dwords, 16), 0u, 1u, true),
-                                         reinterpret_cast<volatile uint32_t *>(smem + 2u * FZ_LUT_BYTES), wave, qn, done, recs, counters);
+            // lane-per-cell verification (Levenshtein budgets 5 .. 15): own queue in mid-scan, the workgroup's pool at the end
+            confirmed += fz_flush_wf<WF ? WFG : 16>(buf, a, smem, pat_lds, w, smem + FZ_TABLE_BYTES + mpad,
+                                                    fz_wave_lds_bytes(fz_wf_fused_dwords(a.win_dwords, WF ? WFG : 16), 0u, 1u, true),
+                                                    reinterpret_cast<volatile uint32_t *>(smem + 2u * FZ_LUT_BYTES), wave, qn, done, recs, counters);
         } else if (qn) {
 #ifndef FZ_LAB_NOPREFETCH
             if (PREF && qn > qf) fz_prefetch_windows(buf, a, w, qf, qn);

@@ -137,6 +137,7 @@ struct DevState {
     // that a search collected in between may have grown)
     uint64_t hit_cap_used = 0, rec_cap_used = 0;
     bool fused_used = false;
+    bool wf32_candidate = false;                 // the search in this slot could have verified inside the scan with 32 lanes per candidate
     bool timed = true;                           // the search being collected recorded its start event
     double last_filter_ms = 0;                   // scan span of the search collected last on this device (fz_device_ms)
     uint64_t fold_guess = 8192, fold_copied = 0; // folded generic search: pairs fetched with the counters
@@ -170,7 +171,7 @@ struct DevState {
     struct Slot {
         hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
         uint8_t *h_stage = nullptr, *h_stage_dev = nullptr;
-        bool last_direct = false, verify_launched = false, fused_used = false, timed = true;
+        bool last_direct = false, verify_launched = false, fused_used = false, timed = true, wf32_candidate = false;
         int scan_end_event = 1, verify_end_event = 2;
         uint64_t hit_cap_used = 0, rec_cap_used = 0;
         int slot_id = 1;
@@ -184,6 +185,7 @@ struct DevState {
         std::swap(verify_launched, other.verify_launched);
         std::swap(timed, other.timed);
         std::swap(fused_used, other.fused_used);
+        std::swap(wf32_candidate, other.wf32_candidate);
         std::swap(scan_end_event, other.scan_end_event);
         std::swap(verify_end_event, other.verify_end_event);
         std::swap(hit_cap_used, other.hit_cap_used);
@@ -307,6 +309,9 @@ struct fz_ctx {
     // resets the back-off): inputs that always fail (dense repeats) pay a wasted launch now and then, not every time.
     bool gen_multi = getenv("FZ_GEN_LEGACY") == nullptr;
     uint32_t gen_multi_skip = 0, gen_multi_backoff = 0;
+    // Levenshtein budgets 8 .. 15 (32 lanes per candidate): verification inside the scan kernel (1) or in a kernel of its
+    // own (0) — chosen by the candidate density the context's previous such search saw (enqueue_shard)
+    std::atomic<int> wf32_fused{0};
     // Single-shard searches in direct mode leave their records in the pinned staging buffer and only
     // publish a view of them (valid until the next search of this context): saves a 24 B x nr memcpy.
     const FzRec *view = nullptr;
@@ -528,25 +533,26 @@ ScanKernel scan_kernel_s(int nwin, int dh, bool sa) {
 // The segmented variants (file API) only exist where a segment changes the outcome: Levenshtein /
 // generic clamps.  Exact and substitutions-only windows fit exactly one chunk (the host assigns it).
 // sa: the launch's blocks are told apart by hash bits 2..6 (slot address = one v_and).
-// The fused lane-per-cell form (Levenshtein budgets 5 .. 7, fz_queue_flush_wf).
-template <bool SEG, bool SA>
+// The fused lane-per-cell form (Levenshtein budgets 5 .. 15 of in-memory searches, fz_flush_wf): GW = 16 or 32 lanes per candidate.
+template <bool SA, int GW>
 ScanKernel scan_kernel_wf(int nwin, int dh) {
-    if (nwin == 1) return fz_scan_kernel<1, 0, true, SEG, SA, true>;
+    if (nwin == 1) return fz_scan_kernel<1, 0, true, false, SA, GW>;
     switch (dh) {
-        case 2: return fz_scan_kernel<2, 2, true, SEG, SA, true>;
-        case 3: return fz_scan_kernel<2, 3, true, SEG, SA, true>;
-        case 4: return fz_scan_kernel<2, 4, true, SEG, SA, true>;
-        default: return fz_scan_kernel<2, 5, true, SEG, SA, true>;
+        case 2: return fz_scan_kernel<2, 2, true, false, SA, GW>;
+        case 3: return fz_scan_kernel<2, 3, true, false, SA, GW>;
+        case 4: return fz_scan_kernel<2, 4, true, false, SA, GW>;
+        default: return fz_scan_kernel<2, 5, true, false, SA, GW>;
     }
 }
 
-ScanKernel scan_kernel(int nwin, int dh, bool fused, bool seg, bool sa, bool wf = false) {
+ScanKernel scan_kernel(int nwin, int dh, bool fused, bool seg, bool sa, int wf_gw = 0) {
 #ifdef FZ_LAB_ONLY      // lab builds (benchmarks/lab_build.sh): only the instances of the headline and exact-search workloads
     if (nwin == 2 && dh == 3 && fused && !seg) return sa ? fz_scan_kernel<2, 3, true, false, true> : fz_scan_kernel<2, 3, true, false, false>;
     if (nwin == 2 && dh == 5 && !fused && !seg) return sa ? fz_scan_kernel<2, 5, false, false, true> : fz_scan_kernel<2, 5, false, false, false>;
     return nullptr;
 #else
-    if (wf) return seg ? nullptr : (sa ? scan_kernel_wf<false, true>(nwin, dh) : scan_kernel_wf<false, false>(nwin, dh));
+    if (wf_gw == 16) return seg ? nullptr : (sa ? scan_kernel_wf<true, 16>(nwin, dh) : scan_kernel_wf<false, 16>(nwin, dh));
+    if (wf_gw == 32) return seg ? nullptr : (sa ? scan_kernel_wf<true, 32>(nwin, dh) : scan_kernel_wf<false, 32>(nwin, dh));
     if (seg) return fused ? scan_kernel_s<true, true>(nwin, dh, sa) : scan_kernel_s<false, true>(nwin, dh, sa);
     return fused ? scan_kernel_s<true, false>(nwin, dh, sa) : scan_kernel_s<false, false>(nwin, dh, sa);
 #endif
@@ -831,15 +837,24 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
         fused_lds = mpad + FZ_TABLE_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fa.win_dwords, fa.band_w, fa.vlanes, true);
     }
     // k > 4 (register band too wide for the scan kernel's VGPR budget) -> lane-per-cell: inside the scan as well while 16
-    // lanes hold the band (budgets 5 .. 7: the candidates of a wave's queue, four at a time, at the end of the wave's
-    // life), in a kernel of its own beyond that
+    // or 32 lanes hold the band (budgets 5 .. 15: the candidates of a wave's queue, four or two at a time), in a kernel of
+    // its own beyond that
     fa.fused = (with_verify && !force_big && q.m <= FZ_MAX_M && q.k <= FZ_MAX_K && fused_lds <= kFusedLdsBudget &&
                 (q.mode != FZ_MODE_LEV || q.k <= 4)) ? 1u : 0u;
     static const bool no_wf_fuse = getenv("FZ_NO_WF_FUSE") != nullptr;          // test / measurement knob: the stand-alone kernel
-    const uint32_t wf_fused_lds = mpad + FZ_TABLE_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fz_wf_fused_dwords(fa.win_dwords, 16), 0, 1, true);
+    const uint32_t wf_fused_lds = mpad + FZ_TABLE_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fz_wf_fused_dwords(fa.win_dwords, (uint32_t)vp.gw), 0, 1, true);
     // (in-memory searches only: the segmented instances of this form spill registers — the file API keeps the kernel of its own)
-    const bool wf_fused = !fa.fused && sh.geom.seg_stride == 0 && with_verify && !force_big && !no_wf_fuse && vp.want_wf && !vp.big && vp.gw == 16 &&
-                          q.m <= FZ_MAX_M && wf_fused_lds <= target + 4096;
+    // 32 lanes per candidate (budgets 8 .. 15): the fused form is 7-14 % behind scan + stand-alone kernel where candidates
+    // are rare (1 GiB of text, m = 64, k = 8 / 12: 0.546 / 0.654 against 0.509 / 0.597 ms) and 1.25 .. 7.7 x ahead where they
+    // are not (DNA, m = 100, k = 10, 4.5e4 candidates: 0.551 against 0.687 ms; m = 54, k = 8, 2.4e6: 2.70 against 20.7 ms —
+    // the hit list outgrows its buffer and the search runs twice).  Which one a text is cannot be told from the pattern:
+    // the context remembers the candidate density of its last such search (collect_shard) and starts with the stand-alone
+    // kernel; FZ_WF32=0 / 1 pins the choice.
+    static const int wf32_env = []() { const char *e = getenv("FZ_WF32"); return e ? atoi(e) : -1; }();
+    const bool wf_candidate = !fa.fused && sh.geom.seg_stride == 0 && with_verify && !force_big && !no_wf_fuse && vp.want_wf && !vp.big && vp.gw <= 32 &&
+                              q.m <= FZ_MAX_M && wf_fused_lds <= target + 4096;
+    d.wf32_candidate = wf_candidate && vp.gw == 32;
+    const bool wf_fused = wf_candidate && (vp.gw == 16 || (wf32_env >= 0 ? wf32_env != 0 : ctx->wf32_fused.load(std::memory_order_relaxed) != 0));
     if (wf_fused) { fa.fused = 1u; fused_lds = wf_fused_lds; fa.vlanes = 64; }
     // (the hit-emitting form keeps no pattern in LDS: fz_confirm reads it from the argument block / HBM)
     const uint32_t scan_lds = fa.fused ? fused_lds : FZ_TABLE_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(0, 0, 64, true);
@@ -889,7 +904,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
         for (uint32_t b = 1; b < nblk; ++b)
             for (uint32_t c = 0; c < b; ++c)
                 if (fa.H[b] == fa.H[c]) fa.flags |= FZ_FLAG_DUP_HASHES;
-        ScanKernel kern = scan_kernel(nwin, dh, fa.fused != 0, sh.geom.seg_stride != 0, fa.lut_shift == 2, wf_fused);
+        ScanKernel kern = scan_kernel(nwin, dh, fa.fused != 0, sh.geom.seg_stride != 0, fa.lut_shift == 2, wf_fused ? vp.gw : 0);
         if (!kern) return fail(FZ_EUNSUPPORTED, "this (lab) build carries no scan kernel for nwin=%d dh=%d", nwin, dh);
         static const uint32_t extra_lds = []() { const char *e = getenv("FZ_EXTRA_LDS_KB"); return e ? (uint32_t)atoi(e) * 1024u : 0u; }();
         hipEvent_t ev_start = (attach && ctx->timing && g0 == 0) ? d.ev[0] : nullptr;
@@ -1006,6 +1021,10 @@ int collect_shard(fz_ctx *ctx, const Shard &sh, bool with_verify, bool view_ok, 
     const uint64_t nr = cnt[1];
     const bool fused = with_verify && d.fused_used;
     if (fused) { nh = 0; for (int i = 0; i < 64; ++i) nh += cnt[8 + i]; }
+    // budgets 8 .. 15: more than ~24 candidates per MiB -> the context's next such search verifies inside the scan
+    // (the crossover lies between 1.5e4 and 4.5e4 candidates per GiB); a hit list that overflowed runs again that way
+    if (with_verify && d.wf32_candidate && sh.geom.buf_len)
+        ctx->wf32_fused.store(nh * 43691ull > sh.geom.buf_len ? 1 : 0, std::memory_order_relaxed);
     bool rerun = false;
     if (nh > d.hit_cap_used && !fused) {
         HIP_TRY(hipStreamSynchronize(d.stream));          // a second search in flight still uses the old buffers

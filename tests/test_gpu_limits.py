@@ -72,13 +72,14 @@ def test_scan_grid_regions_leave_the_streams_alone():
 
 
 def test_lane_per_cell_verification_fused_and_stand_alone():
-    """Levenshtein budgets 5 .. 7 of an in-memory search verify inside the scan kernel (fz_queue_flush_wf: the wave's queued
-    candidates, four at a time on 16 lanes each); FZ_NO_WF_FUSE=1 sends the same searches through the hit list and
-    fz_verify_wf_kernel.  The same random cases — ragged ends, long patterns, alphabets small enough to fill the queues —
+    """Levenshtein budgets 5 .. 15 of an in-memory search verify inside the scan kernel (fz_flush_wf: the queued candidates,
+    four at a time on 16 lanes each up to budget 7, two at a time on 32 lanes beyond); FZ_NO_WF_FUSE=1 sends the same
+    searches through the hit list and fz_verify_wf_kernel.  The same random cases — ragged ends, long patterns, alphabets small enough to fill the queues —
     against the oracle either way."""
-    base = _sub(["wf", 300, 31], {})
-    assert base[0] == 305 and base[1] > 1000
-    assert _sub(["wf", 300, 31], {"FZ_NO_WF_FUSE": "1"}) == base
+    base = _sub(["wf", 300, 31], {})                  # budgets 8 .. 15: fused or not by the density the previous search saw
+    assert base[0] == 308 and base[1] > 1000
+    assert _sub(["wf", 300, 31], {"FZ_WF32": "1"}) == base        # ... always fused
+    assert _sub(["wf", 300, 31], {"FZ_NO_WF_FUSE": "1"}) == base  # nothing fused
 
 
 def test_copy_mode_one_and_two_searches_in_flight():
