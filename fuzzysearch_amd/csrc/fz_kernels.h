@@ -1007,7 +1007,8 @@ __device__ __forceinline__ uint32_t fz_xl_shl1(uint32_t v, uint32_t fill, uint32
     if constexpr (GW == 16) {
         return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x101, 0xf, 0xf, false);   // row_shl:1
     } else {
-        const uint32_t o = (uint32_t)__shfl_down((int)v, 1, 64);
+        // lane l <- lane l + 1 across the wave (wave_shl:1; lane 63 <- fill), then the last lane of every group <- fill
+        const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x130, 0xf, 0xf, false);
         return gl == (uint32_t)GW - 1u ? fill : o;
     }
 }
@@ -1023,11 +1024,15 @@ __device__ __forceinline__ uint32_t fz_xl_prefix_min(uint32_t v, uint32_t gl) {
                      "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
                      : "+v"(v));
     } else {
-#pragma unroll
-        for (int n = 1; n < GW; n <<= 1) {
-            const uint32_t o = (uint32_t)__shfl_up((int)v, n, 64);
-            if (gl >= (uint32_t)n) v = min(v, o);
-        }
+        // inside the 16-lane rows as above, then the last lane of row 0 / 2 into rows 1 / 3 (32-lane groups) and the last
+        // lane of row 1 into rows 2 and 3 (the whole wave): lanes without a source keep their value
+        v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xf, 0xf, false));   // row_shr:1
+        v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x112, 0xf, 0xf, false));   // row_shr:2
+        v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114, 0xf, 0xf, false));   // row_shr:4
+        v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118, 0xf, 0xf, false));   // row_shr:8
+        v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
+        if constexpr (GW == 64)
+            v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3
     }
     return v;
 }

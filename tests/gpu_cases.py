@@ -195,10 +195,10 @@ def main(argv):
     elif what == "wf":
         # Levenshtein budgets 5 .. 15: lane-per-cell verification inside the scan kernel (default; 16 lanes per candidate up
         # to 7, 32 beyond) or in the kernel of its own (FZ_NO_WF_FUSE=1) — ragged ends, patterns up to the argument block, queues that fill up (tiny alphabets)
-        cases = random_cases(rnd, n, [5, 6, 7, 8, 10, 12, 15], 300, 6000)
+        cases = random_cases(rnd, n, [5, 6, 7, 8, 10, 12, 15, 20, 31], 300, 6000)   # (16 .. 31: 64 lanes, stand-alone kernel only)
         from tests import workloads
         for sigma, nn, m, k in ((2, 60000, 40, 5), (4, 400000, 30, 5), (3, 150000, 56, 7), (20, 1 << 20, 64, 6),
-                                (4, 300000, 50, 8), (3, 100000, 96, 15), (20, 1 << 20, 120, 11)):
+                                (4, 300000, 50, 8), (3, 100000, 96, 15), (20, 1 << 20, 120, 11), (4, 200000, 130, 24)):
             alpha = bytes(rnd.sample(range(1, 256), sigma))
             pp = bytes(rnd.choices(alpha, k=m))
             tt = bytearray(rnd.choices(alpha, k=nn))
