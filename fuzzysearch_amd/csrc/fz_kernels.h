@@ -50,6 +50,7 @@
 #ifndef FZ_GROUP
 #define FZ_GROUP 0                                         // lab knob: force 4 or 8 byte offsets per wave-uniform branch (0: by n-gram length)
 #endif
+#define FZ_WF_COMPACT_MIN 8192ull                          // fz_verify_wf_kernel: record slots above which records are appended, not slotted
 #define FZ_QCAP 256                                        // fast-hit queue entries per wave
 #ifndef FZ_LUT_BITS
 #define FZ_LUT_BITS 5                                      // 32 slots: one per LDS bank (6 = the round-1 table, 2-way conflicts)
@@ -1250,7 +1251,10 @@ __device__ __forceinline__ uint32_t fz_flush_wf(const uint8_t *__restrict__ buf,
 // is launch, two dependent load round trips and the finish tickets.)
 // Record slot = hit number (x candidate segment): no slot atomics — all waves of this kernel finish at
 // about the same time, and 1400 atomics on one counter word took longer than the DP rows.  Slots of hits
-// that did not verify carry FZ_REC_NONE; the host drops them.
+// that did not verify carry FZ_REC_NONE; the host drops them.  Long hit lists (more than FZ_WF_COMPACT_MIN
+// slots) append their records instead, one atomic per pass that verified something: a slot per hit of a
+// dense list is megabytes of empty records for the host to copy and skip (2.4e6 hits of 1 GiB of DNA at
+// m = 54, k = 8: 57 MB per search, 16 of the call's 19 ms).
 // Dynamic LDS: pattern + per-wave window areas (one contiguous byte window per hit).
 template <int GW>
 __global__ __launch_bounds__(1024) void fz_verify_wf_kernel(const uint8_t *__restrict__ buf, const FzScanArgs a,
@@ -1276,6 +1280,7 @@ __global__ __launch_bounds__(1024) void fz_verify_wf_kernel(const uint8_t *__res
     uint32_t active_wgs = (uint32_t)((nh + per_wg - 1) / per_wg < gridDim.x ? (nh + per_wg - 1) / per_wg : gridDim.x);
     if (active_wgs == 0) active_wgs = 1;
     if (blockIdx.x >= active_wgs) return;
+    const bool compact = nh * ncand > FZ_WF_COMPACT_MIN;               // (uniform: every wave takes the same form)
     for (uint64_t q0 = wave * NH; q0 < nh; q0 += waves * NH) {
         const uint64_t q = q0 + grp;
         const bool have = q < nh;
@@ -1287,7 +1292,7 @@ __global__ __launch_bounds__(1024) void fz_verify_wf_kernel(const uint8_t *__res
             const FzSeg sg = fz_segment(a.geom, idx, c);
             const bool valid = have && fz_hit_in_range_s(a, s, idx, sg);
             const unsigned long long slot = q * ncand + c;
-            if (have && !valid && gl == 0 && slot < a.rec_cap) recs[slot].dist = FZ_REC_NONE;   // not a hit of this segment
+            if (!compact && have && !valid && gl == 0 && slot < a.rec_cap) recs[slot].dist = FZ_REC_NONE;   // not a hit of this segment
             if (!__ballot(valid)) continue;
             // the hit's window [wlo, whi), staged as plain bytes: byte g of the sequence at gwin[g - wbase]
             uint64_t wlo = 0, whi = 0, wbase = 0;
@@ -1327,16 +1332,32 @@ __global__ __launch_bounds__(1024) void fz_verify_wf_kernel(const uint8_t *__res
             const uint32_t celll = fz_wf_rows<GW>(smem, gl, a.k, (int)(pat_lds - smem) + (int)s - 1, -1, s, lds_of(idx) - 1, -1, lwin,
                                                   bl, ok1);
             const bool ok = fz_wf_pick<GW>(celll, gl, a.k, s, lwin, bl, ok1, dL, l);
-            if (valid && gl == 0 && slot < a.rec_cap) {
-                FzRec rec;
-                rec.key = hit; rec.l = l; rec.r = r; rec.dist = ok ? dL + dR : FZ_REC_NONE; rec.aux = sg.j;
-                recs[slot] = rec;
+            if (!compact) {
+                if (valid && gl == 0 && slot < a.rec_cap) {
+                    FzRec rec;
+                    rec.key = hit; rec.l = l; rec.r = r; rec.dist = ok ? dL + dR : FZ_REC_NONE; rec.aux = sg.j;
+                    recs[slot] = rec;
+                }
+            } else {
+                const bool mine = ok && gl == 0;
+                const unsigned long long mask = __ballot(mine);
+                if (mask) {
+                    unsigned long long base = 0;
+                    if (lane == 0) base = atomicAdd(&counters[1], (unsigned long long)__popcll(mask));
+                    base = fz_bcast64(base);
+                    const unsigned long long at = base + fz_rank(mask);
+                    if (mine && at < a.rec_cap) {
+                        FzRec rec;
+                        rec.key = hit; rec.l = l; rec.r = r; rec.dist = dL + dR; rec.aux = sg.j;
+                        recs[at] = rec;
+                    }
+                }
             }
             fz_wave_lds_sync();
         }
     }
-    // the record count the host sees = number of slots; only workgroups that had hits take a finish ticket
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters[1], nh * ncand);
+    // the record count the host sees = number of slots (or of appended records); only workgroups that had hits take a finish ticket
+    if (!compact && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters[1], nh * ncand);
     fz_finish_launch(a, counters, reinterpret_cast<uint32_t *>(smem), active_wgs);
 }
 

@@ -198,7 +198,8 @@ def main(argv):
         cases = random_cases(rnd, n, [5, 6, 7, 8, 10, 12, 15, 20, 31], 300, 6000)   # (16 .. 31: 64 lanes, stand-alone kernel only)
         from tests import workloads
         for sigma, nn, m, k in ((2, 60000, 40, 5), (4, 400000, 30, 5), (3, 150000, 56, 7), (20, 1 << 20, 64, 6),
-                                (4, 300000, 50, 8), (3, 100000, 96, 15), (20, 1 << 20, 120, 11), (4, 200000, 130, 24)):
+                                (4, 300000, 50, 8), (3, 100000, 96, 15), (20, 1 << 20, 120, 11), (4, 200000, 130, 24),
+                                (2, 400000, 40, 5), (2, 300000, 75, 9), (2, 300000, 140, 19)):   # 2e4 .. 4e4 candidates: the stand-alone kernel appends its records
             alpha = bytes(rnd.sample(range(1, 256), sigma))
             pp = bytes(rnd.choices(alpha, k=m))
             tt = bytearray(rnd.choices(alpha, k=nn))

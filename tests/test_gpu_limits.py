@@ -77,7 +77,7 @@ def test_lane_per_cell_verification_fused_and_stand_alone():
     searches through the hit list and fz_verify_wf_kernel.  The same random cases — ragged ends, long patterns, alphabets small enough to fill the queues —
     against the oracle either way."""
     base = _sub(["wf", 300, 31], {})                  # budgets 8 .. 15: fused or not by the density the previous search saw
-    assert base[0] == 309 and base[1] > 1000
+    assert base[0] == 312 and base[1] > 1000
     assert _sub(["wf", 300, 31], {"FZ_WF32": "1"}) == base        # ... always fused
     assert _sub(["wf", 300, 31], {"FZ_NO_WF_FUSE": "1"}) == base  # nothing fused
 
