@@ -735,7 +735,9 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     //  DNA k = 2: 0.232 / 0.223 / 0.222 / 0.222 / 0.224 / 0.240 / 0.244 / 0.260 ms; exact search: 0.191 / 0.182 /
     //  0.187 / 0.193 / 0.199 / 0.201 / 0.196 / 0.205 ms)
     // Round 3 (two-level finish tickets in place, `profiles/r03_lab_ab.txt`): what matters below ~10 rounds of resident
-    // workgroups is that the grid is a WHOLE number of rounds (6 workgroups per CU are resident; a last round that is
+    // workgroups is that the grid is a WHOLE number of rounds of 6 workgroups per CU (round 4's device stamps show SEVEN
+    // resident per CU — amdgpu_waves_per_eu(7, 7) — so these are not rounds of residents; the multiples of 6 per CU
+    // stay because they measured best, with and without the tapered last round below; a last round that is
     // 56 % full costs 1 GiB 8 us) of ~9.5 tiles per workgroup: 1 GiB, 4 rounds (10.7 tiles) 0.2046 ms, 5 rounds 0.2048,
     // 3 rounds 0.2062, 6 rounds 0.2074, 8 rounds 0.2104 against 0.2121-0.2146 for 12 tiles (3.56 rounds); 2 GiB, 9 rounds
     // 0.3887 against 0.3989; 512 MiB, 2 rounds 0.1165 against 0.1182.  Long inputs keep 12 tiles per workgroup (4 GiB:
