@@ -705,6 +705,49 @@ VerifyPlan plan_verify(const Search &q) {
     return v;
 }
 
+// The regions of a scan grid (FzScanArgs.reg_*; nreg = 0: every workgroup strides over all tiles).  `steps` groups of
+// the last `t_per_cu x n_cus` workgroups take shares shrinking to `fmin` of a full one.
+void plan_scan_regions(FzScanArgs &fa, uint64_t ntiles, uint64_t grid, uint32_t n_cus, int steps, double fmin, int t_per_cu) {
+    fa.nreg = 0;
+    steps = std::min(steps, FZ_MAX_REGIONS - 1);
+    fmin = std::min(1.0, std::max(0.02, fmin));
+    const uint64_t Gw = grid, T = (uint64_t)n_cus * (uint64_t)std::max(1, t_per_cu);
+    if (steps <= 0 || (uint64_t)steps > T || Gw < 2 * T || ntiles < 4 * Gw) return;
+    const uint64_t per = T / steps;                            // workgroups per taper group (the last group takes the rest)
+    double weight = (double)(Gw - T);
+    std::vector<double> f(steps);
+    std::vector<uint64_t> nw(steps);
+    for (int j = 0; j < steps; ++j) {
+        f[j] = 1.0 - (1.0 - fmin) * (j + 1) / steps;
+        nw[j] = j + 1 < steps ? per : T - per * (steps - 1);
+        weight += f[j] * (double)nw[j];
+    }
+    const double share = (double)ntiles / weight;              // tiles of a full workgroup
+    uint64_t at = 0, wg = 0;
+    auto add = [&](uint64_t nwg, uint64_t tiles) {
+        fa.reg_wg0[fa.nreg] = (uint32_t)wg; fa.reg_nwg[fa.nreg] = (uint32_t)nwg;
+        fa.reg_tile0[fa.nreg] = at; fa.reg_end[fa.nreg] = at + tiles;
+        ++fa.nreg; wg += nwg; at += tiles;
+    };
+    add(Gw - T, std::min<uint64_t>(ntiles, (uint64_t)(share * (double)(Gw - T) + 0.5)));
+    for (int j = 0; j < steps; ++j) {
+        const uint64_t left = ntiles - at;
+        add(nw[j], j + 1 < steps ? std::min<uint64_t>(left, (uint64_t)(share * f[j] * (double)nw[j] + 0.5)) : left);
+    }
+    // the queue codes carry a bounded per-workgroup tile iteration
+    for (uint32_t r = 0; r < fa.nreg; ++r)
+        if ((fa.reg_end[r] - fa.reg_tile0[r] + fa.reg_nwg[r] - 1) / fa.reg_nwg[r] >= FZ_TITER_MAX) { fa.nreg = 0; break; }
+}
+
+// ... with the process-wide settings (FZ_TAPER_STEPS, default 4; FZ_TAPER_MIN, default 0.25; FZ_TAPER_WG_PER_CU, default 7 =
+// the workgroups of this kernel that are resident per CU).
+void plan_scan_regions(FzScanArgs &fa, uint64_t ntiles, uint64_t grid, uint32_t n_cus) {
+    static const int steps = []() { const char *e = getenv("FZ_TAPER_STEPS"); return e ? atoi(e) : 4; }();
+    static const double fmin = []() { const char *e = getenv("FZ_TAPER_MIN"); return e ? atof(e) : 0.25; }();
+    static const int t_per_cu = []() { const char *e = getenv("FZ_TAPER_WG_PER_CU"); return e ? atoi(e) : 7; }();
+    plan_scan_regions(fa, ntiles, grid, n_cus, steps, fmin, t_per_cu);
+}
+
 // Enqueue scan (+ separate verify when it cannot be fused) for one shard on its device stream.
 // No host synchronisation.
 int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verify, bool copy_back = true) {
@@ -767,39 +810,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     // 1 792 to 0 over the last 60 us of a 1 GiB launch).  The last `resident` workgroups therefore take shrinking shares
     // (kTaperSteps groups, down to kTaperMin of a full share) of their own tile range at the end of the buffer, the others
     // correspondingly more.
-    fa.nreg = 0;
-    {
-        static const int steps = []() { const char *e = getenv("FZ_TAPER_STEPS"); int v = e ? atoi(e) : 4; return std::min(v, FZ_MAX_REGIONS - 1); }();
-        static const double fmin = []() { const char *e = getenv("FZ_TAPER_MIN"); double v = e ? atof(e) : 0.25; return std::min(1.0, std::max(0.02, v)); }();
-        static const int t_per_cu = []() { const char *e = getenv("FZ_TAPER_WG_PER_CU"); int v = e ? atoi(e) : 7; return std::max(1, v); }();
-        const uint64_t Gw = grid.x, T = (uint64_t)d.n_cus * t_per_cu;
-        if (steps > 0 && Gw >= 2 * T && ntiles >= 4 * Gw) {
-            const uint64_t per = T / steps;                            // workgroups per taper group (the last group takes the rest)
-            double weight = (double)(Gw - T);
-            std::vector<double> f(steps);
-            std::vector<uint64_t> nw(steps);
-            for (int j = 0; j < steps; ++j) {
-                f[j] = 1.0 - (1.0 - fmin) * (j + 1) / steps;
-                nw[j] = j + 1 < steps ? per : T - per * (steps - 1);
-                weight += f[j] * (double)nw[j];
-            }
-            const double share = (double)ntiles / weight;              // tiles of a full workgroup
-            uint64_t at = 0, wg = 0;
-            auto add = [&](uint64_t nwg, uint64_t tiles) {
-                fa.reg_wg0[fa.nreg] = (uint32_t)wg; fa.reg_nwg[fa.nreg] = (uint32_t)nwg;
-                fa.reg_tile0[fa.nreg] = at; fa.reg_end[fa.nreg] = at + tiles;
-                ++fa.nreg; wg += nwg; at += tiles;
-            };
-            add(Gw - T, std::min<uint64_t>(ntiles, (uint64_t)(share * (double)(Gw - T) + 0.5)));
-            for (int j = 0; j < steps; ++j) {
-                const uint64_t left = ntiles - at;
-                add(nw[j], j + 1 < steps ? std::min<uint64_t>(left, (uint64_t)(share * f[j] * (double)nw[j] + 0.5)) : left);
-            }
-            // the queue codes carry a bounded per-workgroup tile iteration
-            for (uint32_t r = 0; r < fa.nreg; ++r)
-                if ((fa.reg_end[r] - fa.reg_tile0[r] + fa.reg_nwg[r] - 1) / fa.reg_nwg[r] >= FZ_TITER_MAX) fa.nreg = 0;
-        }
-    }
+    plan_scan_regions(fa, ntiles, grid.x, (uint32_t)d.n_cus);
     if (q.mode == FZ_MODE_GENERIC && !with_verify) fa.gen_dedup = d.gen_dedup_arg;      // the scan fills the window table (run_generic)
     static const bool force_big = getenv("FZ_FORCE_BIG_VERIFY") != nullptr;
     const VerifyPlan vp = plan_verify(q);
@@ -2960,6 +2971,20 @@ int fz_comm_barrier(fz_ctx *ctx) {
 int fz_comm_gather_ms(fz_ctx *ctx, double *ms) {
     if (!ctx || !ms) return fail(FZ_EINVAL, "null argument");
     *ms = ctx->last_gather_ms;
+    return FZ_OK;
+}
+
+int fz_debug_scan_regions(uint64_t ntiles, uint64_t grid, uint32_t n_cus, int steps, double fmin, int wg_per_cu, uint32_t *n_regions,
+                          uint64_t *table) {
+    if (!n_regions || !table) return fail(FZ_EINVAL, "null argument");
+    static FzScanArgs fa;                                   // (1.7 KB: not on the stack of a ctypes call for nothing)
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    plan_scan_regions(fa, ntiles, grid, n_cus, steps, fmin, wg_per_cu);
+    *n_regions = fa.nreg;
+    for (uint32_t r = 0; r < fa.nreg; ++r) {
+        table[4 * r] = fa.reg_wg0[r]; table[4 * r + 1] = fa.reg_nwg[r]; table[4 * r + 2] = fa.reg_tile0[r]; table[4 * r + 3] = fa.reg_end[r];
+    }
     return FZ_OK;
 }
 

@@ -293,6 +293,14 @@ int fz_debug_order_records_bounded(const void *recs, uint64_t n, uint32_t L, uin
  * owning ascending index ranges; every shard is ordered on its own and the rows are merged block by block. */
 int fz_debug_order_segments(const void *recs, const uint64_t *seg_ends, uint32_t n_segments, uint32_t L, fz_match **out, uint64_t *n_out);
 
+/* Test hook, no device needed: the regions a scan launch of `grid` workgroups over `ntiles` tiles is cut into on a GPU
+ * with `n_cus` compute units (fzhip.hip: plan_scan_regions — the last `wg_per_cu * n_cus` workgroups take `steps` groups of
+ * shrinking tile shares, down to `fmin` of a full one).  table[4 r .. 4 r + 3] = {first workgroup, workgroups, first tile,
+ * end tile} of region r, `*n_regions` of them (0: one region, every workgroup strides over all tiles; at most 8 rows).
+ * tests/test_host_logic.py checks that the regions partition both ranges. */
+int fz_debug_scan_regions(uint64_t ntiles, uint64_t grid, uint32_t n_cus, int steps, double fmin, int wg_per_cu, uint32_t *n_regions,
+                          uint64_t *table);
+
 /* Test hook (no device needed): the host half of the exchange step of a collective search (what follows the
  * ncclAllGather).  `blocks` = `world` blocks of 1024 + cap * 24 bytes, block r = what rank r contributed: 128 64-bit
  * counters (word 1 = records the rank produced) followed by min(count, cap) device records (see fz_debug_order_records);

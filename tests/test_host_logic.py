@@ -628,3 +628,55 @@ def test_rccl_is_loaded_lazily_and_its_absence_only_disables_the_collectives():
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert res.returncode == 0, res.stderr
     assert res.stdout.startswith("%d RCCL is not available" % _native.FZ_EUNSUPPORTED), res.stdout
+
+
+def test_scan_regions_partition_tiles_and_workgroups():
+    """fz_debug_scan_regions (no device): the regions a scan launch is cut into — the last resident round takes shrinking
+    tile shares — must partition the workgroups [0, grid) and the tiles [0, ntiles) in order, shrink monotonically towards
+    the end, keep every workgroup's tile iterations inside what a queue code can carry, and fall back to one region
+    (n_regions = 0) for launches too small to taper."""
+    import ctypes
+    import random
+    import numpy as np
+    from fuzzysearch_amd import _native
+    L = _native.load_library()
+    tab = np.zeros(4 * 8, dtype=np.uint64)
+    n = ctypes.c_uint32(0)
+
+    def regions(ntiles, grid, n_cus, steps=4, fmin=0.25, per_cu=7):
+        rc = L.fz_debug_scan_regions(ntiles, grid, n_cus, steps, fmin, per_cu, ctypes.byref(n), ctypes.c_void_p(tab.ctypes.data))
+        assert rc == 0
+        return [tuple(int(x) for x in tab[4 * r:4 * r + 4]) for r in range(n.value)]
+
+    # the headline launch: 1 GiB = 65 536 tiles, 6 144 workgroups, 256 CUs
+    regs = regions(65536, 6144, 256)
+    assert len(regs) == 5 and regs[0][:3] == (0, 6144 - 1792, 0) and regs[-1][3] == 65536
+    per_wg = [(e - t0) / nw for (_w, nw, t0, e) in regs]
+    assert 12.0 < per_wg[0] < 13.0 and all(a > b for a, b in zip(per_wg, per_wg[1:])) and 0.2 < per_wg[-1] / per_wg[0] < 0.3
+    rnd = random.Random(11)
+    tapered = 0
+    for _ in range(3000):
+        n_cus = rnd.choice([1, 8, 64, 104, 228, 256, 304])
+        grid = rnd.randint(1, 40000)
+        ntiles = rnd.randint(grid, grid * rnd.choice([1, 2, 5, 12, 40, 3000]))
+        steps, fmin, per_cu = rnd.randint(0, 9), rnd.choice([0.0, 0.05, 0.25, 0.5, 1.0, 3.0]), rnd.randint(1, 12)
+        regs = regions(ntiles, grid, n_cus, steps, fmin, per_cu)
+        T = n_cus * per_cu
+        if steps <= 0 or grid < 2 * T or ntiles < 4 * grid or min(steps, 7) > T:
+            assert regs == []
+            continue
+        if not regs:
+            continue                                            # (per-workgroup iterations beyond a queue code: one region)
+        tapered += 1
+        assert len(regs) == min(steps, 7) + 1
+        wg = tile = 0
+        for (w0, nw, t0, e) in regs:
+            assert (w0, t0) == (wg, tile) and nw > 0 and e >= t0
+            assert (e - t0 + nw - 1) // nw < (1 << 15) - 1        # FZ_TITER_MAX
+            wg += nw
+            tile = e
+        assert wg == grid and tile == ntiles and sum(nw for (_w, nw, _t, _e) in regs[1:]) == T
+        shares = [(e - t0) / nw for (_w, nw, t0, e) in regs]
+        if min(nw for (_w, nw, _t, _e) in regs) >= 64:          # (rounding: the last group takes what is left, within a tile per workgroup)
+            assert all(a >= b - 1.0 for a, b in zip(shares, shares[1:]))
+    assert tapered > 300
