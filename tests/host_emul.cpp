@@ -425,4 +425,69 @@ int emul_expand_band(int K, const uint8_t *sub, uint32_t sublen, const uint8_t *
     return fz_expand_any<FZ_REG_BAND_MAX>(sc, (uint32_t)K, s, sublen, w, winlen, budget, *dist, *consumed) ? 1 : 0;
 }
 
+// The lane-per-DP-cell expansion of fz_kernels.h (fz_wf_rows + fz_wf_pick: fz_verify_wf_kernel and the fused form in the
+// scan kernel), restated with a loop over the GW lanes of a group where the device uses DPP: lane gl holds the band cell
+// D[i][i + gl - K] of row i; the upper neighbour is the cell of lane gl + 1 (INF beyond the group), the left-neighbour
+// recurrence is a prefix-min over the lanes of (value + GW - gl), the bottom row is reduced to (min, LAST arg-min) from
+// the column-0 baseline.  `pick_budget` / `pick_winlen` may be smaller than what the rows ran with (the device never
+// does that since the side-by-side variant was dropped, but the property the comment in fz_wf_pick states is checked).
+int emul_wf_expand(int GW, uint32_t K, const uint8_t *sub, uint32_t sublen, const uint8_t *win, uint32_t winlen, uint32_t budget,
+                   uint32_t pick_winlen, uint32_t pick_budget, uint32_t *dist, uint32_t *consumed) {
+    const uint32_t INF = 0x3fffu;
+    if (GW != 16 && GW != 32 && GW != 64) return -1;
+    if (2 * K + 1 > (uint32_t)GW) return -1;
+    std::vector<uint32_t> cell(GW), jv(GW), nv(GW);
+    for (int gl = 0; gl < GW; ++gl) {
+        const bool act = (uint32_t)gl <= 2 * K;
+        jv[gl] = act ? (uint32_t)(gl - (int)K) : 0x7fff0000u;
+        cell[gl] = jv[gl] <= winlen ? jv[gl] : INF;
+    }
+    for (uint32_t i = 1; i <= sublen; ++i) {
+        const uint8_t pc = sub[i - 1];
+        for (int gl = 0; gl < GW; ++gl) {
+            // the character of column j = i + d - 1 ... the device reads one element outside the window for cells that are
+            // forced anyway; here those cells take a character that never equals anything
+            const uint32_t j_prev = jv[gl];                       // column of this lane in row i - 1 = column of the diagonal
+            jv[gl] += 1u;
+            const uint32_t j = jv[gl];
+            const bool in_win = j >= 1 && j <= winlen;
+            const uint32_t chr = in_win ? win[j - 1] : 0x100u;
+            const uint32_t up = gl + 1 < GW ? cell[gl + 1] : INF;
+            uint32_t v = std::min(cell[gl] + (chr != pc ? 1u : 0u), up + 1u);
+            (void)j_prev;
+            if (j == 0u) v = i;                                   // column 0: D[i][0] = i
+            const bool bad = j > winlen;
+            nv[gl] = bad ? INF : v;
+        }
+        // v[gl] = min_{e <= gl} (a[e] + gl - e): prefix-min of a[e] + (GW - e), minus (GW - gl)
+        uint32_t run = 0xffffffffu;
+        for (int gl = 0; gl < GW; ++gl) {
+            run = std::min(run, nv[gl] + (uint32_t)(GW - gl));
+            uint32_t v = run - (uint32_t)(GW - gl);
+            if (jv[gl] > winlen) v = INF;
+            cell[gl] = v;
+        }
+        if ((i & 3u) == 0u) {                                     // row minima never decrease
+            bool any = false;
+            for (int gl = 0; gl < GW; ++gl) any = any || cell[gl] <= budget;
+            if (!any) break;
+        }
+    }
+    // bottom row -> (best, last arg-min) over the columns 1 .. pick_winlen from the column-0 baseline
+    uint32_t key = 0xffffffffu;
+    for (int gl = 0; gl < GW; ++gl) {
+        const int jb = (int)sublen + gl - (int)K;
+        const bool validj = (uint32_t)gl <= 2 * K && jb >= 1 && jb <= (int)pick_winlen;
+        if (validj) key = std::min(key, (cell[gl] << 8) | (255u - (uint32_t)gl));
+    }
+    uint32_t best = sublen, arg = 0;
+    if (key != 0xffffffffu && (key >> 8) <= sublen) {
+        best = key >> 8;
+        arg = (uint32_t)((int)sublen + (int)(255u - (key & 255u)) - (int)K);
+    }
+    *dist = best;
+    *consumed = arg;
+    return best <= pick_budget ? 1 : 0;
+}
+
 }  // extern "C"

@@ -30,6 +30,9 @@ def emul():
                               ctypes.POINTER(OutRec), ctypes.c_int64]
     L.emul_expand.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32,
                               ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
+    L.emul_wf_expand.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32,
+                                 ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                 ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
     yield L
     os.remove(out)
 
@@ -206,3 +209,46 @@ def test_levenshtein_lp_struct_and_slot_steps_equal_oracle(emul):
         done += 1
         nonempty += bool(want)
     assert nonempty > 1500
+
+
+def test_lane_per_cell_expansion_equals_oracle(emul):
+    """The wavefront form of the verification (fz_wf_rows / fz_wf_pick: one lane per band cell, 16 / 32 / 64 lanes per
+    candidate) restated lane by lane on the host: band K >= budget, windows shorter and longer than the pattern piece,
+    the early exit — against the reference's _expand (levenshtein_ngram.py:8-19 through the oracle).  And the property the
+    device comment states: rows run with a LARGER window and budget give the same pick once the bottom row is read with
+    the smaller ones (a cell only depends on cells of smaller or equal columns)."""
+    rnd = random.Random(41)
+    d, c = ctypes.c_uint32(), ctypes.c_uint32()
+    n_ok = 0
+    for it in range(12000):
+        sigma = rnd.choice([2, 2, 3, 4, 20])
+        alpha = bytes(rnd.sample(range(65, 91), sigma))
+        gw = rnd.choice([16, 16, 32, 64])
+        K = rnd.randint(1, (gw - 1) // 2)
+        budget = rnd.randint(0, K)
+        sub = bytes(rnd.choice(alpha) for _ in range(rnd.randint(0, 70)))
+        if rnd.random() < 0.7:                                   # a lightly edited copy, then some tail
+            w = bytearray(sub)
+            for _ in range(rnd.randint(0, budget + 1)):
+                q = rnd.randrange(len(w) + 1)
+                op = rnd.random()
+                if op < 0.4 and q < len(w):
+                    w[q] = rnd.choice(alpha)
+                elif op < 0.7 and q < len(w):
+                    del w[q]
+                else:
+                    w.insert(q, rnd.choice(alpha))
+            win = bytes(w) + bytes(rnd.choice(alpha) for _ in range(rnd.randint(0, 4)))
+        else:
+            win = bytes(rnd.choice(alpha) for _ in range(rnd.randint(0, 80)))
+        win = win[:len(sub) + budget] if rnd.random() < 0.8 else win     # (the search never offers more than sublen + budget)
+        want = oracle.expand(sub, win, budget)
+        r = emul.emul_wf_expand(gw, K, sub, len(sub), win, len(win), budget, len(win), budget, ctypes.byref(d), ctypes.byref(c))
+        assert r >= 0
+        assert ((d.value, c.value) if r else (None, None)) == want, (gw, K, budget, sub, win)
+        n_ok += r
+        # rows with the full band budget and a longer window, the pick with the narrower ones
+        longer = win + bytes(rnd.choice(alpha) for _ in range(rnd.randint(0, K - budget + 2)))
+        r2 = emul.emul_wf_expand(gw, K, sub, len(sub), longer, len(longer), K, len(win), budget, ctypes.byref(d), ctypes.byref(c))
+        assert ((d.value, c.value) if r2 else (None, None)) == want, ("narrowed", gw, K, budget, sub, win, longer)
+    assert n_ok > 3000
