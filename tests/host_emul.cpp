@@ -447,14 +447,12 @@ int emul_wf_expand(int GW, uint32_t K, const uint8_t *sub, uint32_t sublen, cons
         for (int gl = 0; gl < GW; ++gl) {
             // the character of column j = i + d - 1 ... the device reads one element outside the window for cells that are
             // forced anyway; here those cells take a character that never equals anything
-            const uint32_t j_prev = jv[gl];                       // column of this lane in row i - 1 = column of the diagonal
-            jv[gl] += 1u;
+            jv[gl] += 1u;                                         // the lane's column in row i
             const uint32_t j = jv[gl];
             const bool in_win = j >= 1 && j <= winlen;
             const uint32_t chr = in_win ? win[j - 1] : 0x100u;
             const uint32_t up = gl + 1 < GW ? cell[gl + 1] : INF;
             uint32_t v = std::min(cell[gl] + (chr != pc ? 1u : 0u), up + 1u);
-            (void)j_prev;
             if (j == 0u) v = i;                                   // column 0: D[i][0] = i
             const bool bad = j > winlen;
             nv[gl] = bad ? INF : v;
