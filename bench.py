@@ -369,7 +369,10 @@ def main_multi_device(args):
         raise SystemExit("bench.py: --gpus %d needs devices %r but only %d HIP device(s) are visible "
                          "(launch under torch.distributed.run for one rank per GPU, or set FZ_DEVICES)" % (N, devices, have.value))
     distinct = len(set(devices)) == len(devices)
-    collective = distinct and os.environ.get("FZ_BENCH_NO_COLLECTIVE") != "1"
+    # several device states on ONE GPU can only join a communicator of the test suite's stand-in library
+    # (tests/mock_rccl.cpp through FZ_RCCL_LIB: tests/test_gpu_mock_rccl.py); RCCL needs one rank per GPU
+    stand_in = bool(os.environ.get("FZ_RCCL_LIB")) and _native.Engine.comm_backend() == "stand-in"
+    collective = (distinct or stand_in) and os.environ.get("FZ_BENCH_NO_COLLECTIVE") != "1"
     engine = _native.Engine(devices)
     ref_engine = _native.Engine([devices[0]])                    # one shard alone on the first device: the like-for-like 1-GPU figure
     if cpu is not None:
@@ -477,9 +480,10 @@ def main_multi_device(args):
                                  "ncclAllGather of the ranks' record lists per search, every rank's block read on the host; the "
                                  "all-gather of step i runs next to the scan of step i+1" if collective else
                                  "per-device record lists merged on the host; no collective (%s)"
-                                 % ("the devices listed are not distinct: RCCL needs one rank per GPU" if not distinct
+                                 % ("the devices listed are not distinct: RCCL needs one rank per GPU" if not (distinct or stand_in)
                                     else "FZ_BENCH_NO_COLLECTIVE=1")))},
         "rccl_ranks": rccl_ranks,
+        "collective_library": _native.Engine.comm_backend() if collective else None,
         "allgather_ms": None if not gather else round(float(np.mean(gather)), 4),
         "value_no_collective": round(value, 2) if no_coll is None else no_coll["value"],
         "no_collective_ms_per_step": (round(elapsed / args.steps * 1e3, 4) if no_coll is None else no_coll["ms_per_step"]),
@@ -605,9 +609,19 @@ def main():
         del gpu_rows
     cpu_rows = None
     # setup self-check + clock settle (untimed): repeated searches must return the identical stream
+    def any_rank(flag):
+        # a time-based loop around COLLECTIVE searches must take the same number of trips on every rank (a rank that
+        # leaves early would meet the others' all-gather with its next collective: found by the N-rank tests on the
+        # stand-in library, tests/test_gpu_mock_rccl.py) — the ranks agree on every trip
+        if use_torch:
+            f = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(f, op=dist.ReduceOp.MAX)
+            return bool(f.item() > 0)
+        return engine.comm_max(1.0 if flag else 0.0) > 0 if use_dist else flag
+
     t_settle = time.perf_counter()
     first = step()
-    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+    while any_rank((time.perf_counter() - t_settle) * 1e3 < args.settle_ms):
         again = step()
         assert np.array_equal(again, first), "non-deterministic result: two searches returned different streams"
     for _ in range(args.warmup):
@@ -741,6 +755,7 @@ def main():
             "matches_per_s": round(len(matches) * args.steps / elapsed, 1),
             "raw_matches": len(matches),
             "consolidated_matches": len(consolidated),
+            "stream_in_reference_order": [(g_, s_) for (s_, e_, d_, g_) in matches] == sorted((g_, s_) for (s_, e_, d_, g_) in matches),
             "ngram_hits": st["ngram_hits"],
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic_gb,
@@ -754,6 +769,7 @@ def main():
         }
         if use_dist:
             out["rccl_ranks"] = world if native_dist else 0
+            out["collective_library"] = _native.Engine.comm_backend() if native_dist else "torch.distributed"
             out["allgather_ms"] = round(float(np.mean(gather_ms)), 4) if gather_ms else None
             if no_coll:
                 out["value_no_collective"] = no_coll["value"]

@@ -217,6 +217,10 @@ void fz_comm_destroy(fz_ctx *ctx);
 /* Host time (ms) of the exchange step of the collective search collected last on this context: from "every local
  * shard has finished" to "every rank's records are on this host" (all-gather + D2H copy + parsing the ranks' blocks). */
 int  fz_comm_gather_ms(fz_ctx *ctx, double *ms);
+/* Which collective library fz_comm_* would use (loads it): 0 none found (fz_comm_* answer FZ_EUNSUPPORTED), 1 RCCL,
+ * 2 the test suite's stand-in (tests/mock_rccl.cpp named by FZ_RCCL_LIB: the only one that accepts several ranks on
+ * one device — fz_comm_init_all then accepts a context that lists a device more than once). */
+int  fz_comm_backend(void);
 
 /* consolidate_overlapping_matches: overlap groups -> best (dist, -len) per group -> sorted by
  * (start, end, dist).  Ties inside a group (the reference breaks them by set iteration order, i.e.

@@ -1,0 +1,129 @@
+"""-m gpu: the N-RANK collective code of libfzhip.so — gather_records, comm_gather_host, comm_rank_lows, the snapshot /
+hipStreamWaitEvent ordering, the grouped all-gather, capacity regrow, the two-deep pipeline — executed with world 2, 3
+and 8 on ONE GPU.  RCCL refuses two ranks on one device and no box of this pool has two GPUs, so the library's
+collective table is pointed (FZ_RCCL_LIB) at a stand-in with RCCL's stream semantics (tests/mock_rccl.cpp: in-process
+communicators = stream-ordered device-to-device copies, cross-process communicators = shared memory).  Everything
+above the nine ncclXxx entry points is the product's real code; every rank holds only its shard (+ halo) and must
+return the oracle's stream of the whole sequence.  What stays unverified is RCCL's own transport.
+
+Every case is a subprocess: the collective library is a process-wide choice (rccl_api() is resolved once)."""
+import json
+import os
+import subprocess
+import sys
+import uuid
+
+import pytest
+
+from tests import mock_rccl
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "mock_comm_worker.py")
+
+
+def _check(proc_out, what):
+    out, err, rc = proc_out
+    assert rc == 0, "%s failed (rc %s)\n%s\n%s" % (what, rc, out[-2000:], err[-4000:])
+    last = [ln for ln in out.splitlines() if ln.startswith("OK ")]
+    assert last, out[-2000:]
+    n_checks, n_rows = int(last[-1].split()[1]), int(last[-1].split()[2])
+    assert n_checks >= 30 and n_rows > 10000
+    return n_checks, n_rows
+
+
+def _run_inproc(world, *flags):
+    p = subprocess.run([sys.executable, WORKER, "inproc", str(world), *flags], capture_output=True, text=True, timeout=900,
+                       env=mock_rccl.env(), cwd=ROOT)
+    return _check((p.stdout, p.stderr, p.returncode), "inproc world %d %s" % (world, " ".join(flags)))
+
+
+def _run_ranks(world, *flags):
+    env = mock_rccl.env({"FZ_RENDEZVOUS_KEY": "mock_%s" % uuid.uuid4().hex, "WORLD_SIZE": str(world)})
+    procs = []
+    for r in range(world):
+        e = dict(env)
+        e["RANK"] = e["LOCAL_RANK"] = str(r)
+        procs.append(subprocess.Popen([sys.executable, WORKER, "rank", str(world), str(r), *flags], stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True, env=e, cwd=ROOT))
+    results = []
+    try:
+        for p in procs:
+            out, err = p.communicate(timeout=900)
+            results.append((out, err, p.returncode))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return [_check(res, "rank %d of %d %s" % (r, world, " ".join(flags))) for r, res in enumerate(results)]
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_one_process_n_ranks(world):
+    """fz_comm_init_all over `world` device states on device 0: the form the driver's `bench.py --gpus N` runs."""
+    _run_inproc(world)
+
+
+def test_one_process_ranks_not_in_ownership_order():
+    _run_inproc(3, "permute")
+    _run_inproc(8, "permute")
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_one_process_per_rank(world):
+    """fz_comm_init_rank in `world` processes sharing device 0: the launcher form (torch.distributed.run ... bench.py)."""
+    res = _run_ranks(world)
+    assert len({r for r in res}) == 1                      # every rank ran the same checks and saw the same row totals
+
+
+def test_one_process_per_rank_not_in_ownership_order():
+    _run_ranks(3, "permute")
+
+
+def test_bench_collective_line_with_eight_ranks_on_one_gpu():
+    """`bench.py --gpus 8` as the driver runs it (one process, ncclCommInitAll), the eight device states on device 0 and
+    the stand-in as the collective library: the line reports rccl_ranks 8 and the collective search as `value`."""
+    env = mock_rccl.env({"FZ_DEVICES": ",".join(["0"] * 8)})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--mib", "128", "--steps", "12", "--warmup", "3",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["allgather_ms"] > 0
+    assert d["collective_library"] == "stand-in"
+    assert d["boundary_plants_found"] == 3 * 4 + 2 * 3 and d["stream_in_reference_order"] is True
+    assert d["value_no_collective"] > 0 and d["value_no_collective"] != d["value"]
+
+
+def test_launcher_form_of_bench_with_three_ranks_on_one_gpu():
+    """The launch contract's form — one process per rank, RANK / WORLD_SIZE / LOCAL_RANK in the environment — with three
+    ranks on device 0 (LOCAL_RANK beyond the visible devices wraps: distributed.local_device)."""
+    world = 3
+    env = mock_rccl.env({"FZ_RENDEZVOUS_KEY": "mockbench_%s" % uuid.uuid4().hex, "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
+                         "MASTER_PORT": "29571"})
+    procs = []
+    for r in range(world):
+        e = dict(env)
+        e["RANK"] = e["LOCAL_RANK"] = str(r)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--mib", "128", "--steps", "12",
+                                       "--warmup", "3", "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                      env=e, cwd=ROOT))
+    outs = []
+    try:
+        for p in procs:
+            out, err = p.communicate(timeout=900)
+            outs.append((out, err, p.returncode))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (out, err, rc) in enumerate(outs):
+        assert rc == 0, "rank %d: %s" % (r, err[-3000:])
+    lines = [ln for ln in outs[0][0].splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, outs[0][0][-2000:]
+    assert not [ln for o in outs[1:] for ln in o[0].splitlines() if ln.strip().startswith("{")]      # rank 0 prints the line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["rccl_ranks"] == world and d["allgather_ms"] > 0
+    assert d["stream_in_reference_order"] is True
