@@ -263,7 +263,92 @@ def extra_blocks(engine, workloads, reps):
         "ms_per_call": round(ms, 4), "GB_per_s": round(gib / ms / 1e6, 1), "scan_kernel_ms": round(f_ms, 4), "raw_matches": int(len(res))}
     cfgs["configs[1] DNA m=20 max_l_dist=2 (levenshtein_ngram) through find_near_matches"].update(
         api_block(fa, engine, seq, dict(max_l_dist=2), p1, ms, reps))
+    cfgs["configs[1] DNA m=20 max_l_dist=2 (levenshtein_ngram) through find_near_matches"].update(
+        end_to_end_block(fa, seq, p1, reps))
     out["configs"] = cfgs
+    return out
+
+
+def end_to_end_block(fa, seq, p1, reps):
+    """"also report end-to-end (incl. H2D and Python Match construction) separately" — the calls the
+    reference's users make, on configs[1] (1 GiB DNA, |p| = 20, k = 2), NEVER `value`:
+      end_to_end: find_near_matches(p, <bytes>) exactly as the reference is called (__init__.py:35-57).  `first_call` = a
+        bytes object the library has not seen: pageable H2D upload + search + consolidation + Match objects; `repeat_call` =
+        the same object again: the residency cache (engine.ResidencyCache) finds it in HBM, nothing crosses PCIe;
+        `cache_off_call` = the round-4 behaviour (every call uploads).
+      file_api: find_near_matches_in_file (__init__.py:86-171) on the same GiB as a file in the page cache (/dev/shm), the
+        reference's default 1 MiB chunks, through the streaming pipeline; result compared with the in-memory search where
+        the chunk geometry allows (matches that do not straddle a chunk seam are identical)."""
+    import tempfile
+    from fuzzysearch_amd import engine as fzengine
+    cache = fzengine.residency_cache()
+    cache.clear()
+    nbytes = len(seq)
+    data = seq.tobytes()
+    kwargs = dict(max_l_dist=2)
+    t0 = time.perf_counter()
+    first = fa.find_near_matches(p1, data, **kwargs)
+    first_ms = (time.perf_counter() - t0) * 1e3
+    info1 = cache.info()
+    rep_ms, rep = time_api(lambda: fa.find_near_matches(p1, data, **kwargs), reps)
+    info2 = cache.info()
+    assert rep == first, "repeat call on a resident sequence returned different matches"
+    assert info2["misses"] == info1["misses"], "the repeat calls uploaded the sequence again"
+    # a second, never-seen bytes object of the same content: first-call cost once more (median of three fresh objects)
+    fresh = []
+    for _ in range(3):
+        cache.clear()
+        d2 = bytes(memoryview(data))                               # a new object: the cache does not know it
+        t0 = time.perf_counter()
+        r2 = fa.find_near_matches(p1, d2, **kwargs)
+        fresh.append((time.perf_counter() - t0) * 1e3)
+        assert r2 == first
+        del d2
+    first_ms = sorted(fresh + [first_ms])[1]
+    old_budget = cache.budget
+    cache.clear()
+    cache.budget = 0
+    try:
+        off_ms, off = time_api(lambda: fa.find_near_matches(p1, data, **kwargs), 3, warm_s=0.0)
+    finally:
+        cache.budget = old_budget
+    assert off == first
+    out = {"end_to_end": {
+        "call": "find_near_matches(pattern, <bytes>, max_l_dist=2) — the reference's call form, host buffer handed over every call",
+        "first_call_ms": round(first_ms, 2), "first_call_GB_per_s": round(nbytes / first_ms / 1e6, 1),
+        "repeat_call_ms": round(rep_ms, 4), "repeat_call_GB_per_s": round(nbytes / rep_ms / 1e6, 1),
+        "cache_off_call_ms": round(off_ms, 2), "cache_off_GB_per_s": round(nbytes / off_ms / 1e6, 1),
+        "matches": len(first),
+        "note": "first_call includes the pageable H2D upload (PCIe) and is never `value`; repeat_call: the same immutable object is "
+                "found resident (FUZZYSEARCH_HIP_RESIDENT_CACHE, default 8G; bytes / str only)"}}
+    cache.clear()
+    d = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    name = None
+    try:
+        with tempfile.NamedTemporaryFile(delete=False, dir=d) as f:
+            f.write(data)
+            name = f.name
+        best, res = None, None
+        for _ in range(3):
+            with open(name, "rb") as f:
+                t0 = time.perf_counter()
+                res = fa.find_near_matches_in_file(p1, f, **kwargs)
+                dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        chunk, keep = 1 << 20, len(p1) - 1 + 2
+        stride = chunk - keep
+        # away from the chunk seams the file search and the in-memory search see the same bytes around a match
+        def inner(ms):
+            return [(x.start, x.end, x.dist) for x in ms if (x.start % stride) > 2 * len(p1) and (x.end % stride) < stride - 2 * len(p1)]
+        same = inner(res) == inner(first)
+        out["file_api"] = {
+            "call": "find_near_matches_in_file(pattern, open(<1 GiB file in the page cache>, 'rb'), max_l_dist=2), _chunk_size 2**20 (the reference's default)",
+            "seconds": round(best, 4), "GB_per_s": round(nbytes / best / 1e9, 2), "matches": len(res),
+            "matches_equal_in_memory_away_from_chunk_seams": bool(same), "in_memory_matches": len(first),
+            "note": "best of three; page cache -> pinned staging (pread pool) -> H2D -> scan with per-chunk clamps; chunk geometry of the reference kept"}
+    finally:
+        if name:
+            os.remove(name)
     return out
 
 

@@ -20,7 +20,7 @@ import numpy as np
 from . import _native
 from ._native import UnsupportedSearch
 
-__all__ = ['DeviceSequence', 'resident', 'encode_pair', 'is_byteslike']
+__all__ = ['DeviceSequence', 'resident', 'encode_pair', 'is_byteslike', 'ResidencyCache', 'residency_cache']
 
 
 _BIO_SEQ = []                                    # [Seq class or None] once looked up
@@ -172,17 +172,141 @@ def resident(sequence, engine=None):
     return DeviceSequence(sequence, engine)
 
 
+class ResidencyCache(object):
+    """Transparent residency for the reference's call form, ``find_near_matches(subsequence, sequence)`` with a plain
+    sequence (__init__.py:35-57): the last few uploaded IMMUTABLE sequences stay in HBM, so a second query against the
+    same object uploads nothing ("device-buffer cache so a sequence can stay resident across
+    queries").  Only exact ``bytes`` and ``str`` objects qualify — what they hold cannot change, and the cache keeps a
+    strong reference, so an ``id()`` cannot be handed to another object while its entry lives; ``bytearray``,
+    ``memoryview``, numpy arrays, lists ... are uploaded on every call as before.  A ``str`` entry holds its latin-1
+    bytes (symbol-remapped text depends on the subsequence and is never cached).
+
+    Least recently used entries leave when the byte budget or the entry count is exceeded; an entry that a search is
+    still using is released by its last user.  Budget: FUZZYSEARCH_HIP_RESIDENT_CACHE (bytes, K / M / G suffixes; 0 switches
+    the cache off; default 8G — device memory, and as much host memory as the cached objects themselves occupy should
+    their owners drop them)."""
+
+    MIN_BYTES = 1 << 16              # below this an upload costs less than it is worth tracking
+    MAX_ENTRIES = 16
+
+    class _Entry(object):
+        __slots__ = ('obj', 'handle', 'nbytes', 'users', 'evicted', 'engine')
+
+    def __init__(self, budget=None):
+        import collections
+        import threading
+        self._lock = threading.Lock()
+        self._entries = collections.OrderedDict()        # id(obj) -> _Entry, least recently used first
+        self._bytes = 0
+        self.budget = self._env_budget() if budget is None else int(budget)
+        self.hits = self.misses = self.evictions = 0
+
+    @staticmethod
+    def _env_budget():
+        import os
+        raw = os.environ.get('FUZZYSEARCH_HIP_RESIDENT_CACHE', '8G').strip().upper()
+        mult = 1
+        if raw and raw[-1] in 'KMG':
+            mult = 1 << (10 * (1 + 'KMG'.index(raw[-1])))
+            raw = raw[:-1]
+        try:
+            return max(0, int(float(raw) * mult))
+        except ValueError:
+            return 8 << 30
+
+    @staticmethod
+    def cacheable(sequence):
+        return type(sequence) is bytes or type(sequence) is str
+
+    def acquire(self, engine, sequence, make_data):
+        """-> (handle, entry or None).  `make_data()`: the bytes to upload for `sequence` (itself, or its latin-1
+        encoding: one byte per item either way), only called when the sequence is not resident.
+        entry None: not cached, the caller owns the handle; otherwise the caller calls done(entry) after its search."""
+        n = len(sequence)
+        if self.budget <= 0 or n < self.MIN_BYTES or n > self.budget or not self.cacheable(sequence):
+            return engine.upload(make_data()), None
+        key = id(sequence)
+        with self._lock:
+            e = self._entries.get(key)
+            if e is not None and e.obj is sequence and e.engine is engine:
+                self._entries.move_to_end(key)
+                e.users += 1
+                self.hits += 1
+                return e.handle, e
+        handle = engine.upload(make_data())              # outside the lock: tens of milliseconds per GiB
+        e = self._Entry()
+        e.obj, e.handle, e.nbytes, e.users, e.evicted, e.engine = sequence, handle, n, 1, False, engine
+        dead = []
+        with self._lock:
+            self.misses += 1
+            other = self._entries.get(key)
+            if other is not None:                        # another thread uploaded the same object meanwhile: keep the newer
+                self._drop(key, dead)
+            self._entries[key] = e
+            self._bytes += n
+            while self._entries and (self._bytes > self.budget or len(self._entries) > self.MAX_ENTRIES):
+                oldest = next(iter(self._entries))
+                if oldest == key:
+                    break
+                self._drop(oldest, dead)
+        for h in dead:
+            h.release()
+        return handle, e
+
+    def _drop(self, key, dead):
+        e = self._entries.pop(key)
+        self._bytes -= e.nbytes
+        self.evictions += 1
+        e.evicted = True
+        e.obj = None
+        if e.users == 0:
+            dead.append(e.handle)
+
+    def done(self, entry):
+        release = False
+        with self._lock:
+            entry.users -= 1
+            release = entry.evicted and entry.users == 0
+        if release:
+            entry.handle.release()
+
+    def clear(self):
+        dead = []
+        with self._lock:
+            for key in list(self._entries):
+                self._drop(key, dead)
+        for h in dead:
+            h.release()
+
+    def info(self):
+        with self._lock:
+            return {'entries': len(self._entries), 'bytes': self._bytes, 'budget': self.budget, 'hits': self.hits,
+                    'misses': self.misses, 'evictions': self.evictions}
+
+
+_cache = ResidencyCache()
+
+
+def residency_cache():
+    """The process-wide cache behind find_near_matches(subsequence, <bytes or str>): .info(), .clear(), .budget."""
+    return _cache
+
+
 class _Prepared(object):
     """(engine, resident handle, pattern bytes, original sequence, byteslike flag) for one query."""
-    __slots__ = ('engine', 'handle', 'pattern', 'original', 'byteslike', 'owned')
+    __slots__ = ('engine', 'handle', 'pattern', 'original', 'byteslike', 'owned', 'entry')
 
     def release(self):
-        if self.owned:
+        if self.entry is not None:
+            _cache.done(self.entry)
+            self.entry = None
+        elif self.owned:
             self.handle.release()
 
 
 def prepare(subsequence, sequence):
     pr = _Prepared()
+    pr.entry = None
     if isinstance(sequence, DeviceSequence):
         subsequence, was_bio = _unwrap_bio(subsequence)
         if was_bio and not sequence.byteslike:
@@ -210,11 +334,24 @@ def prepare(subsequence, sequence):
                 pr.pattern = p
                 pr.owned = True
         return pr
-    p, t, byteslike = encode_pair(subsequence, sequence)
     pr.engine = _native.default_engine()
+    pr.original = sequence
+    pr.owned = True
+    # the reference's call form on an immutable sequence that is already resident: nothing to encode or upload
+    if _cache.budget > 0 and len(sequence) >= ResidencyCache.MIN_BYTES:
+        if type(sequence) is bytes and is_byteslike(subsequence):
+            pr.pattern, pr.byteslike = subsequence, True
+            pr.handle, pr.entry = _cache.acquire(pr.engine, sequence, lambda: sequence)
+            return pr
+        if type(sequence) is str and type(subsequence) is str:
+            try:
+                pr.pattern, pr.byteslike = subsequence.encode('latin-1'), False
+                pr.handle, pr.entry = _cache.acquire(pr.engine, sequence, lambda: sequence.encode('latin-1'))
+                return pr
+            except UnicodeEncodeError:
+                pass                                     # wide code points: symbol remapping below, never cached
+    p, t, byteslike = encode_pair(subsequence, sequence)
     pr.handle = pr.engine.upload(t)
     pr.pattern = p
-    pr.original = sequence
     pr.byteslike = byteslike
-    pr.owned = True
     return pr
