@@ -605,7 +605,18 @@ FZ_HD void fz_levlp_step(const FzGCand &c, uint8_t ch, uint32_t index, bool more
 
 // The same step with its outputs in the fixed slots of FzGStep (what fz_lp_kernel stores through wave prefix sums):
 // successors in list order a (:103), b (:105-111), c (:114-137), at most one match.  No arrays: the struct form's
-// succ[] was indexed dynamically here and lived in scratch memory (20 bytes per lane in the tiled Levenshtein automaton).
+// succ[] was indexed dynamically and lived in scratch memory (20 bytes per lane in the tiled Levenshtein automaton).
+//
+// The pattern-skip loop (:114-137) is written WITHOUT a lane-divergent exit: every lane runs the same rounds and keeps
+// the first sk that ends its search in `fsk`; the loop leaves on a wave-uniform condition only (as the generic step
+// above does).  Round 4 had the reference's shape here — `for (sk ..) { if (hit) { ..; break; } }` — and hipcc
+// (ROCm 7.2.0, gfx950, -O2 / -O3, inlined into fz_lp_kernel) miscompiled it: the VGPR holding successor a's first word
+// (live across the loop) was reused for the temporary j + sk + 1 of the inner test and restored on ONE side of the
+// branch that follows, so lanes whose skip ended on the last pattern character stored the successor (start = m, j = 0)
+// instead of (start, j): one lost match per ~25 and ghost matches at tile offset + m.  Root-caused in round 5 (ISA in
+// profiles/r05_levlp_miscompile.txt; -O1, noinline or this loop shape compile correctly; extra wave syncs change
+// nothing — it never was a race).  benchmarks/lab_build.sh x -DFZ_LAB_ONLY -DFZ_LEVLP_BREAKLOOP + benchmarks/repro_lp.py
+// rebuilds and shows the miscompiled form.
 template <class PatF>
 FZ_HD void fz_levlp_step_slots(uint32_t w0, uint32_t w1, uint8_t ch, uint32_t index, bool more_seq, uint32_t m, PatF pat,
                                uint32_t k, FzGStep &o) {
@@ -619,6 +630,7 @@ FZ_HD void fz_levlp_step_slots(uint32_t w0, uint32_t w1, uint8_t ch, uint32_t in
     if (l == k) return;                                                // :99-100
     o.fa = 1; o.a0 = w0; o.a1 = w1 + 1u;                               // :103 skip a sequence char (l++)
     if (more_seq && j + 1u < m) { o.fb = 1; o.b0 = w0 + 0x10000u; o.b1 = w1 + 1u; }   // :105-111 skip both
+#ifdef FZ_LEVLP_BREAKLOOP                                              // the miscompiled shape (lab builds only, see above)
     for (uint32_t sk = 1; sk <= k - l; ++sk) {                         // :114-137 skip pattern chars
         const bool at_end = j + sk == m;
         if (at_end || pat(j + sk) == ch) {
@@ -627,6 +639,20 @@ FZ_HD void fz_levlp_step_slots(uint32_t w0, uint32_t w1, uint8_t ch, uint32_t in
             break;
         }
     }
+#else
+    uint32_t fsk = 0;                                                  // :114-137: the first sk in 1..k-l with j + sk == m or pattern[j + sk] == ch
+    for (uint32_t sk = 1; sk <= k; ++sk) {
+        const bool open = (sk <= k - l) & (fsk == 0u);
+        if (!FZ_WAVE_ANY(open ? 1u : 0u)) break;                       // wave-uniform: no lane is still looking
+        const uint32_t pos = j + sk;
+        const bool hit = (pos >= m) | (pat(pos < m ? pos : m - 1u) == ch);
+        fsk = (open & hit) ? sk : fsk;
+    }
+    if (fsk != 0u) {
+        if (j + fsk + 1u >= m) { o.f1 = 1; o.m1 = start | ((index + 1u) << 16); o.d1 = l + fsk; }   // ran off the pattern, or matched its last char
+        else { o.fc = 1; o.c0 = w0 + ((1u + fsk) << 16); o.c1 = w1 + fsk; }
+    }
+#endif
 }
 
 // levenshtein.py:144-148

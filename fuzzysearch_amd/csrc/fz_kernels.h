@@ -1887,13 +1887,17 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
                         const uint2 cw = reinterpret_cast<const uint2 *>(cur)[c0 + lane];
                         const FzGCand c = fz_gcand_of(cw.x, cw.y);
                         if (!last) {
-                            // (the struct form: fz_levlp_step_slots — same step, outputs in fixed slots, no 20-byte scratch array —
-                            //  agrees with it on the host and, lane by lane, inside this kernel, yet the kernel built from it alone
-                            //  returned wrong streams; not understood, so the form that has been right since round 1 stays)
+                            // slot form (no scratch array); its skip loop has no lane-divergent exit — see fz_device.h for the
+                            // hipcc miscompile of the `break` form that kept this out of the kernel in round 4.
+                            // -DFZ_LEVLP_STRUCT: the struct form (the statement of levenshtein.py:52-148, round 1 .. 4's kernel)
+#ifdef FZ_LEVLP_STRUCT
                             FzGOut o;
                             o.nsucc = 0; o.nmatch = 0;
                             fz_levlp_step(c, ch, index, more_seq, a.m, patf, a.k, o);
                             fz_gstep_from_out(o, st);
+#else
+                            fz_levlp_step_slots(cw.x, cw.y, ch, index, more_seq, a.m, patf, a.k, st);
+#endif
                         } else {
                             uint32_t d;
                             const bool hit_end = lev ? fz_levlp_final(c, a.m, a.k, d) : fz_generic_final(c, a.m, a.max_dels, a.k, d);
