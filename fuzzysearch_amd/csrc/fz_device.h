@@ -556,6 +556,55 @@ FZ_HD void fz_generic_step_packed(uint32_t w0, uint32_t w1, uint8_t ch, uint32_t
     o.c1 = w1 + ((fsk << 24) | fsk);
 }
 
+// The same step again for patterns of at most 64 characters and budgets of at most 32 (round 5): the comparisons
+// pattern[j] == ch, pattern[j + 1] == ch, ... are bits of ONE 64-bit word per sequence character — peq, bit i set iff
+// pattern[i] == ch (a 256-entry table per pattern, one look-up per window character, the same for every candidate) — and
+// the skip search of py:141-165 ("the first sk with j + sk == m or pattern[j + sk] == ch") is one find-first-set on
+// (peq with a sentinel bit at m) >> (j + 1).  Every flag is a 0 / 1 WORD computed with integer arithmetic — no
+// comparison results in scalar registers, no lane-mask algebra on the scalar unit, no pattern reads from LDS, no loop:
+// fz_gen_hit_kernel's time is the dependent instruction chain of this step, once per window character (round 4 measured
+// ~2 300 cycles per character for the form above: ~150 instructions of which every second hops between the vector and
+// the scalar unit).  Same outputs as fz_generic_step_packed, bit for bit (tests/host_emul.cpp holds them together).
+FZ_HD uint32_t fz_b_lt(uint32_t a, uint32_t b) { return (a - b) >> 31; }                  // a < b for values below 2^31
+FZ_HD uint32_t fz_b_eq(uint32_t a, uint32_t b) { return ((a ^ b) - 1u) >> 31; }           // a == b (a ^ b below 2^31)
+
+FZ_HD void fz_generic_step_bits(uint32_t w0, uint32_t w1, uint64_t peq, uint32_t index, uint32_t m,
+                                uint32_t max_subs, uint32_t max_ins, uint32_t max_dels, uint32_t max_l, FzGStep &o) {
+    const uint32_t start = w0 & 0xffffu, j = w0 >> 16;
+    const uint32_t l = w1 & 0xffu, ns = (w1 >> 8) & 0xffu, ni = (w1 >> 16) & 0xffu, nd = w1 >> 24;
+    const uint64_t skipw = (peq >> 1) | (1ull << (m - 1u));             // bit (j + sk - 1): j + sk == m or pattern[j + sk] == ch
+    const uint32_t adv = (uint32_t)(peq >> j) & 1u;                     // py:85-94
+    const uint32_t skips = (uint32_t)(skipw >> j);                      // bit sk - 1 for sk = 1 .. 32
+    const uint32_t nadv = adv ^ 1u;
+    const uint32_t at_end = fz_b_eq(j + 1u, m), not_end = at_end ^ 1u;
+    const uint32_t live = nadv & (fz_b_eq(l, max_l) ^ 1u);              // py:101-102
+    const uint32_t can_ins = fz_b_lt(ni, max_ins), can_sub = fz_b_lt(ns, max_subs);
+    const uint32_t second = live & (can_sub | (fz_b_lt(nd, max_dels) & can_ins));
+    o.fa = (adv & not_end) | (live & can_ins);                          // py:104-109
+    o.a0 = w0 + (adv << 16);
+    o.a1 = w1 + nadv * 0x00010001u;                                     // ni++, l++
+    o.fb = second & not_end;                                            // py:111-128
+    o.b0 = w0 + 0x10000u;
+    o.b1 = w1 + 0x01010001u - can_sub * (0x01010001u - 0x00000101u);    // ns++, l++  |  ni++, nd++, l++
+    o.f1 = (adv | second) & at_end;                                     // py:86-88, py:129-138
+    o.m1 = start | ((index + 1u) << 16);
+    o.d1 = l + nadv;
+    uint32_t lim = max_dels - nd;                                       // py:141-165
+    const uint32_t lim2 = max_l - l;
+    lim = lim2 < lim ? lim2 : lim;
+    lim *= live;
+    uint32_t fsk = (uint32_t)__builtin_ffs((int)skips);                 // 0: no such sk among the first 32
+    fsk *= fz_b_lt(fsk, lim + 1u);                                      // beyond the budget: none
+    const uint32_t found = fz_b_lt(0u, fsk);
+    const uint32_t to_end = fz_b_lt(m, j + fsk + 2u);                   // j + fsk + 1 >= m: ran off the pattern, or matched its last char
+    o.f2 = found & to_end;
+    o.m2 = start | (index << 16);
+    o.d2 = l + fsk;
+    o.fc = found & (to_end ^ 1u);
+    o.c0 = w0 + ((1u + fsk) << 16);
+    o.c1 = w1 + ((fsk << 24) | fsk);
+}
+
 FZ_HD void fz_gcand_words(const FzGCand &c, uint32_t &w0, uint32_t &w1) {
     w0 = (uint32_t)c.start | ((uint32_t)c.j << 16);
     w1 = (uint32_t)c.l | ((uint32_t)c.ns << 8) | ((uint32_t)c.ni << 16) | ((uint32_t)c.nd << 24);
@@ -659,6 +708,25 @@ FZ_HD void fz_levlp_step_slots(uint32_t w0, uint32_t w1, uint8_t ch, uint32_t in
 FZ_HD bool fz_levlp_final(const FzGCand &c, uint32_t m, uint32_t k, uint32_t &dist) {
     dist = c.l + m - c.j;
     return dist <= k;
+}
+
+// Which window positions need a fresh candidate at all (round 5).  The automaton of a hit runs over the window
+// [idx - s - k, idx - s + m + k) (generic_search.py:229-231) and the reference spawns a candidate at EVERY window character
+// (py:80).  A candidate that starts at `index` consumes at most wlen - index characters; j advances by at most one per
+// consumed character plus the pattern characters it deletes (nd <= max_dels, and nd <= l <= max_l), and every way of
+// emitting a match — the last pattern character consumed (py:86-88, 129-138), skipping to the pattern's end (py:141-165),
+// the end-of-window flush (py:172-177) — needs j + remaining deletions >= m.  So a start with
+//     index + m > wlen + min(max_dels, max_l)
+// can never emit anything, and since candidates of different starts never interact (successors keep their start, the list
+// only grows by appending) leaving it out changes neither the matches nor their order.  BASELINE configs[3b] (m = 64,
+// k = 5, max_dels = 2): 13 of a window's 74 characters spawn.
+FZ_HD bool fz_gen_start_useful(uint32_t index, uint32_t wlen, uint32_t m, uint32_t max_dels, uint32_t max_l) {
+#ifdef FZ_LAB_GEN_NO_PRUNE                                    // lab builds: every window character spawns, as in rounds 1 .. 4
+    return true;
+#else
+    const uint32_t d = max_dels < max_l ? max_dels : max_l;
+    return index + m <= wlen + d;
+#endif
 }
 
 // End-of-window flush of one surviving candidate (py:172-177): -> true and dist if it matches.

@@ -1770,11 +1770,14 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
                 ch = win[index];
                 if (index < spawn_len) {
                     if (!lev) {                                        // generic: fresh candidate appended (py:80)
+                      // (per-hit windows: only starts that can still reach the pattern's end, fz_gen_start_useful)
+                      if (!per_hit || fz_gen_start_useful(index, wlen, a.m, a.max_dels, a.k)) {
                         if (ncur >= a.cand_cap) { overflow = true; break; }
                         // (start = index, everything else 0) never goes through the list: the lane that owns
                         // position ncur takes it from registers — no LDS store + wait per character
                         fresh_at = ncur;
                         ++ncur;
+                      }
                     } else {                                           // Levenshtein: levenshtein.py:75-80
                         uint32_t f = 0xffffffffu;
                         const uint32_t lim = a.k + 1 < a.m ? a.k + 1 : a.m;
@@ -1944,7 +1947,7 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
 // and the host runs the search again with fz_lp_kernel (which also keeps the lists-in-HBM form, the file API's segments
 // and the tiled whole-sequence automata).
 #define FZ_GH_MAX_WAVES 4u                                  // waves per hit: template parameter W in {2, 4}
-#define FZ_GH_MCAP 256u                                     // matches a wave buffers for one hit
+#define FZ_GH_MCAP_W(W) ((W) == 1u ? 512u : 256u)           // matches a wave buffers for one hit (one wave per hit: the whole hit's)
 #define FZ_HDR_GEN_FAIL 5                                   // counters[5]: hits fz_gen_hit_kernel could not finish
 #define FZ_GH_CTL_BYTES 64u
 
@@ -1959,7 +1962,13 @@ __device__ __forceinline__ uint32_t fz_gh_lower_bound(const uint64_t *mb, uint32
     return lo;
 }
 
-template <uint32_t W>
+// BITS (round 5; patterns of at most 64 characters, budgets of at most 32): the candidate step is fz_generic_step_bits —
+// one 64-bit equality word per window character (a 256-entry table of the pattern in LDS, looked up once per window
+// character when the window is staged), every flag a 0 / 1 word, the five outputs stored UNCONDITIONALLY (an absent output
+// goes to a per-lane dummy slot: no exec-mask juggling around five ds_writes).  With fz_gen_start_useful a window's list
+// rarely passes 64 candidates, so this form runs ONE wave per hit (W = 1: no rank merge, no cross-wave traffic).
+#define FZ_GH_PT_BYTES 2048u
+template <uint32_t W, bool BITS>
 __global__ __launch_bounds__(64 * W) void fz_gen_hit_kernel(const uint8_t *__restrict__ buf, const FzScanArgs a,
                                                                       const uint64_t *__restrict__ hits, FzGenRec *__restrict__ recs,
                                                                       unsigned long long *__restrict__ counters) {
@@ -1977,8 +1986,19 @@ __global__ __launch_bounds__(64 * W) void fz_gen_hit_kernel(const uint8_t *__res
     FzGCand *lists = reinterpret_cast<FzGCand *>(smem + mpad + wpad + FZ_GH_CTL_BYTES);
     FzGCand *cur = lists + (size_t)wave * 2u * capw, *nxt = cur + capw;
     uint64_t *mball = reinterpret_cast<uint64_t *>(lists + (size_t)W * 2u * capw);
+    constexpr uint32_t FZ_GH_MCAP = FZ_GH_MCAP_W(W);
     uint64_t *mbuf = mball + (size_t)wave * FZ_GH_MCAP;
+    // BITS: equality words of the pattern by byte value, of the staged window by position, and the dummy slots
+    unsigned long long *ptab = reinterpret_cast<unsigned long long *>(mball + (size_t)W * FZ_GH_MCAP);
+    unsigned long long *pwin = ptab + 256;
+    uint2 *dummy = reinterpret_cast<uint2 *>(pwin + wpad) + tid;
     fz_copy_pattern(pat, a, tid, 64u * W);
+    if constexpr (BITS) {
+        for (uint32_t i = tid; i < 256u; i += 64u * W) ptab[i] = 0ull;
+        __syncthreads();
+        for (uint32_t i = tid; i < a.m; i += 64u * W) atomicOr(&ptab[pat[i]], 1ull << i);
+        __syncthreads();
+    }
     auto patf = [&](uint32_t i) -> uint8_t { return pat[i]; };
     // (everything that is the same in all lanes goes through v_readfirstlane: values loaded from memory are per-lane values
     //  to the compiler, and list lengths, loop bounds and branch conditions derived from them would become vector registers
@@ -2019,7 +2039,11 @@ __global__ __launch_bounds__(64 * W) void fz_gen_hit_kernel(const uint8_t *__res
             ctl[0] = run; ctl[1] = 0u; ctl[8] = stop;
         }
         FZ_LAB_LP(q, 0, __builtin_readcyclecounter());
-        for (uint32_t i = tid; i < wlen; i += 64u * W) win[i] = buf[(w0 - a.geom.buf_off) + i];
+        for (uint32_t i = tid; i < wlen; i += 64u * W) {
+            const uint8_t c = buf[(w0 - a.geom.buf_off) + i];
+            win[i] = c;
+            if constexpr (BITS) pwin[i] = ptab[c];
+        }
         __syncthreads();
         FZ_LAB_LP(q, 1, __builtin_readcyclecounter());
         if (fz_uniform(ctl[8])) break;                      // has_near_match_*: a record exists somewhere
@@ -2027,18 +2051,99 @@ __global__ __launch_bounds__(64 * W) void fz_gen_hit_kernel(const uint8_t *__res
 
         // ---- this wave's quarter of the candidate list over the whole window; no synchronisation with the other waves ----
         uint32_t ncur = 0, mb = 0;
+        uint32_t pw0l = 0, pw0h = 0, pw1l = 0, pw1h = 0;    // BITS: equality words of window positions lane and 64 + lane (m + 2k <= 128)
+        if constexpr (BITS) {
+            const unsigned long long e0 = lane < wlen ? pwin[lane] : 0ull, e1 = 64u + lane < wlen ? pwin[64u + lane] : 0ull;
+            pw0l = (uint32_t)e0; pw0h = (uint32_t)(e0 >> 32); pw1l = (uint32_t)e1; pw1h = (uint32_t)(e1 >> 32);
+        }
+#ifdef FZ_LAB_LPTIME
+        uint32_t lab_cands = 0, lab_trips = 0;              // (lab builds: candidate steps and slice trips of this hit)
+#endif
         bool fail = false;
         FzGCand *lc = cur, *ln = nxt;
         for (uint32_t index = 0; index <= wlen && !fail; ++index) {
             uint32_t nnext = 0;
+            // nothing alive and no start left that could still reach the pattern's end: the rest of the window emits nothing
+            if (ncur == 0u && !fz_gen_start_useful(index, wlen, a.m, a.max_dels, a.k)) break;
             if (index < wlen) {
-                const uint8_t ch = (uint8_t)fz_uniform(win[index]);
+                const uint8_t ch = BITS ? (uint8_t)0 : (uint8_t)fz_uniform(win[index]);
                 uint32_t fresh_at = 0xffffffffu;
-                if ((index & (W - 1u)) == wave) {   // this start is ours: the fresh candidate (py:80), taken from registers
+                // this start is ours: the fresh candidate (py:80), taken from registers — unless nothing that starts here can
+                // reach the pattern's end inside the window (fz_gen_start_useful)
+                if ((index & (W - 1u)) == wave && fz_gen_start_useful(index, wlen, a.m, a.max_dels, a.k)) {
                     if (ncur >= capw) { fail = true; break; }
                     fresh_at = ncur;
                     ncur = fz_uniform(ncur + 1u);
                 }
+                if constexpr (BITS) {
+                    // One TRIP steps U slices of 64 candidates (U = 2 while more than 64 are left): their loads, steps and prefix
+                    // scans are independent chains that the hardware overlaps, one pass of offsets, 5 U unconditional stores.
+                    // (Measured in round 5: a hit's time is 13k + ~1 500 cycles per window character that has candidates —
+                    // with pruned starts nearly every character is ONE slice, so neither trips of 4 slices nor 2 / 4 waves per hit
+                    // moved the slowest hit; the chain of one trip, ~110 dependent-ish instructions, is what is left.)
+                    // (the window's equality words live in two register pairs, lane = window position: one v_readlane with the
+                    //  character's number instead of an LDS round trip at the head of every character's chain)
+                    const uint32_t il = index & 63u;
+                    const unsigned long long peq = index < 64u
+                        ? ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)pw0l, (int)il) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)pw0h, (int)il) << 32))
+                        : ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)pw1l, (int)il) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)pw1h, (int)il) << 32));
+                    const uint64_t stamp = (uint64_t)index << 48;
+                    auto trip = [&](auto uc, uint32_t c0) -> bool {
+                        constexpr uint32_t U = decltype(uc)::value;
+                        FzGStep st[U];
+                        uint32_t packed[U], incl[U], base[U];
+#pragma unroll
+                        for (uint32_t u = 0; u < U; ++u) {
+                            const uint32_t at = c0 + 64u * u + lane;
+                            const bool valid = at < ncur;
+                            uint2 cw = reinterpret_cast<const uint2 *>(lc)[at];      // (past the list: still this workgroup's LDS)
+                            const bool fresh = at == fresh_at;
+                            cw.x = valid ? (fresh ? index : cw.x) : 0u;
+                            cw.y = valid && !fresh ? cw.y : 0u;
+                            fz_generic_step_bits(cw.x, cw.y, peq, index, a.m, a.max_subs, a.max_ins, a.max_dels, a.k, st[u]);
+                            const uint32_t vm = valid ? 1u : 0u;
+                            st[u].fa &= vm; st[u].fb &= vm; st[u].fc &= vm; st[u].f1 &= vm; st[u].f2 &= vm;
+                            packed[u] = (st[u].fa + st[u].fb + st[u].fc) | ((st[u].f1 + st[u].f2) << 16);
+                        }
+#pragma unroll
+                        for (uint32_t u = 0; u < U; ++u) incl[u] = fz_wave_incl_scan(packed[u]);
+                        uint32_t tot = 0;
+#pragma unroll
+                        for (uint32_t u = 0; u < U; ++u) { base[u] = tot; tot += (uint32_t)__builtin_amdgcn_readlane((int)incl[u], 63); }
+                        const uint32_t tot_s = tot & 0xffffu, tot_m = tot >> 16;
+                        if (nnext + tot_s > capw || mb + tot_m > FZ_GH_MCAP) return false;
+#pragma unroll
+                        for (uint32_t u = 0; u < U; ++u) {
+                            const uint32_t excl = incl[u] - packed[u] + base[u];
+                            uint2 *nx = reinterpret_cast<uint2 *>(ln) + nnext + (excl & 0xffffu);
+                            uint64_t *mp = mbuf + mb + (excl >> 16);
+                            // five stores, none of them conditional: an absent output lands in this lane's dummy slot
+                            uint2 *pa = st[u].fa ? nx : dummy;
+                            uint2 *pb = st[u].fb ? nx + st[u].fa : dummy;
+                            uint2 *pc = st[u].fc ? nx + st[u].fa + st[u].fb : dummy;
+                            uint64_t *p1 = st[u].f1 ? mp : reinterpret_cast<uint64_t *>(dummy);
+                            uint64_t *p2 = st[u].f2 ? mp + st[u].f1 : reinterpret_cast<uint64_t *>(dummy);
+                            *pa = make_uint2(st[u].a0, st[u].a1);
+                            *pb = make_uint2(st[u].b0, st[u].b1);
+                            *pc = make_uint2(st[u].c0, st[u].c1);
+                            *p1 = (uint64_t)st[u].m1 | ((uint64_t)st[u].d1 << 32) | stamp;
+                            *p2 = (uint64_t)st[u].m2 | ((uint64_t)st[u].d2 << 32) | stamp;
+                        }
+                        nnext = fz_uniform(nnext + tot_s);
+                        mb = fz_uniform(mb + tot_m);
+                        return true;
+                    };
+#ifdef FZ_LAB_LPTIME
+                    lab_cands += ncur;
+                    lab_trips += (ncur + 63u) / 64u;
+#endif
+                    for (uint32_t c0 = 0; c0 < ncur && !fail;) {
+                        const uint32_t left = ncur - c0;
+                        if (left > 64u) { fail = !trip(std::integral_constant<uint32_t, 2>{}, c0); c0 += 128u; }
+                        else { fail = !trip(std::integral_constant<uint32_t, 1>{}, c0); c0 += 64u; }
+                    }
+                    if (fail) break;
+                } else
                 for (uint32_t c0 = 0; c0 < ncur; c0 += 64u) {
                     const bool valid = c0 + lane < ncur;
                     uint2 cw = reinterpret_cast<const uint2 *>(lc)[c0 + lane];      // (up to 63 slots past the list: still this workgroup's LDS)
@@ -2089,7 +2194,7 @@ __global__ __launch_bounds__(64 * W) void fz_gen_hit_kernel(const uint8_t *__res
         if (lane == 0) { ctl[2u + wave] = mb; if (fail) ctl[1] = 1u; }
         __syncthreads();
         FZ_LAB_LP(q, 2, __builtin_readcyclecounter());
-        FZ_LAB_LP(q, 3, (unsigned long long)wlen);
+        FZ_LAB_LP(q, 3, ((unsigned long long)lab_cands << 32) | ((unsigned long long)(lab_trips & 0xffffu) << 16) | (unsigned long long)(mb & 0xffffu));
         if (fz_uniform(ctl[1])) {                           // outgrew a list quarter or a match buffer: the host re-runs with fz_lp_kernel
             if (tid == 0) atomicAdd(&counters[FZ_HDR_GEN_FAIL], 1ull);
             continue;

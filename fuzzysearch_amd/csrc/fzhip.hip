@@ -1493,17 +1493,29 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
                                          : reinterpret_cast<FzGenRec *>(d.d_out + kHeaderBytes);
             static_assert(sizeof(FzGenRec) == sizeof(FzRec), "the generic records share the record buffer");
             // fz_gen_hit_kernel: four waves per hit, every wave a quarter of the list (in-memory searches with the lists in LDS)
-            static const uint32_t gh_waves = []() { const char *e = getenv("FZ_GH_WAVES"); return e && atoi(e) == 4 ? 4u : 2u; }();
-            const uint32_t capw = std::max<uint32_t>(64u, cand_cap / 2u);
+            static const uint32_t gh_waves_env = []() { const char *e = getenv("FZ_GH_WAVES"); return e ? (uint32_t)atoi(e) : 0u; }();
+            static const bool gh_no_bits = getenv("FZ_GH_NO_BITS") != nullptr;
+            // the bit-parallel form (fz_gen_hit_kernel<W, true>: 64-bit equality words, flags as words, unconditional stores):
+            // patterns of at most 64 characters and budgets of at most 32.  FZ_GH_NO_BITS=1: the round-4 step (A/B, tests);
+            // FZ_GH_WAVES=1 / 2 / 4: waves per hit.  Default with the bit-parallel form: ONE — measured in round 5 (profiles/
+            // r05_generic_kernels.txt): a hit's time is ~1 500 cycles per window character that has candidates, whatever the
+            // number of waves or of slices per trip (the big tree of a true occurrence belongs to one start, and the per-character
+            // cost is the dependent chain of one trip), so more waves per hit only cost residency; 2 otherwise (round 4)
+            const bool gh_bits = q.m <= 64u && q.k <= 32u && q.m >= 1u && !gh_no_bits;
+            const uint32_t gh_waves = gh_waves_env == 4u || gh_waves_env == 2u || (gh_waves_env == 1u && gh_bits) ? gh_waves_env : gh_bits ? 1u : 2u;
+            const uint32_t capw = gh_waves == 1u ? std::max<uint32_t>(64u, cand_cap) : std::max<uint32_t>(64u, cand_cap / 2u);   // slots per list of one wave
             const size_t lds_multi = (size_t)mpad + wpad + FZ_GH_CTL_BYTES + (size_t)gh_waves * 2u * capw * sizeof(FzGCand) +
-                                     (size_t)gh_waves * FZ_GH_MCAP * 8u;
+                                     (size_t)gh_waves * FZ_GH_MCAP_W(gh_waves) * 8u +
+                                     (gh_bits ? (size_t)FZ_GH_PT_BYTES + (size_t)wpad * 8u + (size_t)64u * gh_waves * 8u : 0u);
+            using GhKernel = void (*)(const uint8_t *, const FzScanArgs, const uint64_t *, FzGenRec *, unsigned long long *);
+            const GhKernel gh = gh_bits ? (gh_waves == 1u ? fz_gen_hit_kernel<1, true> : gh_waves == 2u ? fz_gen_hit_kernel<2, true> : fz_gen_hit_kernel<4, true>)
+                                        : (gh_waves == 4u ? fz_gen_hit_kernel<4, false> : fz_gen_hit_kernel<2, false>);
             const bool multi = ctx->gen_multi && !legacy_now && scratch == 0 && sh.geom.seg_stride == 0 && lds_multi <= 160 * 1024;
             d.gen_multi_used = multi;
             if (multi) {
                 fa.cand_cap = capw;
                 if (lds_multi > 64 * 1024)
-                    HIP_TRY(hipFuncSetAttribute(gh_waves == 4 ? reinterpret_cast<const void *>(fz_gen_hit_kernel<4>) : reinterpret_cast<const void *>(fz_gen_hit_kernel<2>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi));
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gh), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi));
             }
             if (lds > 64 * 1024)
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(lp_kernel(FZ_LP_GENERIC_HIT, scratch != 0)),
@@ -1535,9 +1547,8 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             static const bool no_ext = getenv("FZ_NO_EXT_LAUNCH") != nullptr;
             hipEvent_t lp_stop = no_ext ? nullptr : fold_direct ? d.ev[3] : ctx->timing ? d.ev[2] : nullptr;
             d.lp_end_event = fold_direct ? 3 : 2;
-            static const unsigned multi_per_cu = getenv("FZ_GH_GRID_PER_CU") ? (unsigned)atoi(getenv("FZ_GH_GRID_PER_CU")) : 32u;   // lab knob (configs[3b]: 16 -> 0.130 ms, 32 -> 0.104: every hit of the search needs a workgroup of its own)
-            using GhKernel = void (*)(const uint8_t *, const FzScanArgs, const uint64_t *, FzGenRec *, unsigned long long *);
-            const GhKernel gh = gh_waves == 4 ? fz_gen_hit_kernel<4> : fz_gen_hit_kernel<2>;
+            static const unsigned multi_per_cu_env = getenv("FZ_GH_GRID_PER_CU") ? (unsigned)atoi(getenv("FZ_GH_GRID_PER_CU")) : 0u;
+            const unsigned multi_per_cu = multi_per_cu_env ? multi_per_cu_env : 32u;   // lab knob (configs[3b]: 16 -> 0.130 ms, 32 -> 0.104: every hit of the search needs a workgroup of its own)
             if (multi && lp_stop)
                 hipExtLaunchKernelGGL(gh, dim3(d.n_cus * multi_per_cu), dim3(64 * gh_waves), lds_multi, st2, nullptr, lp_stop, 0u,
                                       sh.d_buf, fa, d.d_hits, recs, counters);

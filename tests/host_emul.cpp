@@ -163,6 +163,18 @@ int64_t emul_generic_lp_packed(const uint8_t *p, uint32_t m, const uint8_t *t, u
             fz_generic_step(fz_gcand_of(w0, w1), t[index], index, m, pat, max_subs, max_ins, max_dels, max_l, o);
             FzGStep ref;
             fz_gstep_from_out(o, ref);
+            if (m <= 64u && max_l <= 32u) {                            // the bit-parallel form of the same step (fz_generic_step_bits)
+                uint64_t peq = 0;
+                for (uint32_t i = 0; i < m; ++i) peq |= (uint64_t)(p[i] == t[index]) << i;
+                FzGStep sb;
+                fz_generic_step_bits(w0, w1, peq, index, m, max_subs, max_ins, max_dels, max_l, sb);
+                agree &= sb.fa == st.fa && sb.fb == st.fb && sb.fc == st.fc && sb.f1 == st.f1 && sb.f2 == st.f2;
+                if (st.fa) agree &= sb.a0 == st.a0 && sb.a1 == st.a1;
+                if (st.fb) agree &= sb.b0 == st.b0 && sb.b1 == st.b1;
+                if (st.fc) agree &= sb.c0 == st.c0 && sb.c1 == st.c1;
+                if (st.f1) agree &= sb.m1 == st.m1 && sb.d1 == st.d1;
+                if (st.f2) agree &= sb.m2 == st.m2 && sb.d2 == st.d2;
+            }
             agree &= st.f1 + st.f2 == ref.f1 + ref.f2;
             if (st.f1 && st.f2) agree &= st.m1 == ref.m1 && st.d1 == ref.d1 && st.m2 == ref.m2 && st.d2 == ref.d2;
             else if (st.f1) agree &= st.m1 == ref.m1 && st.d1 == ref.d1;
@@ -275,7 +287,7 @@ int64_t emul_generic_ngrams_ordered(const uint8_t *p, uint32_t m, const uint8_t 
         for (uint32_t wave = 0; wave < W; ++wave) {
             std::vector<uint64_t> cur, nxt;
             for (uint32_t index = 0; index < wlen; ++index) {
-                if ((index & (W - 1u)) == wave) cur.push_back((uint64_t)index);
+                if ((index & (W - 1u)) == wave && fz_gen_start_useful(index, wlen, m, max_dels, max_l)) cur.push_back((uint64_t)index);
                 nxt.clear();
                 for (uint64_t cw : cur) {
                     FzGStep st;

@@ -149,6 +149,39 @@ def test_generic_automaton_struct_and_packed_steps_equal_oracle(emul):
             assert 0 <= c <= cap, (fn, p, t, limits, max_l)
             assert [(out[i].start, out[i].end, out[i].dist) for i in range(c)] == want, (p, t, limits, max_l)
         done += 1
+    # round 5: long patterns (the 64-bit equality words of fz_generic_step_bits up to their last bit, the sentinel at m = 64)
+    # and larger deletion budgets (find-first-set beyond the first two skip positions); emul_generic_lp_packed compares the
+    # bit-parallel step with the packed one on every candidate
+    done = 0
+    while done < 300:
+        sigma = rnd.choice([2, 3, 4, 20])
+        alpha = bytes(rnd.sample(range(1, 256), sigma))
+        m = rnd.choice([31, 32, 33, 48, 63, 64, 64, rnd.randint(17, 64)])
+        k = rnd.randint(1, 6)
+        p = bytes(rnd.choice(alpha) for _ in range(m))
+        t = bytearray(rnd.choice(alpha) for _ in range(rnd.randint(m, 260)))
+        v = bytearray(p)
+        for _ in range(rnd.randint(0, k)):
+            q = rnd.randrange(len(v))
+            r = rnd.random()
+            if r < 0.34:
+                v[q] = rnd.choice(alpha)
+            elif r < 0.67 and len(v) > 2:
+                del v[q]
+            else:
+                v.insert(q, rnd.choice(alpha))
+        at = rnd.randint(0, max(0, len(t) - len(v)))
+        t[at:at + len(v)] = v
+        t = bytes(t)
+        limits = (rnd.randint(0, k), rnd.randint(0, k), rnd.randint(0, k))
+        max_l = min(k, sum(limits))
+        if max_l == 0:
+            continue
+        want = [r[:3] for r in oracle.generic_lp_raw(p, t, limits[0], limits[1], limits[2], max_l)]
+        c = emul.emul_generic_lp_packed(p, len(p), t, len(t), limits[0], limits[1], limits[2], max_l, out, cap)
+        assert 0 <= c <= cap, (p, t, limits, max_l, c)
+        assert [(out[i].start, out[i].end, out[i].dist) for i in range(c)] == want, (p, t, limits, max_l)
+        done += 1
 
 
 def test_generic_ngram_search_as_ordered_on_the_device_equals_oracle(emul):
