@@ -623,6 +623,8 @@ def main():
     from fuzzysearch_amd import _native
     from fuzzysearch_amd import distributed as fzd
     from tests import workloads
+    if use_torch:
+        from tests import torch_glue          # (test / bench infrastructure: the product never imports torch)
 
     k = 2
     if args.mib <= 0:
@@ -661,7 +663,7 @@ def main():
         handle = engine.upload(seq)
     else:
         # halo exchange, once at load: neighbours' (m + k) edge bytes (one all-gather)
-        left, right = fzd.exchange_halos(seq, halo) if use_torch else fzd.exchange_halos_native(engine, seq, halo)
+        left, right = torch_glue.exchange_halos(seq, halo) if use_torch else fzd.exchange_halos_native(engine, seq, halo)
         buf = np.concatenate([left, seq, right])
         own_lo = rank * shard_bytes
         handle = engine.upload_shard(buf, own_lo - len(left), own_lo, own_lo + shard_bytes, global_n)
@@ -678,7 +680,7 @@ def main():
     def finish(raw):
         # torch glue: this rank's stream -> the merged global stream (ONE all_gather: counts + packed records);
         # native: the search itself was collective and `raw` already is the merged stream
-        return fzd.allgather_matches(raw, as_array=True) if use_torch else raw
+        return torch_glue.allgather_matches(raw, as_array=True) if use_torch else raw
 
     def step():
         # synchronous: on return the ordered raw match stream is on the host (numpy view of the

@@ -1,4 +1,4 @@
-"""Cost of distributed.allgather_matches on one GPU (world = 1, nccl): staging + collective + merge."""
+"""Cost of tests/torch_glue.allgather_matches on one GPU (world = 1, nccl): staging + collective + merge."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, torch.distributed as dist
@@ -6,14 +6,14 @@ os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER
 os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
-from fuzzysearch_amd import distributed as fzd
+from tests import torch_glue
 n = 2409
-raw = np.zeros(n, dtype=fzd.MATCH_DTYPE)
+raw = np.zeros(n, dtype=torch_glue.MATCH_DTYPE)
 raw["start"] = np.sort(np.random.default_rng(1).integers(0, 1 << 30, n)); raw["end"] = raw["start"] + 20
 raw["block"] = np.sort(np.random.default_rng(2).integers(0, 3, n))
-for _ in range(20): fzd.allgather_matches(raw, as_array=True)
+for _ in range(20): torch_glue.allgather_matches(raw, as_array=True)
 t0 = time.perf_counter(); N = 200
-for _ in range(N): out = fzd.allgather_matches(raw, as_array=True)
+for _ in range(N): out = torch_glue.allgather_matches(raw, as_array=True)
 print("allgather_matches: %.1f us/call (%d rows)" % ((time.perf_counter() - t0) / N * 1e6, len(out)))
 st = fzd._gather_state[0]
 def t(fn, name):
@@ -30,7 +30,7 @@ import ctypes
 from fuzzysearch_amd import _native
 lib = _native.load_library()
 t(lambda: lib.fz_wire_pack(raw.__array_interface__["data"][0], n, st["cap"], st["send_ptr"]), "fz_wire_pack")
-out = np.empty(st["cap"], dtype=fzd.MATCH_DTYPE); tot, top = ctypes.c_uint64(), ctypes.c_uint64()
+out = np.empty(st["cap"], dtype=torch_glue.MATCH_DTYPE); tot, top = ctypes.c_uint64(), ctypes.c_uint64()
 t(lambda: lib.fz_wire_merge(st["recv_ptr"], 1, st["rows"], st["cap"], out.__array_interface__["data"][0], len(out),
                             ctypes.byref(tot), ctypes.byref(top)), "fz_wire_merge (1 rank)")
 dist.destroy_process_group()

@@ -19,7 +19,9 @@ for name, fn in (("consolidated", lambda: eng.generic_ngrams_consolidated(h, p, 
         fn()
     print("%s: %.4f ms per call, stats %r" % (name, (time.perf_counter() - t0) / 50 * 1e3, eng.stats()), file=sys.stderr, flush=True)
     os.environ["FZ_TRACE"] = "1"
+    _native.load_library().fz_debug_reload_switches()       # (the library reads its switches once)
     for _ in range(3):
         print("--", name, file=sys.stderr, flush=True)
         fn()
     del os.environ["FZ_TRACE"]
+    _native.load_library().fz_debug_reload_switches()

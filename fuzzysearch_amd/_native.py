@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = (
     "fz_stream_open", "fz_stream_buffer", "fz_stream_submit", "fz_stream_read_fd", "fz_stream_finish", "fz_stream_close",
     "fz_consolidate", "fz_group_best", "fz_merge_ranks", "fz_wire_pack", "fz_wire_merge", "fz_debug_launch_plan", "fz_debug_order_records", "fz_debug_order_records_bounded", "fz_debug_order_segments", "fz_stats", "fz_set_timing", "fz_set_streams", "fz_device_ms", "fz_free",
     "fz_comm_unique_id", "fz_comm_init_rank", "fz_comm_init_all", "fz_comm_info", "fz_comm_set_collective",
-    "fz_comm_allgather", "fz_comm_max_f64", "fz_comm_barrier", "fz_comm_destroy", "fz_comm_gather_ms", "fz_comm_backend", "fz_debug_gather_merge", "fz_debug_scan_regions",
+    "fz_comm_allgather", "fz_comm_max_f64", "fz_comm_barrier", "fz_comm_destroy", "fz_comm_gather_ms", "fz_comm_backend", "fz_debug_reload_switches", "fz_debug_gather_merge", "fz_debug_scan_regions",
 )
 
 
@@ -102,6 +102,8 @@ def load_library():
         L.fz_comm_barrier.argtypes = [vp]
         L.fz_comm_destroy.restype = None
         L.fz_comm_destroy.argtypes = [vp]
+        L.fz_debug_reload_switches.restype = None
+        L.fz_debug_reload_switches.argtypes = []
         L.fz_comm_backend.restype = ci
         L.fz_comm_backend.argtypes = []
         L.fz_comm_gather_ms.restype = ci

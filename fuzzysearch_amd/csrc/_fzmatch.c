@@ -12,6 +12,16 @@
 
 typedef struct { int64_t start, end; int32_t dist, block; } fz_row;     /* fz_match of include/fzhip.h */
 
+/* PyGC_Disable / PyGC_Enable are CPython 3.10+; older interpreters fill the list with the collector left as it is (a
+ * young-generation pass or two that finds nothing: slower, not wrong) instead of failing to build. */
+#if PY_VERSION_HEX >= 0x030A0000
+#define FZ_GC_PAUSE() PyGC_Disable()
+#define FZ_GC_RESUME(was_on) do { if (was_on) PyGC_Enable(); } while (0)
+#else
+#define FZ_GC_PAUSE() 0
+#define FZ_GC_RESUME(was_on) do { (void)(was_on); } while (0)
+#endif
+
 static int slot_offset(PyObject *descr, PyTypeObject *cls, Py_ssize_t *off) {
     if (Py_TYPE(descr) != &PyMemberDescr_Type) {
         PyErr_SetString(PyExc_TypeError, "expected the member descriptors of a __slots__ class");
@@ -40,7 +50,7 @@ static PyObject *fill_matches(PyTypeObject *cls, const fz_row *rows, Py_ssize_t 
     const int is_bytes = PyBytes_CheckExact(seq), is_str = PyUnicode_CheckExact(seq);
     const char *bytes = is_bytes ? PyBytes_AS_STRING(seq) : NULL;
     const Py_ssize_t seq_len = is_bytes ? PyBytes_GET_SIZE(seq) : is_str ? PyUnicode_GET_LENGTH(seq) : 0;
-    const int gc_was_on = PyGC_Disable();
+    const int gc_was_on = FZ_GC_PAUSE();
     for (Py_ssize_t i = 0; i < n; ++i) {
         const fz_row r = rows[i];
         if (r.start < 0 || r.end < r.start || r.dist < 0) {
@@ -70,10 +80,10 @@ static PyObject *fill_matches(PyTypeObject *cls, const fz_row *rows, Py_ssize_t 
         *(PyObject **)((char *)obj + od) = d;
         *(PyObject **)((char *)obj + om) = m;
     }
-    if (gc_was_on) PyGC_Enable();
+    FZ_GC_RESUME(gc_was_on);
     return list;
 fail:
-    if (gc_was_on) PyGC_Enable();
+    FZ_GC_RESUME(gc_was_on);
     /* entries not reached yet are NULL: PyList's deallocator skips them */
     Py_DECREF(list);
     return NULL;

@@ -664,7 +664,7 @@ FZ_HD void fz_levlp_step(const FzGCand &c, uint8_t ch, uint32_t index, bool more
 // branch that follows, so lanes whose skip ended on the last pattern character stored the successor (start = m, j = 0)
 // instead of (start, j): one lost match per ~25 and ghost matches at tile offset + m.  Root-caused in round 5 (ISA in
 // profiles/r05_levlp_miscompile.txt; -O1, noinline or this loop shape compile correctly; extra wave syncs change
-// nothing — it never was a race).  benchmarks/lab_build.sh x -DFZ_LAB_ONLY -DFZ_LEVLP_BREAKLOOP + benchmarks/repro_lp.py
+// nothing — it never was a race).  benchmarks/lab_build.sh x -DFZ_LAB_ONLY -DFZ_LEVLP_BREAKLOOP (applies benchmarks/lab_patches/) + benchmarks/repro_lp.py
 // rebuilds and shows the miscompiled form.
 template <class PatF>
 FZ_HD void fz_levlp_step_slots(uint32_t w0, uint32_t w1, uint8_t ch, uint32_t index, bool more_seq, uint32_t m, PatF pat,
@@ -679,16 +679,6 @@ FZ_HD void fz_levlp_step_slots(uint32_t w0, uint32_t w1, uint8_t ch, uint32_t in
     if (l == k) return;                                                // :99-100
     o.fa = 1; o.a0 = w0; o.a1 = w1 + 1u;                               // :103 skip a sequence char (l++)
     if (more_seq && j + 1u < m) { o.fb = 1; o.b0 = w0 + 0x10000u; o.b1 = w1 + 1u; }   // :105-111 skip both
-#ifdef FZ_LEVLP_BREAKLOOP                                              // the miscompiled shape (lab builds only, see above)
-    for (uint32_t sk = 1; sk <= k - l; ++sk) {                         // :114-137 skip pattern chars
-        const bool at_end = j + sk == m;
-        if (at_end || pat(j + sk) == ch) {
-            if (at_end || j + sk + 1u == m) { o.f1 = 1; o.m1 = start | ((index + 1u) << 16); o.d1 = l + sk; }
-            else { o.fc = 1; o.c0 = w0 + ((1u + sk) << 16); o.c1 = w1 + sk; }
-            break;
-        }
-    }
-#else
     uint32_t fsk = 0;                                                  // :114-137: the first sk in 1..k-l with j + sk == m or pattern[j + sk] == ch
     for (uint32_t sk = 1; sk <= k; ++sk) {
         const bool open = (sk <= k - l) & (fsk == 0u);
@@ -701,7 +691,6 @@ FZ_HD void fz_levlp_step_slots(uint32_t w0, uint32_t w1, uint8_t ch, uint32_t in
         if (j + fsk + 1u >= m) { o.f1 = 1; o.m1 = start | ((index + 1u) << 16); o.d1 = l + fsk; }   // ran off the pattern, or matched its last char
         else { o.fc = 1; o.c0 = w0 + ((1u + fsk) << 16); o.c1 = w1 + fsk; }
     }
-#endif
 }
 
 // levenshtein.py:144-148
@@ -721,12 +710,8 @@ FZ_HD bool fz_levlp_final(const FzGCand &c, uint32_t m, uint32_t k, uint32_t &di
 // only grows by appending) leaving it out changes neither the matches nor their order.  BASELINE configs[3b] (m = 64,
 // k = 5, max_dels = 2): 13 of a window's 74 characters spawn.
 FZ_HD bool fz_gen_start_useful(uint32_t index, uint32_t wlen, uint32_t m, uint32_t max_dels, uint32_t max_l) {
-#ifdef FZ_LAB_GEN_NO_PRUNE                                    // lab builds: every window character spawns, as in rounds 1 .. 4
-    return true;
-#else
     const uint32_t d = max_dels < max_l ? max_dels : max_l;
     return index + m <= wlen + d;
-#endif
 }
 
 // End-of-window flush of one surviving candidate (py:172-177): -> true and dist if it matches.

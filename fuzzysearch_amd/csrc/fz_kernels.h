@@ -118,29 +118,9 @@ __device__ __forceinline__ uint32_t fz_load_win(const uint8_t *__restrict__ buf,
     return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(local & 3));
 }
 
-// Lab knobs (benchmarks/lab_build.sh -D...; never defined in the product build): FZ_LAB_TIMING device timestamps of
-// a few workgroups' phases (printf), FZ_LAB_NOVERIFY / FZ_LAB_NODP / FZ_LAB_NOEXACT / FZ_LAB_NOPREFETCH /
-// FZ_LAB_NOPOOL leave a part of the candidate handling out (DESIGN.md §4 quotes the A/B runs), FZ_GROUP forces the
-// number of offsets per branch.
-#ifdef FZ_LAB_LPTIME
-// lab build (read back by fz_lab_lp_read): time stamps of the automaton kernels' hits, or — FZ_LAB_SCANTIME — of the scan
-// kernel's workgroups: stamp i of workgroup b (its wave 0) at [b * 8 + i], constant-rate clock (100 MHz)
-static __device__ unsigned long long fz_lab_lp[16384 * 4];
-#endif
-#if defined(FZ_LAB_SCANTIME)
-// phases of a scan workgroup: 0 entry, 1 tables ready, 2 tiles done, 3 end-of-life flush done, 4 end (after the finish
-// protocol), 5 / 6 the pooled lane-per-cell flush (after its barrier / done)
-#define FZ_LAB_PHASE(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192u) fz_lab_lp[blockIdx.x * 8u + (i)] = wall_clock64(); } while (0)
-#define FZ_LAB_STAMP(i) do { } while (0)
-#elif defined(FZ_LAB_TIMING)
-static __device__ unsigned long long fz_lab_t[256];
-#define FZ_LAB_STAMP(i) do { if ((blockIdx.x & 127u) == 64u && threadIdx.x == 0) fz_lab_t[((blockIdx.x >> 7) & 31u) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define FZ_LAB_STAMP(i) do { } while (0)
-#endif
-#ifndef FZ_LAB_PHASE
-#define FZ_LAB_PHASE(i) do { } while (0)
-#endif
+// (The lab instrumentation of rounds 2 - 5 — device time stamps per workgroup phase / per n-gram hit, kernels with a part of
+// the candidate handling left out, the miscompiled loop shape of fz_levlp_step_slots — is not in this file: benchmarks/
+// lab_patches/lab_instrumentation.patch re-inserts it, benchmarks/lab_build.sh applies it to a scratch copy.)
 
 // Per-wave LDS areas, carved from dynamic LDS by fz_wave_lds() / fz_wave_lds_pref().
 struct FzWaveLds {
@@ -320,9 +300,6 @@ __device__ __forceinline__ uint32_t fz_wave_verify(const uint8_t *__restrict__ b
     bool ok = false;
     auto run = [&](const auto &t) {
         auto prd = [&](uint32_t o) -> uint32_t { return *reinterpret_cast<const uint32_t *>(pat_lds + o); };
-#ifdef FZ_LAB_NOEXACT
-        valid = valid && a.m > 100000u;                       // lab: neither exact test nor expansion
-#endif
         if constexpr (PREF) {
             // exact n-gram test on registers: 8 bytes of text and pattern, masked to min(L, 8) (uniform), the
             // rest (L > 8) byte by byte
@@ -345,10 +322,6 @@ __device__ __forceinline__ uint32_t fz_wave_verify(const uint8_t *__restrict__ b
             }
         }
         const uint32_t confirmed = (uint32_t)__popcll(__ballot(valid));
-        FZ_LAB_STAMP(5);
-#ifdef FZ_LAB_NODP
-        valid = valid && a.m > 100000u;                       // lab: confirm but do not expand
-#endif
         if (a.mode == FZ_MODE_LEV) {
             FzLdsScores sc{w.scores + (PREF ? 0u : vl), a.vlanes};
             if (valid) ok = fz_verify_lev<MAXK>(sc, t, sg.sa, sg.se, pat_lds, a.m, a.k, a.L, s, idx, rec);
@@ -364,7 +337,6 @@ __device__ __forceinline__ uint32_t fz_wave_verify(const uint8_t *__restrict__ b
         confirmed = run(FzLdsWindow{reinterpret_cast<const uint8_t *>(w.win + vl), wbase, a.vlanes * 4u});
     }
     const unsigned long long mask = __ballot(ok);
-    FZ_LAB_STAMP(6);
     if (mask) {
         unsigned long long base = 0;
         if (lane == 0) base = atomicAdd(&counters[1], (unsigned long long)__popcll(mask));
@@ -560,10 +532,8 @@ __device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ b
     constexpr bool PREF = FUSED && !SEG;
     const uint32_t lane = fz_lane();
     uint32_t confirmed = 0;
-    FZ_LAB_STAMP(1);
     if (PREF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every prefetched window has landed in LDS
     fz_wave_lds_sync();
-    FZ_LAB_STAMP(2);
     const uint32_t width = (FUSED && !PREF) ? a.vlanes : 64u;  // candidates handled per pass
     const uint32_t ncand = (SEG && FUSED) ? fz_segment_candidates(a.geom) : 1u;
     for (uint32_t e0 = 0; e0 < qn; e0 += width) {
@@ -592,12 +562,8 @@ __device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ b
             }
             if (FUSED) {
                 if (SEG && c && !__ballot(valid)) continue;
-#ifdef FZ_LAB_NOVERIFY
-                confirmed += (uint32_t)__popcll(__ballot(valid));
-#else
                 confirmed += fz_wave_verify<4, PREF>(buf, a, pat_lds, w, lane, hit, sg, valid, recs, counters,
                                                      PREF ? reinterpret_cast<const uint8_t *>(w.win) + e * 16u : nullptr);
-#endif
             } else {
                 if (valid) valid = fz_confirm(buf, a, blk, local);
                 const unsigned long long mask = __ballot(valid);
@@ -615,7 +581,6 @@ __device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ b
         }
     }
     fz_wave_lds_sync();
-    FZ_LAB_STAMP(3);
     return confirmed;
 }
 
@@ -653,12 +618,8 @@ __device__ __forceinline__ uint32_t fz_pooled_flush(const uint8_t *__restrict__ 
             valid = fz_hit_in_range(a, blk, idx, sg);
             hit = fz_hit_pack(a.g0 + blk, idx);
         }
-#ifdef FZ_LAB_NOVERIFY
-        confirmed += (uint32_t)__popcll(__ballot(valid));
-#else
         confirmed += fz_wave_verify<MAXK, true>(buf, a, pat_lds, none, lane, hit, sg, valid, recs, counters,
                                                 mine + a.qcap * 4u + li * 16u);
-#endif
     }
     return confirmed;
 }
@@ -702,13 +663,6 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
     static_assert(WFG == 0 || WFG == 16 || WFG == 32, "lanes per candidate of the fused lane-per-cell form");
     static_assert(!WF || (FUSED && !SEG), "the lane-per-cell form is a fused form of the in-memory search");
     constexpr bool PREF = FUSED && !SEG && !WF;       // candidate windows are prefetched by LDS-DMA
-    FZ_LAB_STAMP(0);
-    FZ_LAB_PHASE(0);
-#ifdef FZ_LAB_SCANTIME
-    // where the workgroup runs: HW_ID (wave / SIMD / CU / SH / SE fields) and XCC_ID
-    if (threadIdx.x == 0 && blockIdx.x < 8192u)
-        fz_lab_lp[blockIdx.x * 8u + 7u] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);
-#endif
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t mpad = FUSED ? (a.m + 15u) & ~15u : 0u;   // only the fused verification reads the pattern from LDS (m <= FZ_MAX_M there)
     // [32] hash living in the slot.  The kernel has no static LDS, so the dynamic area, and with it this
@@ -746,7 +700,6 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
         walk[0] = (uint32_t)first_tile; walk[1] = (uint32_t)(first_tile >> 32); walk[2] = stride;
     }
     __syncthreads();
-    FZ_LAB_PHASE(1);
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t qcap = PREF ? a.qcap : (uint32_t)FZ_QCAP;   // queue entries per wave
     const FzWaveLds w = PREF ? fz_wave_lds_pref(smem + FZ_TABLE_BYTES + mpad, FZ_TABLE_BYTES + mpad, wave, qcap, a.win_pieces)
@@ -907,59 +860,40 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                     slow_pos = 0;
                     break;
                 }
-#ifndef FZ_LAB_NOPREFETCH
                 if (PREF && qn > qf) {
                     if (tile) fz_prefetch_tile(buf, a, w, qf, qn, tile * (uint64_t)FZ_TILE_BYTES);
                     else fz_prefetch_windows(buf, a, w, qf, qn);          // the first tile: windows clamped at the start
                     qf = qn;
                 }
-#endif
                 tile = next;
                 ++titer;
             } while (pre);                            // else: the end of the sequence, or a flush is due
         }
         const bool done = !slow && tile >= limit;
-#ifndef FZ_LAB_NOPOOL
         if (PREF && done) break;                      // what is queued now is verified by the pooled flush below
-#endif
         if constexpr (WF) {
             // lane-per-cell verification (Levenshtein budgets 5 .. 15): own queue in mid-scan, the workgroup's pool at the end
             confirmed += fz_flush_wf<WF ? WFG : 16>(buf, a, smem, pat_lds, w, smem + FZ_TABLE_BYTES + mpad,
                                                     fz_wave_lds_bytes(fz_wf_fused_dwords(a.win_dwords, WF ? WFG : 16), 0u, 1u, true),
                                                     reinterpret_cast<volatile uint32_t *>(smem + 2u * FZ_LUT_BYTES), wave, qn, done, recs, counters);
         } else if (qn) {
-#ifndef FZ_LAB_NOPREFETCH
             if (PREF && qn > qf) fz_prefetch_windows(buf, a, w, qf, qn);
-#endif
             confirmed += fz_queue_flush<FUSED, SEG>(buf, a, pat_lds, w, qn, hits, recs, counters);
         }
         qn = 0;
         qf = 0;
         if (done) break;
     }
-    FZ_LAB_PHASE(2);
-#ifndef FZ_LAB_NOPOOL
     if constexpr (PREF) {
         if (qn > qf) fz_prefetch_windows(buf, a, w, qf, qn);
         confirmed += fz_pooled_flush<4>(buf, a, pat_lds, smem + FZ_TABLE_BYTES + mpad, fz_wave_lds_pref_bytes(qcap, a.win_pieces),
                                         reinterpret_cast<volatile uint32_t *>(smem + 2u * FZ_LUT_BYTES), wave, qn, recs, counters);
     }
-#endif
 
-#ifdef FZ_LAB_TIMING
-    FZ_LAB_STAMP(4);
-    if ((blockIdx.x & 127u) == 64u && threadIdx.x == 0) {
-        const unsigned long long *t = fz_lab_t + ((blockIdx.x >> 7) & 31u) * 8;
-        printf("wg %u: life %llu cyc; scan %llu, wait-dma %llu, decode+range+exact %llu, dp %llu, append %llu, tail %llu; confirmed %u\n", blockIdx.x,
-               t[4] - t[0], t[1] - t[0], t[2] - t[1], t[5] - t[2], t[6] - t[5], t[3] - t[6], t[4] - t[3], confirmed);
-    }
-#endif
     // (measured and not kept: one no-return atomic per workgroup — ticket and tallies in one word — with the last-indexed
     // workgroup polling for the others instead of every workgroup waiting for its ticket: 0.2172 vs 0.2183 ms, within noise)
     if (FUSED && lane == 0 && confirmed) atomicAdd(&counters[8 + (blockIdx.x & 63u)], (unsigned long long)confirmed);
-    FZ_LAB_PHASE(3);
     fz_finish_launch(a, counters, lut);
-    FZ_LAB_PHASE(4);
 }
 
 // Verification of a hit list in HBM, one lane per candidate (parameter ranges whose LDS footprint does
@@ -1151,7 +1085,6 @@ __device__ __forceinline__ uint32_t fz_wf_pass(const uint8_t *__restrict__ buf, 
         }
     }
     fz_wave_lds_sync();
-    FZ_LAB_STAMP(5);
     // exact n-gram test: lane gl compares the bytes gl, gl + GW, ...
     bool differs = false;
     if (valid) {
@@ -1180,7 +1113,6 @@ __device__ __forceinline__ uint32_t fz_wf_pass(const uint8_t *__restrict__ buf, 
     const uint32_t lwin = ok1 ? (uint32_t)(idx - lbeg) : 0u;
     const uint32_t celll = fz_wf_rows<GW>(lds0, gl, a.k, prel + (int)s - 1, -1, s, lds_of(idx) - 1, -1, lwin, bl, ok1);
     const bool ok = fz_wf_pick<GW>(celll, gl, a.k, s, lwin, bl, ok1, dL, l) && gl == 0;
-    FZ_LAB_STAMP(6);
     const unsigned long long mask = __ballot(ok);
     if (mask) {
         unsigned long long base = 0;
@@ -1227,8 +1159,6 @@ __device__ __forceinline__ uint32_t fz_flush_wf(const uint8_t *__restrict__ buf,
     const uint32_t total = n0 + n1 + n2 + n3;
     uint8_t *gwin = reinterpret_cast<uint8_t *>(w.win) + grp * (a.win_dwords * 4u + 16u);
     uint32_t confirmed = 0;
-    FZ_LAB_STAMP(1);
-    if (pooled) FZ_LAB_PHASE(5);
     // (Measured: a pass with the hits of one near match — different blocks, so max(right) + max(left) ~ 100 rows of a
     // 64-byte pattern — takes 17 - 23 us, ~400 cycles per row, next to six streaming waves per SIMD; s_setprio(3)
     // around the passes changed nothing: the rows wait for their own dependent instructions, not for issue slots.)
@@ -1239,8 +1169,6 @@ __device__ __forceinline__ uint32_t fz_flush_wf(const uint8_t *__restrict__ buf,
         const uint32_t code = have ? reinterpret_cast<const uint32_t *>(q0 + ow * per_wave)[li] : 0u;
         confirmed += fz_wf_pass<GW>(buf, a, lds0, pat_lds, gwin, have, code, recs, counters);
     }
-    FZ_LAB_STAMP(3);
-    if (pooled) FZ_LAB_PHASE(6);
     return confirmed;
 }
 
@@ -1556,15 +1484,6 @@ __global__ __launch_bounds__(64) void fz_verify_big_kernel(const uint8_t *__rest
 // the row totals across (6 VALU adds; the ds_bpermute form — six __shfl_up — paid six LDS round trips per call,
 // and the automaton calls it once per 64 candidates per window character).
 __device__ __forceinline__ uint32_t fz_wave_incl_scan(uint32_t v) {
-#ifdef FZ_LAB_SHFL_SCAN
-    const uint32_t lane = fz_lane();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(v, d);
-        if (lane >= (uint32_t)d) v += o;
-    }
-    return v;
-#else
     // update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl): lanes without a source keep `old` (0 here)
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
@@ -1573,15 +1492,7 @@ __device__ __forceinline__ uint32_t fz_wave_incl_scan(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1 and 3
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2 and 3
     return v;
-#endif
 }
-
-#ifdef FZ_LAB_LPTIME
-// lab build: per n-gram hit {shader clock at start, after the window is staged, at the end, slice steps << 32 | characters}
-#define FZ_LAB_LP(q, i, v) do { if ((q) < 16384u && (threadIdx.x & 63u) == 0 && (threadIdx.x >> 6) == 0) fz_lab_lp[(q) * 4u + (i)] = (v); } while (0)
-#else
-#define FZ_LAB_LP(q, i, v) do { } while (0)
-#endif
 
 // KIND (FzLpKind) and HBM_LISTS are compile-time: the per-hit instance carries none of the tiled Levenshtein
 // automaton's code, and with the lists in LDS their accesses are ds_ instructions instead of flat ones.
@@ -1640,7 +1551,6 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
                 const uint32_t sl = dd.wslot[q];
                 if (sl != FZ_GEN_DEDUP_NONE && dd.leader(sl) != (uint32_t)q) {
                     if (order && lane == 0) { order_first[q] = 0; order_count[q] = 0; }
-                    FZ_LAB_LP(q, 2, 0ull);
                     continue;
                 }
             }
@@ -1662,11 +1572,8 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
             key_base = w0;                  // elsewhere every candidate of this tile has died by w1
         }
         const uint32_t wlen = (uint32_t)(w1 - w0);
-        FZ_LAB_LP(q, 0, __builtin_readcyclecounter());
         for (uint32_t i = lane; i < wlen; i += 64u) win[i] = buf[(w0 - a.geom.buf_off) + i];
         fz_wave_lds_sync();
-        FZ_LAB_LP(q, 1, __builtin_readcyclecounter());
-        uint32_t lab_slices = 0;
 
         uint32_t ncur = 0, mb = 0, mseq = 0;
         bool overflow = false;
@@ -1881,7 +1788,6 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
                     load_step(c0, st);
                     if (!emit(st)) { overflow = true; break; }
                 }
-                lab_slices += (ncur + 63u) / 64u;
             } else {
                 for (uint32_t c0 = 0; c0 < ncur; c0 += 64u) {
                     FzGStep st;
@@ -1892,15 +1798,7 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
                         if (!last) {
                             // slot form (no scratch array); its skip loop has no lane-divergent exit — see fz_device.h for the
                             // hipcc miscompile of the `break` form that kept this out of the kernel in round 4.
-                            // -DFZ_LEVLP_STRUCT: the struct form (the statement of levenshtein.py:52-148, round 1 .. 4's kernel)
-#ifdef FZ_LEVLP_STRUCT
-                            FzGOut o;
-                            o.nsucc = 0; o.nmatch = 0;
-                            fz_levlp_step(c, ch, index, more_seq, a.m, patf, a.k, o);
-                            fz_gstep_from_out(o, st);
-#else
                             fz_levlp_step_slots(cw.x, cw.y, ch, index, more_seq, a.m, patf, a.k, st);
-#endif
                         } else {
                             uint32_t d;
                             const bool hit_end = lev ? fz_levlp_final(c, a.m, a.k, d) : fz_generic_final(c, a.m, a.max_dels, a.k, d);
@@ -1923,8 +1821,6 @@ __global__ __launch_bounds__(64) void fz_lp_kernel(const uint8_t *__restrict__ b
             if (fold && f_have) emit_pair();
         }
         if (order && q < FZ_GEN_ORDER_MAX && lane == 0) { order_first[q] = 0; order_count[q] = overflow ? 0u : mseq; }
-        FZ_LAB_LP(q, 2, __builtin_readcyclecounter());
-        FZ_LAB_LP(q, 3, ((unsigned long long)lab_slices << 32) | wlen);
         fz_wave_lds_sync();
     }
     // folded search whose pairs went straight into the host's staging buffer: the last workgroup publishes the counters
@@ -2038,16 +1934,14 @@ __global__ __launch_bounds__(64 * W) void fz_gen_hit_kernel(const uint8_t *__res
             }
             ctl[0] = run; ctl[1] = 0u; ctl[8] = stop;
         }
-        FZ_LAB_LP(q, 0, __builtin_readcyclecounter());
         for (uint32_t i = tid; i < wlen; i += 64u * W) {
             const uint8_t c = buf[(w0 - a.geom.buf_off) + i];
             win[i] = c;
             if constexpr (BITS) pwin[i] = ptab[c];
         }
         __syncthreads();
-        FZ_LAB_LP(q, 1, __builtin_readcyclecounter());
         if (fz_uniform(ctl[8])) break;                      // has_near_match_*: a record exists somewhere
-        if (!fz_uniform(ctl[0])) { FZ_LAB_LP(q, 2, 0ull); continue; }   // a hit of a smaller block runs this window
+        if (!fz_uniform(ctl[0])) continue;   // a hit of a smaller block runs this window
 
         // ---- this wave's quarter of the candidate list over the whole window; no synchronisation with the other waves ----
         uint32_t ncur = 0, mb = 0;
@@ -2056,9 +1950,6 @@ __global__ __launch_bounds__(64 * W) void fz_gen_hit_kernel(const uint8_t *__res
             const unsigned long long e0 = lane < wlen ? pwin[lane] : 0ull, e1 = 64u + lane < wlen ? pwin[64u + lane] : 0ull;
             pw0l = (uint32_t)e0; pw0h = (uint32_t)(e0 >> 32); pw1l = (uint32_t)e1; pw1h = (uint32_t)(e1 >> 32);
         }
-#ifdef FZ_LAB_LPTIME
-        uint32_t lab_cands = 0, lab_trips = 0;              // (lab builds: candidate steps and slice trips of this hit)
-#endif
         bool fail = false;
         FzGCand *lc = cur, *ln = nxt;
         for (uint32_t index = 0; index <= wlen && !fail; ++index) {
@@ -2133,10 +2024,6 @@ __global__ __launch_bounds__(64 * W) void fz_gen_hit_kernel(const uint8_t *__res
                         mb = fz_uniform(mb + tot_m);
                         return true;
                     };
-#ifdef FZ_LAB_LPTIME
-                    lab_cands += ncur;
-                    lab_trips += (ncur + 63u) / 64u;
-#endif
                     for (uint32_t c0 = 0; c0 < ncur && !fail;) {
                         const uint32_t left = ncur - c0;
                         if (left > 64u) { fail = !trip(std::integral_constant<uint32_t, 2>{}, c0); c0 += 128u; }
@@ -2193,8 +2080,6 @@ __global__ __launch_bounds__(64 * W) void fz_gen_hit_kernel(const uint8_t *__res
         }
         if (lane == 0) { ctl[2u + wave] = mb; if (fail) ctl[1] = 1u; }
         __syncthreads();
-        FZ_LAB_LP(q, 2, __builtin_readcyclecounter());
-        FZ_LAB_LP(q, 3, ((unsigned long long)lab_cands << 32) | ((unsigned long long)(lab_trips & 0xffffu) << 16) | (unsigned long long)(mb & 0xffffu));
         if (fz_uniform(ctl[1])) {                           // outgrew a list quarter or a match buffer: the host re-runs with fz_lp_kernel
             if (tid == 0) atomicAdd(&counters[FZ_HDR_GEN_FAIL], 1ull);
             continue;

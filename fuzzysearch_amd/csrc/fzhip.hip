@@ -38,17 +38,89 @@
 #include <map>
 #include <mutex>
 #include <vector>
+#include <cassert>
 
 #include "../../include/fzhip.h"
 #include "fz_kernels.h"
 
 namespace {
 
+// Every process-wide switch of the library: read from the environment ONCE, on first use, into this struct.  None of them is
+// needed to use the library; tests, A/B measurements and lab builds set them (INTEGRATION.md §5 describes each).  Results
+// never depend on a switch — the -m gpu suite runs the same cases under the ones marked (t) and compares with the oracle.
+struct Switches {
+    // (t) alternative forms of the same computation
+    bool no_direct = false;            // FZ_NO_DIRECT: records / counters through D2H copies, never the kernels' stores into pinned memory
+    bool no_slot_and = false;          // FZ_NO_SLOT_AND: the filter's general slot form (shift + and) for every launch
+    int max_blocks = 0;                // FZ_MAX_BLOCKS=n: at most n n-gram blocks per scan launch
+    bool force_big_verify = false;     // FZ_FORCE_BIG_VERIFY: every stand-alone verification by fz_verify_big_kernel
+    bool no_wavefront = false;         // FZ_NO_WAVEFRONT: lane-per-candidate verification where lane-per-cell would run
+    bool no_wf_fuse = false;           // FZ_NO_WF_FUSE: budgets 5 .. 15 verified by the stand-alone kernel, not inside the scan
+    int wf32 = -1;                     // FZ_WF32=0 / 1: pin the fused lane-per-cell form off / on for budgets 8 .. 15 (default: by density)
+    bool gen_legacy = false;           // FZ_GEN_LEGACY: the generic automaton as fz_lp_kernel (one wave per hit, round 3's form)
+    bool gen_no_dedup = false;         // FZ_GEN_NO_DEDUP: no window table (every n-gram hit runs its automaton)
+    bool gen_direct = false;           // FZ_GEN_DIRECT: automaton records stored straight into pinned host memory (round 1)
+    bool gen_host_order = false;       // FZ_GEN_HOST_ORDER: the generic rows ordered by the host, not by fz_gen_order / scatter kernels
+    int gh_waves = 0;                  // FZ_GH_WAVES=1 / 2 / 4: waves per hit of fz_gen_hit_kernel
+    bool gh_no_bits = false;           // FZ_GH_NO_BITS: round 4's candidate step instead of the bit-parallel one
+    int cand_lds_max = 0;              // FZ_CAND_LDS_MAX=n: candidate lists beyond n entries live in HBM
+    bool group_best_exact = false;     // FZ_GROUP_BEST_EXACT: fz_group_best by the exact walk only
+    bool no_dev_threads = false;       // FZ_NO_DEV_THREADS: a multi-device context drives every device from the calling thread
+    int taper_steps = 4;               // FZ_TAPER_STEPS (0: no regions), FZ_TAPER_MIN, FZ_TAPER_WG_PER_CU: the scan grid's last round
+    double taper_min = 0.25;
+    int taper_wg_per_cu = 7;
+    bool no_rccl = false;              // FZ_NO_RCCL: behave like an install without librccl
+    std::string rccl_lib;              // FZ_RCCL_LIB=path: the collective library to dlopen first (tests: tests/libmock_rccl.so)
+    std::string rocm_path = "/opt/rocm";   // ROCM_PATH
+    // measurement / lab knobs (same results; they move work or change launch shapes)
+    bool trace = false;                // FZ_TRACE: per-phase host timings of a search on stderr
+    bool no_timing = false;            // FZ_NO_TIMING: contexts start without hipEvent timing of their kernels
+    bool dual_stream = false;          // FZ_DUAL_STREAM: contexts start with fz_set_streams(2)
+    bool no_ext_launch = false;        // FZ_NO_EXT_LAUNCH: events recorded behind the kernels instead of on their dispatch packets
+    bool gen_hi_stream = false;        // FZ_GEN_HI_STREAM: the generic automaton on a high-priority stream of its lane
+    bool no_spin = false;              // FZ_NO_SPIN: no hipDeviceScheduleSpin
+    bool stream_default_priority = false;   // FZ_STREAM_DEFAULT_PRIORITY: the scan streams at default instead of lowest priority
+    bool stream_nofill = false;        // FZ_STREAM_NOFILL: file streams without the reads (H2D + scan alone)
+    bool stream_trace = false;         // FZ_STREAM_TRACE: host time split of a file stream on stderr
+    long worker_spin_us = 1500;        // FZ_WORKER_SPIN_US: how long a device's worker thread spins before it sleeps
+    int fused_lds_kb = 0, fused_target_kb = 0, extra_lds_kb = 0;   // FZ_FUSED_LDS_KB, FZ_FUSED_TARGET_KB, FZ_EXTRA_LDS_KB: LDS shaping of the scan
+    int tiles_per_wg = 0, rounds = 0, wg_per_cu = 0;               // FZ_TILES_PER_WG, FZ_ROUNDS, FZ_WG_PER_CU: the scan grid
+    int lp_grid_per_cu = 24, gh_grid_per_cu = 0;                   // FZ_LP_GRID_PER_CU, FZ_GH_GRID_PER_CU: automaton grids
+};
+
+Switches read_switches() {
+        Switches v;
+        auto flag = [](const char *n) { return getenv(n) != nullptr; };
+        auto num = [](const char *n, int dflt) { const char *e = getenv(n); return e ? atoi(e) : dflt; };
+        v.no_direct = flag("FZ_NO_DIRECT"); v.no_slot_and = flag("FZ_NO_SLOT_AND"); v.max_blocks = num("FZ_MAX_BLOCKS", 0);
+        v.force_big_verify = flag("FZ_FORCE_BIG_VERIFY"); v.no_wavefront = flag("FZ_NO_WAVEFRONT"); v.no_wf_fuse = flag("FZ_NO_WF_FUSE");
+        v.wf32 = num("FZ_WF32", -1); v.gen_legacy = flag("FZ_GEN_LEGACY"); v.gen_no_dedup = flag("FZ_GEN_NO_DEDUP");
+        v.gen_direct = flag("FZ_GEN_DIRECT"); v.gen_host_order = flag("FZ_GEN_HOST_ORDER"); v.gh_waves = num("FZ_GH_WAVES", 0);
+        v.gh_no_bits = flag("FZ_GH_NO_BITS"); v.cand_lds_max = num("FZ_CAND_LDS_MAX", 0); v.group_best_exact = flag("FZ_GROUP_BEST_EXACT");
+        v.no_dev_threads = flag("FZ_NO_DEV_THREADS"); v.taper_steps = num("FZ_TAPER_STEPS", 4);
+        if (const char *e = getenv("FZ_TAPER_MIN")) v.taper_min = atof(e);
+        v.taper_wg_per_cu = num("FZ_TAPER_WG_PER_CU", 7); v.no_rccl = flag("FZ_NO_RCCL");
+        if (const char *e = getenv("FZ_RCCL_LIB")) v.rccl_lib = e;
+        if (const char *e = getenv("ROCM_PATH")) v.rocm_path = e;
+        v.trace = flag("FZ_TRACE"); v.no_timing = flag("FZ_NO_TIMING"); v.dual_stream = num("FZ_DUAL_STREAM", 0) != 0;
+        v.no_ext_launch = flag("FZ_NO_EXT_LAUNCH"); v.gen_hi_stream = flag("FZ_GEN_HI_STREAM"); v.no_spin = flag("FZ_NO_SPIN");
+        v.stream_default_priority = flag("FZ_STREAM_DEFAULT_PRIORITY"); v.stream_nofill = flag("FZ_STREAM_NOFILL");
+        v.stream_trace = flag("FZ_STREAM_TRACE");
+        if (const char *e = getenv("FZ_WORKER_SPIN_US")) v.worker_spin_us = atol(e);
+        v.fused_lds_kb = num("FZ_FUSED_LDS_KB", 0); v.fused_target_kb = num("FZ_FUSED_TARGET_KB", 0); v.extra_lds_kb = num("FZ_EXTRA_LDS_KB", 0);
+        v.tiles_per_wg = num("FZ_TILES_PER_WG", 0); v.rounds = num("FZ_ROUNDS", 0); v.wg_per_cu = num("FZ_WG_PER_CU", 0);
+        v.lp_grid_per_cu = num("FZ_LP_GRID_PER_CU", 24); v.gh_grid_per_cu = num("FZ_GH_GRID_PER_CU", 0);
+        return v;
+}
+
+Switches &switches_storage() { static Switches s = read_switches(); return s; }
+const Switches &sw() { return switches_storage(); }
+
 // FZ_TRACE=1: per-phase host timings of a search call on stderr (tuning aid)
 struct Trace {
     bool on;
     std::chrono::steady_clock::time_point t0, last;
-    Trace() : on(getenv("FZ_TRACE") != nullptr) { t0 = last = std::chrono::steady_clock::now(); }
+    Trace() : on(sw().trace) { t0 = last = std::chrono::steady_clock::now(); }
     void mark(const char *what) {
         if (!on) return;
         auto now = std::chrono::steady_clock::now();
@@ -63,7 +135,7 @@ thread_local std::string g_err;
 
 // FZ_NO_DIRECT=1 (test / lab knob): records and counters always come back through a D2H copy, never by the kernels' own
 // stores into the pinned staging buffer
-bool env_no_direct() { static const bool v = getenv("FZ_NO_DIRECT") != nullptr; return v; }
+bool env_no_direct() { return sw().no_direct; }
 
 int fail(int code, const char *fmt, ...) {
     char tmp[512];
@@ -226,7 +298,7 @@ struct DevWorkers {
     long spin_us = 1500;
 
     explicit DevWorkers(size_t n) {
-        if (const char *e = getenv("FZ_WORKER_SPIN_US")) spin_us = atol(e);
+        spin_us = sw().worker_spin_us;
         for (size_t i = 0; i < n; ++i) {
             W *w = new W();
             ws.push_back(w);
@@ -257,13 +329,23 @@ struct DevWorkers {
                 __builtin_ia32_pause();
             }
             seen = w->posted.load(std::memory_order_acquire);
-            w->rc = w->job();
-            if (w->rc) w->err = g_err;
+            // a job that throws (std::bad_alloc out of a result vector's resize) must not take the process down with
+            // std::terminate, nor leave wait() spinning on a worker that is gone: the error travels like any other
+            try {
+                w->rc = w->job();
+                if (w->rc) w->err = g_err;
+            } catch (const std::bad_alloc &) {
+                w->rc = FZ_ENOMEM; w->err = "out of memory on a device worker thread";
+            } catch (const std::exception &e) {
+                w->rc = FZ_EDEVICE; w->err = std::string("exception on a device worker thread: ") + e.what();
+            }
             w->done.store(seen, std::memory_order_release);
         }
     }
     void post(size_t i, std::function<int()> fn) {
         W *w = ws[i];
+        // one job at a time per worker: the previous one has been waited for (the slot is overwritten below)
+        assert(w->done.load(std::memory_order_acquire) == w->posted.load(std::memory_order_relaxed));
         w->job = std::move(fn);
         w->posted.fetch_add(1, std::memory_order_release);
         { std::lock_guard<std::mutex> g(w->mu); }
@@ -307,7 +389,7 @@ struct fz_ctx {
     // outgrows a wave's share of the candidate list or its match buffer is run again with fz_lp_kernel (one wave per hit),
     // and so are the next gen_multi_skip searches of the context (1, 2, 4 .. 64 after consecutive failures; a success
     // resets the back-off): inputs that always fail (dense repeats) pay a wasted launch now and then, not every time.
-    bool gen_multi = getenv("FZ_GEN_LEGACY") == nullptr;
+    bool gen_multi = !sw().gen_legacy;
     uint32_t gen_multi_skip = 0, gen_multi_backoff = 0;
     // Levenshtein budgets 8 .. 15 (32 lanes per candidate): verification inside the scan kernel (1) or in a kernel of its
     // own (0) — chosen by the candidate density the context's previous such search saw (enqueue_shard)
@@ -351,7 +433,7 @@ struct fz_ctx {
     std::vector<uint32_t> seg_order;
     // hipEvent timing of the kernels (fz_stats: filter_ms / verify_ms / device_ms).  One event record is one more packet
     // in front of the kernel and two hipEventElapsedTime calls behind it: fz_set_timing(ctx, 0) drops them.
-    bool timing = getenv("FZ_NO_TIMING") == nullptr;
+    bool timing = !sw().no_timing;
     // The spans are read from the events only when somebody asks (fz_stats / fz_device_ms): a hipEventElapsedTime call
     // costs ~5 us of host time, two or three of them sat between the completion of every search and its result.  The
     // references die with the next launch of the context (whose enqueue re-records the events).
@@ -361,7 +443,7 @@ struct fz_ctx {
     bool snapshot = false;
     uint64_t gcap = 4096;                        // records per rank the all-gather carries (follows the counts, on all ranks alike)
     // fz_set_streams: 2 = the younger of two fused searches in flight scans on a stream of its own (FZ_DUAL_STREAM=1 presets it)
-    int streams = []() { const char *e = getenv("FZ_DUAL_STREAM"); return e && atoi(e) != 0 ? 2 : 1; }();
+    int streams = sw().dual_stream ? 2 : 1;
     double last_gather_ms = 0;                   // host time of the last search's exchange step (all-gather + D2H + parse)
     // multi-device contexts: one host thread per device (enqueue, wait, collect and order its shard), and what the
     // shards of the search being collected left (rows_ready: every shard's rows are ordered, emit_matches only merges)
@@ -421,8 +503,7 @@ int cand_lists(DevState &d, uint32_t cand_cap, size_t fixed_lds, size_t &lds, ui
     if (fixed_lds > 150 * 1024) return fail(FZ_EUNSUPPORTED, "subsequence + window too long for the automaton kernel's LDS (%zu bytes)", fixed_lds);
     lds = fixed_lds + 2 * (size_t)cand_cap * sizeof(FzGCand);
     scratch = 0;
-    const char *knob = getenv("FZ_CAND_LDS_MAX");              // test knob: force the HBM lists at small sizes
-    const uint32_t lds_max = knob && atoi(knob) > 0 ? (uint32_t)atoi(knob) : kCandLdsMax;
+    const uint32_t lds_max = sw().cand_lds_max > 0 ? (uint32_t)sw().cand_lds_max : kCandLdsMax;   // (test knob: the HBM lists at small sizes)
     if (cand_cap <= lds_max && lds <= 160 * 1024) return FZ_OK;
     if (cand_cap > kCandMax) return fail(FZ_EUNSUPPORTED, "automaton candidate sets beyond %u entries", kCandMax);
     lds = fixed_lds;
@@ -587,10 +668,9 @@ uint32_t choose_launch_blocks(const uint8_t *p, const uint32_t *starts, uint32_t
                               uint32_t &hash_k, uint32_t &lut_shift) {
     const HashGeom hg(L);
     // FZ_MAX_BLOCKS=n (test knob): at most n blocks per launch, to exercise the multi-launch path
-    const char *cap_env = getenv("FZ_MAX_BLOCKS");
-    const uint32_t max_blocks = cap_env && atoi(cap_env) > 0 ? std::min<uint32_t>((uint32_t)atoi(cap_env), FZ_MAX_BLOCKS_PER_LAUNCH)
+    const uint32_t max_blocks = sw().max_blocks > 0 ? std::min<uint32_t>((uint32_t)sw().max_blocks, FZ_MAX_BLOCKS_PER_LAUNCH)
                                                              : FZ_MAX_BLOCKS_PER_LAUNCH;
-    static const bool no_sa = getenv("FZ_NO_SLOT_AND") != nullptr;     // test knob: never use the low-bits form
+    const bool no_sa = sw().no_slot_and;                               // test knob: never use the low-bits form
     const uint32_t want = std::min<uint32_t>(max_blocks, G - g0);
     uint32_t nblk = 0;
     // Pass 0: hash bits 2..6 as they are (lut_shift == 2: the kernel forms the slot address with one v_and; those
@@ -638,7 +718,7 @@ struct Search {
     bool fold = false;             // generic search: the device folds every hit's matches into (hull, best match) pairs
 };
 
-static const uint32_t kFusedLdsBudget = []() { const char *e = getenv("FZ_FUSED_LDS_KB"); int v = e ? atoi(e) : 0; return (uint32_t)(v > 0 ? v : 64) * 1024u; }();   // dynamic LDS per scan workgroup when verification is fused
+static const uint32_t kFusedLdsBudget = (uint32_t)(sw().fused_lds_kb > 0 ? sw().fused_lds_kb : 64) * 1024u;   // dynamic LDS per scan workgroup when verification is fused
 
 // Fields of FzScanArgs that every kernel of a search shares.
 void fill_common_args(FzScanArgs &fa, const Shard &sh, const Search &q) {
@@ -689,8 +769,8 @@ struct VerifyPlan {
 };
 
 VerifyPlan plan_verify(const Search &q) {
-    static const bool force_big = getenv("FZ_FORCE_BIG_VERIFY") != nullptr;     // test knob: every stand-alone verification by fz_verify_big_kernel
-    static const bool no_wf = getenv("FZ_NO_WAVEFRONT") != nullptr;
+    const bool force_big = sw().force_big_verify;                               // test knob: every stand-alone verification by fz_verify_big_kernel
+    const bool no_wf = sw().no_wavefront;
     VerifyPlan v;
     const uint32_t mpad = (q.m + 15u) & ~15u;
     const uint32_t win_dwords = (q.m + 2 * q.k + 6) / 4 + 1;
@@ -742,9 +822,9 @@ void plan_scan_regions(FzScanArgs &fa, uint64_t ntiles, uint64_t grid, uint32_t 
 // ... with the process-wide settings (FZ_TAPER_STEPS, default 4; FZ_TAPER_MIN, default 0.25; FZ_TAPER_WG_PER_CU, default 7 =
 // the workgroups of this kernel that are resident per CU).
 void plan_scan_regions(FzScanArgs &fa, uint64_t ntiles, uint64_t grid, uint32_t n_cus) {
-    static const int steps = []() { const char *e = getenv("FZ_TAPER_STEPS"); return e ? atoi(e) : 4; }();
-    static const double fmin = []() { const char *e = getenv("FZ_TAPER_MIN"); return e ? atof(e) : 0.25; }();
-    static const int t_per_cu = []() { const char *e = getenv("FZ_TAPER_WG_PER_CU"); return e ? atoi(e) : 7; }();
+    const int steps = sw().taper_steps;
+    const double fmin = sw().taper_min;
+    const int t_per_cu = sw().taper_wg_per_cu;
     plan_scan_regions(fa, ntiles, grid, n_cus, steps, fmin, t_per_cu);
 }
 
@@ -785,7 +865,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     // 3 rounds 0.2062, 6 rounds 0.2074, 8 rounds 0.2104 against 0.2121-0.2146 for 12 tiles (3.56 rounds); 2 GiB, 9 rounds
     // 0.3887 against 0.3989; 512 MiB, 2 rounds 0.1165 against 0.1182.  Long inputs keep 12 tiles per workgroup (4 GiB:
     // 0.7743 against 0.7791-0.7855 for 14-18 whole rounds and 0.802 for 8 tiles: the per-workgroup cost wins there).
-    static const int tiles_per_wg_env = []() { const char *e = getenv("FZ_TILES_PER_WG"); int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+    const int tiles_per_wg_env = sw().tiles_per_wg > 0 ? sw().tiles_per_wg : 0;
     const int tiles_per_wg = tiles_per_wg_env ? tiles_per_wg_env : 12;
     const uint64_t resident = (uint64_t)d.n_cus * 6;
     uint64_t max_grid = std::max<uint64_t>(resident, ntiles / tiles_per_wg);
@@ -794,8 +874,8 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
         max_grid = resident * rounds;
     }
     {   // lab knobs: FZ_ROUNDS=r -> a grid of r x (FZ_WG_PER_CU workgroups per CU): whole rounds of resident workgroups
-        static const int rounds = []() { const char *e = getenv("FZ_ROUNDS"); return e ? atoi(e) : 0; }();
-        static const int per_cu = []() { const char *e = getenv("FZ_WG_PER_CU"); int v = e ? atoi(e) : 0; return v > 0 ? v : 6; }();
+        const int rounds = sw().rounds;
+        const int per_cu = sw().wg_per_cu > 0 ? sw().wg_per_cu : 6;
         if (rounds > 0) max_grid = (uint64_t)d.n_cus * per_cu * rounds;
     }
     // the queue codes carry a bounded per-workgroup tile iteration
@@ -812,7 +892,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     // correspondingly more.
     plan_scan_regions(fa, ntiles, grid.x, (uint32_t)d.n_cus);
     if (q.mode == FZ_MODE_GENERIC && !with_verify) fa.gen_dedup = d.gen_dedup_arg;      // the scan fills the window table (run_generic)
-    static const bool force_big = getenv("FZ_FORCE_BIG_VERIFY") != nullptr;
+    const bool force_big = sw().force_big_verify;
     const VerifyPlan vp = plan_verify(q);
     {
         int rc = stage_pattern(d, fa, q.p, q.m, with_verify && vp.big);
@@ -831,7 +911,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     // Lanes that verify at once: all 64 while the staged windows stay small; fewer for long patterns
     // so that the scan keeps ~8 workgroups per CU resident (measured at m = 64, k = 5 on 1 GiB of text:
     // 64 lanes -> 31.6 KB LDS, 5 workgroups/CU, scan 0.540 ms; candidates are rare there anyway).
-    static const uint32_t target = []() { const char *e = getenv("FZ_FUSED_TARGET_KB"); int v = e ? atoi(e) : 0; return (uint32_t)(v > 0 ? v : 18) * 1024u; }();
+    const uint32_t target = (uint32_t)(sw().fused_target_kb > 0 ? sw().fused_target_kb : 18) * 1024u;
     fa.vlanes = 64;
     uint32_t fused_lds;
     if (sh.geom.seg_stride == 0) {
@@ -854,7 +934,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     // its own beyond that
     fa.fused = (with_verify && !force_big && q.m <= FZ_MAX_M && q.k <= FZ_MAX_K && fused_lds <= kFusedLdsBudget &&
                 (q.mode != FZ_MODE_LEV || q.k <= 4)) ? 1u : 0u;
-    static const bool no_wf_fuse = getenv("FZ_NO_WF_FUSE") != nullptr;          // test / measurement knob: the stand-alone kernel
+    const bool no_wf_fuse = sw().no_wf_fuse;                                    // test / measurement knob: the stand-alone kernel
     const uint32_t wf_fused_lds = mpad + FZ_TABLE_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fz_wf_fused_dwords(fa.win_dwords, (uint32_t)vp.gw), 0, 1, true);
     // (in-memory searches only: the segmented instances of this form spill registers — the file API keeps the kernel of its own)
     // 32 lanes per candidate (budgets 8 .. 15): the fused form is 7-14 % behind scan + stand-alone kernel where candidates
@@ -863,7 +943,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     // the hit list outgrows its buffer and the search runs twice).  Which one a text is cannot be told from the pattern:
     // the context remembers the candidate density of its last such search (collect_shard) and starts with the stand-alone
     // kernel; FZ_WF32=0 / 1 pins the choice.
-    static const int wf32_env = []() { const char *e = getenv("FZ_WF32"); return e ? atoi(e) : -1; }();
+    const int wf32_env = sw().wf32;
     const bool wf_candidate = !fa.fused && sh.geom.seg_stride == 0 && with_verify && !force_big && !no_wf_fuse && vp.want_wf && !vp.big && vp.gw <= 32 &&
                               q.m <= FZ_MAX_M && wf_fused_lds <= target + 4096;
     d.wf32_candidate = wf_candidate && vp.gw == 32;
@@ -884,7 +964,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     // the host), the start / completion events ride on the kernels' own dispatch packets (hipExtLaunchKernelGGL)
     // instead of two extra packets around them: fewer packets on the critical path of a synchronous call, and
     // filter_ms becomes the kernels' own span.
-    static const bool no_ext = getenv("FZ_NO_EXT_LAUNCH") != nullptr;
+    const bool no_ext = sw().no_ext_launch;
     const bool ext_events = !no_ext && copy_back && direct && !(with_verify && !fa.fused) && ntiles > 0 && G > 0;
     // ... and whenever the scan launches a kernel at all, its start / end events (ev[0], ev[1]: fz_stats' filter_ms) ride
     // on the first / last launch as well instead of two packets of their own in front of and behind the scan
@@ -919,7 +999,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
                 if (fa.H[b] == fa.H[c]) fa.flags |= FZ_FLAG_DUP_HASHES;
         ScanKernel kern = scan_kernel(nwin, dh, fa.fused != 0, sh.geom.seg_stride != 0, fa.lut_shift == 2, wf_fused ? vp.gw : 0);
         if (!kern) return fail(FZ_EUNSUPPORTED, "this (lab) build carries no scan kernel for nwin=%d dh=%d", nwin, dh);
-        static const uint32_t extra_lds = []() { const char *e = getenv("FZ_EXTRA_LDS_KB"); return e ? (uint32_t)atoi(e) * 1024u : 0u; }();
+        const uint32_t extra_lds = (uint32_t)sw().extra_lds_kb * 1024u;
         hipEvent_t ev_start = (attach && ctx->timing && g0 == 0) ? d.ev[0] : nullptr;
         hipEvent_t ev_stop = g0 + nblk >= G ? (ext_events ? d.ev[3] : (attach && ctx->timing) ? d.ev[1] : nullptr) : nullptr;
         if (ev_start || ev_stop)
@@ -1179,13 +1259,12 @@ struct RcclApi {
 const RcclApi *rccl_api() {
     static const RcclApi api = []() {
         RcclApi a;
-        if (getenv("FZ_NO_RCCL")) { a.error = "disabled by FZ_NO_RCCL"; return a; }      // test knob: an install without librccl
+        if (sw().no_rccl) { a.error = "disabled by FZ_NO_RCCL"; return a; }      // test knob: an install without librccl
         std::vector<std::string> names;
-        if (const char *e = getenv("FZ_RCCL_LIB")) names.push_back(e);
+        if (!sw().rccl_lib.empty()) names.push_back(sw().rccl_lib);
         names.push_back("librccl.so.1");
         names.push_back("librccl.so");
-        const char *rocm = getenv("ROCM_PATH");
-        names.push_back(std::string(rocm ? rocm : "/opt/rocm") + "/lib/librccl.so.1");
+        names.push_back(sw().rocm_path + "/lib/librccl.so.1");
         void *h = nullptr;
         for (const std::string &n : names) {
             h = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL);
@@ -1426,8 +1505,8 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             // once per window (fz_device.h: FzGenDedup; the scan fills the table as it lists the hits).  Where the rows are
             // finished on the device, where only (hull, best) pairs leave it, and for the flag-only search;
             // FZ_GEN_NO_DEDUP=1: every hit on its own (A/B, tests).
-            static const bool no_dedup = getenv("FZ_GEN_NO_DEDUP") != nullptr;
-            static const bool gen_direct0 = getenv("FZ_GEN_DIRECT") != nullptr, host_order0 = getenv("FZ_GEN_HOST_ORDER") != nullptr;
+            const bool no_dedup = sw().gen_no_dedup;
+            const bool gen_direct0 = sw().gen_direct, host_order0 = sw().gen_host_order;
             const bool dev_order0 = !gen_direct0 && !host_order0 && !q.any && !q.fold && seq->shards.size() == 1 && sh.geom.seg_stride == 0 &&
                                     !comm_multi_process(ctx);
             const bool dedup = !no_dedup && sh.geom.seg_stride == 0 && (dev_order0 || q.fold || q.any);
@@ -1465,12 +1544,12 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             // (Round 1 let the kernel store them straight into pinned host memory: 2.1e5 scattered 24-byte stores
             // cross PCIe at ~10 GB/s and the kernel cannot finish before they have drained — 0.49 ms for a kernel
             // whose work takes a fraction of that; FZ_GEN_DIRECT=1 restores that path.)
-            static const bool gen_direct = getenv("FZ_GEN_DIRECT") != nullptr;
+            const bool gen_direct = sw().gen_direct;
             // One shard, no segments: the rows are ordered and finished on the device (fz_gen_order_kernel,
             // fz_gen_scatter_kernel) and cross PCIe once, straight into the caller's buffer; FZ_GEN_HOST_ORDER=1
             // keeps the host's run ordering (emit_generic), which also serves searches with more than
             // FZ_GEN_ORDER_MAX hits, several shards and the file API's segments.
-            static const bool host_order = getenv("FZ_GEN_HOST_ORDER") != nullptr;
+            const bool host_order = sw().gen_host_order;
             const bool dev_order = !gen_direct && !host_order && !q.any && !q.fold && seq->shards.size() == 1 && sh.geom.seg_stride == 0 && !comm_multi_process(ctx);
             if (dev_order) {
                 rc = ensure_gen_rows(d);
@@ -1493,8 +1572,8 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
                                          : reinterpret_cast<FzGenRec *>(d.d_out + kHeaderBytes);
             static_assert(sizeof(FzGenRec) == sizeof(FzRec), "the generic records share the record buffer");
             // fz_gen_hit_kernel: four waves per hit, every wave a quarter of the list (in-memory searches with the lists in LDS)
-            static const uint32_t gh_waves_env = []() { const char *e = getenv("FZ_GH_WAVES"); return e ? (uint32_t)atoi(e) : 0u; }();
-            static const bool gh_no_bits = getenv("FZ_GH_NO_BITS") != nullptr;
+            const uint32_t gh_waves_env = (uint32_t)sw().gh_waves;
+            const bool gh_no_bits = sw().gh_no_bits;
             // the bit-parallel form (fz_gen_hit_kernel<W, true>: 64-bit equality words, flags as words, unconditional stores):
             // patterns of at most 64 characters and budgets of at most 32.  FZ_GH_NO_BITS=1: the round-4 step (A/B, tests);
             // FZ_GH_WAVES=1 / 2 / 4: waves per hit.  Default with the bit-parallel form: ONE — measured in round 5 (profiles/
@@ -1520,7 +1599,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             if (lds > 64 * 1024)
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(lp_kernel(FZ_LP_GENERIC_HIT, scratch != 0)),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            static const unsigned grid_per_cu = getenv("FZ_LP_GRID_PER_CU") ? (unsigned)atoi(getenv("FZ_LP_GRID_PER_CU")) : 24u;   // lab knob
+            const unsigned grid_per_cu = (unsigned)sw().lp_grid_per_cu;   // lab knob
             // (measured on configs[3b], 6144 hits: 16 / 24 / 32 workgroups per CU with 512-entry match buffers 0.325 /
             //  0.310 / 0.310 ms, with 128-entry ones 0.325 / 0.303 / 0.304 ms — once every hit is resident the kernel
             //  takes as long as its slowest hit)
@@ -1529,7 +1608,7 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             // slots the other lane's scan frees instead of waiting behind its grid.  configs[3b], two in flight: 0.364 ms
             // per search against 0.310 ms with the automaton on the lane's own low-priority stream — the automaton's
             // 4 171 waves then hold their CUs' registers for 160 us and the scan, which is what bounds the pair, starves.)
-            static const bool use_hi = getenv("FZ_GEN_HI_STREAM") != nullptr;
+            const bool use_hi = sw().gen_hi_stream;
             hipStream_t st2 = d.stream;
             if (phase == 1 && use_hi) {
                 if (!d.stream_hi) {
@@ -1544,10 +1623,10 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             }
             // the automaton's end event rides on its own launch; for a folded search in direct mode that event is also
             // the search's completion (ev[3]): no event packet of its own anywhere in such a search
-            static const bool no_ext = getenv("FZ_NO_EXT_LAUNCH") != nullptr;
+            const bool no_ext = sw().no_ext_launch;
             hipEvent_t lp_stop = no_ext ? nullptr : fold_direct ? d.ev[3] : ctx->timing ? d.ev[2] : nullptr;
             d.lp_end_event = fold_direct ? 3 : 2;
-            static const unsigned multi_per_cu_env = getenv("FZ_GH_GRID_PER_CU") ? (unsigned)atoi(getenv("FZ_GH_GRID_PER_CU")) : 0u;
+            const unsigned multi_per_cu_env = (unsigned)sw().gh_grid_per_cu;
             const unsigned multi_per_cu = multi_per_cu_env ? multi_per_cu_env : 32u;   // lab knob (configs[3b]: 16 -> 0.130 ms, 32 -> 0.104: every hit of the search needs a workgroup of its own)
             if (multi && lp_stop)
                 hipExtLaunchKernelGGL(gh, dim3(d.n_cus * multi_per_cu), dim3(64 * gh_waves), lds_multi, st2, nullptr, lp_stop, 0u,
@@ -1618,16 +1697,26 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
                 ctx->stats.ngram_hits += nh;
                 continue;
             }
-            static const bool gen_direct2 = getenv("FZ_GEN_DIRECT") != nullptr;
+            const bool gen_direct2 = sw().gen_direct;
             if (nh > d.hit_cap) { int rc = ensure_hits(d, nh + nh / 8 + 1024); if (rc) return rc; rerun = true; }
             if (nr > d.big_cap) { int rc = ensure_big(d, nr + nr / 8 + 1024); if (rc) return rc; if (gen_direct2) rerun = true; }
             if (d.fold_was_direct) {                          // pairs beyond the staging buffer were dropped: again, through d_out
                 if (nr > kHostRecs) { d.fold_direct = false; rerun = true; }
             } else if (q.fold && nr * 4 < kHostRecs) d.fold_direct = true;
             if (!gen_direct2 && !d.fold_was_direct && std::max(nr, nrows) > d.rec_cap) { int rc = ensure_recs(d, std::max(nr, nrows) + nrows / 8 + 1024); if (rc) return rc; rerun = true; }
-            static const bool host_order2 = getenv("FZ_GEN_HOST_ORDER") != nullptr;
+            const bool host_order2 = sw().gen_host_order;
             const bool rows_ready = !gen_direct2 && !host_order2 && !q.fold && seq->shards.size() == 1 && sh.geom.seg_stride == 0 &&
                                     nh <= FZ_GEN_ORDER_MAX && nrows <= d.gen_rows_cap && !comm_multi_process(ctx);
+            // Window table + device ordering: only the windows' LEADERS left automaton records, the members' rows exist on the
+            // device-ordered path alone.  If that path cannot be taken for this attempt (the row buffer is smaller than the row
+            // count: the record buffers were regrown between the launch and this collection, e.g. by the other lane's search),
+            // the host-ordered fallback below would silently miss the members' rows — run again, the launch sizes the row buffer
+            // by the record capacity (ensure_gen_rows).  Not reachable with today's capacity bookkeeping (rows <= rec_cap is
+            // checked above); kept as the invariant's enforcement.
+            if (d.dedup_used && !q.fold && !q.any && !rows_ready && !rerun && nh <= FZ_GEN_ORDER_MAX && nrows > d.gen_rows_cap) {
+                if (d.rec_cap < nrows) { int rc = ensure_recs(d, nrows + nrows / 8 + 1024); if (rc) return rc; }
+                rerun = true;
+            }
             const bool in_stage = q.fold && nr <= d.fold_copied && seq->shards.size() == 1;   // the pairs are in h_stage already
             if (q.fold) d.fold_guess = std::max<uint64_t>(4096, nr + nr / 4 + 256);
             if (!gen_direct2 && !rerun && !novf && nr && !rows_ready && !in_stage)
@@ -2003,7 +2092,7 @@ static int devstate_init(DevState &d) {
     HIP_TRY(hipSetDevice(d.device));
     // a search call is ~0.3 ms: spin instead of sleeping on the completion interrupt — on EVERY device of the context
     // (the flag is per device; refused with hipErrorSetOnActiveProcess once a device is in use: then it stays as it is)
-    if (!getenv("FZ_NO_SPIN")) (void)hipSetDeviceFlags(hipDeviceScheduleSpin);
+    if (!sw().no_spin) (void)hipSetDeviceFlags(hipDeviceScheduleSpin);
     (void)hipGetLastError();
     // Lowest priority: a different hardware queue than the default-priority streams of the rest of
     // the process, and the dispatcher prefers their workgroups.  Measured with RCCL on torch's
@@ -2011,7 +2100,7 @@ static int devstate_init(DevState &d) {
     // after it (250 us); the scan alone is not slower at low priority.
     int prio_least = 0, prio_greatest = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    static const bool default_prio = getenv("FZ_STREAM_DEFAULT_PRIORITY") != nullptr;
+    const bool default_prio = sw().stream_default_priority;
     HIP_TRY(hipStreamCreateWithPriority(&d.stream, hipStreamNonBlocking, default_prio ? 0 : prio_least));
     HIP_TRY(hipStreamCreateWithPriority(&d.stream_alt, hipStreamNonBlocking, default_prio ? 0 : prio_least));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d.d_hdr_alt), kHeaderBytes));
@@ -2088,7 +2177,7 @@ int fz_create(const int *device_ids, int n_devices, fz_ctx **out) {
         return fail(FZ_EDEVICE, "no HIP device available (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
     // a search call is ~0.3 ms: spin instead of sleeping on the completion interrupt (ignored if the
     // runtime was already initialised with other flags, e.g. by torch in a distributed job)
-    if (!getenv("FZ_NO_SPIN")) (void)hipSetDeviceFlags(hipDeviceScheduleSpin);
+    if (!sw().no_spin) (void)hipSetDeviceFlags(hipDeviceScheduleSpin);
     (void)hipGetLastError();
     std::vector<int> ids;
     if (!device_ids || n_devices <= 0) ids.push_back(0);
@@ -2110,7 +2199,7 @@ int fz_create(const int *device_ids, int n_devices, fz_ctx **out) {
         int rc = devstate_init(d);
         if (rc) { fz_destroy(ctx); return rc; }
     }
-    if (ctx->devs.size() > 1 && !getenv("FZ_NO_DEV_THREADS")) {
+    if (ctx->devs.size() > 1 && !sw().no_dev_threads) {
         ctx->workers = new (std::nothrow) DevWorkers(ctx->devs.size());
         if (!ctx->workers) { fz_destroy(ctx); return fail(FZ_ENOMEM, "out of memory"); }
     }
@@ -2983,6 +3072,10 @@ int fz_comm_barrier(fz_ctx *ctx) {
     return fz_comm_max_f64(ctx, &one);
 }
 
+// Test hook: read the FZ_* switches from the environment again (they are read once, on first use; a test that changes one
+// inside a running process calls this — no search may be in flight anywhere in the process).
+void fz_debug_reload_switches(void) { switches_storage() = read_switches(); }
+
 int fz_comm_backend(void) { return !rccl_api()->ok ? 0 : rccl_api()->stand_in ? 2 : 1; }
 
 int fz_comm_gather_ms(fz_ctx *ctx, double *ms) {
@@ -3680,7 +3773,7 @@ int fz_stream_read_fd(fz_stream *st, int fd, int64_t offset, int threads, uint64
         uint64_t n = 0;
         bool short_read = false;
         const auto tf = std::chrono::steady_clock::now();
-        static const bool nofill = getenv("FZ_STREAM_NOFILL") != nullptr;     // lab: the H2D + scan pipeline alone
+        const bool nofill = sw().stream_nofill;     // lab: the H2D + scan pipeline alone
         if (nofill) {
             struct stat sb;
             if (fstat(fd, &sb) != 0) return fail(FZ_EDEVICE, "fstat failed");
@@ -3710,7 +3803,7 @@ int fz_stream_finish(fz_stream *st, fz_match **out, uint32_t **seg, uint64_t *n)
     }
     int rc = stream_collect(st);
     if (rc) return rc;
-    if (getenv("FZ_STREAM_TRACE"))
+    if (sw().stream_trace)
         fprintf(stderr, "[fz_stream] %.1f MiB: fill %.2f ms, collect %.2f ms, launch %.2f ms, carry %.2f ms\n",
                 st->bytes_total / 1048576.0, st->t_fill, st->t_collect, st->t_launch, st->t_carry);
     void *mem = nullptr, *smem_ = nullptr;
@@ -4044,7 +4137,7 @@ static int group_best_exact(const fz_match *in, uint64_t n, fz_match **out, uint
 int fz_group_best(const fz_match *in, uint64_t n, fz_match **out, uint64_t *n_out) {
     if (!out || !n_out || (!in && n)) return fail(FZ_EINVAL, "null argument");
     *out = nullptr; *n_out = 0;
-    static const bool no_fast = getenv("FZ_GROUP_BEST_EXACT") != nullptr;      // test knob
+    const bool no_fast = sw().group_best_exact;                                // test knob
     if (n < 32 || n > 0x7fffffffull || no_fast) return group_best_exact(in, n, out, n_out);
     auto better = [](const fz_match &a, const fz_match &b) {
         const int64_t la = a.end - a.start, lb = b.end - b.start;
@@ -4257,12 +4350,5 @@ int fz_stats(fz_ctx *ctx, fz_stats_t *out) {
 
 void fz_free(void *p) { release_out(p); }
 
-#ifdef FZ_LAB_LPTIME
-// lab builds only (benchmarks/lab_build.sh ... -DFZ_LAB_LPTIME; not part of the C-ABI): the per-hit time stamps of the
-// automaton kernels of the last generic search
-int fz_lab_lp_read(unsigned long long *out, uint64_t n_words) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(fz_lab_lp), std::min<uint64_t>(n_words, 16384ull * 4) * 8, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
-}
-#endif
 
 }  // extern "C"

@@ -86,8 +86,17 @@ def _remap_items(subsequence, sequence):
         p = np.asarray(subsequence)
         t = np.asarray(sequence)
         if p.dtype.kind in 'iub' and t.dtype.kind in 'iub' and p.ndim == 1 and t.ndim == 1:
-            p = p.astype(np.int64, copy=False) if p.dtype.kind != 'u' or p.dtype.itemsize < 8 else p
-            t = t.astype(p.dtype, copy=False)
+            # one common integer type that holds every value of both arrays WITHOUT wrapping (uint64 values >= 2**63 do not
+            # fit int64 and negative values do not fit uint64: casting would code 2**64 - 1 as -1 and report a match the
+            # reference's == does not see) — otherwise the general form below
+            big_p = p.dtype == np.uint64 and len(p) and int(p.max()) > np.iinfo(np.int64).max
+            big_t = t.dtype == np.uint64 and len(t) and int(t.max()) > np.iinfo(np.int64).max
+            if big_p or big_t:
+                if (p.dtype.kind == 'i' and len(p) and int(p.min()) < 0) or (t.dtype.kind == 'i' and len(t) and int(t.min()) < 0):
+                    raise OverflowError('no common integer type')
+                p, t = p.astype(np.uint64, copy=False), t.astype(np.uint64, copy=False)
+            else:
+                p, t = p.astype(np.int64, copy=False), t.astype(np.int64, copy=False)
             symbols = np.unique(p)
             if len(symbols) > 255:
                 raise UnsupportedSearch('subsequences with more than 255 distinct symbols are not supported')

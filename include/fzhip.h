@@ -280,6 +280,10 @@ int  fz_stream_read_fd(fz_stream *st, int fd, int64_t offset, int threads, uint6
 int  fz_stream_finish(fz_stream *st, fz_match **out, uint32_t **seg, uint64_t *n);
 void fz_stream_close(fz_stream *st);
 
+/* Test hook: the library reads its FZ_* environment switches (none is needed to use it) once,
+ * on first use; this reads them again.  For tests that flip a switch inside one process; nothing may be in flight. */
+void fz_debug_reload_switches(void);
+
 /* Test hook (no device needed): how the scan would split the n-gram blocks of pattern p (block
  * length L, blocks at 0, L, 2L, ...) into launches.  out[4i .. 4i+3] = first block, number of blocks,
  * hash multiplier, slot shift of launch i (at most `cap` launches are written); *n_launches = total. */

@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 
 import oracle  # noqa: E402
 from fuzzysearch_amd import distributed as fzd  # noqa: E402
-from tests import workloads  # noqa: E402
+from tests import torch_glue, workloads  # noqa: E402
 
 
 class OutRec(ctypes.Structure):
@@ -46,7 +46,7 @@ def main():
             workloads.apply_plants(seq, 0, plants, pattern)
         p, halo = pattern.tobytes(), m + k
         shard = seq[lo:hi].copy()                      # all this rank keeps of the sequence
-        left, right = fzd.exchange_halos(shard, halo)
+        left, right = torch_glue.exchange_halos(shard, halo)
         assert bytes(left) == seq[max(0, lo - halo):lo].tobytes() and bytes(right) == seq[hi:hi + halo].tobytes()
         buf = np.concatenate([left, shard, right])
         buf_off = lo - len(left)
@@ -58,7 +58,7 @@ def main():
         c = L.emul_search(1, p, m, fake.tobytes(), n, k, buf_off, len(buf), lo, hi, out, cap)
         assert 0 <= c <= cap
         mine = [(out[i].start, out[i].end, out[i].dist, out[i].block) for i in range(c)]
-        merged = fzd.allgather_matches(mine)
+        merged = torch_glue.allgather_matches(mine)
         exp = oracle.lev_ngrams_raw(p, seq.tobytes(), k)
         if case == 0 and n % world == 0:
             found = {(int(a), int(b), int(c)) for (a, b, c, _g) in merged}

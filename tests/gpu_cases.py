@@ -184,10 +184,21 @@ def main(argv):
         h = eng.upload(seq)
         dig = hashlib.sha1()
         n_rec = 0
-        for rows in (eng.lev_ngrams(h, p, 2, as_array=True), eng.search_exact(h, p, as_array=True),
+        lev = eng.lev_ngrams(h, p, 2, as_array=True)
+        for rows in (lev, eng.search_exact(h, p, as_array=True),
                      eng.subs_ngrams(h, p, 2, as_array=True), eng.lev_ngrams(h, workloads.dna(36, 9).tobytes(), 5, as_array=True)):
             dig.update(rows.tobytes())
             n_rec += len(rows)
+        # ... and the END of the buffer — where the tapered workgroups of the grid's last resident round work — against the
+        # ORACLE, so that whichever grid form this process runs (no regions, the default taper, a steep one) is held against
+        # the reference's algorithm and not only against another run of this library: the oracle on the last 64 MiB, rows
+        # that start at least 64 bytes behind the cut (their windows do not reach across it), shifted, in stream order
+        import oracle
+        tail = 64 << 20
+        off = len(seq) - tail
+        want = [(s_ + off, e_ + off, d_, g_) for (s_, e_, d_, g_) in oracle.lev_ngrams_raw(p, seq[off:].tobytes(), 2) if s_ >= 64]
+        got = [tuple(int(x) for x in r) for r in lev.tolist() if int(r[0]) >= off + 64]
+        assert got == want and len(want) > 30, (len(got), len(want))
         h.release()
         eng.close()
         print("OK %d %d %d" % (n, n_rec, int(dig.hexdigest()[:12], 16)))

@@ -41,6 +41,7 @@ def test_sharded_search_allgather_equals_unsharded(world, emul_so):
 def test_shard_bounds_and_merge():
     import numpy as np
     from fuzzysearch_amd import distributed as fzd
+    from tests import torch_glue
     for n in (0, 1, 7, 100, 1 << 20):
         for world in (1, 2, 3, 8):
             b = [fzd.shard_bounds(n, world, r) for r in range(world)]
@@ -67,7 +68,7 @@ def test_shard_bounds_and_merge():
             parts.append(rows)
             base += 1000
         exp = fzd.merge_rank_streams(parts)
-        got = fzd.merge_rank_arrays([fzd._as_match_array(p) for p in parts])
+        got = torch_glue.merge_rank_arrays([torch_glue._as_match_array(p) for p in parts])
         assert [tuple(x) for x in got.tolist()] == [tuple(x) for x in exp.tolist()]
 
 

@@ -97,3 +97,41 @@ def test_beyond_4gib_indices(engine):
     assert got_tail == [r for r in exp_tail if r[0] >= margin]
     assert len(planted) >= 200 and len(got_tail) >= len(planted)
     assert any(s == (1 << 32) - 10 and e == (1 << 32) + 10 and d == 0 for (s, e, d, g) in got)
+
+
+def test_has_near_match_leaves_a_4gib_scan_early(engine):
+    """has_near_match_* (substitutions_only.py:218-233 returns at the first match): a match in the first MiB of a 4 GiB
+    sequence answers in a fraction of a full scan — workgroups that start after a record has been counted skip their tiles
+    (fz_scan_kernel: the FZ_FLAG_ANY check), so the launch costs about one workgroup life instead of the whole buffer.
+    Same flag, no match: the whole buffer is scanned and the answer is False."""
+    import time
+    n = 4 << 30
+    seq = np.empty(n, dtype=np.uint8)
+    for i in range(4):
+        seq[i << 30:(i + 1) << 30] = workloads.dna(1 << 30, 700 + i)
+    pattern = workloads.text65(24, 5)                   # letters a DNA sequence does not have: no match unless planted
+    p = pattern.tobytes()
+    h = engine.upload(seq)
+    del seq
+
+    def timed(fn, reps):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r = fn()
+        return (time.perf_counter() - t0) / reps, r
+    t_full, none = timed(lambda: engine.subs_ngrams_any(h, p, 2), 10)
+    assert none is False
+    h.release()
+    seq2 = np.empty(n, dtype=np.uint8)
+    for i in range(4):
+        seq2[i << 30:(i + 1) << 30] = workloads.dna(1 << 30, 700 + i)
+    seq2[500000:500000 + len(pattern)] = pattern
+    h2 = engine.upload(seq2)
+    del seq2
+    t_hit, found = timed(lambda: engine.subs_ngrams_any(h2, p, 2), 10)
+    t_gen, found_g = timed(lambda: engine.generic_ngrams_any(h2, p, 2, 1, 1, 2), 10)
+    h2.release()
+    assert found is True and found_g is True
+    assert t_hit < 0.2 * t_full, (t_hit, t_full)
+    assert t_gen < 0.35 * t_full, (t_gen, t_full)       # (scan + automaton launch behind it)

@@ -10,6 +10,11 @@ from tests import workloads
 pytestmark = pytest.mark.gpu
 
 
+def _reload_switches():
+    from fuzzysearch_amd import _native
+    _native.load_library().fz_debug_reload_switches()
+
+
 def _rand_case(rnd, max_n=300, max_m=24, max_k=4):
     sigma = rnd.choice([2, 2, 3, 4, 4, 20])
     alpha = bytes(rnd.sample(range(33, 127), sigma))
@@ -245,11 +250,13 @@ def test_blocks_split_over_several_launches(engine, monkeypatch):
     h = engine.upload(t)
     for cap in ("1", "2"):
         monkeypatch.setenv("FZ_MAX_BLOCKS", cap)
+        _reload_switches()
         for p, k in pats:
             assert engine.lev_ngrams(h, p, k) == oracle.lev_ngrams_raw(p, t, k)
             assert engine.subs_ngrams(h, p, k) == oracle.subs_ngrams_raw(p, t, k)
         assert engine.stats()["filter_launches"] >= 2
     monkeypatch.delenv("FZ_MAX_BLOCKS")
+    _reload_switches()
     h.release()
 
 
@@ -309,11 +316,13 @@ def test_automaton_candidate_lists_in_hbm(engine, monkeypatch):
     h, h_ok = engine.upload(t), engine.upload(t_ok)
     want_ok = oracle.generic_ngrams_raw(p_ok, t_ok, 2, 1, 1, 2)
     monkeypatch.setenv("FZ_CAND_LDS_MAX", "16")
+    _reload_switches()
     assert engine.generic_ngrams(h, p, 3, 3, 3, 3) == oracle.generic_ngrams_raw(p, t, 3, 3, 3, 3)
     assert engine.generic_ngrams(h_ok, p_ok, 2, 1, 1, 2) == want_ok
     assert engine.lev_lp(h, p[:8], 3) == oracle.lev_lp_raw(p[:8], t, 3)
     assert engine.generic_lp(h, p[:8], 2, 2, 2, 3) == oracle.generic_lp_raw(p[:8], t, 2, 2, 2, 3)
     monkeypatch.delenv("FZ_CAND_LDS_MAX")
+    _reload_switches()
     assert engine.generic_ngrams(h_ok, p_ok, 2, 1, 1, 2) == want_ok
     assert engine.generic_ngrams(h, p, 3, 3, 3, 3) == oracle.generic_ngrams_raw(p, t, 3, 3, 3, 3)
     h.release(); h_ok.release()
@@ -576,7 +585,10 @@ def test_multi_device_context_on_one_gpu(dev_threads, monkeypatch):
     from fuzzysearch_amd import _native
     if not dev_threads:
         monkeypatch.setenv("FZ_NO_DEV_THREADS", "1")
+    _reload_switches()                          # (the library reads its switches once; see fz_debug_reload_switches)
     eng = _native.Engine([0, 0, 0])
+    monkeypatch.delenv("FZ_NO_DEV_THREADS", raising=False)
+    _reload_switches()
     rnd = random.Random(51)
     for n in (0, 5, 100, 5000, 1 << 20):
         seq = workloads.dna(n, 500 + n % 97)

@@ -293,10 +293,11 @@ def test_wire_format_pack_and_merge_round_trip():
     random rank streams in reference order, header-only overflow signalling, rejected records."""
     import ctypes
     import numpy as np
-    from fuzzysearch_amd import distributed as fzd
+    from fuzzysearch_amd import distributed as fzd  # noqa: F401
+    from tests import torch_glue
     lib = _native.load_library()
     rnd = random.Random(9)
-    H = fzd.WIRE_HEADER_ROWS
+    H = torch_glue.WIRE_HEADER_ROWS
     for _ in range(100):
         world, nblocks, cap = rnd.randint(1, 6), rnd.randint(1, 5), rnd.choice([4, 16, 64])
         rows = H + cap
@@ -309,11 +310,11 @@ def test_wire_format_pack_and_merge_round_trip():
                     st = base + rnd.randint(0, 400)
                     rec.append((st, st + rnd.randint(0, 30), rnd.randint(0, 7), g))
             rec.sort(key=lambda x: (x[3], x[0], x[1]))
-            arr = fzd._as_match_array(rec) if rec else np.empty(0, dtype=fzd.MATCH_DTYPE)
+            arr = torch_glue._as_match_array(rec) if rec else np.empty(0, dtype=torch_glue.MATCH_DTYPE)
             parts.append(rec)
             _native._check(lib.fz_wire_pack(arr.ctypes.data, len(arr), cap, recv[r].ctypes.data))
             base += 1000
-        out = np.empty(world * cap, dtype=fzd.MATCH_DTYPE)
+        out = np.empty(world * cap, dtype=torch_glue.MATCH_DTYPE)
         total, top = ctypes.c_uint64(), ctypes.c_uint64()
         _native._check(lib.fz_wire_merge(recv.ctypes.data, world, rows, cap, out.ctypes.data, len(out),
                                          ctypes.byref(total), ctypes.byref(top)))
@@ -322,7 +323,7 @@ def test_wire_format_pack_and_merge_round_trip():
             continue                                              # the caller would re-gather with a larger capacity
         exp = [x for g in range(nblocks) for p in parts for x in p if x[3] == g]
         assert [tuple(x) for x in out[:total.value].tolist()] == exp
-    bad = fzd._as_match_array([(10, 5, 0, 0)])                    # end < start cannot be encoded
+    bad = torch_glue._as_match_array([(10, 5, 0, 0)])                    # end < start cannot be encoded
     assert lib.fz_wire_pack(bad.ctypes.data, 1, 4, np.zeros((H + 4, 2), dtype=np.int64).ctypes.data) != 0
 
 
@@ -680,3 +681,38 @@ def test_scan_regions_partition_tiles_and_workgroups():
         if min(nw for (_w, nw, _t, _e) in regs) >= 64:          # (rounding: the last group takes what is left, within a tile per workgroup)
             assert all(a >= b - 1.0 for a, b in zip(shares, shares[1:]))
     assert tapered > 300
+
+
+def test_symbol_remapping_of_integer_items_never_wraps():
+    """engine._remap_items codes list / tuple inputs for the kernels (every distinct subsequence item -> 1..255, anything else
+    -> 0).  Its vectorised integer path must agree with Python's == on every pair of items: uint64 values >= 2**63 next to
+    negative values used to be cast to one dtype and wrap (2**64 - 1 coded as -1: a match the reference does not see)."""
+    import numpy as np
+    rm = engine._remap_items
+
+    def check(sub, seq):
+        """The coding is any relabelling that keeps every comparison: code(sub[i]) == code(seq[j]) iff sub[i] == seq[j]
+        (and likewise inside the subsequence), nonzero codes for subsequence items."""
+        ps, pt = rm(sub, seq)
+        sub, seq = list(sub), list(seq)
+        assert len(ps) == len(sub) and len(pt) == len(seq) and all(c != 0 for c in ps)
+        for i, a in enumerate(sub):
+            for j, b in enumerate(sub):
+                assert (ps[i] == ps[j]) == bool(a == b), (sub, seq)
+            for j, b in enumerate(seq):
+                assert (ps[i] == pt[j]) == bool(a == b), (sub, seq, i, j)
+        for j, b in enumerate(seq):
+            if pt[j] == 0:
+                assert all(not (a == b) for a in sub), (sub, seq)
+    cases = [([2 ** 64 - 1], [-1, 5]), ([-1], [2 ** 64 - 1, -1]), ([2 ** 64 - 1, 7], [2 ** 64 - 1, 5, 7, 2 ** 63]),
+             ([1, 2, 3], [3, 2, 1, 9]), ([2 ** 63], [-2 ** 63, 2 ** 63]), ([0, -5, 5], [5, -5, 0, 2 ** 40]), ([True, 2], [1, 2, 0])]
+    for sub, seq in cases:
+        check(sub, seq)
+    assert rm(np.array([2 ** 64 - 1], dtype=np.uint64), np.array([-1, 5], dtype=np.int64)) == (b"\x01", b"\x00\x00")
+    assert rm(np.array([3, 4], dtype=np.uint8), np.array([4, 3, 200], dtype=np.int16)) == (b"\x01\x02", b"\x02\x01\x00")
+    rnd = random.Random(4)
+    for _ in range(300):
+        pool = [rnd.choice([0, 1, -1, 2 ** 63 - 1, 2 ** 63, 2 ** 64 - 1, -2 ** 63, rnd.randint(-9, 9)]) for _ in range(6)]
+        sub = [rnd.choice(pool) for _ in range(rnd.randint(1, 5))]
+        seq = [rnd.choice(pool) for _ in range(rnd.randint(0, 12))]
+        check(sub, seq)
