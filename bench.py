@@ -478,11 +478,24 @@ def main_multi_device(args):
             ref_handle = ref_engine.upload(buf[:shard_bytes])
     t_build = time.perf_counter() - t_build
     rccl_ranks = 0
+    collective_error = None
     if collective:
-        with stdout_to_stderr():
-            engine.comm_init_all()                               # ncclCommInitAll: every device of the context = one rank
-            first_coll = engine.lev_ngrams(handle, p, k, as_array=True)      # (RCCL sets its channels up on first use)
-        rccl_ranks = engine.comm_info()[0]
+        try:
+            with stdout_to_stderr():
+                engine.comm_init_all()                           # ncclCommInitAll: every device of the context = one rank
+                first_coll = engine.lev_ngrams(handle, p, k, as_array=True)      # (RCCL sets its channels up on first use)
+            rccl_ranks = engine.comm_info()[0]
+        except Exception as exc:  # noqa: BLE001
+            # a node whose RCCL cannot set this communicator up (no peer access, a missing library) still gets its scaling
+            # number: the same shards searched without the collective, per-device record lists merged on the host — and the
+            # line says so (`rccl_ranks` 0, `collective_error`)
+            collective_error = "%s: %s" % (type(exc).__name__, exc)
+            sys.stderr.write("bench.py: the collective form is not available (%s); running the host-merged form\n" % collective_error)
+            try:
+                engine.comm_destroy()
+            except Exception:  # noqa: BLE001
+                pass
+            collective = False
 
     first = engine.lev_ngrams(handle, p, k, as_array=True)
     t_settle = time.perf_counter()
@@ -566,9 +579,11 @@ def main_multi_device(args):
                                  "all-gather of step i runs next to the scan of step i+1" if collective else
                                  "per-device record lists merged on the host; no collective (%s)"
                                  % ("the devices listed are not distinct: RCCL needs one rank per GPU" if not (distinct or stand_in)
+                                    else "the communicator could not be set up: see collective_error" if collective_error
                                     else "FZ_BENCH_NO_COLLECTIVE=1")))},
         "rccl_ranks": rccl_ranks,
         "collective_library": _native.Engine.comm_backend() if collective else None,
+        "collective_error": collective_error,
         "allgather_ms": None if not gather else round(float(np.mean(gather)), 4),
         "value_no_collective": round(value, 2) if no_coll is None else no_coll["value"],
         "no_collective_ms_per_step": (round(elapsed / args.steps * 1e3, 4) if no_coll is None else no_coll["ms_per_step"]),

@@ -55,3 +55,11 @@ def test_launcher_form_with_one_rank():
                "--steps", "20", "--warmup", "5", "--no-cpu-baseline")
     assert d["rccl_ranks"] == 1 and d["allgather_ms"] > 0 and d["value_no_collective"] > 0
     assert d["scaling_ref_1gpu"]["value"] > 0
+
+
+def test_collective_form_unavailable_falls_back_to_the_host_merged_form():
+    """A node whose collective library cannot be loaded (FZ_NO_RCCL=1 stands for it) still gets its line: the same shards,
+    per-device record lists merged on the host, `rccl_ranks` 0 and the reason in `collective_error`."""
+    d = _bench({"FZ_BENCH_FORCE_COLLECTIVE": "1", "FZ_NO_RCCL": "1"}, "--gpus", "1", "--mib", "128", "--steps", "10", "--warmup", "3", "--no-cpu-baseline")
+    assert d["rccl_ranks"] == 0 and d["allgather_ms"] is None and "RCCL is not available" in d["collective_error"]
+    assert d["value"] > 0 and d["stream_in_reference_order"] is True and d["value_no_collective"] == d["value"]

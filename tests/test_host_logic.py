@@ -435,11 +435,12 @@ def test_no_kernel_spills_to_scratch():
     assert len(scan) == 60
     assert len(rows) >= 60 and any("fz_gen_hit_kernel" in k for k in rows) and any("fz_verify_kernel" in k for k in rows)
     for name, r in rows.items():
-        # round 4: EVERY kernel (fz_verify_kernel had 232 B of scratch and 57 spilled VGPRs) — except the tiled Levenshtein
-        # automaton of the short-pattern fallback, which keeps the 20-byte successor array of the struct form of its step
-        # (fz_kernels.h says why the slot form is not used there)
-        allowed = 32 if "fz_lp_kernelILi2E" in name else 0
-        assert int(r["scratch"]) <= allowed and int(r["vgpr_spill"]) == 0, (name, r)
+        # round 4: EVERY kernel (fz_verify_kernel had 232 B of scratch and 57 spilled VGPRs); round 5: the tiled Levenshtein
+        # automaton as well (its step's slot form, kept out of the kernel by a compiler bug in round 4, now has a loop shape
+        # hipcc compiles correctly: fz_device.h, profiles/r05_levlp_miscompile.txt)
+        assert int(r["scratch"]) == 0 and int(r["vgpr_spill"]) == 0, (name, r)
+    bits = [v for k, v in rows.items() if "fz_gen_hit_kernelILj1ELb1EE" in k]
+    assert len(bits) == 1 and int(bits[0]["vgprs"]) <= 72          # the bit-parallel automaton: one wave per hit, 7 waves per SIMD fit
     headline = [v for k, v in scan.items() if "ILi2ELi3ELb1ELb0ELb1ELi0EE" in k]
     assert len(headline) == 1 and int(headline[0]["occupancy"]) == 7 and int(headline[0]["vgprs"]) <= 72
 
