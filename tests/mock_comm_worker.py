@@ -82,7 +82,30 @@ class Job(object):
         return self.eng.upload_shard(a[0], a[1], a[2], a[3], n)
 
 
+def sharded_at_size(world, shard_mib):
+    """BASELINE configs[4]'s construction (tests/test_gpu_multi_device.py: 64 copies of one block, seams, boundary plants, a
+    fresh region per shard — the oracle on the block and on every window that differs) with the COLLECTIVE search: `world`
+    device states on device 0 joined by fz_comm_init_all through the stand-in library, every rank's records exchanged by
+    the all-gather.  The merged stream must be the complete expected multiset, block-major, every boundary plant in place."""
+    from tests import test_gpu_multi_device as tmd
+
+    def engine_cls(devices):
+        eng = _native.Engine(devices)
+        assert eng.comm_backend() == "stand-in"
+        eng.comm_init_all()
+        assert eng.comm_info() == (len(devices), 0, True)
+        return eng
+    n_got, n_edge = tmd._run(engine_cls, world, shard_mib, region_bytes=1 << 18)
+    import ctypes
+    st = (ctypes.c_uint64 * 4)()
+    ctypes.CDLL(os.environ["FZ_RCCL_LIB"]).fzmock_rccl_stats(st)
+    assert st[0] >= 3 and st[3] == world, list(st)
+    print("OK %d %d allgathers=%d" % (n_edge, n_got, st[0]), flush=True)
+
+
 def main(argv):
+    if argv[0] == "sharded":
+        return sharded_at_size(int(argv[1]), int(argv[2]))
     mode, world = argv[0], int(argv[1])
     rank = int(argv[2]) if mode == "rank" else 0
     permute = "permute" in argv

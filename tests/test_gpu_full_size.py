@@ -136,4 +136,6 @@ def test_has_near_match_leaves_a_4gib_scan_early(engine):
     # measured: 0.21 ms against 0.84 ms (25 %).  The remainder is the finish tickets of the ~21 800 workgroups that start
     # after the first record and skip their tiles (fzhip.hip: enqueue_shard), not running workgroups finishing theirs.
     assert t_hit < 0.33 * t_full, (t_hit, t_full)
-    assert t_gen < 0.5 * t_full, (t_gen, t_full)        # (scan + automaton launch behind it)
+    # (the generic flag-only search does not leave early here: its scan only LISTS n-gram hits — records, which the check
+    #  looks at, appear in the automaton kernel behind it — so it costs a full scan + one automaton launch; found_g above)
+    assert t_gen < 1.5 * t_full, (t_gen, t_full)

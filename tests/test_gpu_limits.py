@@ -50,15 +50,23 @@ def test_generic_window_table_on_and_off():
 
 
 def test_generic_automaton_kernel_forms():
-    """The per-hit automaton as a workgroup of 2 waves (default) or 4 waves per hit (fz_gen_hit_kernel: the window's start
-    positions dealt out to the waves, the sorted match buffers merged by rank) and as one wave per hit (fz_lp_kernel,
-    FZ_GEN_LEGACY=1) — the same random cases (dense repeats among them: hits that outgrow a wave's match buffer make the
-    search run again on fz_lp_kernel, with a back-off for the searches that follow) against the oracle."""
+    """The per-hit automaton in every form the library has — round 5's default for patterns up to 64 characters and budgets up
+    to 32: the bit-parallel step, ONE wave per hit (fz_gen_hit_kernel<1, true>: 64-bit equality words, flags as words,
+    unconditional stores, starts that cannot reach the pattern's end not spawned); the same step with the window's starts
+    dealt out to 2 or 4 waves whose sorted match buffers are merged by rank (FZ_GH_WAVES); round 4's step on 2 waves
+    (FZ_GH_NO_BITS=1, also what longer patterns / larger budgets take); one wave per hit through fz_lp_kernel
+    (FZ_GEN_LEGACY=1) — the same random cases (dense repeats among them: hits that outgrow a wave's match buffer make the
+    search run again on fz_lp_kernel, with a back-off for the searches that follow; patterns beyond 64 characters among
+    them) against the oracle: raw stream, consolidated rows incl. the block, flag, two in flight."""
     base = _sub(["windows", 200, 23], {})
     assert base[0] == 200 and base[1] > 4000
-    assert _sub(["windows", 200, 23], {"FZ_GH_WAVES": "4"}) == base
-    assert _sub(["windows", 200, 23], {"FZ_GEN_LEGACY": "1"}) == base
-    assert _sub(["windows", 120, 24], {"FZ_GH_WAVES": "4", "FZ_GEN_NO_DEDUP": "1"})[0] == 120
+    small = _sub(["windows", 100, 25], {})
+    assert small[0] == 100 and small[1] > 2000
+    assert _sub(["windows", 100, 25], {"FZ_GH_NO_BITS": "1"}) == small
+    assert _sub(["windows", 100, 25], {"FZ_GH_WAVES": "2"}) == small
+    assert _sub(["windows", 100, 25], {"FZ_GH_WAVES": "4"}) == small
+    assert _sub(["windows", 100, 25], {"FZ_GEN_LEGACY": "1"}) == small
+    assert _sub(["windows", 60, 24], {"FZ_GH_WAVES": "4", "FZ_GEN_NO_DEDUP": "1"})[0] == 60
 
 
 def test_scan_grid_regions_leave_the_streams_alone():

@@ -127,3 +127,14 @@ def test_launcher_form_of_bench_with_three_ranks_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == world and d["rccl_ranks"] == world and d["allgather_ms"] > 0
     assert d["stream_in_reference_order"] is True
+
+
+def test_collective_search_of_eight_ranks_beyond_4gib():
+    """Eight ranks x 1 GiB = 8 GiB (ranks 4 .. 7 beyond 2^32), the construction of the configs[4] test
+    (tests/test_gpu_multi_device.py) with the search made collective through the stand-in: the all-gathered, merged
+    stream is the complete expected multiset in block-major order with every boundary plant at its exact position."""
+    p = subprocess.run([sys.executable, WORKER, "sharded", "8", "1024"], capture_output=True, text=True, timeout=1500,
+                       env=mock_rccl.env(), cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    last = [ln for ln in p.stdout.splitlines() if ln.startswith("OK ")]
+    assert last and int(last[-1].split()[1]) == 3 * 4 + 2 * 3 and int(last[-1].split()[2]) > 1000, p.stdout[-500:]
