@@ -15,6 +15,16 @@ no data-path collective and the ranks' match lists are all-gathered over RCCL (S
 all-gather of step i runs while the scan of step i + 1 is on the GPU (fz_lev_ngrams_begin / _end, two
 searches in flight, separate HIP streams); value = 4N GiB / max-over-ranks time.
 
+`python bench.py --gpus N` WITHOUT a launcher (what the driver runs for N > 1 on one node): one torch-free process, N device
+states joined into an RCCL communicator (ncclCommInitAll), the collective search timed as `value` (main_multi_device); if the
+communicator cannot be set up the same shards are searched without it and the line says so (`collective_error`).
+
+Next to the contract's fields the N = 1 line carries `roofline`, `cpu_baseline` (the reference's natives, rows compared
+with the GPU stream before timing), `target_4gib` (the north-star size) and `configs` — the other BASELINE configs at 1 GiB
+and, for configs[1], `end_to_end` (the reference's call form on plain bytes: first / repeat / cache-off call, PCIe
+included, never `value`) and `file_api` (find_near_matches_in_file on the same GiB).  A failure in those secondary blocks
+is reported in the line (`extras_error`, `end_to_end_error`, `file_api.error`), never instead of it.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -263,8 +273,11 @@ def extra_blocks(engine, workloads, reps):
         "ms_per_call": round(ms, 4), "GB_per_s": round(gib / ms / 1e6, 1), "scan_kernel_ms": round(f_ms, 4), "raw_matches": int(len(res))}
     cfgs["configs[1] DNA m=20 max_l_dist=2 (levenshtein_ngram) through find_near_matches"].update(
         api_block(fa, engine, seq, dict(max_l_dist=2), p1, ms, reps))
-    cfgs["configs[1] DNA m=20 max_l_dist=2 (levenshtein_ngram) through find_near_matches"].update(
-        end_to_end_block(fa, seq, p1, reps))
+    try:
+        cfgs["configs[1] DNA m=20 max_l_dist=2 (levenshtein_ngram) through find_near_matches"].update(
+            end_to_end_block(fa, seq, p1, reps))
+    except Exception as exc:  # noqa: BLE001 — the secondary numbers must not cost the run its headline line
+        cfgs["configs[1] DNA m=20 max_l_dist=2 (levenshtein_ngram) through find_near_matches"]["end_to_end_error"] = "%s: %s" % (type(exc).__name__, exc)
     out["configs"] = cfgs
     return out
 
@@ -323,6 +336,13 @@ def end_to_end_block(fa, seq, p1, reps):
                 "found resident (FUZZYSEARCH_HIP_RESIDENT_CACHE, default 8G; bytes / str only)"}}
     cache.clear()
     d = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    if d is not None:
+        try:                                   # (a tmpfs too small for the GiB: the default temporary directory)
+            st = os.statvfs(d)
+            if st.f_bavail * st.f_frsize < nbytes + (64 << 20):
+                d = None
+        except OSError:
+            d = None
     name = None
     try:
         with tempfile.NamedTemporaryFile(delete=False, dir=d) as f:
@@ -346,9 +366,14 @@ def end_to_end_block(fa, seq, p1, reps):
             "seconds": round(best, 4), "GB_per_s": round(nbytes / best / 1e9, 2), "matches": len(res),
             "matches_equal_in_memory_away_from_chunk_seams": bool(same), "in_memory_matches": len(first),
             "note": "best of three; page cache -> pinned staging (pread pool) -> H2D -> scan with per-chunk clamps; chunk geometry of the reference kept"}
+    except Exception as exc:  # noqa: BLE001
+        out["file_api"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     finally:
         if name:
-            os.remove(name)
+            try:
+                os.remove(name)
+            except OSError:
+                pass
     return out
 
 
@@ -883,7 +908,10 @@ def main():
         if world == 1 and not use_dist and not args.no_extras:
             handle.release()
             del seq
-            out.update(extra_blocks(engine, workloads, max(20, args.steps // 2)))
+            try:
+                out.update(extra_blocks(engine, workloads, max(20, args.steps // 2)))
+            except Exception as exc:  # noqa: BLE001 — the headline line is printed whatever happens to the secondary blocks
+                out["extras_error"] = "%s: %s" % (type(exc).__name__, exc)
         print(json.dumps(out), flush=True)
     if use_dist:
         sys.stdout.flush()
