@@ -41,6 +41,8 @@ while time.time() < t_end:
         continue
     h = eng.upload(t)
     tag = (sigma, len(t), len(p), k)
+    if os.environ.get("FZ_STRESS_VERBOSE"):                      # (which case a timeout interrupted)
+        print("case %d %r at %.1f s" % (n_cases, tag, time.time() - (t_end - budget)), file=sys.stderr, flush=True)
     got = eng.lev_ngrams(h, p, k); exp = oracle.lev_ngrams_raw(p, t, k)
     assert got == exp, ("lev", tag, p, seed)
     n_recs += len(got)

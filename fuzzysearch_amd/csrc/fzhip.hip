@@ -874,12 +874,12 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
         max_grid = resident * rounds;
     }
     // (has_near_match_*, measured in round 5 on 4 GiB with a match in the first MiB: 0.21 ms against 0.84 ms for the full
-    //  scan.  What is left is NOT the running workgroups finishing their tiles — a check per tile would not help and cannot
-    //  be afforded: one scalar load + branch per 16 KiB tile in the scan's loop was tried — but the ~21 800 workgroups that
-    //  start after the first record, skip their tiles and still take their finish tickets: ~100 agent-scope atomics per
-    //  microsecond on the sixteen shard words, which share one cache line.  Shorter workgroups (6 tiles) made it 0.31 ms;
-    //  the shard words spread over four lines of the header made every scan slower — 1 GiB exact search 0.188-0.193 ->
-    //  0.197 ms, same box: those lines also hold the statistics words.)
+    //  scan.  What is left is NOT the running workgroups finishing their tiles but the ~21 800 workgroups that start after
+    //  the first record, skip their tiles and still take their finish tickets: ~100 agent-scope atomics per microsecond on
+    //  the sixteen shard words, which share one cache line.  Tried and dropped: a check of the record counter per tile in
+    //  the scan's loop (cannot shorten what the tickets bound); workgroups of 6 tiles (0.31 ms: twice the tickets); the shard
+    //  words spread over four lines of the header (every scan slower — 1 GiB exact search 0.188-0.193 -> 0.197 ms, same
+    //  box: those lines also hold the statistics words).)
     {   // lab knobs: FZ_ROUNDS=r -> a grid of r x (FZ_WG_PER_CU workgroups per CU): whole rounds of resident workgroups
         const int rounds = sw().rounds;
         const int per_cu = sw().wg_per_cu > 0 ? sw().wg_per_cu : 6;
