@@ -55,7 +55,10 @@ while time.time() < t_end:
         assert eng.search_end() == oracle.lev_ngrams_raw(p, t, k), ("lev pipelined", tag, p)
     if len(t) <= 60000:
         assert eng.search_exact(h, p[:max(1, len(p) // 3)]) == oracle.search_exact(p[:max(1, len(p) // 3)], t), ("exact", tag)
-        if k and len(t) <= 5000 and (k <= 5 or len(t) <= 500):   # (the oracle's automaton takes minutes on long texts with large budgets)
+        # (the oracle's automaton takes minutes on long texts with large budgets; one-byte n-grams with a large budget make
+        #  EVERY position a hit whose window emits 1e5+ matches — 500 bytes of text gave 2.9e8 rows, all equal, in 92 s:
+        #  round 5 — such cases are left to benchmarks/slow_case.py)
+        if k and len(t) <= 5000 and (k <= 5 or (len(t) <= 500 and len(p) // (k + 1) >= 2)):
             lim = (rnd.randint(0, k), rnd.randint(0, k), rnd.randint(0, k), k)
             try:
                 got = eng.generic_ngrams(h, p, *lim)
