@@ -1,5 +1,5 @@
-"""Sharded search across the GPUs of a node, one process per GPU (torch.distributed; the "nccl"
-backend is RCCL over xGMI on ROCm, "gloo" works on CPUs for tests).
+"""Sharded search across the GPUs of a node, one process per GPU (RCCL over xGMI behind the C-ABI; any launcher that
+sets RANK / WORLD_SIZE / LOCAL_RANK, e.g. torch.distributed.run — torch itself is not imported).
 
 The path shards with ONE exchange step: every raw match is a pure function of its
 n-gram hit index and the bytes within (m + k) of it, so
@@ -15,7 +15,7 @@ n-gram hit index and the bytes within (m + k) of it, so
 Consolidation then runs once on the gathered list (overlap groups can span shard boundaries).
 
 Two ways to run it:
-  * torch-free (the product path): the collective lives behind the C-ABI (fz_comm_*, RCCL linked into libfzhip.so).
+  * torch-free (the product path): the collective lives behind the C-ABI (fz_comm_*, RCCL loaded by libfzhip.so on first use).
     `init_engine_from_env()` turns the launcher's environment (RANK / WORLD_SIZE / LOCAL_RANK, as set by
     torch.distributed.run, mpirun wrappers, ...) into a single-device engine that has joined the job's communicator:
     rank 0 creates the RCCL unique id and hands it over through a small rendezvous file; from then on
