@@ -274,6 +274,26 @@ def extra_blocks(engine, workloads, reps):
     cfgs["configs[1] DNA m=20 max_l_dist=2 (levenshtein_ngram) through find_near_matches"].update(
         api_block(fa, engine, seq, dict(max_l_dist=2), p1, ms, reps))
     try:
+        # Levenshtein budgets 8 .. 15 choose their verification form by what the context's PREVIOUS such search saw (DESIGN.md
+        # §4: lane-per-cell inside the scan when candidates are dense, the stand-alone kernel when they are rare).  The same
+        # GiB of DNA with m = 54, k = 8 makes ~2.4e6 candidates: the first call of this context runs the stand-alone form, the
+        # following ones the fused 32-lane form — both figures, so that the switch is visible where the driver looks.
+        p54 = workloads.dna(54, 7).tobytes()
+        h = engine.upload(seq)
+        t0 = time.perf_counter()
+        r_first = engine.lev_ngrams(h, p54, 8, as_array=True)
+        first_ms = (time.perf_counter() - t0) * 1e3
+        ms54, f54, v54, r54 = time_call(engine, lambda: engine.lev_ngrams(h, p54, 8, as_array=True), 10, warm_s=0.05)
+        st54 = engine.stats()
+        h.release()
+        assert np.array_equal(r_first, r54), "the two verification forms returned different streams"
+        cfgs["lane-per-cell form switch: DNA m=54 max_l_dist=8 (dense candidates)"] = {
+            "first_call_ms": round(first_ms, 3), "steady_ms_per_call": round(ms54, 4), "steady_GB_per_s": round(gib / ms54 / 1e6, 1),
+            "scan_kernel_ms": round(f54, 4), "verify_kernel_ms": round(v54, 4), "ngram_hits": int(st54["ngram_hits"]), "raw_matches": int(len(r54)),
+            "note": "first call of the context: stand-alone lane-per-cell kernel behind a hit list; then fused into the scan (32 lanes per candidate), chosen by the density the previous search saw; identical streams"}
+    except Exception as exc:  # noqa: BLE001
+        cfgs["lane-per-cell form switch: DNA m=54 max_l_dist=8 (dense candidates)"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    try:
         cfgs["configs[1] DNA m=20 max_l_dist=2 (levenshtein_ngram) through find_near_matches"].update(
             end_to_end_block(fa, seq, p1, reps))
     except Exception as exc:  # noqa: BLE001 — the secondary numbers must not cost the run its headline line
