@@ -1952,12 +1952,125 @@ __global__ __launch_bounds__(64 * W) void fz_gen_hit_kernel(const uint8_t *__res
         }
         bool fail = false;
         FzGCand *lc = cur, *ln = nxt;
+        // end of the window (py:172-177): the survivors that reach the pattern's end by deletions
+        auto final_flush = [&]() {
+            for (uint32_t c0 = 0; c0 < ncur; c0 += 64u) {
+                const bool valid = c0 + lane < ncur;
+                const uint2 cw = reinterpret_cast<const uint2 *>(lc)[c0 + lane];
+                const FzGCand c = fz_gcand_of(cw.x, cw.y);
+                uint32_t d = 0;
+                const bool hit_end = valid && fz_generic_final(c, a.m, a.max_dels, a.k, d);
+                const unsigned long long mask = __ballot(hit_end);
+                const uint32_t tot_m = (uint32_t)__popcll(mask);
+                if (mb + tot_m > FZ_GH_MCAP) { fail = true; break; }
+                if (hit_end) mbuf[mb + fz_rank(mask)] = (uint64_t)((uint32_t)c.start | (wlen << 16)) | ((uint64_t)d << 32) | ((uint64_t)wlen << 48);
+                mb = fz_uniform(mb + tot_m);
+            }
+        };
+        if constexpr (BITS) {
+            // The window in two runs with straight-line bodies: characters whose start can still reach the pattern's end
+            // (fz_gen_start_useful is monotone: index <= wlen + min(max_dels, max_l) - m) spawn, the others only step what is
+            // alive and stop when nothing is.  Round 5's phase stamps (profiles/r05_lab_ab.txt) had shown ~740 of a character's
+            // ~1 640 cycles OUTSIDE the trip — loop control: the one loop over "spawn? / last character? / failed? / which half of
+            // the equality words?" compiled into a maze of ~15 scalar branches and SGPR-spill reloads per character.
+            const uint32_t dlim = a.max_dels < a.k ? a.max_dels : a.k;
+            const uint32_t n_spawn = wlen + dlim >= a.m ? (wlen + dlim - a.m + 1u < wlen ? wlen + dlim - a.m + 1u : wlen) : 0u;
+            // one window character over this wave's list (the fresh candidate, if any, at list position fresh_at)
+            auto one_char = [&](uint32_t index, uint32_t fresh_at) -> bool {
+                // (the window's equality words live in two register pairs, lane = window position: v_readlane with the
+                //  character's number instead of an LDS round trip at the head of every character's chain; both halves are
+                //  read and one is selected — no branch)
+                const uint32_t il = index & 63u;
+                const uint32_t l0 = (uint32_t)__builtin_amdgcn_readlane((int)pw0l, (int)il), h0 = (uint32_t)__builtin_amdgcn_readlane((int)pw0h, (int)il);
+                const uint32_t l1 = (uint32_t)__builtin_amdgcn_readlane((int)pw1l, (int)il), h1 = (uint32_t)__builtin_amdgcn_readlane((int)pw1h, (int)il);
+                const bool low = index < 64u;
+                const unsigned long long peq = (unsigned long long)(low ? l0 : l1) | ((unsigned long long)(low ? h0 : h1) << 32);
+                const uint64_t stamp = (uint64_t)index << 48;
+                uint32_t nnext = 0;
+                // One TRIP steps U slices of 64 candidates: their loads, steps and prefix scans are independent chains that the
+                // hardware overlaps, one pass of offsets, 5 U unconditional stores.  With pruned starts nearly every character
+                // is ONE slice: that case is a straight line.
+                auto trip = [&](auto uc, uint32_t c0) -> bool {
+                    constexpr uint32_t U = decltype(uc)::value;
+                    FzGStep st[U];
+                    uint32_t packed[U], incl[U], base[U];
+#pragma unroll
+                    for (uint32_t u = 0; u < U; ++u) {
+                        const uint32_t at = c0 + 64u * u + lane;
+                        const bool valid = at < ncur;
+                        uint2 cw = reinterpret_cast<const uint2 *>(lc)[at];      // (past the list: still this workgroup's LDS)
+                        const bool fresh = at == fresh_at;
+                        cw.x = valid ? (fresh ? index : cw.x) : 0u;
+                        cw.y = valid && !fresh ? cw.y : 0u;
+                        fz_generic_step_bits(cw.x, cw.y, peq, index, a.m, a.max_subs, a.max_ins, a.max_dels, a.k, st[u]);
+                        const uint32_t vm = valid ? 1u : 0u;
+                        st[u].fa &= vm; st[u].fb &= vm; st[u].fc &= vm; st[u].f1 &= vm; st[u].f2 &= vm;
+                        packed[u] = (st[u].fa + st[u].fb + st[u].fc) | ((st[u].f1 + st[u].f2) << 16);
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < U; ++u) incl[u] = fz_wave_incl_scan(packed[u]);
+                    uint32_t tot = 0;
+#pragma unroll
+                    for (uint32_t u = 0; u < U; ++u) { base[u] = tot; tot += (uint32_t)__builtin_amdgcn_readlane((int)incl[u], 63); }
+                    const uint32_t tot_s = tot & 0xffffu, tot_m = tot >> 16;
+                    if (nnext + tot_s > capw || mb + tot_m > FZ_GH_MCAP) return false;
+#pragma unroll
+                    for (uint32_t u = 0; u < U; ++u) {
+                        const uint32_t excl = incl[u] - packed[u] + base[u];
+                        uint2 *nx = reinterpret_cast<uint2 *>(ln) + nnext + (excl & 0xffffu);
+                        uint64_t *mp = mbuf + mb + (excl >> 16);
+                        // five stores, none of them conditional: an absent output lands in this lane's dummy slot
+                        uint2 *pa = st[u].fa ? nx : dummy;
+                        uint2 *pb = st[u].fb ? nx + st[u].fa : dummy;
+                        uint2 *pc = st[u].fc ? nx + st[u].fa + st[u].fb : dummy;
+                        uint64_t *p1 = st[u].f1 ? mp : reinterpret_cast<uint64_t *>(dummy);
+                        uint64_t *p2 = st[u].f2 ? mp + st[u].f1 : reinterpret_cast<uint64_t *>(dummy);
+                        *pa = make_uint2(st[u].a0, st[u].a1);
+                        *pb = make_uint2(st[u].b0, st[u].b1);
+                        *pc = make_uint2(st[u].c0, st[u].c1);
+                        *p1 = (uint64_t)st[u].m1 | ((uint64_t)st[u].d1 << 32) | stamp;
+                        *p2 = (uint64_t)st[u].m2 | ((uint64_t)st[u].d2 << 32) | stamp;
+                    }
+                    nnext = fz_uniform(nnext + tot_s);
+                    mb = fz_uniform(mb + tot_m);
+                    return true;
+                };
+                bool ok = true;
+                if (ncur <= 64u) {
+                    ok = trip(std::integral_constant<uint32_t, 1>{}, 0u);
+                } else {
+                    for (uint32_t c0 = 0; c0 < ncur && ok;) {
+                        if (ncur - c0 > 64u) { ok = trip(std::integral_constant<uint32_t, 2>{}, c0); c0 += 128u; }
+                        else { ok = trip(std::integral_constant<uint32_t, 1>{}, c0); c0 += 64u; }
+                    }
+                }
+                // the next character reads what this one stored: a wave's LDS operations are performed in issue order
+                asm volatile("" ::: "memory");
+                FzGCand *tmp = lc; lc = ln; ln = tmp;
+                ncur = fz_uniform(nnext);
+                return ok;
+            };
+            uint32_t index = 0;
+            for (; index < n_spawn; ++index) {
+                uint32_t fresh_at = 0xffffffffu;
+                if ((index & (W - 1u)) == wave) {               // this start is ours: the fresh candidate (py:80), taken from registers
+                    if (ncur >= capw) { fail = true; break; }
+                    fresh_at = ncur;
+                    ncur = fz_uniform(ncur + 1u);
+                }
+                if (ncur != 0u && !one_char(index, fresh_at)) { fail = true; break; }
+            }
+            if (!fail)
+                for (; index < wlen && ncur != 0u; ++index)
+                    if (!one_char(index, 0xffffffffu)) { fail = true; break; }
+            if (!fail && ncur != 0u) final_flush();
+        } else {
         for (uint32_t index = 0; index <= wlen && !fail; ++index) {
             uint32_t nnext = 0;
             // nothing alive and no start left that could still reach the pattern's end: the rest of the window emits nothing
             if (ncur == 0u && !fz_gen_start_useful(index, wlen, a.m, a.max_dels, a.k)) break;
             if (index < wlen) {
-                const uint8_t ch = BITS ? (uint8_t)0 : (uint8_t)fz_uniform(win[index]);
+                const uint8_t ch = (uint8_t)fz_uniform(win[index]);
                 uint32_t fresh_at = 0xffffffffu;
                 // this start is ours: the fresh candidate (py:80), taken from registers — unless nothing that starts here can
                 // reach the pattern's end inside the window (fz_gen_start_useful)
@@ -1966,71 +2079,6 @@ __global__ __launch_bounds__(64 * W) void fz_gen_hit_kernel(const uint8_t *__res
                     fresh_at = ncur;
                     ncur = fz_uniform(ncur + 1u);
                 }
-                if constexpr (BITS) {
-                    // One TRIP steps U slices of 64 candidates (U = 2 while more than 64 are left): their loads, steps and prefix
-                    // scans are independent chains that the hardware overlaps, one pass of offsets, 5 U unconditional stores.
-                    // (Measured in round 5: a hit's time is 13k + ~1 500 cycles per window character that has candidates —
-                    // with pruned starts nearly every character is ONE slice, so neither trips of 4 slices nor 2 / 4 waves per hit
-                    // moved the slowest hit; the chain of one trip, ~110 dependent-ish instructions, is what is left.)
-                    // (the window's equality words live in two register pairs, lane = window position: one v_readlane with the
-                    //  character's number instead of an LDS round trip at the head of every character's chain)
-                    const uint32_t il = index & 63u;
-                    const unsigned long long peq = index < 64u
-                        ? ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)pw0l, (int)il) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)pw0h, (int)il) << 32))
-                        : ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)pw1l, (int)il) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)pw1h, (int)il) << 32));
-                    const uint64_t stamp = (uint64_t)index << 48;
-                    auto trip = [&](auto uc, uint32_t c0) -> bool {
-                        constexpr uint32_t U = decltype(uc)::value;
-                        FzGStep st[U];
-                        uint32_t packed[U], incl[U], base[U];
-#pragma unroll
-                        for (uint32_t u = 0; u < U; ++u) {
-                            const uint32_t at = c0 + 64u * u + lane;
-                            const bool valid = at < ncur;
-                            uint2 cw = reinterpret_cast<const uint2 *>(lc)[at];      // (past the list: still this workgroup's LDS)
-                            const bool fresh = at == fresh_at;
-                            cw.x = valid ? (fresh ? index : cw.x) : 0u;
-                            cw.y = valid && !fresh ? cw.y : 0u;
-                            fz_generic_step_bits(cw.x, cw.y, peq, index, a.m, a.max_subs, a.max_ins, a.max_dels, a.k, st[u]);
-                            const uint32_t vm = valid ? 1u : 0u;
-                            st[u].fa &= vm; st[u].fb &= vm; st[u].fc &= vm; st[u].f1 &= vm; st[u].f2 &= vm;
-                            packed[u] = (st[u].fa + st[u].fb + st[u].fc) | ((st[u].f1 + st[u].f2) << 16);
-                        }
-#pragma unroll
-                        for (uint32_t u = 0; u < U; ++u) incl[u] = fz_wave_incl_scan(packed[u]);
-                        uint32_t tot = 0;
-#pragma unroll
-                        for (uint32_t u = 0; u < U; ++u) { base[u] = tot; tot += (uint32_t)__builtin_amdgcn_readlane((int)incl[u], 63); }
-                        const uint32_t tot_s = tot & 0xffffu, tot_m = tot >> 16;
-                        if (nnext + tot_s > capw || mb + tot_m > FZ_GH_MCAP) return false;
-#pragma unroll
-                        for (uint32_t u = 0; u < U; ++u) {
-                            const uint32_t excl = incl[u] - packed[u] + base[u];
-                            uint2 *nx = reinterpret_cast<uint2 *>(ln) + nnext + (excl & 0xffffu);
-                            uint64_t *mp = mbuf + mb + (excl >> 16);
-                            // five stores, none of them conditional: an absent output lands in this lane's dummy slot
-                            uint2 *pa = st[u].fa ? nx : dummy;
-                            uint2 *pb = st[u].fb ? nx + st[u].fa : dummy;
-                            uint2 *pc = st[u].fc ? nx + st[u].fa + st[u].fb : dummy;
-                            uint64_t *p1 = st[u].f1 ? mp : reinterpret_cast<uint64_t *>(dummy);
-                            uint64_t *p2 = st[u].f2 ? mp + st[u].f1 : reinterpret_cast<uint64_t *>(dummy);
-                            *pa = make_uint2(st[u].a0, st[u].a1);
-                            *pb = make_uint2(st[u].b0, st[u].b1);
-                            *pc = make_uint2(st[u].c0, st[u].c1);
-                            *p1 = (uint64_t)st[u].m1 | ((uint64_t)st[u].d1 << 32) | stamp;
-                            *p2 = (uint64_t)st[u].m2 | ((uint64_t)st[u].d2 << 32) | stamp;
-                        }
-                        nnext = fz_uniform(nnext + tot_s);
-                        mb = fz_uniform(mb + tot_m);
-                        return true;
-                    };
-                    for (uint32_t c0 = 0; c0 < ncur && !fail;) {
-                        const uint32_t left = ncur - c0;
-                        if (left > 64u) { fail = !trip(std::integral_constant<uint32_t, 2>{}, c0); c0 += 128u; }
-                        else { fail = !trip(std::integral_constant<uint32_t, 1>{}, c0); c0 += 64u; }
-                    }
-                    if (fail) break;
-                } else
                 for (uint32_t c0 = 0; c0 < ncur; c0 += 64u) {
                     const bool valid = c0 + lane < ncur;
                     uint2 cw = reinterpret_cast<const uint2 *>(lc)[c0 + lane];      // (up to 63 slots past the list: still this workgroup's LDS)
@@ -2059,24 +2107,13 @@ __global__ __launch_bounds__(64 * W) void fz_gen_hit_kernel(const uint8_t *__res
                     mb = fz_uniform(mb + tot_m);
                 }
             } else {
-                // end of the window (py:172-177): the survivors that reach the pattern's end by deletions
-                for (uint32_t c0 = 0; c0 < ncur; c0 += 64u) {
-                    const bool valid = c0 + lane < ncur;
-                    const uint2 cw = reinterpret_cast<const uint2 *>(lc)[c0 + lane];
-                    const FzGCand c = fz_gcand_of(cw.x, cw.y);
-                    uint32_t d = 0;
-                    const bool hit_end = valid && fz_generic_final(c, a.m, a.max_dels, a.k, d);
-                    const unsigned long long mask = __ballot(hit_end);
-                    const uint32_t tot_m = (uint32_t)__popcll(mask);
-                    if (mb + tot_m > FZ_GH_MCAP) { fail = true; break; }
-                    if (hit_end) mbuf[mb + fz_rank(mask)] = (uint64_t)((uint32_t)c.start | (wlen << 16)) | ((uint64_t)d << 32) | ((uint64_t)index << 48);
-                    mb = fz_uniform(mb + tot_m);
-                }
+                final_flush();
             }
             // the next character reads what this one stored: a wave's LDS operations are performed in issue order
             asm volatile("" ::: "memory");
             FzGCand *tmp = lc; lc = ln; ln = tmp;
             ncur = fz_uniform(nnext);
+        }
         }
         if (lane == 0) { ctl[2u + wave] = mb; if (fail) ctl[1] = 1u; }
         __syncthreads();
