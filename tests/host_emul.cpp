@@ -216,8 +216,11 @@ int64_t emul_generic_ngrams_ordered(const uint8_t *p, uint32_t m, const uint8_t 
     // mode: bit 0 = the window table (fz_device.h: FzGenDedup — the scan enters every hit, the smallest block of a window
     // leads, members take the leader's rows); bits 1..2 = waves per hit (0: one wave, fz_lp_kernel; 1: two, 2: four —
     // fz_gen_hit_kernel: starts dealt out to the waves, match buffers merged by rank); bits 8.. = member-list length to
-    // model (0: the real one), so that windows with more hits than a slot lists are reached with few blocks
+    // model (0: the real one), so that windows with more hits than a slot lists are reached with few blocks; bit 3 = the
+    // window walked as fz_gen_hit_kernel<W, true> walks it (round 5): the spawning characters up to the closed-form bound
+    // n_spawn, then the rest until nothing is alive, the step through the window's equality words (fz_generic_step_bits)
     const bool dedup = mode & 1u;
+    const bool two_runs = (mode & 8u) && m <= 64u && max_l <= 32u;
     const uint32_t W = 1u << ((mode >> 1) & 3u);
     const uint32_t members_cap = (mode >> 8) ? std::min<uint32_t>(mode >> 8, FZ_GEN_DEDUP_MEMBERS) : FZ_GEN_DEDUP_MEMBERS;
     const uint32_t k = max_l, L = m / (k + 1);
@@ -286,6 +289,31 @@ int64_t emul_generic_ngrams_ordered(const uint8_t *p, uint32_t m, const uint8_t 
         std::vector<std::vector<uint64_t>> mbuf(W);
         for (uint32_t wave = 0; wave < W; ++wave) {
             std::vector<uint64_t> cur, nxt;
+            if (two_runs) {
+                const uint32_t dlim = max_dels < max_l ? max_dels : max_l;     // (the kernel's own expressions)
+                const uint32_t n_spawn = wlen + dlim >= m ? (wlen + dlim - m + 1u < wlen ? wlen + dlim - m + 1u : wlen) : 0u;
+                auto one_char = [&](uint32_t index) {
+                    uint64_t peq = 0;
+                    for (uint32_t i = 0; i < m; ++i) peq |= (uint64_t)(p[i] == t[w0 + index]) << i;
+                    nxt.clear();
+                    for (uint64_t cw : cur) {
+                        FzGStep st;
+                        fz_generic_step_bits((uint32_t)cw, (uint32_t)(cw >> 32), peq, index, m, max_subs, max_ins, max_dels, max_l, st);
+                        if (st.fa) nxt.push_back(st.a0 | ((uint64_t)st.a1 << 32));
+                        if (st.fb) nxt.push_back(st.b0 | ((uint64_t)st.b1 << 32));
+                        if (st.fc) nxt.push_back(st.c0 | ((uint64_t)st.c1 << 32));
+                        if (st.f1) mbuf[wave].push_back((uint64_t)st.m1 | ((uint64_t)st.d1 << 32) | ((uint64_t)index << 48));
+                        if (st.f2) mbuf[wave].push_back((uint64_t)st.m2 | ((uint64_t)st.d2 << 32) | ((uint64_t)index << 48));
+                    }
+                    cur.swap(nxt);
+                };
+                uint32_t index = 0;
+                for (; index < n_spawn; ++index) {
+                    if ((index & (W - 1u)) == wave) cur.push_back((uint64_t)index);
+                    if (!cur.empty()) one_char(index);
+                }
+                for (; index < wlen && !cur.empty(); ++index) one_char(index);
+            } else
             for (uint32_t index = 0; index < wlen; ++index) {
                 if ((index & (W - 1u)) == wave && fz_gen_start_useful(index, wlen, m, max_dels, max_l)) cur.push_back((uint64_t)index);
                 nxt.clear();

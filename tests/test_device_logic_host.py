@@ -190,7 +190,9 @@ def test_generic_ngram_search_as_ordered_on_the_device_equals_oracle(emul):
     oracle's list (blocks in order, hits by index, matches in emission order, duplicates included).  Round 4: with the
     window table (the scan enters every hit; only the smallest block of a window runs, the others take its rows; member
     lists shortened to 2 so that windows with more hits than a slot lists occur) and with the starts of a window dealt
-    out to 2 or 4 waves whose sorted match buffers are merged by rank (fz_gen_hit_kernel)."""
+    out to 2 or 4 waves whose sorted match buffers are merged by rank (fz_gen_hit_kernel).  Round 5 (mode bit 3): the window
+    walked in the kernel's two runs (spawning characters up to the closed-form n_spawn, then until nothing is alive) with
+    the bit-parallel step on the window's equality words."""
     fn = emul.emul_generic_ngrams_ordered
     fn.restype = ctypes.c_int64
     fn.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
@@ -199,7 +201,7 @@ def test_generic_ngram_search_as_ordered_on_the_device_equals_oracle(emul):
     cap = 1 << 17
     out = (OutRec * cap)()
     done = total = 0
-    modes = [0, 1, 1 | (1 << 1), 1 | (2 << 1), (1 << 1), 1 | (1 << 1) | (2 << 8), 1 | (2 << 8)]
+    modes = [0, 1, 1 | (1 << 1), 1 | (2 << 1), (1 << 1), 1 | (1 << 1) | (2 << 8), 1 | (2 << 8), 1 | 8, 8 | (1 << 1), 1 | 8 | (2 << 1)]
     while done < 1500:
         p, t, k = _case(rnd, max_n=120, max_m=24, max_k=4)
         if done % 3 == 0 and len(t) > 3 * len(p):                   # exact copies: every block hits, the windows are shared
