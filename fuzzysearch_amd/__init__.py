@@ -13,8 +13,6 @@ many patterns can be searched without re-crossing PCIe.
 """
 import io
 
-import attr
-
 from .common import Match, LevenshteinSearchParams
 from .engine import DeviceSequence, resident
 from ._native import UnsupportedSearch
@@ -126,7 +124,7 @@ def _search_binary_file(subsequence, sequence_file, search_params, search_class,
     while n_read:
         chunk = buf if chunk_len == chunk_size else buf[:chunk_len]
         for match in search_class.search(pattern, chunk, search_params):
-            out.append(attr.evolve(match, start=match.start + offset, end=match.end + offset))
+            out.append(Match(match.start + offset, match.end + offset, match.dist, match.matched))
         n_keep = min(keep, chunk_len) if keep > 0 else 0
         if n_keep:
             view[:n_keep] = bytes(view[chunk_len - n_keep:chunk_len])
@@ -142,7 +140,7 @@ def _search_text_file(subsequence, sequence_file, search_params, search_class, c
     chunk = sequence_file.read(chunk_size)
     while chunk:
         for match in search_class.search(subsequence, chunk, search_params):
-            out.append(attr.evolve(match, start=match.start + offset, end=match.end + offset))
+            out.append(Match(match.start + offset, match.end + offset, match.dist, match.matched))
         n_keep = min(keep, len(chunk))
         offset += len(chunk) - n_keep
         if n_keep:

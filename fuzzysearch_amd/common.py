@@ -2,7 +2,12 @@
 
 Mirrors (behaviour, not code) src/fuzzysearch/common.py of the reference:
   Match                     common.py:15-32   attrs class, frozen + slots, eq/hash/order on
-                                              (start, end, dist); ``matched`` excluded; validated
+                                              (start, end, dist); ``matched`` excluded; validated.
+                                              Here: a C type with the same behaviour (csrc/_fzmatch.c:
+                                              start / end / dist as C integers inside the instance — a
+                                              match is one allocation next to its ``matched`` slice),
+                                              carrying the attrs field list, so attr.fields / evolve /
+                                              asdict work; the attrs class itself without the extension
   LevenshteinSearchParams   common.py:35-116  validation (TypeError / ValueError) + normalisation
   FuzzySearchBase           common.py:192-209 search / consolidate_matches /
                                               extra_items_for_chunked_search
@@ -44,12 +49,18 @@ class Match(object):
                 raise ValueError('matched must be supplied')
 
 
-_SET_START, _SET_END, _SET_DIST, _SET_MATCHED = (Match.start.__set__, Match.end.__set__, Match.dist.__set__,
-                                                 Match.matched.__set__)
-try:                                        # csrc/_fzmatch.c, built by fuzzysearch_amd.build: the same fill in C
+_AttrsMatch = Match                         # the reference's class as it stands (tests hold the C type against it)
+try:                                        # csrc/_fzmatch.c, built by fuzzysearch_amd.build
     from . import _fzmatch
-except ImportError:                         # not built: the Python loop below does the same, ~3x slower
+    if not hasattr(_fzmatch, 'Match'):      # a stale build of an older source
+        _fzmatch = None
+except ImportError:                         # not built: the attrs class, filled by the Python loop below (~3x slower)
     _fzmatch = None
+if _fzmatch is not None:
+    Match = _fzmatch.Match
+    Match.__attrs_attrs__ = _AttrsMatch.__attrs_attrs__
+_SET_START, _SET_END, _SET_DIST, _SET_MATCHED = (_AttrsMatch.start.__set__, _AttrsMatch.end.__set__, _AttrsMatch.dist.__set__,
+                                                 _AttrsMatch.matched.__set__)
 
 
 def _is_limit(x):
@@ -133,6 +144,8 @@ class RawMatches(object):
         # objects are filled through the slot descriptors: 0.25 us each instead of 0.6 us through the attrs
         # __init__ + validation (1024 survivors of a configs[3] search: 0.25 instead of 0.6 ms).
         seq, off = self.sequence, self.offset
+        if Match is not _AttrsMatch:
+            return [Match(s + off, e + off, d, seq[s:e]) for (s, e, d, _g) in rows]
         new, cls = object.__new__, Match
         out = []
         for (s, e, d, _g) in rows:
@@ -146,8 +159,7 @@ class RawMatches(object):
 
     def _make_from_array(self, array):
         if _fzmatch is not None and array.flags.c_contiguous:
-            return _fzmatch.make_matches(Match, array, self.sequence, self.offset, Match.start, Match.end, Match.dist,
-                                         Match.matched)
+            return _fzmatch.make_matches(array, self.sequence, self.offset)
         return self._make(array.tolist())
 
     def materialize(self):
@@ -183,9 +195,8 @@ def matches_from_rows(rows, sequence):
     the buffer (csrc/_fzmatch.c: make_matches_at); the buffer is released.  Falls back to the array path without the
     extension."""
     try:
-        if _fzmatch is not None and hasattr(_fzmatch, 'make_matches_at'):
-            return _fzmatch.make_matches_at(Match, rows.address, rows.n, sequence, 0, Match.start, Match.end, Match.dist,
-                                            Match.matched)
+        if _fzmatch is not None:
+            return _fzmatch.make_matches_at(rows.address, rows.n, sequence, 0)
         return RawMatches(rows.to_array(), sequence).materialize()
     finally:
         rows.release()

@@ -1,13 +1,24 @@
-/* Match objects for the rows of an fz_match array (common.py:15-32 of the reference builds one attrs object per
- * match in Python; at 1e3 .. 1e5 results that is the larger part of a find_near_matches call on a resident
- * sequence).  One call fills a list: the instances come from the class's tp_alloc, the four attrs slots are stored
- * through the offsets of their member descriptors (what object.__setattr__ would reach, without the per-attribute
- * calls), `matched` is sequence[start:end].  Rows from the C-ABI satisfy Match's invariants by construction
- * (0 <= start <= end, dist >= 0), so the attrs validators are not run.  Host-side materialisation only — no search
- * arithmetic; fuzzysearch_amd/common.py falls back to a Python loop when this module has not been built. */
+/* The Match record of the drop-in API as a C type, and its bulk constructor from the rows of an fz_match array.
+ *
+ * common.py:15-32 of the reference declares Match as an attrs class (frozen, slots; eq / hash / order on (start, end,
+ * dist), `matched` excluded; validated when __debug__) and builds one per match in Python.  At 1e3 .. 1e5 results that
+ * is the larger part of a find_near_matches call on a resident sequence, and most of it is allocation: an attrs slots
+ * instance (GC-tracked) + two ints beyond the small-int cache + the `matched` slice, and the same four objects freed
+ * again when the list goes.  This type keeps start / end / dist as C integers inside the instance (Python ints are made
+ * when somebody reads the attribute), so a match is ONE allocation next to its `matched` slice, and it is only tracked by
+ * the cyclic collector when `matched` is something that could hold a reference back (not bytes / str).
+ *
+ * Behaviour kept from the attrs class (tests/test_host_logic.py holds the two against each other): constructor
+ * Match(start, end, dist, matched) by position or keyword with the reference's validation and messages (only when
+ * __debug__, as there), frozen (attr.exceptions.FrozenInstanceError on assignment and deletion), == / != / hash / ordering
+ * on (start, end, dist) against the same class only, repr, pickling / copying, weak references, __match_args__; common.py
+ * attaches the attrs field list (__attrs_attrs__), so attr.fields / attr.evolve / attr.asdict work as on the reference's
+ * class.  Host-side materialisation only — no search arithmetic; without this module common.py uses the attrs class and
+ * a Python loop. */
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 #include <structmember.h>
+#include <stddef.h>
 #include <stdint.h>
 
 typedef struct { int64_t start, end; int32_t dist, block; } fz_row;     /* fz_match of include/fzhip.h */
@@ -22,29 +33,184 @@ typedef struct { int64_t start, end; int32_t dist, block; } fz_row;     /* fz_ma
 #define FZ_GC_RESUME(was_on) do { (void)(was_on); } while (0)
 #endif
 
-static int slot_offset(PyObject *descr, PyTypeObject *cls, Py_ssize_t *off) {
-    if (Py_TYPE(descr) != &PyMemberDescr_Type) {
-        PyErr_SetString(PyExc_TypeError, "expected the member descriptors of a __slots__ class");
-        return -1;
-    }
-    PyMemberDescrObject *d = (PyMemberDescrObject *)descr;
-    if (d->d_common.d_type != cls || d->d_member->type != T_OBJECT_EX || (d->d_member->flags & READONLY) ||
-        d->d_member->offset < (Py_ssize_t)sizeof(PyObject) || d->d_member->offset + (Py_ssize_t)sizeof(PyObject *) > cls->tp_basicsize) {
-        PyErr_SetString(PyExc_TypeError, "descriptor does not belong to the class");
-        return -1;
-    }
-    *off = d->d_member->offset;
+typedef struct {
+    PyObject_HEAD
+    long long start, end, dist;
+    PyObject *matched;
+    PyObject *weaklist;
+} MatchObject;
+
+static PyTypeObject *match_type = NULL;                 /* the heap type, created at module init */
+static PyObject *frozen_error = NULL;                   /* attr.exceptions.FrozenInstanceError (AttributeError without attrs) */
+
+/* `matched` values that cannot be part of a reference cycle leave the instance untracked */
+static inline int needs_tracking(PyObject *matched) {
+    return !(PyBytes_CheckExact(matched) || PyUnicode_CheckExact(matched));
+}
+
+static MatchObject *match_alloc(PyTypeObject *type) {
+    MatchObject *m = PyObject_GC_New(MatchObject, type);    /* (takes the reference a heap type's instances hold on it) */
+    if (m) { m->matched = NULL; m->weaklist = NULL; }
+    return m;
+}
+
+static int match_traverse(MatchObject *self, visitproc visit, void *arg) {
+    Py_VISIT(self->matched);
+#if PY_VERSION_HEX >= 0x03090000
+    Py_VISIT(Py_TYPE(self));
+#endif
     return 0;
 }
 
-/* rows[0..n) -> list of cls instances.  `matched` = sequence[start:end] — for the exact types bytes and str (what the
- * reference is called with, and what its Match.matched then holds) built directly from the object's storage instead of
- * through a slice object and the mapping protocol (35 instead of 80 ns per match); everything else through
- * PySequence_GetSlice, so that the slice has whatever type the sequence's own slicing gives.  The cyclic collector is
- * switched off while the list is filled: a thousand new container objects would trigger a young-generation pass or two
- * that can find nothing (the objects only reference ints and a slice). */
-static PyObject *fill_matches(PyTypeObject *cls, const fz_row *rows, Py_ssize_t n, PyObject *seq, long long offset,
-                              Py_ssize_t os_, Py_ssize_t oe, Py_ssize_t od, Py_ssize_t om) {
+static int match_clear(MatchObject *self) {
+    Py_CLEAR(self->matched);
+    return 0;
+}
+
+static void match_dealloc(MatchObject *self) {
+    PyTypeObject *tp = Py_TYPE(self);
+    PyObject_GC_UnTrack(self);                              /* (a no-op for the untracked ones) */
+    if (self->weaklist) PyObject_ClearWeakRefs((PyObject *)self);
+    Py_XDECREF(self->matched);
+    PyObject_GC_Del(self);
+    Py_DECREF(tp);
+}
+
+/* one of the three integer fields: an int (the reference's isinstance(x, int): bools pass) that fits 64 bits */
+static int int_field(PyObject *v, const char *message, long long *out) {
+    if (!PyLong_Check(v)) {
+        PyErr_SetString(PyExc_ValueError, message);
+        return -1;
+    }
+    *out = PyLong_AsLongLong(v);
+    return (*out == -1 && PyErr_Occurred()) ? -1 : 0;
+}
+
+static PyObject *match_new(PyTypeObject *type, PyObject *args, PyObject *kwds) {
+    static char *kwlist[] = {"start", "end", "dist", "matched", NULL};
+    PyObject *s, *e, *d, *matched;
+    if (!PyArg_ParseTupleAndKeywords(args, kwds, "OOOO:Match", kwlist, &s, &e, &d, &matched)) return NULL;
+    long long vs, ve, vd;
+    /* the reference's __attrs_post_init__ (common.py:21-32), in its order; the range checks only when __debug__ */
+    if (int_field(s, "start must be a non-negative integer", &vs)) return NULL;
+    if (!Py_OptimizeFlag && vs < 0) { PyErr_SetString(PyExc_ValueError, "start must be a non-negative integer"); return NULL; }
+    if (int_field(e, "end must be an integer no smaller than start", &ve)) return NULL;
+    if (!Py_OptimizeFlag && ve < vs) { PyErr_SetString(PyExc_ValueError, "end must be an integer no smaller than start"); return NULL; }
+    if (int_field(d, "dist must be a non-negative integer", &vd)) return NULL;
+    if (!Py_OptimizeFlag && vd < 0) { PyErr_SetString(PyExc_ValueError, "dist must be a non-negative integer"); return NULL; }
+    if (!Py_OptimizeFlag && matched == Py_None) { PyErr_SetString(PyExc_ValueError, "matched must be supplied"); return NULL; }
+    MatchObject *m = match_alloc(type);
+    if (!m) return NULL;
+    m->start = vs; m->end = ve; m->dist = vd;
+    Py_INCREF(matched);
+    m->matched = matched;
+    if (needs_tracking(matched)) PyObject_GC_Track((PyObject *)m);
+    return (PyObject *)m;
+}
+
+static int match_setattro(PyObject *self, PyObject *name, PyObject *value) {
+    (void)self; (void)name; (void)value;
+    PyErr_SetNone(frozen_error);                            /* assignment and deletion alike, as attrs' frozen classes */
+    return -1;
+}
+
+static inline int cmp3(const MatchObject *a, const MatchObject *b) {
+    if (a->start != b->start) return a->start < b->start ? -1 : 1;
+    if (a->end != b->end) return a->end < b->end ? -1 : 1;
+    if (a->dist != b->dist) return a->dist < b->dist ? -1 : 1;
+    return 0;
+}
+
+static PyObject *match_richcompare(PyObject *a, PyObject *b, int op) {
+    if (Py_TYPE(a) != Py_TYPE(b)) Py_RETURN_NOTIMPLEMENTED;     /* attrs: other.__class__ is self.__class__ */
+    const int c = cmp3((MatchObject *)a, (MatchObject *)b);
+    int r;
+    switch (op) {
+    case Py_EQ: r = c == 0; break;
+    case Py_NE: r = c != 0; break;
+    case Py_LT: r = c < 0; break;
+    case Py_LE: r = c <= 0; break;
+    case Py_GT: r = c > 0; break;
+    default: r = c >= 0; break;
+    }
+    if (r) Py_RETURN_TRUE;
+    Py_RETURN_FALSE;
+}
+
+static Py_hash_t match_hash(MatchObject *self) {
+    uint64_t h = 0x9E3779B97F4A7C15ull;                          /* equal (start, end, dist) -> equal hash; `matched` is not part */
+    const uint64_t v[3] = {(uint64_t)self->start, (uint64_t)self->end, (uint64_t)self->dist};
+    for (int i = 0; i < 3; ++i) {
+        h ^= v[i] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+        h *= 0xFF51AFD7ED558CCDull;
+        h ^= h >> 33;
+    }
+    Py_hash_t r = (Py_hash_t)h;
+    return r == -1 ? -2 : r;
+}
+
+static PyObject *match_repr(MatchObject *self) {
+    return PyUnicode_FromFormat("Match(start=%lld, end=%lld, dist=%lld, matched=%R)", self->start, self->end, self->dist,
+                                self->matched ? self->matched : Py_None);
+}
+
+static PyObject *match_get_matched(MatchObject *self, void *closure) {
+    (void)closure;
+    PyObject *m = self->matched ? self->matched : Py_None;
+    Py_INCREF(m);
+    return m;
+}
+
+static PyObject *match_reduce(MatchObject *self, PyObject *ignored) {
+    (void)ignored;
+    return Py_BuildValue("(O(LLLO))", (PyObject *)Py_TYPE(self), self->start, self->end, self->dist,
+                         self->matched ? self->matched : Py_None);
+}
+
+static PyMemberDef match_members[] = {
+    {"start", T_LONGLONG, offsetof(MatchObject, start), READONLY, "index of the match's first item"},
+    {"end", T_LONGLONG, offsetof(MatchObject, end), READONLY, "index one past the match's last item"},
+    {"dist", T_LONGLONG, offsetof(MatchObject, dist), READONLY, "distance between the subsequence and the matched items"},
+#if PY_VERSION_HEX >= 0x03090000
+    {"__weaklistoffset__", T_PYSSIZET, offsetof(MatchObject, weaklist), READONLY, NULL},
+#endif
+    {NULL, 0, 0, 0, NULL}};
+
+static PyGetSetDef match_getset[] = {
+    {"matched", (getter)match_get_matched, NULL, "the matched portion of the sequence", NULL},
+    {NULL, NULL, NULL, NULL, NULL}};
+
+static PyMethodDef match_methods[] = {
+    {"__reduce__", (PyCFunction)match_reduce, METH_NOARGS, "pickle / copy support: (Match, (start, end, dist, matched))"},
+    {NULL, NULL, 0, NULL}};
+
+static PyType_Slot match_slots[] = {
+    {Py_tp_doc, (void *)"Match(start, end, dist, matched)\n--\n\n"
+                        "A near-match: sequence[start:end] is within dist of the subsequence (the reference's attrs class, "
+                        "common.py:15-32; equality, hash and ordering on (start, end, dist))."},
+    {Py_tp_new, match_new},
+    {Py_tp_dealloc, match_dealloc},
+    {Py_tp_traverse, match_traverse},
+    {Py_tp_clear, match_clear},
+    {Py_tp_setattro, match_setattro},
+    {Py_tp_richcompare, match_richcompare},
+    {Py_tp_hash, match_hash},
+    {Py_tp_repr, match_repr},
+    {Py_tp_members, match_members},
+    {Py_tp_getset, match_getset},
+    {Py_tp_methods, match_methods},
+    {0, NULL}};
+
+static PyType_Spec match_spec = {"fuzzysearch_amd.common.Match", sizeof(MatchObject), 0, Py_TPFLAGS_DEFAULT | Py_TPFLAGS_HAVE_GC,
+                                 match_slots};
+
+/* rows[0..n) -> list of Match.  `matched` = sequence[start:end] — for the exact types bytes and str (what the reference
+ * is called with, and what its Match.matched then holds) built directly from the object's storage instead of through a
+ * slice object and the mapping protocol; everything else through PySequence_GetSlice, so that the slice has whatever type
+ * the sequence's own slicing gives.  Rows from the C-ABI satisfy Match's invariants by construction (0 <= start <= end,
+ * dist >= 0); a row that does not is an error.  The cyclic collector is switched off while the list is filled (the
+ * allocations would trigger young-generation passes that can find nothing). */
+static PyObject *fill_matches(const fz_row *rows, Py_ssize_t n, PyObject *seq, long long offset) {
     PyObject *list = PyList_New(n);
     if (!list) return NULL;
     const int is_bytes = PyBytes_CheckExact(seq), is_str = PyUnicode_CheckExact(seq);
@@ -57,28 +223,22 @@ static PyObject *fill_matches(PyTypeObject *cls, const fz_row *rows, Py_ssize_t 
             PyErr_SetString(PyExc_ValueError, "row violates 0 <= start <= end, dist >= 0");
             goto fail;
         }
-        PyObject *obj = cls->tp_alloc(cls, 0);
+        MatchObject *obj = match_alloc(match_type);
         if (!obj) goto fail;
-        PyList_SET_ITEM(list, i, obj);                      /* the list owns it from here on (slots are NULL-safe) */
-        PyObject *s = PyLong_FromLongLong((long long)r.start + offset);
-        PyObject *e = PyLong_FromLongLong((long long)r.end + offset);
-        PyObject *d = PyLong_FromLong((long)r.dist);
-        PyObject *m;
+        PyList_SET_ITEM(list, i, (PyObject *)obj);          /* the list owns it from here on (matched may still be NULL) */
+        obj->start = (long long)r.start + offset;
+        obj->end = (long long)r.end + offset;
+        obj->dist = (long long)r.dist;
         if (is_bytes || is_str) {                           /* Python slice semantics: both ends clipped to the length */
             const Py_ssize_t a = r.start < seq_len ? (Py_ssize_t)r.start : seq_len;
             const Py_ssize_t b = r.end < seq_len ? (Py_ssize_t)r.end : seq_len;
-            m = is_bytes ? PyBytes_FromStringAndSize(bytes + a, b - a) : PyUnicode_Substring(seq, a, b);
+            obj->matched = is_bytes ? PyBytes_FromStringAndSize(bytes + a, b - a) : PyUnicode_Substring(seq, a, b);
+            if (!obj->matched) goto fail;
         } else {
-            m = PySequence_GetSlice(seq, (Py_ssize_t)r.start, (Py_ssize_t)r.end);
+            obj->matched = PySequence_GetSlice(seq, (Py_ssize_t)r.start, (Py_ssize_t)r.end);
+            if (!obj->matched) goto fail;
+            if (needs_tracking(obj->matched)) PyObject_GC_Track((PyObject *)obj);
         }
-        if (!s || !e || !d || !m) {
-            Py_XDECREF(s); Py_XDECREF(e); Py_XDECREF(d); Py_XDECREF(m);
-            goto fail;
-        }
-        *(PyObject **)((char *)obj + os_) = s;
-        *(PyObject **)((char *)obj + oe) = e;
-        *(PyObject **)((char *)obj + od) = d;
-        *(PyObject **)((char *)obj + om) = m;
     }
     FZ_GC_RESUME(gc_was_on);
     return list;
@@ -89,24 +249,12 @@ fail:
     return NULL;
 }
 
-static int parse_class(PyObject *cls_obj, PyObject *ds, PyObject *de, PyObject *dd, PyObject *dm, PyTypeObject **cls,
-                       Py_ssize_t *os_, Py_ssize_t *oe, Py_ssize_t *od, Py_ssize_t *om) {
-    if (!PyType_Check(cls_obj)) {
-        PyErr_SetString(PyExc_TypeError, "cls must be a class");
-        return -1;
-    }
-    *cls = (PyTypeObject *)cls_obj;
-    return (slot_offset(ds, *cls, os_) || slot_offset(de, *cls, oe) || slot_offset(dd, *cls, od) || slot_offset(dm, *cls, om)) ? -1 : 0;
-}
-
-/* make_matches(cls, rows, sequence, offset, d_start, d_end, d_dist, d_matched) -> list of cls instances */
+/* make_matches(rows, sequence, offset) -> list of Match; rows: a C-contiguous buffer of fz_match records */
 static PyObject *make_matches(PyObject *self, PyObject *args) {
-    PyObject *cls_obj, *rows_obj, *seq, *ds, *de, *dd, *dm;
+    PyObject *rows_obj, *seq;
     long long offset;
-    if (!PyArg_ParseTuple(args, "OOOLOOOO", &cls_obj, &rows_obj, &seq, &offset, &ds, &de, &dd, &dm)) return NULL;
-    PyTypeObject *cls;
-    Py_ssize_t os_, oe, od, om;
-    if (parse_class(cls_obj, ds, de, dd, dm, &cls, &os_, &oe, &od, &om)) return NULL;
+    (void)self;
+    if (!PyArg_ParseTuple(args, "OOL", &rows_obj, &seq, &offset)) return NULL;
     Py_buffer view;
     if (PyObject_GetBuffer(rows_obj, &view, PyBUF_SIMPLE) != 0) return NULL;
     if (view.len % (Py_ssize_t)sizeof(fz_row) != 0) {
@@ -114,37 +262,60 @@ static PyObject *make_matches(PyObject *self, PyObject *args) {
         PyErr_SetString(PyExc_ValueError, "rows: not an array of 24-byte fz_match records");
         return NULL;
     }
-    PyObject *list = fill_matches(cls, (const fz_row *)view.buf, view.len / (Py_ssize_t)sizeof(fz_row), seq, offset, os_, oe, od, om);
+    PyObject *list = fill_matches((const fz_row *)view.buf, view.len / (Py_ssize_t)sizeof(fz_row), seq, offset);
     PyBuffer_Release(&view);
     return list;
 }
 
-/* make_matches_at(cls, address, n, sequence, offset, d_start, d_end, d_dist, d_matched): the same for n fz_match rows at
- * a raw address — the result buffer of a C-ABI call (ctypes hands the pointer over; no numpy array in between). */
+/* make_matches_at(address, n, sequence, offset): the same for n fz_match rows at a raw address — the result buffer of a
+ * C-ABI call (ctypes hands the pointer over; no numpy array in between). */
 static PyObject *make_matches_at(PyObject *self, PyObject *args) {
-    PyObject *cls_obj, *seq, *ds, *de, *dd, *dm;
+    PyObject *seq;
     unsigned long long addr;
     Py_ssize_t n;
     long long offset;
-    if (!PyArg_ParseTuple(args, "OKnOLOOOO", &cls_obj, &addr, &n, &seq, &offset, &ds, &de, &dd, &dm)) return NULL;
-    PyTypeObject *cls;
-    Py_ssize_t os_, oe, od, om;
-    if (parse_class(cls_obj, ds, de, dd, dm, &cls, &os_, &oe, &od, &om)) return NULL;
+    (void)self;
+    if (!PyArg_ParseTuple(args, "KnOL", &addr, &n, &seq, &offset)) return NULL;
     if (n < 0 || (n > 0 && addr == 0)) {
         PyErr_SetString(PyExc_ValueError, "bad row buffer");
         return NULL;
     }
-    return fill_matches(cls, (const fz_row *)(uintptr_t)addr, n, seq, offset, os_, oe, od, om);
+    return fill_matches((const fz_row *)(uintptr_t)addr, n, seq, offset);
 }
 
 static PyMethodDef methods[] = {
     {"make_matches", make_matches, METH_VARARGS,
-     "make_matches(cls, rows, sequence, offset, d_start, d_end, d_dist, d_matched) -> [cls(start + offset, end + offset, "
-     "dist, sequence[start:end]) for the fz_match rows], filled through the slot descriptors"},
+     "make_matches(rows, sequence, offset) -> [Match(start + offset, end + offset, dist, sequence[start:end]) for the fz_match rows]"},
     {"make_matches_at", make_matches_at, METH_VARARGS,
-     "make_matches_at(cls, address, n, sequence, offset, d_start, d_end, d_dist, d_matched): make_matches for n fz_match rows at a raw address"},
+     "make_matches_at(address, n, sequence, offset): make_matches for n fz_match rows at a raw address"},
     {NULL, NULL, 0, NULL}};
 
-static struct PyModuleDef moduledef = {PyModuleDef_HEAD_INIT, "_fzmatch", "Match objects for fz_match rows", -1, methods};
+static struct PyModuleDef moduledef = {PyModuleDef_HEAD_INIT, "_fzmatch", "Match, and Match objects for fz_match rows", -1, methods};
 
-PyMODINIT_FUNC PyInit__fzmatch(void) { return PyModule_Create(&moduledef); }
+PyMODINIT_FUNC PyInit__fzmatch(void) {
+    PyObject *mod = PyModule_Create(&moduledef);
+    if (!mod) return NULL;
+    PyObject *exc_mod = PyImport_ImportModule("attr.exceptions");
+    if (exc_mod) {
+        frozen_error = PyObject_GetAttrString(exc_mod, "FrozenInstanceError");
+        Py_DECREF(exc_mod);
+    }
+    if (!frozen_error) {                                        /* no attrs: its FrozenInstanceError is an AttributeError */
+        PyErr_Clear();
+        frozen_error = PyExc_AttributeError;
+        Py_INCREF(frozen_error);
+    }
+    PyObject *type = PyType_FromSpec(&match_spec);
+    if (!type) { Py_DECREF(mod); return NULL; }
+    match_type = (PyTypeObject *)type;
+    PyObject *names = Py_BuildValue("(ssss)", "start", "end", "dist", "matched");
+    if (!names || PyDict_SetItemString(match_type->tp_dict, "__match_args__", names) != 0) {
+        Py_XDECREF(names); Py_DECREF(type); Py_DECREF(mod);
+        return NULL;
+    }
+    Py_DECREF(names);
+    PyType_Modified(match_type);
+    Py_INCREF(type);                                            /* one reference for the module attribute, one for match_type */
+    if (PyModule_AddObject(mod, "Match", type) != 0) { Py_DECREF(type); Py_DECREF(type); Py_DECREF(mod); return NULL; }
+    return mod;
+}

@@ -3889,6 +3889,55 @@ int consolidate_hulls(std::vector<Hull> &hulls, fz_match **out, uint64_t *n_out)
     // the 40-byte hulls themselves into the slices instead of their numbers measured slower.)
     static thread_local std::vector<uint32_t> order, cnt;       // hull numbers in sweep order; slice boundaries
     Trace trc;
+    // The stream of an n-gram search arrives block-major with every block's rows in index order: the hulls are a handful
+    // of ASCENDING RUNS (one per n-gram block).  Those are merged and swept in one sequential pass — no counting pass, no
+    // scatter, no gathers in random order (configs[1], 2 409 rows: 40 -> ~15 us on the host).  Ties go to the earlier
+    // run, which is the input order the sweep order asks for.
+    {
+        constexpr uint32_t kMaxRuns = 8;
+        uint64_t head[kMaxRuns], end[kMaxRuns];
+        uint32_t nruns = nh ? 1u : 0u;
+        head[0] = 0;
+        auto hull_before = [](const Hull &a, const Hull &b) {
+            if (a.h0 != b.h0) return a.h0 < b.h0;
+            return (a.h1 == a.h0) && (b.h1 != b.h0);
+        };
+        for (uint64_t i = 1; i < nh && nruns <= kMaxRuns; ++i)
+            if (hull_before(hulls[i], hulls[i - 1])) {
+                if (nruns < kMaxRuns) { end[nruns - 1] = i; head[nruns] = i; }
+                ++nruns;
+            }
+        if (nruns && nruns <= kMaxRuns) {
+            end[nruns - 1] = nh;
+            void *mem = nullptr;
+            int rc = alloc_out(nh, sizeof(fz_match), &mem);
+            if (rc) return rc;
+            fz_match *best = static_cast<fz_match *>(mem);
+            uint64_t nbest = 0;
+            int64_t h0 = 0, h1 = 0;
+            for (;;) {
+                uint32_t r = nruns;
+                for (uint32_t c = 0; c < nruns; ++c)
+                    if (head[c] < end[c] && (r == nruns || hull_before(hulls[head[c]], hulls[head[r]]))) r = c;
+                if (r == nruns) break;
+                const Hull &h = hulls[head[r]++];
+                if (nbest && !(h.h1 <= h0 || h.h0 >= h1)) {
+                    h0 = std::min(h0, h.h0);
+                    h1 = std::max(h1, h.h1);
+                    if (better(h.best, best[nbest - 1])) best[nbest - 1] = h.best;
+                } else {
+                    h0 = h.h0; h1 = h.h1;
+                    best[nbest++] = h.best;
+                }
+            }
+            trc.mark("  runs merged + sweep");
+            if (!std::is_sorted(best, best + nbest, by_start_end_dist)) std::sort(best, best + nbest, by_start_end_dist);
+            trc.mark("  final order");
+            *out = best;
+            *n_out = nbest;
+            return FZ_OK;
+        }
+    }
     order.resize(nh);
     auto before = [&](uint32_t x, uint32_t y) {
         const Hull &a = hulls[x], &b = hulls[y];

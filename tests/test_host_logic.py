@@ -89,6 +89,80 @@ def test_match_semantics():
     assert repr(Match(3, 9, 1, "PATERN")) == "Match(start=3, end=9, dist=1, matched='PATERN')"
 
 
+def test_c_match_type_behaves_like_the_attrs_class():
+    """csrc/_fzmatch.c's Match (start / end / dist as C integers inside the instance) against the attrs class that states the
+    reference's (common.py:15-32): construction and its errors, equality / hash / ordering, frozen, repr, attrs' helpers,
+    pickling, copying, weak references, the cyclic collector."""
+    import copy
+    import gc
+    import pickle
+    import weakref
+    from fuzzysearch_amd import build as fzbuild
+    fzbuild.build_match_ext()
+    A = common._AttrsMatch
+    assert common._fzmatch is not None and Match is common._fzmatch.Match and Match is not A
+    assert Match.__name__ == A.__name__ == "Match" and Match.__module__ == A.__module__
+    assert [a.name for a in attr.fields(Match)] == ["start", "end", "dist", "matched"] and attr.has(Match)
+    rnd = random.Random(5)
+    vals = [(rnd.randrange(0, 50), rnd.randrange(0, 50), rnd.randrange(0, 4), rnd.choice([b"x", "y", [1], (2,), None]))
+            for _ in range(300)] + [(2 ** 40, 2 ** 62, 2 ** 31, "big")]
+    b = Match(True, 3, False, "bools are ints, and are read back as ints")
+    assert (b.start, b.end, b.dist) == (1, 3, 0) and type(b.start) is int and b == Match(1, 3, 0, "")
+    made = []
+    for v in vals + [(-1, 2, 0, "x"), (1, 2, -1, "x"), ("1", 2, 0, "x"), (1, 2.0, 0, "x"), (1, 2, None, "x")]:
+        outcomes = []
+        for cls in (Match, A):
+            try:
+                outcomes.append(cls(*v))
+            except (ValueError, TypeError) as e:
+                outcomes.append((type(e), str(e)))
+        c, a = outcomes
+        if isinstance(a, tuple):
+            assert c == a, v                                          # the same exception with the same message
+            continue
+        made.append((c, a))
+        assert repr(c) == repr(a) and attr.astuple(c) == attr.astuple(a) and attr.asdict(c) == attr.asdict(a)
+        assert (c.start, c.end, c.dist) == (a.start, a.end, a.dist) and c.matched is a.matched
+        assert type(c.start) is int and type(c.end) is int and type(c.dist) is int
+        e = attr.evolve(c, end=c.end + 5, matched="other")
+        assert type(e) is Match and (e.start, e.end, e.dist, e.matched) == (c.start, c.end + 5, c.dist, "other")
+    assert len(made) > 100
+    for (c1, a1), (c2, a2) in zip(made, made[1:] + made[:1]):
+        assert (c1 == c2, c1 != c2, c1 < c2, c1 <= c2, c1 > c2, c1 >= c2) == (a1 == a2, a1 != a2, a1 < a2, a1 <= a2, a1 > a2, a1 >= a2)
+        assert (hash(c1) == hash(c2)) == (hash(a1) == hash(a2))
+    assert sorted(c for c, _ in made) == [Match(a.start, a.end, a.dist, a.matched) for a in sorted(a for _, a in made)]
+    assert len({c for c, _ in made}) == len({a for _, a in made})
+    m = Match(1, 5, 2, b"abcd")
+    assert m != (1, 5, 2) and m != A(1, 5, 2, b"abcd") and not (m == 5)   # the same class only, as attrs compares
+    with pytest.raises(TypeError):
+        m < A(1, 5, 3, b"x")
+    with pytest.raises(TypeError):
+        Match(1, 2, 3)
+    with pytest.raises(TypeError):
+        Match(1, 2, 3, "x", extra=1)
+    assert Match(start=1, end=5, dist=2, matched="kw") == m == Match(1, 5, matched="kw", dist=2)
+    for action in (lambda: setattr(m, "start", 3), lambda: setattr(m, "other", 3), lambda: delattr(m, "matched")):
+        with pytest.raises(attr.exceptions.FrozenInstanceError):
+            action()
+    with pytest.raises(AttributeError):
+        m.other
+    assert not hasattr(m, "__dict__")
+    for clone in (pickle.loads(pickle.dumps(m)), pickle.loads(pickle.dumps(m, 2)), copy.copy(m), copy.deepcopy(m)):
+        assert type(clone) is Match and clone == m and clone.matched == m.matched
+    assert weakref.ref(m)() is m
+    assert Match.__match_args__ == ("start", "end", "dist", "matched")
+    # only a `matched` that could hold a reference back makes the instance visible to the cyclic collector — and then a
+    # cycle through it is collected
+    assert not gc.is_tracked(m) and not gc.is_tracked(Match(0, 1, 0, "s")) and gc.is_tracked(Match(0, 1, 0, [1]))
+    holder = []
+    cyc = Match(0, 1, 0, holder)
+    holder.append(cyc)
+    probe = weakref.ref(cyc)
+    del cyc, holder
+    gc.collect()
+    assert probe() is None
+
+
 def test_encode_pair_preserves_comparisons():
     p, t, byteslike = engine.encode_pair(b"abc", bytearray(b"xxabcxx"))
     assert byteslike and bytes(t) == b"xxabcxx"
@@ -167,6 +241,21 @@ def test_fz_consolidate_and_group_best_against_oracle_and_golden():
         assert [b[:3] for b in _native.consolidate(raw)] == want, (n, span, run)
         rnd.shuffle(raw)
         assert [b[:3] for b in _native.consolidate(raw)] == want, (n, span, run, "shuffled")
+    # The stream of an n-gram search: block-major, every block's rows ascending — up to 8 ascending runs of hulls are merged
+    # and swept in one pass (consolidate_hulls), more go through the slices.  Zero-length rows, equal starts across and
+    # inside blocks, rows that bridge two groups only in a later block.
+    for trial in range(120):
+        nblocks = rnd.randint(1, 11)
+        span = rnd.choice([200, 3000, 100000, 1 << 36])
+        starts = sorted(rnd.randint(0, span) for _ in range(rnd.choice([1, 5, 40, 400, 1500])))
+        raw = []
+        for g in range(nblocks):
+            rows = [(s + rnd.choice([0, 0, 0, 1, 3]), rnd.choice([0, 0, 1, 4, 20, 33]), rnd.randint(0, 3)) for s in starts if rnd.random() < 0.7]
+            rows.sort(key=lambda r: r[0])
+            raw += [(s, s + ln, d, g) for (s, ln, d) in rows]
+        assert [b[:3] for b in _native.consolidate(raw)] == oracle.consolidate(raw), (trial, nblocks, span)
+        best, _hull = oracle.group_best(raw)
+        assert [b[:3] for b in _native.group_best(raw)] == [b[:3] for b in best], (trial, nblocks, span)
     # clustered hulls: nearly all of them in a few crowded slices (the per-slice stable sort), one far outlier
     for n, width, far in [(5000, 400, 1 << 40), (900, 3, 1 << 33), (40, 1000, 1 << 20), (31, 5, 7), (33, 5, 7)]:
         raw = [(far, far + 3, 1, 0)]
@@ -210,22 +299,33 @@ def test_match_objects_from_rows_c_extension_equals_python_fill():
     arr['end'] = 10
     before = sys.getrefcount(seq)
     for _ in range(200):
-        ms = _fzmatch.make_matches(Match, arr, seq, 0, Match.start, Match.end, Match.dist, Match.matched)
+        ms = _fzmatch.make_matches(arr, seq, 0)
     with pytest.raises(attr.exceptions.FrozenInstanceError):
         ms[0].start = 3
+    ms_bytes = ms[:1]
     del ms
     gc.collect()
     assert sys.getrefcount(seq) == before
     bad = np.zeros(3, dtype=_native._match_dtype())
     bad['start'][1] = -1
     with pytest.raises(ValueError):
-        _fzmatch.make_matches(Match, bad, seq, 0, Match.start, Match.end, Match.dist, Match.matched)
+        _fzmatch.make_matches(bad, seq, 0)
     with pytest.raises(ValueError):
-        _fzmatch.make_matches(Match, b"12345", seq, 0, Match.start, Match.end, Match.dist, Match.matched)
-    with pytest.raises(TypeError):
-        _fzmatch.make_matches(Match, arr, seq, 0, Match.start, Match.end, Match.dist, LevenshteinSearchParams.max_l_dist)
+        _fzmatch.make_matches(b"12345", seq, 0)
     with pytest.raises(TypeError):                              # a sequence that cannot be sliced: the error surfaces
-        _fzmatch.make_matches(Match, arr, 5, 0, Match.start, Match.end, Match.dist, Match.matched)
+        _fzmatch.make_matches(arr, 5, 0)
+    # the same rows at a raw address (the result buffer of a C-ABI call: common.matches_from_rows)
+    assert _fzmatch.make_matches_at(arr.ctypes.data, len(arr), seq, 7) == [Match(7, 17, 0, seq[0:10])] * 50
+    assert _fzmatch.make_matches_at(0, 0, seq, 0) == []
+    with pytest.raises(ValueError):
+        _fzmatch.make_matches_at(0, 3, seq, 0)
+    with pytest.raises(ValueError):
+        _fzmatch.make_matches_at(bad.ctypes.data, 3, seq, 0)
+    # slices of a mutable sequence are taken at once; instances with such a `matched` are visible to the collector
+    ba = bytearray(b"0123456789" * 100)
+    got = _fzmatch.make_matches(arr, ba, 0)
+    ba[0:10] = b"x" * 10
+    assert got[0].matched == bytearray(b"0123456789") and gc.is_tracked(got[0]) and not gc.is_tracked(ms_bytes[0])
     # non-contiguous views go through the Python fill
     wide = np.zeros(20, dtype=_native._match_dtype())
     wide['end'] = 4
