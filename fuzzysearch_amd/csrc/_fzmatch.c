@@ -48,7 +48,10 @@ static inline int needs_tracking(PyObject *matched) {
     return !(PyBytes_CheckExact(matched) || PyUnicode_CheckExact(matched));
 }
 
+/* An instance of Match itself: allocated without being handed to the collector (PyType_GenericAlloc would track it).
+ * Subclasses (which may add a __dict__ or slots of their own) take their type's tp_alloc: zeroed and tracked. */
 static MatchObject *match_alloc(PyTypeObject *type) {
+    if (type != match_type) return (MatchObject *)type->tp_alloc(type, 0);
     MatchObject *m = PyObject_GC_New(MatchObject, type);    /* (takes the reference a heap type's instances hold on it) */
     if (m) { m->matched = NULL; m->weaklist = NULL; }
     return m;
@@ -72,7 +75,7 @@ static void match_dealloc(MatchObject *self) {
     PyObject_GC_UnTrack(self);                              /* (a no-op for the untracked ones) */
     if (self->weaklist) PyObject_ClearWeakRefs((PyObject *)self);
     Py_XDECREF(self->matched);
-    PyObject_GC_Del(self);
+    tp->tp_free((PyObject *)self);
     Py_DECREF(tp);
 }
 
@@ -104,7 +107,7 @@ static PyObject *match_new(PyTypeObject *type, PyObject *args, PyObject *kwds) {
     m->start = vs; m->end = ve; m->dist = vd;
     Py_INCREF(matched);
     m->matched = matched;
-    if (needs_tracking(matched)) PyObject_GC_Track((PyObject *)m);
+    if (type == match_type && needs_tracking(matched)) PyObject_GC_Track((PyObject *)m);
     return (PyObject *)m;
 }
 
@@ -150,8 +153,19 @@ static Py_hash_t match_hash(MatchObject *self) {
 }
 
 static PyObject *match_repr(MatchObject *self) {
-    return PyUnicode_FromFormat("Match(start=%lld, end=%lld, dist=%lld, matched=%R)", self->start, self->end, self->dist,
-                                self->matched ? self->matched : Py_None);
+    /* attrs: self.__class__.__qualname__.rsplit(">.", 1)[-1] */
+    PyObject *qual = PyObject_GetAttrString((PyObject *)Py_TYPE(self), "__qualname__");
+    if (!qual) return NULL;
+    PyObject *parts = PyObject_CallMethod(qual, "rsplit", "si", ">.", 1);
+    Py_DECREF(qual);
+    if (!parts) return NULL;
+    PyObject *name = PySequence_GetItem(parts, PySequence_Size(parts) - 1);
+    Py_DECREF(parts);
+    if (!name) return NULL;
+    PyObject *r = PyUnicode_FromFormat("%U(start=%lld, end=%lld, dist=%lld, matched=%R)", name, self->start, self->end, self->dist,
+                                       self->matched ? self->matched : Py_None);
+    Py_DECREF(name);
+    return r;
 }
 
 static PyObject *match_get_matched(MatchObject *self, void *closure) {
@@ -201,7 +215,7 @@ static PyType_Slot match_slots[] = {
     {Py_tp_methods, match_methods},
     {0, NULL}};
 
-static PyType_Spec match_spec = {"fuzzysearch_amd.common.Match", sizeof(MatchObject), 0, Py_TPFLAGS_DEFAULT | Py_TPFLAGS_HAVE_GC,
+static PyType_Spec match_spec = {"fuzzysearch_amd.common.Match", sizeof(MatchObject), 0, Py_TPFLAGS_DEFAULT | Py_TPFLAGS_HAVE_GC | Py_TPFLAGS_BASETYPE,
                                  match_slots};
 
 /* rows[0..n) -> list of Match.  `matched` = sequence[start:end] — for the exact types bytes and str (what the reference

@@ -151,6 +151,23 @@ def test_c_match_type_behaves_like_the_attrs_class():
         assert type(clone) is Match and clone == m and clone.matched == m.matched
     assert weakref.ref(m)() is m
     assert Match.__match_args__ == ("start", "end", "dist", "matched")
+
+    class Sub(Match):                                             # subclasses work as with the attrs class
+        def span(self):
+            return self.end - self.start
+
+    class SubA(A):
+        def span(self):
+            return self.end - self.start
+
+    sub, sub_a = Sub(1, 5, 2, "x"), SubA(1, 5, 2, "x")
+    assert sub.span() == sub_a.span() == 4 and repr(sub) == repr(sub_a).replace("SubA", "Sub") and sub == Sub(1, 5, 2, "y") and sub != m
+    with pytest.raises(attr.exceptions.FrozenInstanceError):
+        sub.start = 2
+    assert weakref.ref(sub)() is sub and gc.is_tracked(sub)
+    many = [Sub(i, i + 1, 0, [i]) for i in range(2000)]
+    del many, sub
+    gc.collect()
     # only a `matched` that could hold a reference back makes the instance visible to the cyclic collector — and then a
     # cycle through it is collected
     assert not gc.is_tracked(m) and not gc.is_tracked(Match(0, 1, 0, "s")) and gc.is_tracked(Match(0, 1, 0, [1]))
