@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 #include "../fuzzysearch_amd/csrc/fz_device.h"
@@ -219,8 +220,14 @@ int64_t emul_generic_ngrams_ordered(const uint8_t *p, uint32_t m, const uint8_t 
     // model (0: the real one), so that windows with more hits than a slot lists are reached with few blocks; bit 3 = the
     // window walked as fz_gen_hit_kernel<W, true> walks it (round 5): the spawning characters up to the closed-form bound
     // n_spawn, then the rest until nothing is alive, the step through the window's equality words (fz_generic_step_bits)
+    // bit 4 = the fused consolidation (fz_generic_ngrams_consolidated): every running hit folds its matches into (hull, best)
+    // pairs as fz_gen_hit_kernel does (slices of 64 lanes, ballots as loops), a pair with an empty hull is left once per
+    // member of the window, and the pairs go through the second stage of the consolidation; -> the consolidated rows
     const bool dedup = mode & 1u;
     const bool two_runs = (mode & 8u) && m <= 64u && max_l <= 32u;
+    const bool folded = (mode & 16u) != 0;
+    struct Pair { uint64_t key; uint32_t se, dist, win; };
+    std::vector<Pair> pairs;
     const uint32_t W = 1u << ((mode >> 1) & 3u);
     const uint32_t members_cap = (mode >> 8) ? std::min<uint32_t>(mode >> 8, FZ_GEN_DEDUP_MEMBERS) : FZ_GEN_DEDUP_MEMBERS;
     const uint32_t k = max_l, L = m / (k + 1);
@@ -336,6 +343,64 @@ int64_t emul_generic_ngrams_ordered(const uint8_t *p, uint32_t m, const uint8_t 
                     mbuf[wave].push_back((uint64_t)((uint32_t)c.start | (wlen << 16)) | ((uint64_t)d << 32) | ((uint64_t)wlen << 48));
             }
         }
+        if (folded) {
+            // first stage of consolidate_overlapping_matches on the device (common.py:150-159): every match that overlaps the
+            // running hull is folded into it; wave 0 takes the W buffers one after the other
+            bool f_have = false;
+            uint32_t f_lo = 0, f_hi = 0, f_k1 = 0, f_k2 = 0;
+            auto emit_pair = [&]() {
+                const uint32_t sl = dedup ? dd.wslot[q] : FZ_GEN_DEDUP_NONE;
+                uint32_t copies = 1u;
+                if (sl != FZ_GEN_DEDUP_NONE && f_lo == f_hi) copies = std::min<uint32_t>(dd.nmem[sl], members_cap);
+                for (uint32_t cpy = 0; cpy < copies; ++cpy) {
+                    const uint32_t len = 0xffffu - (f_k1 & 0xffffu);
+                    pairs.push_back(Pair{copies > 1u ? hits[dd.mem[sl * FZ_GEN_DEDUP_MEMBERS + cpy]] : hit, f_k2 | ((f_k2 + len) << 16),
+                                         f_k1 >> 16, f_lo | (f_hi << 16)});
+                }
+                f_have = false;
+            };
+            for (uint32_t w = 0; w < W; ++w) {
+                const uint32_t nw = (uint32_t)mbuf[w].size();
+                for (uint32_t e0 = 0; e0 < nw; e0 += 64u) {
+                    uint32_t rs[64], re[64], k1[64];
+                    uint64_t pending = 0;
+                    for (uint32_t lane = 0; lane < 64u; ++lane) {
+                        const bool have_row = e0 + lane < nw;
+                        const uint64_t v = have_row ? mbuf[w][e0 + lane] : 0ull;
+                        rs[lane] = (uint32_t)v & 0xffffu; re[lane] = ((uint32_t)v >> 16) & 0xffffu;
+                        k1[lane] = (((uint32_t)(v >> 32) & 0xffffu) << 16) | (0xffffu - (re[lane] - rs[lane]));
+                        if (have_row) pending |= 1ull << lane;
+                    }
+                    while (pending) {
+                        if (!f_have) {
+                            const uint32_t l0 = (uint32_t)__builtin_ctzll(pending);
+                            f_lo = rs[l0]; f_hi = re[l0]; f_k1 = k1[l0]; f_k2 = f_lo;
+                            f_have = true;
+                            pending &= pending - 1ull;
+                            continue;
+                        }
+                        uint64_t ov = 0;
+                        uint32_t mlo = ~0u, nhi = ~0u, mk1 = ~0u;
+                        for (uint32_t lane = 0; lane < 64u; ++lane)
+                            if (((pending >> lane) & 1ull) && !(re[lane] <= f_lo || rs[lane] >= f_hi)) {
+                                ov |= 1ull << lane;
+                                mlo = std::min(mlo, rs[lane]); nhi = std::min(nhi, ~re[lane]); mk1 = std::min(mk1, k1[lane]);
+                            }
+                        if (!ov) { emit_pair(); continue; }
+                        uint32_t mk2 = ~0u;
+                        for (uint32_t lane = 0; lane < 64u; ++lane)
+                            if (((ov >> lane) & 1ull) && k1[lane] == mk1) mk2 = std::min(mk2, rs[lane]);
+                        const uint32_t mhi = ~nhi;
+                        f_lo = mlo < f_lo ? mlo : f_lo;
+                        f_hi = mhi > f_hi ? mhi : f_hi;
+                        if (mk1 < f_k1 || (mk1 == f_k1 && mk2 < f_k2)) { f_k1 = mk1; f_k2 = mk2; }
+                        pending &= ~ov;
+                    }
+                }
+            }
+            if (f_have) emit_pair();
+            continue;
+        }
         // merge by rank: own position + the entries of the other waves with a smaller (step, start)
         auto key_of = [](uint64_t v) { return ((uint32_t)(v >> 48) << 16) | ((uint32_t)v & 0xffffu); };
         uint32_t total = 0;
@@ -353,6 +418,46 @@ int64_t emul_generic_ngrams_ordered(const uint8_t *p, uint32_t m, const uint8_t 
                 recs.push_back(Rec{(uint32_t)q, rank, (uint32_t)v, (uint32_t)(v >> 32) & 0xffffu});
             }
         count[q] = total;
+    }
+    if (folded) {
+        // second stage (emit_generic_result + consolidate_hulls, restated without its slices): the pairs by (hull start,
+        // zero-length first, input order), overlapping hulls merged with the better of their best rows, survivors by
+        // (start, end, dist, block)
+        struct H { int64_t h0, h1; FzOutRow best; };
+        std::vector<H> hs;
+        for (const Pair &pr : pairs) {
+            const FzOutRow best = fz_gen_row(pr.key, L, k, 0, pr.se, pr.dist), hull = fz_gen_row(pr.key, L, k, 0, pr.win, 0);
+            hs.push_back(H{hull.start, hull.end, best});
+        }
+        std::stable_sort(hs.begin(), hs.end(), [](const H &a, const H &b) {
+            if (a.h0 != b.h0) return a.h0 < b.h0;
+            return (a.h1 == a.h0) && (b.h1 != b.h0);
+        });
+        auto better = [](const FzOutRow &x, const FzOutRow &y) {
+            const int64_t lx = x.end - x.start, ly = y.end - y.start;
+            return x.dist < y.dist || (x.dist == y.dist && (lx > ly || (lx == ly && (x.start < y.start || (x.start == y.start && x.block < y.block)))));
+        };
+        std::vector<FzOutRow> best;
+        int64_t h0 = 0, h1 = 0;
+        for (const H &h : hs) {
+            if (!best.empty() && !(h.h1 <= h0 || h.h0 >= h1)) {
+                h0 = std::min(h0, h.h0); h1 = std::max(h1, h.h1);
+                if (better(h.best, best.back())) best.back() = h.best;
+            } else {
+                h0 = h.h0; h1 = h.h1;
+                best.push_back(h.best);
+            }
+        }
+        std::sort(best.begin(), best.end(), [](const FzOutRow &a, const FzOutRow &b) {
+            if (a.start != b.start) return a.start < b.start;
+            if (a.end != b.end) return a.end < b.end;
+            if (a.dist != b.dist) return a.dist < b.dist;
+            return a.block < b.block;
+        });
+        for (size_t i = 0; i < best.size() && (int64_t)i < cap; ++i) {
+            out[i].start = best[i].start; out[i].end = best[i].end; out[i].dist = best[i].dist; out[i].block = best[i].block;
+        }
+        return (int64_t)best.size();
     }
     auto rows_of = [&](size_t j) -> uint32_t {
         if (!dedup) return count[j];

@@ -222,6 +222,43 @@ def test_generic_ngram_search_as_ordered_on_the_device_equals_oracle(emul):
     assert total > 20000
 
 
+def test_generic_search_consolidated_on_the_device_equals_oracle(emul):
+    """fz_generic_ngrams_consolidated as the GPU runs it: every running hit folds its matches into (hull, best) pairs in
+    slices of 64 lanes (fz_gen_hit_kernel's fold, ballots restated as loops), a pair with an empty hull is left once per
+    member of its window (zero-length matches never merge: the reference keeps one per n-gram hit), and the pairs go
+    through the second stage — against consolidate_overlapping_matches (common.py:185-189) of the oracle's raw stream.
+    With and without the window table, 1 / 2 / 4 waves per hit, short member lists, the kernel's two-run window walk."""
+    fn = emul.emul_generic_ngrams_ordered
+    fn.restype = ctypes.c_int64
+    fn.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
+                   ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(OutRec), ctypes.c_int64]
+    rnd = random.Random(31)
+    cap = 1 << 16
+    out = (OutRec * cap)()
+    done = total = zero_len = 0
+    modes = [16, 16 | 1, 16 | 1 | 8, 16 | 1 | (1 << 1), 16 | (2 << 1), 16 | 1 | (2 << 1) | 8, 16 | 1 | (2 << 8), 16 | 1 | (1 << 1) | (2 << 8)]
+    while done < 1500:
+        p, t, k = _case(rnd, max_n=120, max_m=24, max_k=4)
+        if done % 3 == 0 and len(t) > 3 * len(p):                   # exact copies: every block hits, the windows are shared
+            at = rnd.randint(0, len(t) - len(p))
+            t = t[:at] + p + t[at + len(p):]
+        limits = (rnd.randint(0, k), rnd.randint(0, k), rnd.randint(0, k))
+        max_l = min(k, sum(limits))
+        if max_l == 0 or len(p) // (max_l + 1) == 0:
+            continue
+        raw = oracle.generic_ngrams_raw(p, t, limits[0], limits[1], limits[2], max_l)
+        want = [tuple(r) for r in oracle.consolidate([tuple(r)[:3] for r in raw])]
+        zero_len += sum(1 for r in want if r[0] == r[1])
+        for mode in (modes if done % 4 == 0 else [modes[done % len(modes)]]):
+            c = fn(p, len(p), t, len(t), limits[0], limits[1], limits[2], max_l, done, mode, out, cap)
+            assert 0 <= c <= cap, (c, mode, p, t, limits, max_l)
+            got = [(out[i].start, out[i].end, out[i].dist) for i in range(c)]
+            assert got == want, (mode, p, t, limits, max_l)
+        done += 1
+        total += c
+    assert total > 1500 and zero_len > 20
+
+
 def test_levenshtein_lp_struct_and_slot_steps_equal_oracle(emul):
     """fz_levlp_step (the statement of levenshtein.py:52-148) and fz_levlp_step_slots (what fz_lp_kernel stores from since
     round 4: no arrays, no scratch memory) driven over whole sequences: the oracle's list, and the two forms agree
