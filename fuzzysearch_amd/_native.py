@@ -38,7 +38,12 @@ class FzStats(ctypes.Structure):
     _fields_ = [("bytes_scanned", ctypes.c_uint64), ("ngram_hits", ctypes.c_uint64),
                 ("raw_matches", ctypes.c_uint64), ("filter_ms", ctypes.c_double),
                 ("verify_ms", ctypes.c_double), ("device_ms", ctypes.c_double),
-                ("filter_launches", ctypes.c_uint32), ("n_devices", ctypes.c_uint32)]
+                ("filter_launches", ctypes.c_uint32), ("n_devices", ctypes.c_uint32),
+                ("verify_form", ctypes.c_uint32), ("reserved_", ctypes.c_uint32)]
+
+
+# FzStats.verify_form (include/fzhip.h: FZ_FORM_*)
+FORM_NONE, FORM_FUSED_BAND, FORM_FUSED_CELLS, FORM_FUSED_BITS1, FORM_FUSED_BITS2, FORM_KERNEL = range(6)
 
 
 class HipEngineError(RuntimeError):

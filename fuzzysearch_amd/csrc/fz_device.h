@@ -22,11 +22,14 @@
 // in host code (tests/host_emul.cpp drives one candidate at a time)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define FZ_WAVE_ANY(x) (__ballot((x) != 0) != 0ull)
+#define FZ_WAVE_BALLOT(x) __ballot((x) != 0)
 #else
 #define FZ_WAVE_ANY(x) ((x) != 0)
+#define FZ_WAVE_BALLOT(x) ((x) ? 1ull : 0ull)
 #endif
 
-#define FZ_MAX_BLOCKS_PER_LAUNCH 8     // n-gram blocks tested by one filter launch
+#define FZ_MAX_BLOCKS_PER_LAUNCH 16    // n-gram blocks tested by one filter launch (round 6: 8 -> 16; a pattern of 9 .. 16 blocks is ONE pass)
+#define FZ_BLK_BITS 4                  // log2(FZ_MAX_BLOCKS_PER_LAUNCH): bits of the block number in a queue code
 #define FZ_MAX_REGIONS 8               // regions of a scan grid (FzScanArgs.reg_*)
 #define FZ_MAX_M 1024                  // pattern bytes carried in the kernel argument block (longer patterns: FzScanArgs.pat_g)
 #define FZ_MAX_K 255                   // largest budget of the LDS-ring verification and of the candidate automata (8-bit counters)
@@ -94,7 +97,7 @@ FZ_HD FzSeg fz_segment(const FzGeom &g, uint64_t idx, uint32_t c) {
 }
 FZ_HD uint32_t fz_segment_candidates(const FzGeom &g) { return (g.seg_stride && (g.seg_pre || g.seg_post)) ? 2u : 1u; }
 
-// One scan launch: up to 8 n-gram blocks of length L.  A hit of block b at global index idx is
+// One scan launch: up to FZ_MAX_BLOCKS_PER_LAUNCH n-gram blocks of length L.  A hit of block b at global index idx is
 // accepted for the segment [sa, se) iff
 //     sa + lo_rel[b] <= idx  &&  idx + L <= se - hi_sub[b]  &&  abs_lo <= idx  &&  idx + L <= abs_hi
 //     &&  own_lo <= idx < own_hi
@@ -393,6 +396,169 @@ FZ_HD bool fz_verify_lev(Sc &sc, const Seq &t, uint64_t sa, uint64_t se, const u
     }
     rec.l = l; rec.r = r; rec.dist = dL + dR; rec.aux = 0;
     return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bit-vector expansion — the same table as fz_expand (c_expand_short / c_expand_long, _levenshtein_ngrams.pyx:9-154),
+// evaluated one COLUMN (= one sequence character) at a time by the column recurrence of Myers (1999) in Hyyrö's (2001)
+// form: a column of the table is held as its vertical differences, two bit vectors over the piece's rows
+//     VP bit i: D[i+1][j] - D[i][j] = +1        VN bit i: D[i+1][j] - D[i][j] = -1
+// and one step takes the column j-1 to the column j with ~15 word operations, whatever the budget — no band, no cell
+// outside it, every cell exact.  The piece's last row is the TOP bit of the vector, so the score D[m'][j] follows from the
+// sign bits of the horizontal differences; the reference's `D[0][j] = j` boundary (the window is matched from its first
+// character: prefix distance, not the search-anywhere form) is the 1 shifted into the horizontal +1 vector.
+// One candidate per LANE; a piece of up to 64 rows is one 64-bit word (NW = 1), up to 128 rows two (NW = 2).
+//
+// Both pieces of a hit come out of TWO tables per search, not two per n-gram block: with the whole pattern laid down top-
+// aligned, position q at bit q + (64 NW - m) of the forward table Peq[c] and at bit 64 NW - 1 - q of the reversed one,
+//     the right piece p[s+L:]         (rows i = q - s - L)  occupies the top  m - s - L  bits of the forward table,
+//     the left piece  reversed(p[:s]) (rows i = s - 1 - q)  occupies the top  s          bits of the reversed table
+// for EVERY block start s: a piece is selected by masking Eq with its top bits (`hm`), never by a shift.  The rows below
+// a piece then hold Eq = 0, VP = 0, VN = 0, stay that way under the recurrence (their horizontal +1 bits are all set, which
+// is exactly the boundary's +1 entering the piece's first row) and feed no carry into it.
+template <int NW> struct FzBitsWord;
+template <> struct FzBitsWord<1> { typedef uint64_t T; };
+template <> struct FzBitsWord<2> { typedef unsigned __int128 T; };
+#define FZ_BITS_MAX_M(NW) (64u * (NW))                   // longest pattern of the NW-word form
+
+template <int NW> FZ_HD uint32_t fz_bits_fwd_bit(uint32_t m, uint32_t q) { return q + (64u * NW - m); }
+template <int NW> FZ_HD uint32_t fz_bits_rev_bit(uint32_t, uint32_t q) { return 64u * NW - 1u - q; }
+
+template <int NW>
+struct FzBitsCol {
+    typename FzBitsWord<NW>::T vp, vn;
+};
+
+// a | ~x
+FZ_HD uint32_t fz_or_not32(uint32_t a, uint32_t x) { return a | ~x; }
+template <class T> FZ_HD T fz_or_not(T a, T x) { return a | ~x; }
+
+// Column j-1 -> column j.  `eq`: the piece's rows whose character equals the column's (masked to the piece).
+// -> D[m'][j] - D[m'][j-1] (-1, 0 or +1).
+template <int NW>
+FZ_HD int32_t fz_bits_column(FzBitsCol<NW> &c, typename FzBitsWord<NW>::T eq) {
+    typedef typename FzBitsWord<NW>::T T;
+    constexpr int TOP = 64 * NW - 1;
+    const T d0 = (((eq & c.vp) + c.vp) ^ c.vp) | eq | c.vn;     // rows whose diagonal difference is 0
+    T hp = fz_or_not<T>(c.vn, d0 | c.vp);                       // horizontal +1
+    T hn = c.vp & d0;                                           // horizontal -1
+    const int32_t delta = (int32_t)(uint32_t)(uint64_t)(hp >> TOP) - (int32_t)(uint32_t)(uint64_t)(hn >> TOP);
+    hp = (hp << 1) | (T)1;                                      // D[0][j] - D[0][j-1] = +1
+    hn = hn << 1;
+    c.vp = fz_or_not<T>(hn, d0 | hp);
+    c.vn = hp & d0;
+    return delta;
+}
+
+// One expansion on its own (tests, and the statement of what the two-phase loop below computes per side):
+// peq(c) = the piece's rows that hold character c, bit i = row i + 1 at bit 64 NW - sublen + i.
+template <int NW, class PeqF, class WinF>
+FZ_HD bool fz_expand_bits(PeqF peq, uint32_t sublen, WinF win, uint32_t winlen, uint32_t budget,
+                          uint32_t &dist, uint32_t &consumed) {
+    typedef typename FzBitsWord<NW>::T T;
+    if (sublen == 0) { dist = 0; consumed = 0; return true; }       // pyx:28-30
+    const T hm = ~(T)0 << (64u * NW - sublen);
+    FzBitsCol<NW> c;
+    c.vp = hm; c.vn = 0;                                             // column 0: D[i][0] = i
+    uint32_t score = sublen, best = sublen, arg = 0;                 // pyx:33-34
+    for (uint32_t j = 1; j <= winlen; ++j) {
+        score += (uint32_t)fz_bits_column<NW>(c, peq(win(j - 1)) & hm);
+        if (score <= best) { best = score; arg = j; }                // '<=' -> LAST arg-min (pyx:67-69)
+    }
+    if (best <= budget) { dist = best; consumed = arg; return true; }
+    return false;
+}
+
+// levenshtein_ngram.py:177-198 for one hit by the bit-vector recurrence: right expansion with budget k, then the left one
+// with what is left of it, as ONE loop in which every lane walks through its own two expansions — a lane's right piece has
+// m - s - L rows and its left one s, so the lanes of a wave differ in both but hardly in the sum (~ m - L + 2k columns):
+// run one after the other the wave would pay max(right) + max(left) columns, this way it pays max(right + left).
+//   peq.table(side)    -> handle of the forward (0) / reversed (1) table,   peq.at(handle, c) -> its word for character c
+//   txt(o)             -> sequence byte at global index wbase + o.  The loop requests a column's Peq word one column
+//                         ahead and its character two ahead (on the GPU both are LDS reads: their latency then hides behind
+//                         the ~40 instructions of a column), so txt is also asked for up to TWO positions past the end of
+//                         an expansion's window (either side); what it returns there is never used.
+// `valid` = false: the lane has no candidate (it still takes part in the wave-uniform loop control).
+template <int NW, class PeqT, class TxtF>
+FZ_HD bool fz_verify_lev_bits(const PeqT &peq, TxtF txt, uint64_t wbase, uint64_t sa, uint64_t se, uint32_t m, uint32_t k,
+                              uint32_t L, uint32_t s, uint64_t idx, bool valid, FzRec &rec) {
+    typedef typename FzBitsWord<NW>::T T;
+    constexpr uint32_t NB = 64u * NW;
+    FzBitsCol<NW> col;
+    T hm = 0;
+    uint32_t rem = 0, wl = 0, score = 0, key = 0, budget = k, dR = 0, r = 0;
+    // start an expansion of a piece of `rows` rows over `cols` window characters: column 0 is D[i][0] = i, the running
+    // minimum starts at the column-0 baseline (best = rows, arg = 0: pyx:33-34).  key = (score << 8) | columns left: the
+    // minimum over the columns prefers, among equal scores, the LATER column ('<=': last arg-min, pyx:67-69).
+    auto start = [&](uint32_t rows, uint32_t cols) {
+        hm = rows ? ~(T)0 << (NB - rows) : (T)0;
+        col.vp = hm; col.vn = 0;
+        score = rows;
+        wl = rows ? cols : 0u;                                       // an empty piece expands to (0, 0) (pyx:28-30)
+        rem = wl;
+        key = (rows << 8) | wl;
+    };
+    // right: p[s+L:] vs t[idx+L : min(se, idx-s+m+k)]
+    uint64_t rbeg = idx + L, rend = idx + m + k - s;
+    if (rend > se) rend = se;
+    if (rbeg > se) rbeg = se;
+    if (rend < rbeg) rend = rbeg;
+    start(m - s - L, (uint32_t)(rend - rbeg));
+    uint32_t phase = valid ? 0u : 2u;                                // 0 right, 1 left, 2 done
+    if (!valid) rem = 0;
+    uint32_t pos = (uint32_t)(rbeg - wbase), dir = 1u;
+    uint32_t tab = peq.table(0);
+    uint32_t chn = 0;                                                // character of the column after the next one
+    T eqn = 0;                                                       // Peq word of the next column
+    auto prime = [&]() {
+        if (rem != 0u) {
+            eqn = peq.at(tab, txt(pos));
+            chn = txt(pos + dir);
+            pos += 2u * dir;
+        }
+    };
+    prime();
+    bool ok = false;
+    // Loop control on wave masks (the host model is a wave of one lane): `live` = lanes that still have an expansion to
+    // finish.  A column costs ~40 vector instructions; what is added per column for control is one compare and scalar work.
+    unsigned long long live = FZ_WAVE_BALLOT(phase < 2u);
+    while (live) {
+        if (FZ_WAVE_BALLOT(rem == 0u) & live) {                     // some lane's expansion has seen its last column
+            if (rem == 0u && phase < 2u) {
+                const uint32_t best = key >> 8, arg = wl - (key & 255u);
+                if (best > budget) {
+                    phase = 2;
+                } else if (phase == 0) {
+                    // left: reversed p[:s] vs reversed t[max(sa, idx-s-(k-dR)) : idx], budget k - dR
+                    dR = best; r = arg;
+                    budget = k - dR;
+                    const uint64_t want = (uint64_t)s + budget;
+                    const uint64_t lbeg = (idx - sa > want) ? idx - want : sa;
+                    start(s, (uint32_t)(idx - lbeg));
+                    pos = (uint32_t)(idx - wbase) - 1u; dir = ~0u;
+                    tab = peq.table(1);
+                    phase = 1;
+                    prime();
+                } else {
+                    rec.l = arg; rec.r = r; rec.dist = dR + best; rec.aux = 0;
+                    ok = true;
+                    phase = 2;
+                }
+            }
+            live = FZ_WAVE_BALLOT(phase < 2u);
+        }
+        if (rem != 0u) {                                             // (rem != 0 only in phases 0 and 1)
+            const T eq = eqn & hm;
+            eqn = peq.at(tab, chn);
+            chn = txt(pos);
+            pos += dir;
+            score += (uint32_t)fz_bits_column<NW>(col, eq);
+            --rem;
+            const uint32_t cand = (score << 8) | rem;
+            if (cand < key) key = cand;
+        }
+    }
+    return ok;
 }
 
 // _substitutions_only_ngrams_template.h:103-121 for one hit h of the block starting at s:

@@ -44,7 +44,7 @@
 #define FZ_ROW_BYTES (FZ_FILTER_THREADS * 16)              // 4 KiB
 #define FZ_TILE_BYTES (FZ_ROW_BYTES * FZ_FILTER_ROWS)      // 16 KiB (4 rows)
 #define FZ_TILE_BITS 14                                    // log2(FZ_TILE_BYTES)
-#define FZ_TITER_MAX ((1u << (32 - FZ_TILE_BITS - 3)) - 1) // tile iterations a queue code can carry
+#define FZ_TITER_MAX ((1u << (32 - FZ_TILE_BITS - FZ_BLK_BITS)) - 1) // tile iterations a queue code can carry
 #define FZ_PAD_FRONT 256                                   // zero bytes before buf[0]
 #define FZ_PAD_BACK 256                                    // zero bytes the kernels may over-read (halo loads, whole 16-byte window pieces)
 #ifndef FZ_GROUP
@@ -124,7 +124,7 @@ __device__ __forceinline__ uint32_t fz_load_win(const uint8_t *__restrict__ buf,
 
 // Per-wave LDS areas, carved from dynamic LDS by fz_wave_lds() / fz_wave_lds_pref().
 struct FzWaveLds {
-    uint32_t *queue;      // [qcap]  fast hits: tile-local offset | block << 14 | tile iteration << 17
+    uint32_t *queue;      // [qcap]  fast hits: tile-local offset | block << 14 | tile iteration << (14 + FZ_BLK_BITS)
     uint32_t *win;        // staged layout:     [win_dwords * vlanes]  dword d of the hit in slot l at d*vlanes+l
                           // prefetched layout: [win_pieces][qcap][16 bytes]  piece c of queue entry e at (c*qcap+e)*16
     uint16_t *scores;     // [band_w * vlanes]  ring of DP score slots (slot s of lane l at s*vlanes+l); none when prefetched
@@ -204,6 +204,23 @@ struct FzDmaWindow {
     __device__ __forceinline__ uint32_t dword(uint32_t o) const {
         return *reinterpret_cast<const uint32_t *>(base + (o >> 4) * rstride + (o & 15u));
     }
+    // byte at window offset o
+    __device__ __forceinline__ uint32_t byte(uint32_t o) const { return base[(o >> 4) * rstride + (o & 15u)]; }
+};
+
+// The two whole-pattern Peq tables of the bit-vector verification in LDS (fz_device.h: fz_verify_lev_bits): [side][256]
+// words of NW x 8 bytes, forward table first.
+#define FZ_PEQ_BYTES(NW) (2u * 256u * 8u * (uint32_t)(NW))
+template <int NW>
+struct FzPeqLds {
+    typedef typename FzBitsWord<NW>::T T;
+    typedef __attribute__((address_space(3))) const T LdsT;
+    uint32_t tabs;                                         // LDS byte address of the forward table
+    // a table's handle = its LDS address: a word's address is one v_lshl_add_u32
+    __device__ __forceinline__ uint32_t table(uint32_t side) const { return tabs + side * (256u * 8u * (uint32_t)NW); }
+    __device__ __forceinline__ T at(uint32_t tab, uint32_t ch) const {
+        return *(LdsT *)(uintptr_t)(tab + ch * (8u * (uint32_t)NW));
+    }
 };
 
 // N dwords of the byte string that starts at byte offset `off` of a dword-readable source: rd(o) = the aligned
@@ -263,12 +280,15 @@ __device__ __forceinline__ unsigned long long fz_bcast64(unsigned long long v) {
 //     reference's per-hit logic (fz_verify_lev / fz_verify_subs) runs out of LDS,
 //  3. the wave appends its records with ONE global atomic.
 // Returns the number of exactly-confirmed n-gram hits (wave-uniform, statistics).
-template <int MAXK, bool PREF>
+//  BITS = 1 / 2 (prefetched form, Levenshtein): the two expansions run as bit-vector columns on 64 / 128-bit words
+//  (fz_verify_lev_bits) with the Peq tables at `peq_tabs` in LDS, instead of the register band.
+template <int MAXK, bool PREF, int BITS = 0>
 __device__ __forceinline__ uint32_t fz_wave_verify(const uint8_t *__restrict__ buf, const FzScanArgs &a,
                                                    const uint8_t *pat_lds, const FzWaveLds &w, uint32_t vl,
                                                    uint64_t hit, const FzSeg &sg, bool valid,
                                                    FzRec *__restrict__ recs, unsigned long long *__restrict__ counters,
-                                                   const uint8_t *pref_win = nullptr) {
+                                                   const uint8_t *pref_win = nullptr, const uint8_t *peq_tabs = nullptr) {
+    static_assert(BITS == 0 || PREF, "the bit-vector form verifies prefetched windows");
     const uint32_t lane = fz_lane();
     const uint32_t g = fz_hit_block(hit);
     const uint64_t idx = fz_hit_index(hit);
@@ -322,7 +342,12 @@ __device__ __forceinline__ uint32_t fz_wave_verify(const uint8_t *__restrict__ b
             }
         }
         const uint32_t confirmed = (uint32_t)__popcll(__ballot(valid));
-        if (a.mode == FZ_MODE_LEV) {
+        if constexpr (BITS != 0) {
+            // every lane takes part: the loop's control is wave-uniform (lanes without a candidate idle in it)
+            const FzPeqLds<BITS> peq{(uint32_t)(uintptr_t)(FzLdsU8 *)peq_tabs};
+            ok = fz_verify_lev_bits<BITS>(peq, [&](uint32_t o) -> uint32_t { return t.byte(o); }, wbase, sg.sa, sg.se, a.m, a.k,
+                                          a.L, s, idx, valid, rec);
+        } else if (a.mode == FZ_MODE_LEV) {
             FzLdsScores sc{w.scores + (PREF ? 0u : vl), a.vlanes};
             if (valid) ok = fz_verify_lev<MAXK>(sc, t, sg.sa, sg.se, pat_lds, a.m, a.k, a.L, s, idx, rec);
         } else if (valid) {
@@ -418,18 +443,18 @@ __device__ __forceinline__ void fz_finish_launch(const FzScanArgs &a, unsigned l
 // call folds away.
 __device__ __forceinline__ uint32_t fz_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-// Candidate code of the queue: tile-local byte offset (14 bits) | block (3 bits) | tile iteration.
+// Candidate code of the queue: tile-local byte offset (14 bits) | block (FZ_BLK_BITS bits) | tile iteration.
 __device__ __forceinline__ uint32_t fz_code(uint32_t off, uint32_t blk, uint32_t titer) {
-    return off | (blk << FZ_TILE_BITS) | (titer << (FZ_TILE_BITS + 3));
+    return off | (blk << FZ_TILE_BITS) | (titer << (FZ_TILE_BITS + FZ_BLK_BITS));
 }
 
 // Queue entry -> (block of this launch, local byte position in the buffer).
 __device__ __forceinline__ uint64_t fz_code_local(uint32_t code, uint32_t &blk) {
-    blk = (code >> FZ_TILE_BITS) & 7u;
+    blk = (code >> FZ_TILE_BITS) & (FZ_MAX_BLOCKS_PER_LAUNCH - 1u);
     // the workgroup's tile walk (first tile, stride) as the scan kernel left it in LDS
     FzLdsU32 *walk = (FzLdsU32 *)(uintptr_t)FZ_WALK_LDS;
     const uint64_t first = ((uint64_t)walk[1] << 32) | walk[0];
-    const uint64_t tile = first + (uint64_t)(code >> (FZ_TILE_BITS + 3)) * walk[2];
+    const uint64_t tile = first + (uint64_t)(code >> (FZ_TILE_BITS + FZ_BLK_BITS)) * walk[2];
     return tile * (uint64_t)FZ_TILE_BYTES + (code & (FZ_TILE_BYTES - 1u));
 }
 
@@ -476,7 +501,7 @@ __device__ __forceinline__ void fz_prefetch_tile(const uint8_t *__restrict__ buf
         const uint32_t e = e0 + lane;
         if (e < qn) {
             const uint32_t code = w.queue[e];
-            const uint32_t reach = ((code >> FZ_TILE_BITS) & 7u) * a.L + c0;           // (g0 + block) * L + k
+            const uint32_t reach = ((code >> FZ_TILE_BITS) & (FZ_MAX_BLOCKS_PER_LAUNCH - 1u)) * a.L + c0;           // (g0 + block) * L + k
             const uint32_t voff = (((code & (FZ_TILE_BYTES - 1u)) - reach) & ~3u) + BIAS;
             for (uint32_t c = 0; c < a.win_pieces; ++c) {
                 const uint32_t lds_dst = fz_uniform(w.win_lds + (c * a.qcap + e0) * 16u);
@@ -590,11 +615,12 @@ __device__ __forceinline__ uint32_t fz_queue_flush(const uint8_t *__restrict__ b
 // barrier and verify the concatenation of the four queues 64 entries at a time, pass p on wave p mod 4: a lane
 // finds the wave that owns its entry by three compares and reads code and prefetched window out of that wave's
 // area.  `area` = first wave's queue, `per_wave` = bytes per wave area, `fills` = four LDS dwords.
-template <int MAXK>
+template <int MAXK, int BITS = 0>
 __device__ __forceinline__ uint32_t fz_pooled_flush(const uint8_t *__restrict__ buf, const FzScanArgs &a,
                                                     const uint8_t *pat_lds, const uint8_t *area, uint32_t per_wave,
                                                     volatile uint32_t *fills, uint32_t wave, uint32_t qn,
-                                                    FzRec *__restrict__ recs, unsigned long long *__restrict__ counters) {
+                                                    FzRec *__restrict__ recs, unsigned long long *__restrict__ counters,
+                                                    const uint8_t *peq_tabs = nullptr) {
     const uint32_t lane = fz_lane();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's prefetched windows have landed in LDS
     if (lane == 0) fills[wave] = qn;
@@ -618,9 +644,50 @@ __device__ __forceinline__ uint32_t fz_pooled_flush(const uint8_t *__restrict__ 
             valid = fz_hit_in_range(a, blk, idx, sg);
             hit = fz_hit_pack(a.g0 + blk, idx);
         }
-        confirmed += fz_wave_verify<MAXK, true>(buf, a, pat_lds, none, lane, hit, sg, valid, recs, counters,
-                                                mine + a.qcap * 4u + li * 16u);
+        confirmed += fz_wave_verify<MAXK, true, BITS>(buf, a, pat_lds, none, lane, hit, sg, valid, recs, counters,
+                                                      mine + a.qcap * 4u + li * 16u, peq_tabs);
     }
+    return confirmed;
+}
+
+// Mid-scan flush of the fused bit-vector form (in-memory Levenshtein searches, fz_scan_kernel<..., WFG = 1 / 2>).  A pass
+// costs the wave ~m - L + 2k columns whatever its number of candidates, so passes are FULL: the queue is worked off 64
+// entries at a time, and what is left below 64 moves to the front of the queue — code and prefetched window pieces —
+// and waits for the next tiles' entries (only a queue that holds fewer than 64 in the first place is verified as it is:
+// the scan loop asks for that when it expects the next tile to overflow it).  `qn` -> the entries kept.
+template <int NW>
+__device__ __forceinline__ uint32_t fz_bits_flush(const uint8_t *__restrict__ buf, const FzScanArgs &a, const uint8_t *pat_lds,
+                                                  const uint8_t *peq_tabs, const FzWaveLds &w, uint32_t &qn,
+                                                  FzRec *__restrict__ recs, unsigned long long *__restrict__ counters) {
+    const uint32_t lane = fz_lane();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every prefetched window has landed in LDS
+    fz_wave_lds_sync();
+    const uint32_t end = qn >= 64u ? qn & ~63u : qn;
+    uint32_t confirmed = 0;
+    for (uint32_t e0 = 0; e0 < end; e0 += 64u) {
+        const uint32_t e = e0 + lane;
+        bool valid = e < end;
+        uint64_t hit = 0;
+        FzSeg sg;
+        sg.sa = 0; sg.se = a.geom.n; sg.j = 0; sg.ok = 1;
+        if (valid) {
+            uint32_t blk;
+            const uint64_t idx = a.geom.buf_off + fz_code_local(w.queue[e], blk);
+            valid = fz_hit_in_range(a, blk, idx, sg);
+            hit = fz_hit_pack(a.g0 + blk, idx);
+        }
+        confirmed += fz_wave_verify<4, true, NW>(buf, a, pat_lds, w, lane, hit, sg, valid, recs, counters,
+                                                 reinterpret_cast<const uint8_t *>(w.win) + e * 16u, peq_tabs);
+    }
+    const uint32_t rem = qn - end;                          // < 64, and only behind at least one full pass
+    if (lane < rem) {
+        w.queue[lane] = w.queue[end + lane];
+        uint8_t *wb = reinterpret_cast<uint8_t *>(w.win);
+        for (uint32_t c = 0; c < a.win_pieces; ++c)
+            *reinterpret_cast<uint4 *>(wb + (c * a.qcap + lane) * 16u) = *reinterpret_cast<const uint4 *>(wb + (c * a.qcap + end + lane) * 16u);
+    }
+    qn = rem;
+    fz_wave_lds_sync();
     return confirmed;
 }
 
@@ -656,13 +723,19 @@ __device__ __forceinline__ uint32_t fz_pooled_flush(const uint8_t *__restrict__ 
 // 7 waves per SIMD (72 VGPRs): measured 2-3 % faster than the natural 79-VGPR / 6-wave allocation;
 // 8 waves (64 VGPRs) spills 27 VGPRs in the verify path and is 50 % slower.
 template <int NWIN, int DH, bool FUSED, bool SEG, bool SA, int WFG = 0>
-__global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_eu(7, 7))) void fz_scan_kernel(
+// (the bit-vector forms: 6 waves per SIMD = 80 VGPRs with one-word columns, 5 = 96 with two-word ones — their queues and Peq
+//  tables leave LDS for at most that many workgroups per CU anyway, and the column loop keeps the next column's Peq word and
+//  character in flight)
+#define FZ_SCAN_WAVES(WFG) ((WFG) == 1 ? 6 : (WFG) == 2 ? 5 : 7)
+__global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_eu(FZ_SCAN_WAVES(WFG), FZ_SCAN_WAVES(WFG)))) void fz_scan_kernel(
     const uint8_t *__restrict__ buf, const FzScanArgs a, uint64_t ntiles,
     uint64_t *__restrict__ hits, FzRec *__restrict__ recs, unsigned long long *__restrict__ counters) {
-    constexpr bool WF = WFG != 0;                     // lane-per-cell verification inside the scan, WFG lanes per candidate
-    static_assert(WFG == 0 || WFG == 16 || WFG == 32, "lanes per candidate of the fused lane-per-cell form");
-    static_assert(!WF || (FUSED && !SEG), "the lane-per-cell form is a fused form of the in-memory search");
+    constexpr bool WF = WFG == 16 || WFG == 32;       // lane-per-cell verification inside the scan, WFG lanes per candidate
+    constexpr int BITS = (WFG == 1 || WFG == 2) ? WFG : 0;   // bit-vector verification inside the scan, one candidate per lane, WFG words
+    static_assert(WFG == 0 || BITS != 0 || WF, "0: register band / Hamming count; 1, 2: bit-vector words; 16, 32: lanes per candidate");
+    static_assert(WFG == 0 || (FUSED && !SEG), "the lane-per-cell and bit-vector forms are fused forms of the in-memory search");
     constexpr bool PREF = FUSED && !SEG && !WF;       // candidate windows are prefetched by LDS-DMA
+    constexpr uint32_t peq_bytes = BITS ? FZ_PEQ_BYTES(BITS ? BITS : 1) : 0u;   // the two Peq tables behind the pattern
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t mpad = FUSED ? (a.m + 15u) & ~15u : 0u;   // only the fused verification reads the pattern from LDS (m <= FZ_MAX_M there)
     // [32] hash living in the slot.  The kernel has no static LDS, so the dynamic area, and with it this
@@ -673,6 +746,19 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
     uint8_t *pat_lds = smem + FZ_TABLE_BYTES;
     if constexpr (FUSED)
         for (uint32_t i = threadIdx.x; i < a.m; i += FZ_FILTER_THREADS) pat_lds[i] = a.pat[i];
+    if constexpr (BITS != 0) {
+        // Peq tables (fz_device.h: fz_verify_lev_bits): zero, then one LDS atomic per pattern position and table
+        unsigned long long *peq = reinterpret_cast<unsigned long long *>(smem + FZ_TABLE_BYTES + mpad);
+        for (uint32_t i = threadIdx.x; i < peq_bytes / 8u; i += FZ_FILTER_THREADS) peq[i] = 0ull;
+        __syncthreads();
+        if (threadIdx.x < a.m) {
+            constexpr int NWc = BITS ? BITS : 1;
+            const uint32_t q = threadIdx.x, c = pat_lds[q];
+            const uint32_t bf = fz_bits_fwd_bit<NWc>(a.m, q), br = fz_bits_rev_bit<NWc>(a.m, q);
+            atomicOr(&peq[c * NWc + (bf >> 6)], 1ull << (bf & 63u));
+            atomicOr(&peq[(256u + c) * NWc + (br >> 6)], 1ull << (br & 63u));
+        }
+    }
     if (threadIdx.x < FZ_LUT_SLOTS) {
         uint32_t t = ((threadIdx.x + 1u) & (FZ_LUT_SLOTS - 1u)) << a.lut_shift;   // free slot: a value of the next slot
         uint32_t who = 0xffu;                                                     // ... and the block that lives in the slot
@@ -702,7 +788,7 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
     __syncthreads();
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t qcap = PREF ? a.qcap : (uint32_t)FZ_QCAP;   // queue entries per wave
-    const FzWaveLds w = PREF ? fz_wave_lds_pref(smem + FZ_TABLE_BYTES + mpad, FZ_TABLE_BYTES + mpad, wave, qcap, a.win_pieces)
+    const FzWaveLds w = PREF ? fz_wave_lds_pref(smem + FZ_TABLE_BYTES + mpad + peq_bytes, FZ_TABLE_BYTES + mpad + peq_bytes, wave, qcap, a.win_pieces)
                         : WF ? fz_wave_lds(smem + FZ_TABLE_BYTES + mpad, wave, fz_wf_fused_dwords(a.win_dwords, WF ? WFG : 16), 0u, 1u, true)
                              : fz_wave_lds(smem + FZ_TABLE_BYTES + mpad, wave, FUSED ? a.win_dwords : 0u,
                                            FUSED ? a.band_w : 0u, a.vlanes, true);
@@ -724,6 +810,15 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
     if ((a.flags & FZ_FLAG_ANY) && __hip_atomic_load(&counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) tile = limit;
     bool slow = false;                                // a tile is being re-scanned by enumeration
     uint32_t slow_pos = 0;
+    // Bit-vector form: the queue is worked off in full passes (fz_bits_flush) and filled as far as the tiles' recent yield
+    // lets expect it to hold: `ylast` = entries the last tile queued (wave-uniform).  The expectation only steers; a tile that
+    // overflows the queue all the same is scanned again behind a flush (and by enumeration if it overflows an empty queue).
+    uint32_t ylast = 0;
+    // ... and where the data is denser than any queue (DNA with 4-character n-grams: hundreds of hits per tile and wave), a
+    // tile is taken in several passes, each for the blocks [b0, b0 + bw) of the launch only: a tile that overflows the EMPTY
+    // queue halves bw and starts again, tiles that queue little double it.  Only a tile that overflows the empty queue with
+    // one block (a run of one character meeting an n-gram of that character) is enumerated.
+    uint32_t b0 = 0, bw = FZ_MAX_BLOCKS_PER_LAUNCH;
 
     // the filter over one row (row R of the tile)
     auto test_row = [&](const uint4 &v, const uint2 &h, auto Rc) {
@@ -769,14 +864,24 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                             if constexpr (SA) asm("v_and_b32 %0, " FZ_LUT_ADDR_MASK_STR ", %1" : "=v"(slot4) : "v"(hv[i]));
                             else asm("v_lshrrev_b32 %0, %1, %2\n\tv_and_b32 %0, " FZ_LUT_ADDR_MASK_STR ", %0" : "=v"(slot4) : "v"(slot_shift), "v"(hv[i]));
                             const uint32_t g = *reinterpret_cast<FzLdsU32 *>(slot4 + FZ_LUT_BYTES);
-                            const uint32_t slot = qn + fz_rank(mi);
-                            // the queue code is recomputed here: a (tid << 4 | titer << 17) kept in a VGPR across the tile
+                            // the queue code is recomputed here: a (tid << 4 | titer << 18) kept in a VGPR across the tile
                             // saves three ops per firing but is the register that spills (measured: 0.218 -> 0.221 ms)
                             uint32_t pos = threadIdx.x;
                             asm volatile("v_lshlrev_b32 %0, 4, %0" : "+v"(pos));
-                            if (hv[i] == lv[i] && slot < qcap)
-                                w.queue[slot] = fz_code(pos + (uint32_t)(r * FZ_ROW_BYTES + GRP * j + i), g, titer);
-                            qn += (uint32_t)__popcll(mi);
+                            if constexpr (BITS != 0) {
+                                // only the blocks of this pass over the tile (b0, bw below): g = 0xff (a free slot) never passes
+                                const bool take = hv[i] == lv[i] && g - b0 < bw;
+                                const unsigned long long mt = __ballot(take);
+                                const uint32_t slot = qn + fz_rank(mt);
+                                if (take && slot < qcap)
+                                    w.queue[slot] = fz_code(pos + (uint32_t)(r * FZ_ROW_BYTES + GRP * j + i), g, titer);
+                                qn += (uint32_t)__popcll(mt);
+                            } else {
+                                const uint32_t slot = qn + fz_rank(mi);
+                                if (hv[i] == lv[i] && slot < qcap)
+                                    w.queue[slot] = fz_code(pos + (uint32_t)(r * FZ_ROW_BYTES + GRP * j + i), g, titer);
+                                qn += (uint32_t)__popcll(mi);
+                            }
                         }
                     }
                 } else {
@@ -790,7 +895,7 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                         asm volatile("v_lshlrev_b32 %0, 4, %0" : "+v"(pos));
                         pos += (uint32_t)(r * FZ_ROW_BYTES + GRP * j) + ofs;
 #pragma unroll 1
-                        for (uint32_t g = 0; g < a.nblk; ++g) {
+                        for (uint32_t g = BITS ? b0 : 0u; g < (BITS ? min(a.nblk, b0 + bw) : a.nblk); ++g) {
                             const uint32_t hg = (uint32_t)__builtin_amdgcn_readlane((int)hvec, (int)g);
                             const unsigned long long mk = __ballot(hvi == hg);
                             if (mk) {
@@ -808,16 +913,21 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
     for (;;) {
         if (slow) {
             // enumerate (row, offset, block) candidates of tile `tile`, 64 lanes at a time
-            const uint32_t steps = FZ_FILTER_ROWS * 16u * a.nblk;
+            const uint32_t nb = BITS ? min(bw, a.nblk - b0) : a.nblk;      // (bit-vector form: the blocks of this pass)
+            const uint32_t steps = FZ_FILTER_ROWS * 16u * nb;
             while (slow_pos < steps && qn + 64u <= qcap) {
-                const uint32_t blk = slow_pos % a.nblk;
-                const uint32_t ro = slow_pos / a.nblk;
+                const uint32_t blk = (BITS ? b0 : 0u) + slow_pos % nb;
+                const uint32_t ro = slow_pos / nb;
                 w.queue[qn + lane] = fz_code((ro >> 4) * FZ_ROW_BYTES + lane_off + (ro & 15u), blk, titer);
                 qn += 64u;
                 ++slow_pos;
             }
-            if (slow_pos >= steps) { slow = false; tile += stride; ++titer; }
-        } else if (tile < limit && qn <= qcap / 2) {
+            if (slow_pos >= steps) {
+                slow = false;
+                if (BITS != 0 && b0 + bw < a.nblk) b0 += bw;
+                else { b0 = 0; tile += stride; ++titer; }
+            }
+        } else if (tile < limit && (BITS ? (qn == 0u || qn + ylast + (ylast >> 2) + 8u <= qcap) : qn <= qcap / 2)) {
             uint4 va[2], vb[2];
             uint2 ha[2], hb[2];
             bool pre;                                 // va / ha hold rows 0-1 of the next tile
@@ -840,8 +950,10 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                 const uint32_t q_tile = qn;
                 test_row(va[0], ha[0], std::integral_constant<int, 0>{});
                 test_row(va[1], ha[1], std::integral_constant<int, 1>{});
-                const uint64_t next = tile + stride;
-                pre = next < limit && qn <= qcap / 2;
+                const bool same_tile = BITS != 0 && b0 + bw < a.nblk;       // the next pass is over this tile again (its other blocks)
+                const uint64_t next = same_tile ? tile : tile + stride;
+                if constexpr (BITS != 0) pre = next < limit && qn + 3u * (qn - q_tile) + 8u <= qcap;   // this pass's second half + the next pass
+                else pre = next < limit && qn <= qcap / 2;
                 {   // unconditional (a branch here would make the compiler wait for the prefetch at the join):
                     // without a next tile the loads re-read this one (L2 hits, results unused)
                     const uint8_t *nsrc = buf + fz_bcast64((pre ? next : tile) * (uint64_t)FZ_TILE_BYTES);
@@ -856,17 +968,41 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                 test_row(vb[1], hb[1], std::integral_constant<int, 3>{});
                 if (qn > qcap) {                      // this tile overflowed the queue: drop its
                     qn = q_tile;                      // partial entries and re-scan it by enumeration
+                    if constexpr (BITS != 0) {        // ... or, bit-vector form:
+                        if (q_tile != 0u) {           // once more behind a flush of what the queue held,
+                            ylast = qcap;
+                            break;
+                        }
+                        const uint32_t nb = min(bw, a.nblk - b0);
+                        if (nb > 1u) {                // once more for half of the blocks (the queue is empty: no flush)
+                            bw = (nb + 1u) >> 1;
+                            ylast = qcap >> 1;
+                            break;
+                        }
+                    }
                     slow = true;
                     slow_pos = 0;
                     break;
                 }
+                if constexpr (BITS != 0) ylast = qn - q_tile;
                 if (PREF && qn > qf) {
                     if (tile) fz_prefetch_tile(buf, a, w, qf, qn, tile * (uint64_t)FZ_TILE_BYTES);
                     else fz_prefetch_windows(buf, a, w, qf, qn);          // the first tile: windows clamped at the start
                     qf = qn;
                 }
-                tile = next;
-                ++titer;
+                if constexpr (BITS != 0) {
+                    if (same_tile) {
+                        b0 += bw;
+                    } else {
+                        b0 = 0;
+                        if (bw < a.nblk && ylast <= (qcap >> 3)) bw <<= 1;   // little queued: twice the blocks per pass from the next tile on
+                        tile = next;
+                        ++titer;
+                    }
+                } else {
+                    tile = next;
+                    ++titer;
+                }
             } while (pre);                            // else: the end of the sequence, or a flush is due
         }
         const bool done = !slow && tile >= limit;
@@ -878,7 +1014,13 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                                                     reinterpret_cast<volatile uint32_t *>(smem + 2u * FZ_LUT_BYTES), wave, qn, done, recs, counters);
         } else if (qn) {
             if (PREF && qn > qf) fz_prefetch_windows(buf, a, w, qf, qn);
-            confirmed += fz_queue_flush<FUSED, SEG>(buf, a, pat_lds, w, qn, hits, recs, counters);
+            if constexpr (BITS != 0) {
+                confirmed += fz_bits_flush<BITS ? BITS : 1>(buf, a, pat_lds, smem + FZ_TABLE_BYTES + mpad, w, qn, recs, counters);
+                qf = qn;                              // what stays queued has its window
+                continue;
+            } else {
+                confirmed += fz_queue_flush<FUSED, SEG>(buf, a, pat_lds, w, qn, hits, recs, counters);
+            }
         }
         qn = 0;
         qf = 0;
@@ -886,8 +1028,9 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
     }
     if constexpr (PREF) {
         if (qn > qf) fz_prefetch_windows(buf, a, w, qf, qn);
-        confirmed += fz_pooled_flush<4>(buf, a, pat_lds, smem + FZ_TABLE_BYTES + mpad, fz_wave_lds_pref_bytes(qcap, a.win_pieces),
-                                        reinterpret_cast<volatile uint32_t *>(smem + 2u * FZ_LUT_BYTES), wave, qn, recs, counters);
+        confirmed += fz_pooled_flush<4, BITS>(buf, a, pat_lds, smem + FZ_TABLE_BYTES + mpad + peq_bytes, fz_wave_lds_pref_bytes(qcap, a.win_pieces),
+                                              reinterpret_cast<volatile uint32_t *>(smem + 2u * FZ_LUT_BYTES), wave, qn, recs, counters,
+                                              smem + FZ_TABLE_BYTES + mpad);
     }
 
     // (measured and not kept: one no-return atomic per workgroup — ticket and tallies in one word — with the last-indexed

@@ -57,6 +57,10 @@ struct Switches {
     bool no_wavefront = false;         // FZ_NO_WAVEFRONT: lane-per-candidate verification where lane-per-cell would run
     bool no_wf_fuse = false;           // FZ_NO_WF_FUSE: budgets 5 .. 15 verified by the stand-alone kernel, not inside the scan
     int wf32 = -1;                     // FZ_WF32=0 / 1: pin the fused lane-per-cell form off / on for budgets 8 .. 15 (default: by density)
+    bool no_bits = false;              // FZ_NO_BITS: no bit-vector verification (Levenshtein budgets >= FZ_BITS_MIN_K take round 5's forms)
+    int bits_min_k = 5;                // FZ_BITS_MIN_K=k: smallest Levenshtein budget verified by bit-vector columns (below: the register band)
+    int bits_qcap = 0;                 // FZ_BITS_QCAP=n: queue entries per wave of the bit-vector form (default: by LDS)
+    int bits_lds_kb = 0;               // FZ_BITS_LDS_KB: LDS per scan workgroup the bit-vector form may take (default 26)
     bool gen_legacy = false;           // FZ_GEN_LEGACY: the generic automaton as fz_lp_kernel (one wave per hit, round 3's form)
     bool gen_no_dedup = false;         // FZ_GEN_NO_DEDUP: no window table (every n-gram hit runs its automaton)
     bool gen_direct = false;           // FZ_GEN_DIRECT: automaton records stored straight into pinned host memory (round 1)
@@ -94,6 +98,8 @@ Switches read_switches() {
         auto num = [](const char *n, int dflt) { const char *e = getenv(n); return e ? atoi(e) : dflt; };
         v.no_direct = flag("FZ_NO_DIRECT"); v.no_slot_and = flag("FZ_NO_SLOT_AND"); v.max_blocks = num("FZ_MAX_BLOCKS", 0);
         v.force_big_verify = flag("FZ_FORCE_BIG_VERIFY"); v.no_wavefront = flag("FZ_NO_WAVEFRONT"); v.no_wf_fuse = flag("FZ_NO_WF_FUSE");
+        v.no_bits = flag("FZ_NO_BITS"); v.bits_min_k = num("FZ_BITS_MIN_K", 5); v.bits_qcap = num("FZ_BITS_QCAP", 0);
+        v.bits_lds_kb = num("FZ_BITS_LDS_KB", 0);
         v.wf32 = num("FZ_WF32", -1); v.gen_legacy = flag("FZ_GEN_LEGACY"); v.gen_no_dedup = flag("FZ_GEN_NO_DEDUP");
         v.gen_direct = flag("FZ_GEN_DIRECT"); v.gen_host_order = flag("FZ_GEN_HOST_ORDER"); v.gh_waves = num("FZ_GH_WAVES", 0);
         v.gh_no_bits = flag("FZ_GH_NO_BITS"); v.cand_lds_max = num("FZ_CAND_LDS_MAX", 0); v.group_best_exact = flag("FZ_GROUP_BEST_EXACT");
@@ -209,6 +215,7 @@ struct DevState {
     // that a search collected in between may have grown)
     uint64_t hit_cap_used = 0, rec_cap_used = 0;
     bool fused_used = false;
+    uint32_t form_used = 0;                      // FZ_FORM_* of the last enqueue
     bool wf32_candidate = false;                 // the search in this slot could have verified inside the scan with 32 lanes per candidate
     bool timed = true;                           // the search being collected recorded its start event
     double last_filter_ms = 0;                   // scan span of the search collected last on this device (fz_device_ms)
@@ -626,12 +633,17 @@ ScanKernel scan_kernel_wf(int nwin, int dh) {
     }
 }
 
+// wf_gw: 0 = register band / Hamming count, 1 / 2 = bit-vector columns on one / two 64-bit words, 16 / 32 = lanes per candidate
 ScanKernel scan_kernel(int nwin, int dh, bool fused, bool seg, bool sa, int wf_gw = 0) {
 #ifdef FZ_LAB_ONLY      // lab builds (benchmarks/lab_build.sh): only the instances of the headline and exact-search workloads
+    if (wf_gw == 1 && nwin == 2 && dh == 3 && fused && !seg) return sa ? fz_scan_kernel<2, 3, true, false, true, 1> : fz_scan_kernel<2, 3, true, false, false, 1>;
+    if (wf_gw) return nullptr;
     if (nwin == 2 && dh == 3 && fused && !seg) return sa ? fz_scan_kernel<2, 3, true, false, true> : fz_scan_kernel<2, 3, true, false, false>;
     if (nwin == 2 && dh == 5 && !fused && !seg) return sa ? fz_scan_kernel<2, 5, false, false, true> : fz_scan_kernel<2, 5, false, false, false>;
     return nullptr;
 #else
+    if (wf_gw == 1) return seg ? nullptr : (sa ? scan_kernel_wf<true, 1>(nwin, dh) : scan_kernel_wf<false, 1>(nwin, dh));
+    if (wf_gw == 2) return seg ? nullptr : (sa ? scan_kernel_wf<true, 2>(nwin, dh) : scan_kernel_wf<false, 2>(nwin, dh));
     if (wf_gw == 16) return seg ? nullptr : (sa ? scan_kernel_wf<true, 16>(nwin, dh) : scan_kernel_wf<false, 16>(nwin, dh));
     if (wf_gw == 32) return seg ? nullptr : (sa ? scan_kernel_wf<true, 32>(nwin, dh) : scan_kernel_wf<false, 32>(nwin, dh));
     if (seg) return fused ? scan_kernel_s<true, true>(nwin, dh, sa) : scan_kernel_s<false, true>(nwin, dh, sa);
@@ -640,10 +652,13 @@ ScanKernel scan_kernel(int nwin, int dh, bool fused, bool seg, bool sa, int wf_g
 }
 
 // Odd multipliers tried for the window hash (24-bit ones serve v_mad_u32_u24).  One search needs a
-// multiplier under which its (at most 8 per launch) distinct block hashes fall into distinct slots of
+// multiplier under which its (at most 16 per launch) distinct block hashes fall into distinct slots of
 // the 32-slot table: a random one works with probability 0.91 for 3 blocks, 0.39 for 8.
 const uint32_t kHashMultipliers[] = {0x9E3779u, 0x85EBCBu, 0xC2B2AFu, 0x27D4EBu, 0x165667u, 0xD3A264u | 1u, 0xFD7047u, 0xB55A4Fu,
-                                     0x7FEB35u, 0x846CA7u, 0x9E6C63u, 0x3243F7u, 0x517CC1u, 0xB7E151u, 0x6A09E7u, 0xBB67AFu};
+                                     0x7FEB35u, 0x846CA7u, 0x9E6C63u, 0x3243F7u, 0x517CC1u, 0xB7E151u, 0x6A09E7u, 0xBB67AFu,
+                                     // (round 6: launches carry up to 16 blocks — more tries for the rarer perfect placements)
+                                     0x3C6EF3u, 0xA54FF5u, 0x510E53u, 0x9B0569u, 0x1F83D9u, 0x5BE0CDu, 0xCA62C1u, 0x8F1BBDu,
+                                     0x6ED9EBu, 0x5A8279u, 0xC3D2E1u, 0x10325Fu, 0x98BADDu, 0xEFCDABu, 0x674523u, 0x2B7E15u};
 
 // Window geometry of the filter's hash for n-gram length L (see fz_hash_windows / fz_hash_short).
 struct HashGeom {
@@ -660,7 +675,7 @@ struct HashGeom {
 };
 
 // Blocks [g0, g0 + n) of one scan launch, the hash multiplier and the slot bits: the longest run of
-// blocks (at most 8) whose distinct hashes land in distinct slots of the 32-slot table under some
+// blocks (at most 16) whose distinct hashes land in distinct slots of the 32-slot table under some
 // (multiplier, shift).  One block always fits; equal n-grams (equal hashes) share a slot.
 // h = yh * K + x mixes x only through the addition: which five bits tell the blocks apart depends on
 // where their bytes differ, so the slot bits are a per-launch choice as well.
@@ -941,6 +956,36 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     // its own beyond that
     fa.fused = (with_verify && !force_big && q.m <= FZ_MAX_M && q.k <= FZ_MAX_K && fused_lds <= kFusedLdsBudget &&
                 (q.mode != FZ_MODE_LEV || q.k <= 4)) ? 1u : 0u;
+    // Levenshtein budgets from FZ_BITS_MIN_K on, patterns up to 128 characters, in-memory: bit-vector columns, one candidate
+    // per lane, inside the scan (fz_verify_lev_bits) — a column costs the same whatever the budget, so neither the band's
+    // width nor the candidates' density decides the form.  The queue takes what LDS allows (full passes: fz_bits_flush).
+    int bits_nw = 0;
+    if (q.mode == FZ_MODE_LEV && with_verify && !force_big && !sw().no_bits && sh.geom.seg_stride == 0 && q.k >= (uint32_t)sw().bits_min_k &&
+        q.m <= FZ_BITS_MAX_M(2) && q.k <= FZ_MAX_K && fa.win_pieces * 16u + 16u <= FZ_PAD_BACK) {
+        bits_nw = q.m <= FZ_BITS_MAX_M(1) ? 1 : 2;
+        // (26 KB: six workgroups per CU.  Measured on 1 GiB of DNA, m = 54, k = 8, 2.4e6 candidates: 64 / 96 / 128 / 160 entries
+        //  per wave = 26 / 37 / 47 / 58 KB -> 0.463 / 0.517 / 0.656 / 0.830 ms: fuller passes do not pay for the lost waves)
+        const uint32_t budget = (uint32_t)(sw().bits_lds_kb > 0 ? sw().bits_lds_kb : 26) * 1024u;
+        const uint32_t fixed = mpad + FZ_TABLE_BYTES + FZ_PEQ_BYTES(bits_nw);
+        // Queue entries per wave: one full pass (64) + twice what a wave is expected to find in one tile (4 KiB of offsets per
+        // wave) if the sequence is uniform over the symbols the PATTERN uses — G blocks of L characters over sigma symbols:
+        // 4096 G / sigma^L.  DNA patterns get the queue DNA needs (m = 54, k = 8: 9 -> 96 entries; m = 20, k = 4: 80 -> what
+        // LDS allows), text patterns the smallest one (more workgroups per CU for the streaming part).  A function of the
+        // search's arguments, not of earlier calls; an estimate that is off costs time, never rows (fz_scan_kernel: overflow).
+        bool seen[256] = {false};
+        uint32_t sigma = 0;
+        for (uint32_t i = 0; i < q.m; ++i)
+            if (!seen[q.p[i]]) { seen[q.p[i]] = true; ++sigma; }
+        double per_tile = 4096.0 * std::min<uint32_t>(G, FZ_MAX_BLOCKS_PER_LAUNCH);
+        for (uint32_t i = 0; i < L && per_tile > 0.01; ++i) per_tile /= (double)std::max(2u, sigma);
+        uint32_t qc = sw().bits_qcap > 0 ? (uint32_t)sw().bits_qcap
+                                         : (uint32_t)std::min(512.0, 64.0 + 32.0 * std::ceil(2.0 * per_tile / 32.0));
+        while (qc > 64u && fixed + FZ_WAVES_PER_BLOCK * fz_wave_lds_pref_bytes(qc, fa.win_pieces) > budget) qc -= 32u;
+        fa.qcap = qc;
+        fused_lds = fixed + FZ_WAVES_PER_BLOCK * fz_wave_lds_pref_bytes(fa.qcap, fa.win_pieces);
+        if (fused_lds > kFusedLdsBudget) bits_nw = 0;
+        else fa.fused = 1u;
+    }
     const bool no_wf_fuse = sw().no_wf_fuse;                                    // test / measurement knob: the stand-alone kernel
     const uint32_t wf_fused_lds = mpad + FZ_TABLE_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fz_wf_fused_dwords(fa.win_dwords, (uint32_t)vp.gw), 0, 1, true);
     // (in-memory searches only: the segmented instances of this form spill registers — the file API keeps the kernel of its own)
@@ -951,7 +996,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     // the context remembers the candidate density of its last such search (collect_shard) and starts with the stand-alone
     // kernel; FZ_WF32=0 / 1 pins the choice.
     const int wf32_env = sw().wf32;
-    const bool wf_candidate = !fa.fused && sh.geom.seg_stride == 0 && with_verify && !force_big && !no_wf_fuse && vp.want_wf && !vp.big && vp.gw <= 32 &&
+    const bool wf_candidate = !bits_nw && !fa.fused && sh.geom.seg_stride == 0 && with_verify && !force_big && !no_wf_fuse && vp.want_wf && !vp.big && vp.gw <= 32 &&
                               q.m <= FZ_MAX_M && wf_fused_lds <= target + 4096;
     d.wf32_candidate = wf_candidate && vp.gw == 32;
     const bool wf_fused = wf_candidate && (vp.gw == 16 || (wf32_env >= 0 ? wf32_env != 0 : ctx->wf32_fused.load(std::memory_order_relaxed) != 0));
@@ -1004,7 +1049,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
         for (uint32_t b = 1; b < nblk; ++b)
             for (uint32_t c = 0; c < b; ++c)
                 if (fa.H[b] == fa.H[c]) fa.flags |= FZ_FLAG_DUP_HASHES;
-        ScanKernel kern = scan_kernel(nwin, dh, fa.fused != 0, sh.geom.seg_stride != 0, fa.lut_shift == 2, wf_fused ? vp.gw : 0);
+        ScanKernel kern = scan_kernel(nwin, dh, fa.fused != 0, sh.geom.seg_stride != 0, fa.lut_shift == 2, bits_nw ? bits_nw : wf_fused ? vp.gw : 0);
         if (!kern) return fail(FZ_EUNSUPPORTED, "this (lab) build carries no scan kernel for nwin=%d dh=%d", nwin, dh);
         const uint32_t extra_lds = (uint32_t)sw().extra_lds_kb * 1024u;
         hipEvent_t ev_start = (attach && ctx->timing && g0 == 0) ? d.ev[0] : nullptr;
@@ -1096,6 +1141,8 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     }
     d.launches_used = launches;                  // (summed by search_enqueue: this may run on the device's worker thread)
     d.fused_used = fa.fused != 0;
+    d.form_used = !with_verify ? FZ_FORM_NONE : bits_nw == 1 ? FZ_FORM_FUSED_BITS1 : bits_nw == 2 ? FZ_FORM_FUSED_BITS2
+                  : wf_fused ? FZ_FORM_FUSED_CELLS : fa.fused ? FZ_FORM_FUSED_BAND : FZ_FORM_KERNEL;
     d.hit_cap_used = d.hit_cap;
     d.rec_cap_used = d.rec_cap;
     return FZ_OK;
@@ -1385,6 +1432,7 @@ int search_enqueue(fz_ctx *ctx, fz_seq *seq, const Search &q, bool with_verify) 
     for (const Shard &sh : seq->shards) {
         const DevState &d = lane_dev(ctx, sh.dev);
         ctx->stats.filter_launches += d.launches_used;
+        ctx->stats.verify_form = d.form_used;
         ctx->last_fused = d.fused_used;
     }
     return FZ_OK;

@@ -73,7 +73,17 @@ typedef struct {
     double   device_ms;        /* hipEvent span first launch -> results on host, last call   */
     uint32_t filter_launches;  /* number of filter kernel launches in the last call          */
     uint32_t n_devices;
+    uint32_t verify_form;      /* how the last call's n-gram hits were verified (FZ_FORM_*)   */
+    uint32_t reserved_;
 } fz_stats_t;
+
+/* fz_stats_t.verify_form: chosen from the search's arguments alone (pattern, budget, sequence kind) */
+#define FZ_FORM_NONE        0u   /* no verification (exact search, automaton searches)                          */
+#define FZ_FORM_FUSED_BAND  1u   /* inside the scan: register band / Hamming count, one candidate per lane     */
+#define FZ_FORM_FUSED_CELLS 2u   /* inside the scan: lane-per-DP-cell, 16 or 32 lanes per candidate            */
+#define FZ_FORM_FUSED_BITS1 3u   /* inside the scan: bit-vector columns on one 64-bit word, candidate per lane */
+#define FZ_FORM_FUSED_BITS2 4u   /* ... on two 64-bit words (patterns of 65 .. 128 characters)                 */
+#define FZ_FORM_KERNEL      5u   /* a verification kernel of its own behind a hit list                         */
 
 int         fz_abi_version(void);
 const char *fz_last_error(void);

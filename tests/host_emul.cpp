@@ -634,3 +634,88 @@ int emul_wf_expand(int GW, uint32_t K, const uint8_t *sub, uint32_t sublen, cons
 }
 
 }  // extern "C"
+
+// The bit-vector expansion (fz_device.h: fz_bits_column / fz_expand_bits): one piece on its own, its Peq words built for
+// the piece alone (row i at bit 64 NW - sublen + i).
+template <int NW>
+static int expand_bits_nw(const uint8_t *sub, uint32_t sublen, const uint8_t *win, uint32_t winlen, uint32_t budget,
+                          uint32_t *dist, uint32_t *consumed) {
+    typedef typename FzBitsWord<NW>::T T;
+    if (sublen > 64u * NW) return -1;
+    std::vector<T> tab(256, (T)0);
+    for (uint32_t i = 0; i < sublen; ++i) tab[sub[i]] |= (T)1 << (64u * NW - sublen + i);
+    auto peq = [&](uint8_t c) -> T { return tab[c]; };
+    auto w = [&](uint32_t j) -> uint8_t { return win[j]; };
+    return fz_expand_bits<NW>(peq, sublen, w, winlen, budget, *dist, *consumed) ? 1 : 0;
+}
+
+template <int NW>
+struct HostPeq {
+    typedef typename FzBitsWord<NW>::T T;
+    std::vector<T> tab[2];
+    HostPeq(const uint8_t *p, uint32_t m) {
+        tab[0].assign(256, (T)0); tab[1].assign(256, (T)0);
+        for (uint32_t q = 0; q < m; ++q) {
+            tab[0][p[q]] |= (T)1 << fz_bits_fwd_bit<NW>(m, q);
+            tab[1][p[q]] |= (T)1 << fz_bits_rev_bit<NW>(m, q);
+        }
+    }
+    uint32_t table(uint32_t side) const { return side; }
+    T at(uint32_t h, uint32_t ch) const { return tab[h][ch]; }
+};
+
+// emul_search's Levenshtein form with the per-hit logic of the fused bit-vector verification (fz_verify_lev_bits): both
+// pieces of every hit out of the two whole-pattern tables, selected by their top-bit masks.
+template <int NW>
+static int64_t search_bits_nw(const uint8_t *p, uint32_t m, const uint8_t *t, uint64_t n, uint32_t k,
+                              uint64_t buf_off, uint64_t buf_len, uint64_t own_lo, uint64_t own_hi, OutRec *out, int64_t cap) {
+    const uint32_t L = m / (k + 1);
+    if (L == 0 || m > 64u * NW) return -1;
+    std::vector<uint8_t> shard(buf_len + 64, 0xEE);
+    memcpy(shard.data(), t + buf_off, buf_len);
+    const HostPeq<NW> peq(p, m);
+    int64_t cnt = 0;
+    uint32_t g = 0;
+    const int64_t N = (int64_t)n;
+    for (uint32_t s = 0; s + L <= m; s += L, ++g) {
+        int64_t lo = (int64_t)s - (int64_t)k; if (lo < 0) lo = 0; if (lo > N) lo = N;
+        int64_t hi = N - (int64_t)m + s + L + k; if (hi > N) hi = N; if (hi < lo) hi = lo;
+        for (int64_t idx = lo; idx + (int64_t)L <= hi; ++idx) {
+            if ((uint64_t)idx < own_lo || (uint64_t)idx >= own_hi) continue;
+            if (memcmp(t + idx, p + s, L) != 0) continue;
+            // the window base the kernel uses: the dword-aligned buffer position at or below max(0, idx - s - k)
+            const uint64_t reach = (uint64_t)s + k;
+            uint64_t wlo = (uint64_t)idx > reach ? (uint64_t)idx - reach : 0;
+            if (wlo < buf_off) wlo = buf_off;
+            const uint64_t wbase = buf_off + ((wlo - buf_off) & ~(uint64_t)3);
+            // (the loop reads up to two positions past either end of an expansion's window and ignores them: poison here)
+            auto txt = [&](uint32_t o) -> uint8_t {
+                const uint64_t at = wbase + (uint64_t)(int64_t)(int32_t)o - buf_off;
+                return at < shard.size() ? shard[at] : (uint8_t)0xEE;
+            };
+            FzRec rec;
+            if (!fz_verify_lev_bits<NW>(peq, txt, wbase, 0, n, m, k, L, s, (uint64_t)idx, true, rec)) continue;
+            if (cnt < cap) {
+                out[cnt].start = idx - (int64_t)rec.l;
+                out[cnt].end = idx + L + rec.r;
+                out[cnt].dist = (int32_t)rec.dist;
+                out[cnt].block = (int32_t)g;
+            }
+            ++cnt;
+        }
+    }
+    return cnt;
+}
+
+extern "C" {
+int emul_expand_bits(int NW, const uint8_t *sub, uint32_t sublen, const uint8_t *win, uint32_t winlen, uint32_t budget,
+                     uint32_t *dist, uint32_t *consumed) {
+    return NW == 1 ? expand_bits_nw<1>(sub, sublen, win, winlen, budget, dist, consumed)
+                   : expand_bits_nw<2>(sub, sublen, win, winlen, budget, dist, consumed);
+}
+int64_t emul_search_bits(int NW, const uint8_t *p, uint32_t m, const uint8_t *t, uint64_t n, uint32_t k,
+                         uint64_t buf_off, uint64_t buf_len, uint64_t own_lo, uint64_t own_hi, OutRec *out, int64_t cap) {
+    return NW == 1 ? search_bits_nw<1>(p, m, t, n, k, buf_off, buf_len, own_lo, own_hi, out, cap)
+                   : search_bits_nw<2>(p, m, t, n, k, buf_off, buf_len, own_lo, own_hi, out, cap);
+}
+}

@@ -33,6 +33,12 @@ def emul():
     L.emul_wf_expand.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32,
                                  ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                  ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
+    L.emul_expand_bits.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32,
+                                   ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
+    L.emul_search_bits.restype = ctypes.c_int64
+    L.emul_search_bits.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32,
+                                   ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
+                                   ctypes.POINTER(OutRec), ctypes.c_int64]
     yield L
     os.remove(out)
 
@@ -94,6 +100,97 @@ def test_banded_ring_expand_equals_full_dp(emul):
         d, c = ctypes.c_uint32(), ctypes.c_uint32()
         r = emul.emul_expand(sub, len(sub), win, len(win), b, ctypes.byref(d), ctypes.byref(c))
         assert ((d.value, c.value) if r else (None, None)) == oracle.expand(sub, win, b), (sub, win, b)
+
+
+def _edited(rnd, sub, alpha, n_edits, tail):
+    w = bytearray(sub)
+    for _ in range(n_edits):
+        q = rnd.randrange(len(w) + 1)
+        op = rnd.random()
+        if op < 0.4 and q < len(w):
+            w[q] = rnd.choice(alpha)
+        elif op < 0.7 and q < len(w):
+            del w[q]
+        else:
+            w.insert(q, rnd.choice(alpha))
+    return bytes(w) + bytes(rnd.choice(alpha) for _ in range(tail))
+
+
+def test_bit_vector_expand_equals_full_dp(emul):
+    """fz_expand_bits / fz_bits_column (the column recurrence the fused bit-vector verification runs per lane) against the
+    oracle's full DP with the LAST arg-min rule, on >= 1e5 random pieces: one-word pieces up to 64 rows, two-word pieces
+    up to 128, small alphabets (ties along the bottom row are the rule there), windows shorter and longer than the piece,
+    empty pieces and windows, budgets from 0 to beyond the piece."""
+    rnd = random.Random(61)
+    done = {1: 0, 2: 0}
+    for it in range(125000):
+        nw = 1 if it < 100000 else 2
+        alpha = bytes(rnd.sample(range(1, 256), rnd.choice([1, 2, 2, 3, 4, 4, 20])))
+        top = 64 * nw
+        ln = rnd.choice([0, 1, 2, top - 1, top, rnd.randint(0, top), rnd.randint(0, 24), rnd.randint(0, 24)])
+        sub = bytes(rnd.choice(alpha) for _ in range(ln))
+        b = rnd.choice([0, 1, 2, 3, 5, 8, 13, 21, ln, ln + 1])
+        if rnd.random() < 0.6 and sub:
+            win = _edited(rnd, sub, alpha, rnd.randint(0, b + 1), rnd.randint(0, 3))
+            win = win[:rnd.choice([len(win), len(win), rnd.randint(0, len(win))])]
+        else:
+            win = bytes(rnd.choice(alpha) for _ in range(rnd.randint(0, min(250, ln + b + 3))))
+        win = win[:250]
+        d, c = ctypes.c_uint32(), ctypes.c_uint32()
+        r = emul.emul_expand_bits(nw, sub, len(sub), win, len(win), b, ctypes.byref(d), ctypes.byref(c))
+        assert r in (0, 1)
+        assert ((d.value, c.value) if r else (None, None)) == oracle.expand(sub, win, b), (nw, sub, win, b)
+        done[nw] += 1
+    assert done[1] >= 100000 and done[2] >= 25000
+
+
+def _search_bits(L, nw, p, t, k, buf_off=0, buf_len=None, own_lo=0, own_hi=None):
+    n = len(t)
+    cap = 1 << 15
+    out = (OutRec * cap)()
+    c = L.emul_search_bits(nw, p, len(p), t, n, k, buf_off, n - buf_off if buf_len is None else buf_len,
+                           own_lo, n if own_hi is None else own_hi, out, cap)
+    assert 0 <= c <= cap, c
+    return [(out[i].start, out[i].end, out[i].dist, out[i].block) for i in range(c)]
+
+
+def test_bit_vector_per_hit_verification_equals_oracle(emul):
+    """fz_verify_lev_bits — both expansions of a hit in one loop, both pieces taken out of the two whole-pattern tables by
+    their top-bit masks — against the oracle's raw stream: patterns up to 64 (one word) and 128 (two words) characters,
+    budgets 1 .. 21, hits at both sequence ends (Python-slice clamps), planted occurrences with up to k edits, and the
+    shard geometry with a poisoned halo."""
+    rnd = random.Random(62)
+    done = 0
+    while done < 6000:
+        nw = 1 if done < 4500 else 2
+        sigma = rnd.choice([2, 3, 4, 4, 4, 20])
+        alpha = bytes(rnd.sample(range(1, 256), sigma))
+        k = rnd.choice([1, 2, 3, 4, 5, 6, 8, 8, 12, 21])
+        lo_m = max(k + 1, 2)
+        m = rnd.choice([lo_m, 64 * nw, 64 * nw - 1, rnd.randint(lo_m, max(lo_m, 64 * nw)), rnd.randint(lo_m, max(lo_m, 30))])
+        if m > 64 * nw or m // (k + 1) == 0:
+            continue
+        p = bytes(rnd.choice(alpha) for _ in range(m))
+        n = rnd.choice([0, rnd.randint(0, m), rnd.randint(m, 3 * m + 40), rnd.randint(m, 400)])
+        t = bytearray(rnd.choice(alpha) for _ in range(n))
+        for _ in range(rnd.randint(0, 3)):
+            v = _edited(rnd, p, alpha, rnd.randint(0, k), 0)
+            if len(v) <= n:
+                at = rnd.choice([0, n - len(v), rnd.randint(0, n - len(v))])
+                t[at:at + len(v)] = v
+        t = bytes(t)
+        want = oracle.lev_ngrams_raw(p, t, k)
+        if len(want) > 20000:
+            continue
+        assert _search_bits(emul, nw, p, t, k) == want, (nw, p, t, k)
+        if n >= 3 and done % 3 == 0:
+            halo = m + k
+            cut = rnd.randint(0, n)
+            a = _search_bits(emul, nw, p, t, k, 0, min(n, cut + halo), 0, cut)
+            lo = max(0, cut - halo)
+            b = _search_bits(emul, nw, p, t, k, lo, n - lo, cut, n)
+            assert sorted(a + b, key=lambda r: r[3]) == want, (nw, p, t, k, cut)
+        done += 1
 
 
 def test_per_hit_verification_equals_oracle(emul):
