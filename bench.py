@@ -274,25 +274,9 @@ def extra_blocks(engine, workloads, reps):
     cfgs["configs[1] DNA m=20 max_l_dist=2 (levenshtein_ngram) through find_near_matches"].update(
         api_block(fa, engine, seq, dict(max_l_dist=2), p1, ms, reps))
     try:
-        # Levenshtein budgets 8 .. 15 choose their verification form by what the context's PREVIOUS such search saw (DESIGN.md
-        # §4: lane-per-cell inside the scan when candidates are dense, the stand-alone kernel when they are rare).  The same
-        # GiB of DNA with m = 54, k = 8 makes ~2.4e6 candidates: the first call of this context runs the stand-alone form, the
-        # following ones the fused 32-lane form — both figures, so that the switch is visible where the driver looks.
-        p54 = workloads.dna(54, 7).tobytes()
-        h = engine.upload(seq)
-        t0 = time.perf_counter()
-        r_first = engine.lev_ngrams(h, p54, 8, as_array=True)
-        first_ms = (time.perf_counter() - t0) * 1e3
-        ms54, f54, v54, r54 = time_call(engine, lambda: engine.lev_ngrams(h, p54, 8, as_array=True), 10, warm_s=0.05)
-        st54 = engine.stats()
-        h.release()
-        assert np.array_equal(r_first, r54), "the two verification forms returned different streams"
-        cfgs["lane-per-cell form switch: DNA m=54 max_l_dist=8 (dense candidates)"] = {
-            "first_call_ms": round(first_ms, 3), "steady_ms_per_call": round(ms54, 4), "steady_GB_per_s": round(gib / ms54 / 1e6, 1),
-            "scan_kernel_ms": round(f54, 4), "verify_kernel_ms": round(v54, 4), "ngram_hits": int(st54["ngram_hits"]), "raw_matches": int(len(r54)),
-            "note": "first call of the context: stand-alone lane-per-cell kernel behind a hit list; then fused into the scan (32 lanes per candidate), chosen by the density the previous search saw; identical streams"}
+        out["regimes"] = regimes_block(engine, workloads, seq)
     except Exception as exc:  # noqa: BLE001
-        cfgs["lane-per-cell form switch: DNA m=54 max_l_dist=8 (dense candidates)"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        out["regimes"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     try:
         cfgs["configs[1] DNA m=20 max_l_dist=2 (levenshtein_ngram) through find_near_matches"].update(
             end_to_end_block(fa, seq, p1, reps))
@@ -300,6 +284,35 @@ def extra_blocks(engine, workloads, reps):
         cfgs["configs[1] DNA m=20 max_l_dist=2 (levenshtein_ngram) through find_near_matches"]["end_to_end_error"] = "%s: %s" % (type(exc).__name__, exc)
     out["configs"] = cfgs
     return out
+
+
+FORM_NAMES = ["none", "fused register band", "fused lane-per-cell", "fused bit-vector (64-bit columns)",
+              "fused bit-vector (128-bit columns)", "stand-alone kernel"]
+
+
+def regimes_block(engine, workloads, seq):
+    """The verification cliff map: the Levenshtein n-gram search on the SAME GiB of DNA as configs[1]
+    with |p| = 20, k = 1 .. 4 (3.3e3 .. 2.1e7 candidates), |p| = 54, k = 8 (2.4e6) and |p| = 100, k = 20 (1.0e8: four-
+    character n-grams, one hit per 10 bytes) — ms per synchronous C-ABI call, GB/s, verified candidates, and the verification
+    form, which is a function of the search's arguments alone (first call == steady state: `first_ms`)."""
+    rows = []
+    h = engine.upload(seq)
+    gib = len(seq)
+    for m, k in [(20, 1), (20, 2), (20, 3), (20, 4), (54, 8), (100, 20)]:
+        p = workloads.dna(m, 7 if m != 20 else 1).tobytes()
+        t0 = time.perf_counter()
+        first = engine.lev_ngrams(h, p, k, as_array=True)
+        first_ms = (time.perf_counter() - t0) * 1e3
+        slow = first_ms > 20.0
+        ms, f_ms, v_ms, res = time_call(engine, lambda: engine.lev_ngrams(h, p, k, as_array=True), 3 if slow else 20,
+                                        warm_s=0.0 if slow else 0.1)
+        st = engine.stats()
+        assert np.array_equal(first, res), "the first and the later calls returned different streams"
+        rows.append({"m": m, "k": k, "ms_per_call": round(ms, 4), "GB_per_s": round(gib / ms / 1e6, 1), "first_call_ms": round(first_ms, 3),
+                     "kernel_ms": round(f_ms + v_ms, 4), "candidates": int(st["ngram_hits"]), "raw_matches": int(len(res)),
+                     "verify_form": FORM_NAMES[int(st["verify_form"])], "scan_launches": int(st["filter_launches"])})
+    h.release()
+    return {"workload": "configs[1]'s 1 GiB of DNA; Levenshtein n-gram search, resident, one synchronous C-ABI call", "rows": rows}
 
 
 def end_to_end_block(fa, seq, p1, reps):

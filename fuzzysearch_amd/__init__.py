@@ -14,7 +14,7 @@ many patterns can be searched without re-crossing PCIe.
 import io
 
 from .common import Match, LevenshteinSearchParams
-from .engine import DeviceSequence, resident
+from .engine import DeviceSequence, resident, cache_info, cache_clear, residency_cache
 from ._native import UnsupportedSearch
 from .generic_search import GenericSearch
 from .levenshtein import LevenshteinSearch
@@ -29,6 +29,8 @@ __all__ = [
     'find_near_matches_in_file',
     'Match',
     'resident',
+    'cache_info',
+    'cache_clear',
     'UnsupportedSearch',
 ]
 
@@ -62,6 +64,13 @@ def find_near_matches(subsequence, sequence,
     insertion / deletion limits and for the short-pattern routes), more than 255 distinct symbols in a
     subsequence that is neither bytes nor latin-1 text, and generic searches whose candidate sets outgrow
     2**18 entries.  The reference accepts all of these: catch the exception to route such a call there.
+
+    Residency: a ``bytes`` or ``str`` sequence of 64 KiB or more stays in device memory after the call, so the next
+    query against the SAME object uploads nothing.  The cache lets go of a sequence as soon as the caller has (the
+    entry of an object that nothing else references is dropped at the next call, with its device memory), holds at
+    most 16 sequences and a quarter of the device memory that was free at its first use (at most 8 GiB;
+    ``FUZZYSEARCH_HIP_RESIDENT_CACHE=<bytes, K / M / G>`` sets the budget, ``0`` switches the cache off);
+    ``fuzzysearch_amd.cache_info()`` shows what it holds, ``cache_clear()`` empties it.
     """
     search_params = LevenshteinSearchParams(max_substitutions, max_insertions,
                                             max_deletions, max_l_dist)
@@ -106,10 +115,11 @@ def find_near_matches_in_file(subsequence, sequence_file,
             return _file_stream.run(plan, search_class, subsequence, sequence_file)
         except _file_stream.Unsupported:
             pass                                   # nothing has been read yet: take the per-chunk path
-    if binary:
-        matches = _search_binary_file(subsequence, sequence_file, search_params, search_class, _chunk_size, keep)
-    else:
-        matches = _search_text_file(subsequence, sequence_file, search_params, search_class, _chunk_size, keep)
+    with residency_cache().bypass():               # every chunk is a new object that is searched once: nothing to keep resident
+        if binary:
+            matches = _search_binary_file(subsequence, sequence_file, search_params, search_class, _chunk_size, keep)
+        else:
+            matches = _search_text_file(subsequence, sequence_file, search_params, search_class, _chunk_size, keep)
     return search_class.consolidate_matches(matches)
 
 

@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = (
     "fz_lev_lp", "fz_subs_lp", "fz_generic_lp", "fz_subs_ngrams_any", "fz_subs_lp_any", "fz_generic_ngrams_any", "fz_generic_ngrams_consolidated",
     "fz_lev_ngrams_consolidated", "fz_subs_ngrams_best",
     "fz_stream_open", "fz_stream_buffer", "fz_stream_submit", "fz_stream_read_fd", "fz_stream_finish", "fz_stream_close",
-    "fz_consolidate", "fz_group_best", "fz_merge_ranks", "fz_wire_pack", "fz_wire_merge", "fz_debug_launch_plan", "fz_debug_order_records", "fz_debug_order_records_bounded", "fz_debug_order_segments", "fz_stats", "fz_set_timing", "fz_set_streams", "fz_device_ms", "fz_free",
+    "fz_consolidate", "fz_group_best", "fz_merge_ranks", "fz_wire_pack", "fz_wire_merge", "fz_debug_launch_plan", "fz_debug_order_records", "fz_debug_order_records_bounded", "fz_debug_order_segments", "fz_stats", "fz_mem_info", "fz_set_timing", "fz_set_streams", "fz_device_ms", "fz_free",
     "fz_comm_unique_id", "fz_comm_init_rank", "fz_comm_init_all", "fz_comm_info", "fz_comm_set_collective",
     "fz_comm_allgather", "fz_comm_max_f64", "fz_comm_barrier", "fz_comm_destroy", "fz_comm_gather_ms", "fz_comm_backend", "fz_debug_reload_switches", "fz_debug_gather_merge", "fz_debug_scan_regions",
 )
@@ -189,6 +189,8 @@ def load_library():
         L.fz_merge_ranks.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, u32, u32, ctypes.c_void_p]
         L.fz_stats.restype = ci
         L.fz_stats.argtypes = [vp, ctypes.POINTER(FzStats)]
+        L.fz_mem_info.restype = ci
+        L.fz_mem_info.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
         L.fz_set_timing.restype = ci
         L.fz_set_timing.argtypes = [vp, ci]
         L.fz_set_streams.restype = ci
@@ -765,6 +767,13 @@ class Engine(object):
         with self._lock:                           # fz_stats resolves the event spans: it mutates the context
             _check(self._lib.fz_stats(self._h, ctypes.byref(st)))
         return {f: getattr(st, f) for f, _ in FzStats._fields_}
+
+    def mem_info(self):
+        """(free, total) device memory in bytes: the minimum over the engine's devices."""
+        f, t = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        with self._lock:
+            _check(self._lib.fz_mem_info(self._h, ctypes.byref(f), ctypes.byref(t)))
+        return f.value, t.value
 
     def kernel_ms(self):
         """(filter_ms, verify_ms, device_ms) of the last call: the cheap subset of stats()."""

@@ -58,7 +58,8 @@ struct Switches {
     bool no_wf_fuse = false;           // FZ_NO_WF_FUSE: budgets 5 .. 15 verified by the stand-alone kernel, not inside the scan
     int wf32 = -1;                     // FZ_WF32=0 / 1: pin the fused lane-per-cell form off / on for budgets 8 .. 15 (default: by density)
     bool no_bits = false;              // FZ_NO_BITS: no bit-vector verification (Levenshtein budgets >= FZ_BITS_MIN_K take round 5's forms)
-    int bits_min_k = 5;                // FZ_BITS_MIN_K=k: smallest Levenshtein budget verified by bit-vector columns (below: the register band)
+    int bits_min_k = 3;                // FZ_BITS_MIN_K=k: smallest Levenshtein budget always verified by bit-vector columns (below: the register
+                                       // band unless the pattern lets expect dense candidates)
     int bits_qcap = 0;                 // FZ_BITS_QCAP=n: queue entries per wave of the bit-vector form (default: by LDS)
     int bits_lds_kb = 0;               // FZ_BITS_LDS_KB: LDS per scan workgroup the bit-vector form may take (default 26)
     bool gen_legacy = false;           // FZ_GEN_LEGACY: the generic automaton as fz_lp_kernel (one wave per hit, round 3's form)
@@ -98,7 +99,7 @@ Switches read_switches() {
         auto num = [](const char *n, int dflt) { const char *e = getenv(n); return e ? atoi(e) : dflt; };
         v.no_direct = flag("FZ_NO_DIRECT"); v.no_slot_and = flag("FZ_NO_SLOT_AND"); v.max_blocks = num("FZ_MAX_BLOCKS", 0);
         v.force_big_verify = flag("FZ_FORCE_BIG_VERIFY"); v.no_wavefront = flag("FZ_NO_WAVEFRONT"); v.no_wf_fuse = flag("FZ_NO_WF_FUSE");
-        v.no_bits = flag("FZ_NO_BITS"); v.bits_min_k = num("FZ_BITS_MIN_K", 5); v.bits_qcap = num("FZ_BITS_QCAP", 0);
+        v.no_bits = flag("FZ_NO_BITS"); v.bits_min_k = num("FZ_BITS_MIN_K", 3); v.bits_qcap = num("FZ_BITS_QCAP", 0);
         v.bits_lds_kb = num("FZ_BITS_LDS_KB", 0);
         v.wf32 = num("FZ_WF32", -1); v.gen_legacy = flag("FZ_GEN_LEGACY"); v.gen_no_dedup = flag("FZ_GEN_NO_DEDUP");
         v.gen_direct = flag("FZ_GEN_DIRECT"); v.gen_host_order = flag("FZ_GEN_HOST_ORDER"); v.gh_waves = num("FZ_GH_WAVES", 0);
@@ -960,24 +961,32 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     // per lane, inside the scan (fz_verify_lev_bits) — a column costs the same whatever the budget, so neither the band's
     // width nor the candidates' density decides the form.  The queue takes what LDS allows (full passes: fz_bits_flush).
     int bits_nw = 0;
-    if (q.mode == FZ_MODE_LEV && with_verify && !force_big && !sw().no_bits && sh.geom.seg_stride == 0 && q.k >= (uint32_t)sw().bits_min_k &&
+    // Candidates a wave is expected to find in one tile (4 KiB of offsets per wave) if the sequence is uniform over the
+    // symbols the PATTERN uses — G blocks of L characters over sigma symbols: 4096 G / sigma^L (DNA, m = 54, k = 8: 9;
+    // m = 20, k = 4: 80; text patterns: next to nothing).  A function of the search's arguments, not of earlier calls; an
+    // estimate that is off costs time, never rows.
+    double per_tile = 0;
+    {
+        bool seen[256] = {false};
+        uint32_t sigma = 0;
+        for (uint32_t i = 0; i < q.m; ++i)
+            if (!seen[q.p[i]]) { seen[q.p[i]] = true; ++sigma; }
+        per_tile = 4096.0 * std::min<uint32_t>(G, FZ_MAX_BLOCKS_PER_LAUNCH);
+        for (uint32_t i = 0; i < L && per_tile > 0.01; ++i) per_tile /= (double)std::max(2u, sigma);
+    }
+    // Which budgets: from FZ_BITS_MIN_K (3) on always — at k = 3 on DNA it is 20 % ahead of the register band, at k >= 5 it
+    // replaces the lane-per-cell forms; below that only where the expected density is beyond what the register-band form's
+    // queue discipline takes (more than ~16 candidates per tile and wave: short DNA patterns), the headline workload
+    // (k = 2, 3 per tile) keeps the band.
+    const bool bits_budget = q.k >= (uint32_t)sw().bits_min_k || per_tile > 16.0;
+    if (q.mode == FZ_MODE_LEV && with_verify && !force_big && !sw().no_bits && sh.geom.seg_stride == 0 && bits_budget &&
         q.m <= FZ_BITS_MAX_M(2) && q.k <= FZ_MAX_K && fa.win_pieces * 16u + 16u <= FZ_PAD_BACK) {
         bits_nw = q.m <= FZ_BITS_MAX_M(1) ? 1 : 2;
         // (26 KB: six workgroups per CU.  Measured on 1 GiB of DNA, m = 54, k = 8, 2.4e6 candidates: 64 / 96 / 128 / 160 entries
         //  per wave = 26 / 37 / 47 / 58 KB -> 0.463 / 0.517 / 0.656 / 0.830 ms: fuller passes do not pay for the lost waves)
         const uint32_t budget = (uint32_t)(sw().bits_lds_kb > 0 ? sw().bits_lds_kb : 26) * 1024u;
         const uint32_t fixed = mpad + FZ_TABLE_BYTES + FZ_PEQ_BYTES(bits_nw);
-        // Queue entries per wave: one full pass (64) + twice what a wave is expected to find in one tile (4 KiB of offsets per
-        // wave) if the sequence is uniform over the symbols the PATTERN uses — G blocks of L characters over sigma symbols:
-        // 4096 G / sigma^L.  DNA patterns get the queue DNA needs (m = 54, k = 8: 9 -> 96 entries; m = 20, k = 4: 80 -> what
-        // LDS allows), text patterns the smallest one (more workgroups per CU for the streaming part).  A function of the
-        // search's arguments, not of earlier calls; an estimate that is off costs time, never rows (fz_scan_kernel: overflow).
-        bool seen[256] = {false};
-        uint32_t sigma = 0;
-        for (uint32_t i = 0; i < q.m; ++i)
-            if (!seen[q.p[i]]) { seen[q.p[i]] = true; ++sigma; }
-        double per_tile = 4096.0 * std::min<uint32_t>(G, FZ_MAX_BLOCKS_PER_LAUNCH);
-        for (uint32_t i = 0; i < L && per_tile > 0.01; ++i) per_tile /= (double)std::max(2u, sigma);
+        // Queue entries per wave: one full pass (64) + twice the expected candidates per tile, within the LDS budget.
         uint32_t qc = sw().bits_qcap > 0 ? (uint32_t)sw().bits_qcap
                                          : (uint32_t)std::min(512.0, 64.0 + 32.0 * std::ceil(2.0 * per_tile / 32.0));
         while (qc > 64u && fixed + FZ_WAVES_PER_BLOCK * fz_wave_lds_pref_bytes(qc, fa.win_pieces) > budget) qc -= 32u;
@@ -4449,6 +4458,21 @@ int fz_stats(fz_ctx *ctx, fz_stats_t *out) {
     if (!ctx || !out) return fail(FZ_EINVAL, "null argument");
     resolve_timing(ctx);
     *out = ctx->stats;
+    return FZ_OK;
+}
+
+int fz_mem_info(fz_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes) {
+    if (!ctx || !free_bytes || !total_bytes) return fail(FZ_EINVAL, "null argument");
+    uint64_t fmin = ~0ull, tmin = ~0ull;
+    for (const DevState &d : ctx->devs) {
+        HIP_TRY(hipSetDevice(d.device));
+        size_t f = 0, t = 0;
+        HIP_TRY(hipMemGetInfo(&f, &t));
+        fmin = std::min<uint64_t>(fmin, f);
+        tmin = std::min<uint64_t>(tmin, t);
+    }
+    *free_bytes = fmin;
+    *total_bytes = tmin;
     return FZ_OK;
 }
 

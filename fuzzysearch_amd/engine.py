@@ -190,13 +190,20 @@ class ResidencyCache(object):
     ``memoryview``, numpy arrays, lists ... are uploaded on every call as before.  A ``str`` entry holds its latin-1
     bytes (symbol-remapped text depends on the subsequence and is never cached).
 
-    Least recently used entries leave when the byte budget or the entry count is exceeded; an entry that a search is
-    still using is released by its last user.  Budget: FUZZYSEARCH_HIP_RESIDENT_CACHE (bytes, K / M / G suffixes; 0 switches
-    the cache off; default 8G — device memory, and as much host memory as the cached objects themselves occupy should
-    their owners drop them)."""
+    The reference holds nothing once it has returned (__init__.py:35-57), and neither does the cache for long: every
+    call first drops the entries whose object only the cache still references (the caller has let go — such an entry can
+    never be hit again), so a dropped sequence gives its host bytes and its HBM back at the next search, whatever the
+    budget.  Beyond that, least recently used entries leave BEFORE a new sequence is uploaded, until it fits the byte
+    budget and the entry count; an upload that fails all the same empties the cache and is tried once more; an entry that
+    a search is still using is released by its last user.
+    Budget: FUZZYSEARCH_HIP_RESIDENT_CACHE (bytes, K / M / G suffixes; 0 switches the cache off); by default a quarter of the
+    device memory that is free when the cache is first used, at most 8G.  ``fuzzysearch_amd.cache_info()`` /
+    ``cache_clear()`` are the public handles."""
 
     MIN_BYTES = 1 << 16              # below this an upload costs less than it is worth tracking
     MAX_ENTRIES = 16
+    DEFAULT_MAX = 8 << 30
+    DEFAULT_FRACTION = 0.25          # of the free device memory at first use
 
     class _Entry(object):
         __slots__ = ('obj', 'handle', 'nbytes', 'users', 'evicted', 'engine')
@@ -207,60 +214,136 @@ class ResidencyCache(object):
         self._lock = threading.Lock()
         self._entries = collections.OrderedDict()        # id(obj) -> _Entry, least recently used first
         self._bytes = 0
-        self.budget = self._env_budget() if budget is None else int(budget)
-        self.hits = self.misses = self.evictions = 0
+        self._budget = self._env_budget() if budget is None else int(budget)     # None: derived from the device at first use
+        self.hits = self.misses = self.evictions = self.orphans = self.retries = 0
+        self._tls = threading.local()
 
     @staticmethod
     def _env_budget():
         import os
-        raw = os.environ.get('FUZZYSEARCH_HIP_RESIDENT_CACHE', '8G').strip().upper()
+        raw = os.environ.get('FUZZYSEARCH_HIP_RESIDENT_CACHE', '').strip().upper()
+        if not raw:
+            return None
         mult = 1
-        if raw and raw[-1] in 'KMG':
+        if raw[-1] in 'KMG':
             mult = 1 << (10 * (1 + 'KMG'.index(raw[-1])))
             raw = raw[:-1]
         try:
             return max(0, int(float(raw) * mult))
         except ValueError:
-            return 8 << 30
+            return None
+
+    @property
+    def budget(self):
+        """Bytes the cache may hold.  Not set by the environment: DEFAULT_FRACTION of the free device memory, found when the
+        cache first needs the number (it takes a device), capped at DEFAULT_MAX."""
+        if self._budget is None:
+            try:
+                free, _total = _native.default_engine().mem_info()
+                self._budget = min(self.DEFAULT_MAX, int(free * self.DEFAULT_FRACTION))
+            except Exception:                            # no device yet / no such entry point: decide again next time
+                return self.DEFAULT_MAX
+        return self._budget
+
+    @budget.setter
+    def budget(self, value):
+        self._budget = None if value is None else int(value)
 
     @staticmethod
     def cacheable(sequence):
         return type(sequence) is bytes or type(sequence) is str
+
+    def bypassed(self):
+        """Inside a `with cache.bypass():` block of this thread (the per-chunk file searches: every chunk is a new object that
+        is searched once)."""
+        return getattr(self._tls, 'off', 0) > 0
+
+    def bypass(self):
+        cache = self
+
+        class _Bypass(object):
+            def __enter__(self_inner):
+                cache._tls.off = getattr(cache._tls, 'off', 0) + 1
+
+            def __exit__(self_inner, *exc):
+                cache._tls.off -= 1
+        return _Bypass()
+
+    def sweep(self):
+        """Drop the entries whose objects nobody but the cache references any more; -> how many."""
+        dead = []
+        with self._lock:
+            if self._entries:
+                self._sweep(dead)
+        for h in dead:
+            h.release()
+        return len(dead)
+
+    def _sweep(self, dead, keep=None):
+        """Under the lock: drop every entry whose object is referenced by nothing but its entry (the attribute and
+        getrefcount's own argument make 2)."""
+        import sys
+        for key in [k for k, e in self._entries.items() if e.obj is not keep and e.users == 0 and sys.getrefcount(e.obj) <= 2]:
+            self._drop(key, dead)
+            self.orphans += 1
 
     def acquire(self, engine, sequence, make_data):
         """-> (handle, entry or None).  `make_data()`: the bytes to upload for `sequence` (itself, or its latin-1
         encoding: one byte per item either way), only called when the sequence is not resident.
         entry None: not cached, the caller owns the handle; otherwise the caller calls done(entry) after its search."""
         n = len(sequence)
-        if self.budget <= 0 or n < self.MIN_BYTES or n > self.budget or not self.cacheable(sequence):
-            return engine.upload(make_data()), None
-        key = id(sequence)
-        with self._lock:
-            e = self._entries.get(key)
-            if e is not None and e.obj is sequence and e.engine is engine:
-                self._entries.move_to_end(key)
-                e.users += 1
-                self.hits += 1
-                return e.handle, e
-        handle = engine.upload(make_data())              # outside the lock: tens of milliseconds per GiB
-        e = self._Entry()
-        e.obj, e.handle, e.nbytes, e.users, e.evicted, e.engine = sequence, handle, n, 1, False, engine
         dead = []
-        with self._lock:
-            self.misses += 1
-            other = self._entries.get(key)
-            if other is not None:                        # another thread uploaded the same object meanwhile: keep the newer
-                self._drop(key, dead)
-            self._entries[key] = e
-            self._bytes += n
-            while self._entries and (self._bytes > self.budget or len(self._entries) > self.MAX_ENTRIES):
-                oldest = next(iter(self._entries))
-                if oldest == key:
-                    break
-                self._drop(oldest, dead)
-        for h in dead:
-            h.release()
-        return handle, e
+        try:
+            if self.bypassed() or not self.cacheable(sequence) or n < self.MIN_BYTES:
+                with self._lock:
+                    self._sweep(dead)
+                return self._upload(engine, make_data), None
+            budget = self.budget
+            key = id(sequence)
+            with self._lock:
+                self._sweep(dead, keep=sequence)
+                e = self._entries.get(key)
+                if e is not None and e.obj is sequence and e.engine is engine and budget > 0:
+                    self._entries.move_to_end(key)
+                    e.users += 1
+                    self.hits += 1
+                    return e.handle, e
+                if budget <= 0 or n > budget:
+                    cached = False
+                else:
+                    cached = True
+                    # room first: the new sequence is uploaded into memory the cache has already given back
+                    while self._entries and (self._bytes + n > budget or len(self._entries) + 1 > self.MAX_ENTRIES):
+                        self._drop(next(iter(self._entries)), dead)
+            for h in dead:
+                h.release()
+            del dead[:]
+            handle = self._upload(engine, make_data)         # outside the lock: tens of milliseconds per GiB
+            if not cached:
+                return handle, None
+            e = self._Entry()
+            e.obj, e.handle, e.nbytes, e.users, e.evicted, e.engine = sequence, handle, n, 1, False, engine
+            with self._lock:
+                self.misses += 1
+                if key in self._entries:                     # another thread uploaded the same object meanwhile: keep the newer
+                    self._drop(key, dead)
+                self._entries[key] = e
+                self._bytes += n
+            return handle, e
+        finally:
+            for h in dead:
+                h.release()
+
+    def _upload(self, engine, make_data):
+        """One upload; if the device has no room for it, everything the cache holds goes and it is tried once more."""
+        try:
+            return engine.upload(make_data())
+        except (_native.HipEngineError, MemoryError):
+            if not self._entries:
+                raise
+            self.retries += 1
+            self.clear()
+            return engine.upload(make_data())
 
     def _drop(self, key, dead):
         e = self._entries.pop(key)
@@ -289,8 +372,9 @@ class ResidencyCache(object):
 
     def info(self):
         with self._lock:
-            return {'entries': len(self._entries), 'bytes': self._bytes, 'budget': self.budget, 'hits': self.hits,
-                    'misses': self.misses, 'evictions': self.evictions}
+            return {'entries': len(self._entries), 'bytes': self._bytes, 'budget': self._budget, 'hits': self.hits,
+                    'misses': self.misses, 'evictions': self.evictions, 'orphans_dropped': self.orphans,
+                    'upload_retries': self.retries}
 
 
 _cache = ResidencyCache()
@@ -299,6 +383,17 @@ _cache = ResidencyCache()
 def residency_cache():
     """The process-wide cache behind find_near_matches(subsequence, <bytes or str>): .info(), .clear(), .budget."""
     return _cache
+
+
+def cache_info():
+    """What the residency cache holds: {'entries', 'bytes', 'budget' (None: not derived from the device yet), 'hits',
+    'misses', 'evictions', 'orphans_dropped', 'upload_retries'}."""
+    return _cache.info()
+
+
+def cache_clear():
+    """Release every cached sequence (host reference and HBM) now."""
+    _cache.clear()
 
 
 class _Prepared(object):
@@ -346,8 +441,9 @@ def prepare(subsequence, sequence):
     pr.engine = _native.default_engine()
     pr.original = sequence
     pr.owned = True
+    _cache.sweep()                                       # sequences their owners have dropped give HBM and host bytes back now
     # the reference's call form on an immutable sequence that is already resident: nothing to encode or upload
-    if _cache.budget > 0 and len(sequence) >= ResidencyCache.MIN_BYTES:
+    if len(sequence) >= ResidencyCache.MIN_BYTES and not _cache.bypassed() and _cache.budget > 0:
         if type(sequence) is bytes and is_byteslike(subsequence):
             pr.pattern, pr.byteslike = subsequence, True
             pr.handle, pr.entry = _cache.acquire(pr.engine, sequence, lambda: sequence)

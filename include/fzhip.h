@@ -333,6 +333,10 @@ int fz_debug_gather_merge(const void *blocks, uint32_t world, uint64_t cap, cons
  * call (and by fz_device_ms), not by the search: they describe it until the next search of the context is launched
  * (its launch re-records the events; the fields then read 0). */
 int  fz_stats(fz_ctx *ctx, fz_stats_t *out);
+/* Device memory of the context: the smallest free / total byte counts over its devices (hipMemGetInfo).  The host layer
+ * sizes its residency cache with it (fuzzysearch_amd/engine.py: the reference itself holds nothing between calls,
+ * __init__.py:35-57). */
+int  fz_mem_info(fz_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
 /* hipEvent timing of the kernels (filter_ms / verify_ms / device_ms of fz_stats, fz_device_ms): on by default.
  * Off, no events are recorded around the kernels and the *_ms fields read 0. */
 int  fz_set_timing(fz_ctx *ctx, int on);

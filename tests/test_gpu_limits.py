@@ -143,7 +143,7 @@ def test_long_patterns_and_wide_budgets_levenshtein(engine, m, k, sigma, n, edit
     h.release()
     exp = oracle.lev_ngrams_raw(p, t, k)
     assert got == exp
-    assert len(exp) >= 1 and st["filter_launches"] >= (m // (m // (k + 1)) + 7) // 8
+    assert len(exp) >= 1 and st["filter_launches"] >= (m // (m // (k + 1)) + 15) // 16
 
 
 def test_m_16384_k_300(engine):

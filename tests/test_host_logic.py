@@ -482,8 +482,8 @@ def test_scan_launch_plan_separates_block_hashes():
                 assert slots.setdefault((h >> shift) & 31, h) == h, (p, L, i)
             nxt = g0 + nb
         assert nxt == m // L
-        n_multi += nl.value > -(-(m // L) // 8)
-    assert n_multi < 200            # splitting beyond ceil(G / 8) launches is the exception (low-entropy patterns)
+        n_multi += nl.value > -(-(m // L) // 16)
+    assert n_multi < 300            # splitting beyond ceil(G / 16) launches is the exception (low-entropy patterns)
 
 
 def test_record_ordering_host_step():

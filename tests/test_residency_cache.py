@@ -67,6 +67,88 @@ def test_lru_budget_and_reference_counts_on_a_stub_engine():
     assert e is None
 
 
+def test_dropped_sequences_leave_the_cache_at_the_next_call():
+    """The reference holds nothing once it has returned (__init__.py:35-57): an entry whose object only the cache still
+    references can never be hit again and is dropped — handle released — by the next call, whatever the budget."""
+    eng = _StubEngine()
+    c = fzengine.ResidencyCache(budget=1 << 30)
+    a, b = b"a" * 100000, b"b" * 120000
+    ha, ea = c.acquire(eng, a, lambda: a)
+    c.done(ea)
+    hb, eb = c.acquire(eng, b, lambda: b)
+    c.done(eb)
+    assert c.info()["entries"] == 2 and c.sweep() == 0            # both still referenced by their owners
+    del a
+    assert not ha.released
+    small = b"s" * 10
+    hs, es = c.acquire(eng, small, lambda: small)                  # ANY call sweeps, also one the cache does not track
+    assert es is None and ha.released and not hb.released
+    assert c.info()["entries"] == 1 and c.info()["bytes"] == 120000 and c.info()["orphans_dropped"] == 1
+    # an entry in use is never an orphan, even if its only other owner is the searching frame's argument
+    hb2, eb2 = c.acquire(eng, b, lambda: b)
+    del b
+    assert c.sweep() == 0 and not hb.released
+    c.done(eb2)
+    assert c.sweep() == 1 and hb.released and c.info()["entries"] == 0 and c.info()["bytes"] == 0
+
+
+def test_room_is_made_before_the_upload_and_a_failed_upload_is_retried_on_an_empty_cache():
+    eng = _StubEngine()
+    c = fzengine.ResidencyCache(budget=250000)
+    a, b, d = b"a" * 100000, b"b" * 100000, b"d" * 100000
+    for s_ in (a, b):
+        c.done(c.acquire(eng, s_, lambda s_=s_: s_)[1])
+    del eng.log[:]
+    c.done(c.acquire(eng, d, lambda: d)[1])
+    assert eng.log == [("release", 100000), ("upload", 100000)]   # the evicted sequence's memory is free when the new one arrives
+
+    class _Full(_StubEngine):                                      # the device has room for one more upload only after a release
+        def __init__(self):
+            _StubEngine.__init__(self)
+            self.fail = 1
+
+        def upload(self, data):
+            if self.fail and not any(k == "release" for k, _n in self.log):
+                self.fail -= 1
+                raise fzengine._native.HipEngineError("hipMalloc: out of memory")
+            return _StubEngine.upload(self, data)
+    full = _Full()
+    c2 = fzengine.ResidencyCache(budget=1 << 30)
+    full.fail = 0
+    c2.done(c2.acquire(full, a, lambda: a)[1])
+    full.fail = 1
+    h, e = c2.acquire(full, b, lambda: b)
+    assert e is not None and not h.released and c2.info()["upload_retries"] == 1
+    assert [k for k, _n in full.log] == ["upload", "release", "upload"] and c2.info()["entries"] == 1
+    c2.done(e)
+    # with nothing to give back the failure is the caller's
+    empty = fzengine.ResidencyCache(budget=1 << 30)
+    never = _Full()
+    never.fail = 5
+    with pytest.raises(fzengine._native.HipEngineError):
+        empty.acquire(never, a, lambda: a)
+
+
+def test_bypass_for_the_chunked_file_searches():
+    eng = _StubEngine()
+    c = fzengine.ResidencyCache(budget=1 << 30)
+    a = b"a" * 100000
+    with c.bypass():
+        assert c.bypassed()
+        h, e = c.acquire(eng, a, lambda: a)
+        assert e is None and c.info()["entries"] == 0
+        with c.bypass():
+            assert c.bypassed()
+        assert c.bypassed()
+    assert not c.bypassed()
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(c.bypassed()))  # per thread
+    with c.bypass():
+        t.start()
+        t.join()
+    assert seen == [False]
+
+
 def test_concurrent_acquire_release_on_a_stub_engine():
     eng = _StubEngine()
     c = fzengine.ResidencyCache(budget=250000)
@@ -109,7 +191,7 @@ def test_find_near_matches_on_plain_bytes_uploads_once(engine):
     from tests import workloads
     cache = fzengine.residency_cache()
     cache.clear()
-    old_budget = cache.budget
+    old_budget = cache._budget
     try:
         cache.budget = 24 << 20
         seq = workloads.dna(8 << 20, 41)
@@ -169,4 +251,44 @@ def test_find_near_matches_on_plain_bytes_uploads_once(engine):
         assert cache.info()["entries"] == 0
     finally:
         cache.clear()
-        cache.budget = old_budget
+        cache._budget = old_budget
+
+
+@pytest.mark.gpu
+def test_a_dropped_sequence_gives_its_device_memory_back_at_the_next_call(engine):
+    """upload, `del`, the next call — any call — frees the HBM and the host bytes; the public handles
+    cache_info() / cache_clear(); the default budget comes from the device's free memory."""
+    import gc
+    import fuzzysearch_amd as fa
+    from tests import workloads
+    cache = fzengine.residency_cache()
+    cache.clear()
+    old_budget = cache._budget
+    try:
+        cache.budget = None                                        # default: a quarter of the free device memory, at most 8 GiB
+        free0, total = engine.mem_info()
+        assert 0 < cache.budget <= min(8 << 30, free0 // 4 + 1) and total >= free0
+        p = workloads.dna(20, 1).tobytes()
+        big = workloads.dna(256 << 20, 77).tobytes()
+        fa.find_near_matches(p, big, max_l_dist=2)
+        info = fa.cache_info()
+        assert info["entries"] == 1 and info["bytes"] == len(big)
+        free1, _t = engine.mem_info()
+        assert free0 - free1 >= 200 << 20                          # the sequence is resident
+        del big
+        gc.collect()
+        assert fa.cache_info()["entries"] == 1                     # nothing has looked yet
+        fa.find_near_matches(p, b"ACGT" * 10, max_l_dist=2)        # a small, uncached search is enough
+        info = fa.cache_info()
+        assert info["entries"] == 0 and info["bytes"] == 0 and info["orphans_dropped"] >= 1
+        free2, _t = engine.mem_info()
+        assert free2 - free1 >= 200 << 20                          # ... and its device memory is back
+        # cache_clear()
+        other = workloads.dna(16 << 20, 78).tobytes()
+        fa.find_near_matches(p, other, max_l_dist=2)
+        assert fa.cache_info()["entries"] == 1
+        fa.cache_clear()
+        assert fa.cache_info()["entries"] == 0
+    finally:
+        cache.clear()
+        cache._budget = old_budget
