@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FUZZYSEARCH_HIP_LIB: another build of the same C-ABI (A/B benchmarking of kernel versions)
 LIB_PATH = os.environ.get("FUZZYSEARCH_HIP_LIB") or os.path.join(_HERE, "libfzhip.so")
 
-FZ_OK, FZ_EINVAL, FZ_ENOMEM, FZ_EDEVICE, FZ_EUNSUPPORTED, FZ_EHALO = 0, -1, -2, -3, -4, -5
+FZ_OK, FZ_EINVAL, FZ_ENOMEM, FZ_EDEVICE, FZ_EUNSUPPORTED, FZ_EHALO, FZ_ETIMEOUT = 0, -1, -2, -3, -4, -5, -6
 UINT64_MAX = (1 << 64) - 1
 
 # every symbol include/fzhip.h declares (tests check the library exports exactly these)
@@ -48,6 +48,10 @@ FORM_NONE, FORM_FUSED_BAND, FORM_FUSED_CELLS, FORM_FUSED_BITS1, FORM_FUSED_BITS2
 
 class HipEngineError(RuntimeError):
     """libfzhip.so missing / no usable gfx950 device / HIP runtime failure."""
+
+
+class CollectiveTimeout(HipEngineError):
+    """A collective of the context's communicator did not complete within FZ_COMM_TIMEOUT_MS (a rank never arrived)."""
 
 
 _lib = None
@@ -219,6 +223,8 @@ def _raise(rc):
         raise MemoryError(msg)
     if rc == FZ_EUNSUPPORTED:
         raise UnsupportedSearch(msg)
+    if rc == FZ_ETIMEOUT:
+        raise CollectiveTimeout("libfzhip error %d: %s" % (rc, msg))
     raise HipEngineError("libfzhip error %d: %s" % (rc, msg))
 
 

@@ -88,6 +88,7 @@ struct Switches {
     bool stream_nofill = false;        // FZ_STREAM_NOFILL: file streams without the reads (H2D + scan alone)
     bool stream_trace = false;         // FZ_STREAM_TRACE: host time split of a file stream on stderr
     long worker_spin_us = 1500;        // FZ_WORKER_SPIN_US: how long a device's worker thread spins before it sleeps
+    long comm_timeout_ms = 60000;      // FZ_COMM_TIMEOUT_MS: deadline of every wait for a collective (then FZ_ETIMEOUT, not a hung job)
     int fused_lds_kb = 0, fused_target_kb = 0, extra_lds_kb = 0;   // FZ_FUSED_LDS_KB, FZ_FUSED_TARGET_KB, FZ_EXTRA_LDS_KB: LDS shaping of the scan
     int tiles_per_wg = 0, rounds = 0, wg_per_cu = 0;               // FZ_TILES_PER_WG, FZ_ROUNDS, FZ_WG_PER_CU: the scan grid
     int lp_grid_per_cu = 24, gh_grid_per_cu = 0;                   // FZ_LP_GRID_PER_CU, FZ_GH_GRID_PER_CU: automaton grids
@@ -114,6 +115,7 @@ Switches read_switches() {
         v.stream_default_priority = flag("FZ_STREAM_DEFAULT_PRIORITY"); v.stream_nofill = flag("FZ_STREAM_NOFILL");
         v.stream_trace = flag("FZ_STREAM_TRACE");
         if (const char *e = getenv("FZ_WORKER_SPIN_US")) v.worker_spin_us = atol(e);
+        if (const char *e = getenv("FZ_COMM_TIMEOUT_MS")) v.comm_timeout_ms = std::max(1L, atol(e));
         v.fused_lds_kb = num("FZ_FUSED_LDS_KB", 0); v.fused_target_kb = num("FZ_FUSED_TARGET_KB", 0); v.extra_lds_kb = num("FZ_EXTRA_LDS_KB", 0);
         v.tiles_per_wg = num("FZ_TILES_PER_WG", 0); v.rounds = num("FZ_ROUNDS", 0); v.wg_per_cu = num("FZ_WG_PER_CU", 0);
         v.lp_grid_per_cu = num("FZ_LP_GRID_PER_CU", 24); v.gh_grid_per_cu = num("FZ_GH_GRID_PER_CU", 0);
@@ -449,6 +451,8 @@ struct fz_ctx {
     std::vector<TimingRef> tref;
     int comm_world = 0;
     bool snapshot = false;
+    bool comm_broken = false;                    // a collective ran into its deadline: the communicator is abandoned (no further
+                                                 // collective is started, its streams and buffers are not waited for or freed)
     uint64_t gcap = 4096;                        // records per rank the all-gather carries (follows the counts, on all ranks alike)
     // fz_set_streams: 2 = the younger of two fused searches in flight scans on a stream of its own (FZ_DUAL_STREAM=1 presets it)
     int streams = sw().dual_stream ? 2 : 1;
@@ -1365,6 +1369,26 @@ const RcclApi *rccl_api() {
         if (r_ != ncclSuccess) return fail(FZ_EDEVICE, "%s failed: %s", #expr, rccl_api()->GetErrorString(r_)); \
     } while (0)
 
+// Every wait for a collective has a deadline (FZ_COMM_TIMEOUT_MS, default 60 s): a rank that never arrives — a peer process
+// that died, a link that does not come up — is an error the caller can act on (bench.py prints its line with
+// `collective_error` and the host-merged value), not a job that hangs until somebody kills it.  Polling (hipStreamQuery)
+// instead of hipStreamSynchronize: spinning at first — a gather takes tens of microseconds —, yielding after 200 us.
+int comm_wait(hipStream_t st, const char *what) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const long limit_ms = sw().comm_timeout_ms;
+    for (;;) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e == hipSuccess) return FZ_OK;
+        (void)hipGetLastError();                           // (hipErrorNotReady is an answer, not a failure of a later launch)
+        if (e != hipErrorNotReady) return fail(FZ_EDEVICE, "%s: %s", what, hipGetErrorString(e));
+        const auto waited = std::chrono::steady_clock::now() - t0;
+        if (waited > std::chrono::milliseconds(limit_ms))
+            return fail(FZ_ETIMEOUT, "%s did not complete within %ld ms (FZ_COMM_TIMEOUT_MS): a rank of the communicator never arrived",
+                        what, limit_ms);
+        if (waited > std::chrono::microseconds(200)) std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+}
+
 // The exchange step of a sharded search: every rank of the communicator contributes the
 // snapshot of its counters + records (FzRec, unordered), ONE ncclAllGather of kHeaderBytes + gcap records per
 // rank (a group call over the device states of this process), one D2H copy of the gathered block, and every rank
@@ -1375,6 +1399,8 @@ const RcclApi *rccl_api() {
 int gather_records(fz_ctx *ctx, fz_seq *seq, std::vector<FzRec> &recs) {
     const int world = ctx->comm_world;
     if (world <= 0) return fail(FZ_EINVAL, "the context has not joined a communicator");
+    if (ctx->comm_broken) return fail(FZ_ETIMEOUT, "the communicator was abandoned after a collective ran into its deadline: "
+                                                   "fz_comm_set_collective(ctx, 0) searches without it");
     recs.clear();
     const auto t_start = std::chrono::steady_clock::now();
     int rcl = comm_rank_lows(ctx, seq);
@@ -1407,10 +1433,14 @@ int gather_records(fz_ctx *ctx, fz_seq *seq, std::vector<FzRec> &recs) {
         HIP_TRY(hipSetDevice(d0.device));
         HIP_TRY(hipMemcpyAsync(d0.h_recv, d0.d_recv, (uint64_t)world * bytes, hipMemcpyDeviceToHost, d0.comm_stream));
         HIP_TRY(hipEventRecord(d0.ev_done, d0.comm_stream));
-        HIP_TRY(hipEventSynchronize(d0.ev_done));
+        {
+            int rcw = comm_wait(d0.comm_stream, "the all-gather of the ranks' records");
+            if (rcw) { if (rcw == FZ_ETIMEOUT) ctx->comm_broken = true; return rcw; }
+        }
         for (size_t i = 1; i < ctx->devs.size(); ++i) {      // the other device states of this process: only wait
             HIP_TRY(hipSetDevice(ctx->devs[i].device));
-            HIP_TRY(hipStreamSynchronize(ctx->devs[i].comm_stream));
+            int rcw = comm_wait(ctx->devs[i].comm_stream, "the all-gather of the ranks' records");
+            if (rcw) { if (rcw == FZ_ETIMEOUT) ctx->comm_broken = true; return rcw; }
         }
         uint64_t top = 0, total = 0;
         parse_gathered(d0.h_recv, world, bytes, ctx->gcap, seq->rank_lo.data(), recs, ctx->seg_ends, ctx->seg_order, &top, &total);
@@ -2916,6 +2946,18 @@ int comm_setup_dev(DevState &d) {
 }
 
 void comm_teardown(fz_ctx *ctx) {
+    if (ctx->comm_broken) {
+        // a collective never completed: waiting for its stream or freeing what it may still write would hang as well —
+        // the communicator, its streams and buffers are left behind (the process is about to report the failure)
+        for (DevState &d : ctx->devs) {
+            d.comm = nullptr; d.comm_stream = nullptr; d.d_recv = nullptr; d.h_recv = nullptr; d.recv_bytes = 0; d.send_cap = 0;
+            for (auto &b : d.d_send) b = nullptr;
+            for (auto &ev : d.ev_snap) ev = nullptr;
+            d.ev_done = nullptr; d.comm_rank = -1; d.snap_taken[0] = d.snap_taken[1] = false;
+        }
+        ctx->comm_world = 0; ctx->snapshot = false; ctx->comm_broken = false;
+        return;
+    }
     for (DevState &d : ctx->devs) {
         (void)hipSetDevice(d.device);
         if (d.comm_stream) (void)hipStreamSynchronize(d.comm_stream);
@@ -2946,6 +2988,7 @@ bool comm_multi_process(const fz_ctx *ctx) { return ctx->snapshot && ctx->comm_w
 
 // nbytes from every rank of a one-process-per-GPU communicator, rank order, through device buffers (blocking).
 int comm_allgather_fixed(fz_ctx *ctx, const void *send, uint64_t nbytes, void *recv) {
+    if (ctx->comm_broken) return fail(FZ_ETIMEOUT, "the communicator was abandoned after a collective ran into its deadline");
     DevState &d = ctx->devs[0];
     HIP_TRY(hipSetDevice(d.device));
     const uint64_t world = (uint64_t)ctx->comm_world;
@@ -2955,11 +2998,11 @@ int comm_allgather_fixed(fz_ctx *ctx, const void *send, uint64_t nbytes, void *r
         HIP_TRY(hipMemcpyAsync(tmp, send, nbytes, hipMemcpyHostToDevice, d.comm_stream));
         NCCL_TRY(rccl_api()->AllGather(tmp, tmp + nbytes, nbytes, ncclChar, d.comm, d.comm_stream));
         HIP_TRY(hipMemcpyAsync(recv, tmp + nbytes, world * nbytes, hipMemcpyDeviceToHost, d.comm_stream));
-        HIP_TRY(hipStreamSynchronize(d.comm_stream));
-        return FZ_OK;
+        return comm_wait(d.comm_stream, "an all-gather over the job's ranks");
     };
     int rc = body();
-    (void)hipFree(tmp);
+    if (rc == FZ_ETIMEOUT) ctx->comm_broken = true;        // (and the buffer stays: the stream may still write to it)
+    else (void)hipFree(tmp);
     return rc;
 }
 
@@ -3114,6 +3157,7 @@ int fz_comm_max_f64(fz_ctx *ctx, double *value) {
     if (rc) return rc;
     if (!ctx->comm_world || !value) return fail(FZ_EINVAL, "no communicator / null argument");
     if (ctx->devs.size() != 1) return FZ_OK;               // one process holds every rank: nothing to reduce
+    if (ctx->comm_broken) return fail(FZ_ETIMEOUT, "the communicator was abandoned after a collective ran into its deadline");
     DevState &d = ctx->devs[0];
     HIP_TRY(hipSetDevice(d.device));
     double *tmp = nullptr;
@@ -3122,11 +3166,11 @@ int fz_comm_max_f64(fz_ctx *ctx, double *value) {
         HIP_TRY(hipMemcpyAsync(tmp, value, sizeof(double), hipMemcpyHostToDevice, d.comm_stream));
         NCCL_TRY(rccl_api()->AllReduce(tmp, tmp, 1, ncclDouble, ncclMax, d.comm, d.comm_stream));
         HIP_TRY(hipMemcpyAsync(value, tmp, sizeof(double), hipMemcpyDeviceToHost, d.comm_stream));
-        HIP_TRY(hipStreamSynchronize(d.comm_stream));
-        return FZ_OK;
+        return comm_wait(d.comm_stream, "an all-reduce over the job's ranks");
     };
     rc = body();
-    (void)hipFree(tmp);
+    if (rc == FZ_ETIMEOUT) ctx->comm_broken = true;
+    else (void)hipFree(tmp);
     return rc;
 }
 

@@ -51,6 +51,8 @@ extern "C" {
 #define FZ_EDEVICE    -3   /* HIP runtime error / no usable gfx950 device (RuntimeError)   */
 #define FZ_EUNSUPPORTED -4 /* parameters outside what the kernels support (m, k limits)    */
 #define FZ_EHALO      -5   /* shard halo too small for this pattern (m + k bytes needed)   */
+#define FZ_ETIMEOUT   -6   /* a collective did not complete within FZ_COMM_TIMEOUT_MS (a rank never arrived): the
+                            * communicator is unusable from then on; searches without the collective still work  */
 
 typedef struct fz_ctx fz_ctx;
 typedef struct fz_seq fz_seq;

@@ -20,6 +20,13 @@
 //   * misuse that would hang or corrupt with the real library is an ERROR here: a collective with fewer calls than
 //     ranks, differing byte counts between ranks, a rank used twice in one group.
 //
+//   * fault injection (tests/test_gpu_mock_rccl.py: what bench.py --gpus N must survive on its first real node):
+//       FZMOCK_FAIL_INIT=1            ncclCommInitAll / ncclCommInitRank return ncclSystemError
+//       FZMOCK_FAIL_ALLGATHER=n       the n-th all-gather of the process (1-based) returns ncclSystemError
+//       FZMOCK_LATE_RANK=r:ms         rank r's send buffer becomes "ready" ms milliseconds late in every in-process all-gather
+//                                     (a host function sleeping on its stream): slower, never wrong
+//       FZMOCK_STALL_ALLGATHER=n:ms   the n-th in-process all-gather stalls rank 0's stream for ms milliseconds — a rank that
+//                                     (for the caller's deadline) never arrives
 // Not emulated: RCCL's transports (xGMI rings, IPC handles, channels) — those stay unverified until an 8-GPU node
 // runs bench.py.  The product never loads this file; tests/ and nothing else names it.
 //
@@ -66,6 +73,18 @@ ncclResult_t bad(ncclResult_t code, const char *fmt, ...) {
         hipError_t e_ = (expr);                                                                      \
         if (e_ != hipSuccess) return bad(ncclUnhandledCudaError, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
+
+long env_long(const char *name, long dflt) { const char *e = getenv(name); return e ? atol(e) : dflt; }
+// "a:b" -> (a, b); (-1, 0) when unset
+void env_pair(const char *name, long &a, long &b) {
+    a = -1; b = 0;
+    const char *e = getenv(name);
+    if (!e) return;
+    a = atol(e);
+    const char *c = strchr(e, ':');
+    b = c ? atol(c + 1) : 0;
+}
+void sleep_on_stream(void *ms) { std::this_thread::sleep_for(std::chrono::milliseconds((long)(intptr_t)ms)); }
 
 double timeout_s() {
     static const double t = []() { const char *e = getenv("FZ_MOCK_RCCL_TIMEOUT_S"); return e ? atof(e) : 120.0; }();
@@ -181,11 +200,18 @@ ncclResult_t local_allgather(Clique *q, const std::vector<const Op *> &ops) {   
         ncclResult_t rc = ensure_events(q->members[r]);
         if (rc != ncclSuccess) return rc;
     }
-    g_stats[0]++; g_stats[1] += bytes;
+    const uint64_t call_no = ++g_stats[0];
+    g_stats[1] += bytes;
+    if ((long)call_no == env_long("FZMOCK_FAIL_ALLGATHER", -1)) return bad(ncclSystemError, "mock: injected failure of all-gather %llu", (unsigned long long)call_no);
     if (!bytes) return ncclSuccess;
+    long late_rank, late_ms, stall_no, stall_ms;
+    env_pair("FZMOCK_LATE_RANK", late_rank, late_ms);
+    env_pair("FZMOCK_STALL_ALLGATHER", stall_no, stall_ms);
     for (int j = 0; j < n; ++j) {                              // "send buffer of rank j is ready" — on j's stream
         ncclComm *c = q->members[j];
         HIPQ(hipSetDevice(c->device));
+        if (j == late_rank && late_ms > 0) HIPQ(hipLaunchHostFunc(ops[j]->stream, sleep_on_stream, (void *)(intptr_t)late_ms));
+        if (j == 0 && (long)call_no == stall_no && stall_ms > 0) HIPQ(hipLaunchHostFunc(ops[j]->stream, sleep_on_stream, (void *)(intptr_t)stall_ms));
         HIPQ(hipEventRecord(c->ev_ready, ops[j]->stream));
     }
     for (int r = 0; r < n; ++r) {
@@ -409,6 +435,7 @@ ncclResult_t ncclGetUniqueId(ncclUniqueId *id) {
 
 ncclResult_t ncclCommInitAll(ncclComm_t *comms, int ndev, const int *devlist) {
     if (!comms || ndev < 1 || ndev > kMaxRanks) return bad(ncclInvalidArgument, "mock: ncclCommInitAll(%d)", ndev);
+    if (env_long("FZMOCK_FAIL_INIT", 0)) return bad(ncclSystemError, "mock: injected failure of ncclCommInitAll");
     Clique *q = new Clique;
     q->members.resize(ndev);
     q->alive = ndev;
@@ -423,6 +450,7 @@ ncclResult_t ncclCommInitAll(ncclComm_t *comms, int ndev, const int *devlist) {
 
 ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int rank) {
     if (!comm || nranks < 1 || nranks > kMaxRanks || rank < 0 || rank >= nranks) return bad(ncclInvalidArgument, "mock: ncclCommInitRank(%d, %d)", nranks, rank);
+    if (env_long("FZMOCK_FAIL_INIT", 0)) return bad(ncclSystemError, "mock: injected failure of ncclCommInitRank");
     int dev = 0;
     HIPQ(hipGetDevice(&dev));
     ncclComm *c = new ncclComm;

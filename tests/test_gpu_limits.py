@@ -165,7 +165,7 @@ def test_m_16384_k_300(engine):
 
 
 def test_1000_blocks(engine):
-    """m = 3000, k = 999: L = 3, G = 1000 blocks (125 launches), band of 1999 cells = 32 per lane."""
+    """m = 3000, k = 999: L = 3, G = 1000 blocks (at least 63 launches of up to 16), band of 1999 cells = 32 per lane."""
     rnd = random.Random(3000)
     alpha = bytes(rnd.sample(range(1, 256), 90))
     m, k = 3000, 999
@@ -177,7 +177,7 @@ def test_1000_blocks(engine):
     h.release()
     exp = oracle.lev_ngrams_raw(p, t, k)
     assert got == exp
-    assert len(exp) >= 90 and max(g for (_s, _e, _d, g) in exp) > 255 and st["filter_launches"] >= 125
+    assert len(exp) >= 90 and max(g for (_s, _e, _d, g) in exp) > 255 and st["filter_launches"] >= 63
 
 
 def test_long_patterns_other_routes(engine):

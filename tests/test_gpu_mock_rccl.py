@@ -138,3 +138,40 @@ def test_collective_search_of_eight_ranks_beyond_4gib():
     assert p.returncode == 0, p.stderr[-3000:]
     last = [ln for ln in p.stdout.splitlines() if ln.startswith("OK ")]
     assert last and int(last[-1].split()[1]) == 3 * 4 + 2 * 3 and int(last[-1].split()[2]) > 1000, p.stdout[-500:]
+
+
+def _bench8(extra_env, timeout=900):
+    env = mock_rccl.env(dict({"FZ_DEVICES": ",".join(["0"] * 8)}, **extra_env))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--mib", "64", "--steps", "8", "--warmup", "2",
+                          "--settle-ms", "200", "--no-cpu-baseline"], capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-2000:]
+    return json.loads(lines[0]), out.stderr
+
+
+@pytest.mark.parametrize("fault,env", [
+    ("init fails", {"FZMOCK_FAIL_INIT": "1"}),
+    ("an all-gather returns an error in the middle of the run", {"FZMOCK_FAIL_ALLGATHER": "40"}),
+    ("a rank never arrives (deadline)", {"FZMOCK_STALL_ALLGATHER": "40:4000", "FZ_COMM_TIMEOUT_MS": "300"}),
+])
+def test_bench_prints_its_line_when_the_collective_fails(fault, env):
+    """First contact with a real 8-GPU node: whatever the collective library does — refuse the
+    communicator, fail an all-gather in the middle of the timed run, never complete one — `bench.py --gpus 8` prints ITS LINE:
+    `collective_error` says what happened, `value` is the host-merged search of the same shards (correct: boundary plants
+    found, reference order), nothing hangs (every wait of the collective path has a deadline: FZ_COMM_TIMEOUT_MS)."""
+    d, err = _bench8(env)
+    assert d["n_gpus"] == 8 and d["rccl_ranks"] == 0 and d["collective_error"], (fault, d.get("collective_error"))
+    assert d["value"] > 0 and d["boundary_plants_found"] == 3 * 4 + 2 * 3 and d["stream_in_reference_order"] is True
+    assert "host-merged" in err
+    if "STALL" in "".join(env):
+        assert "did not complete within 300 ms" in d["collective_error"]
+    if "FAIL_ALLGATHER" in "".join(env):
+        assert "injected failure" in d["collective_error"]
+
+
+def test_a_late_rank_is_slow_not_wrong():
+    """One rank 50 ms late in every all-gather: the collective line as usual (rccl_ranks 8, plants found), only slower."""
+    d, _err = _bench8({"FZMOCK_LATE_RANK": "5:50"}, timeout=1500)
+    assert d["rccl_ranks"] == 8 and d["collective_error"] is None and d["allgather_ms"] >= 40
+    assert d["boundary_plants_found"] == 3 * 4 + 2 * 3 and d["stream_in_reference_order"] is True
