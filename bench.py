@@ -258,6 +258,18 @@ def extra_blocks(engine, workloads, reps):
     gpipe_ms = (time.perf_counter() - t0) / g_reps * 1e3
     glast = engine.search_end(as_array=True)
     assert np.array_equal(graw, res) and np.array_equal(glast, res), "pipelined generic search returned a different stream"
+    # ... and two CONSOLIDATED generic searches in flight (what find_near_matches runs for a GenericSearch)
+    engine.generic_ngrams_begin(h, p3, 5, 2, 2, 5, consolidated=True)
+    for _ in range(5):
+        engine.generic_ngrams_begin(h, p3, 5, 2, 2, 5, consolidated=True)
+        engine.search_end(as_array=True)
+    t0 = time.perf_counter()
+    for _ in range(g_reps):
+        engine.generic_ngrams_begin(h, p3, 5, 2, 2, 5, consolidated=True)
+        craw = engine.search_end(as_array=True)
+    cpipe_ms = (time.perf_counter() - t0) / g_reps * 1e3
+    clast = engine.search_end(as_array=True)
+    assert np.array_equal(craw, cres) and np.array_equal(clast, cres), "pipelined consolidated generic search returned different rows"
     h.release()
     api3b = api_block(fa, engine, seq, dict(max_substitutions=5, max_insertions=2, max_deletions=2, max_l_dist=5), p3, ms, max(20, reps // 4))
     cfgs["configs[3b] UTF-8 m=64 limits (5,2,2,5) (generic_search)"] = {
@@ -266,6 +278,7 @@ def extra_blocks(engine, workloads, reps):
         "two_in_flight_ms_per_call": round(gpipe_ms, 4), "two_in_flight_GB_per_s": round(gib / gpipe_ms / 1e6, 1),
         "consolidated_ms_per_call": round(cms, 4), "consolidated_GB_per_s": round(gib / cms / 1e6, 1),
         "consolidated_automaton_kernel_ms": round(cv_ms, 4), "consolidated_matches": int(len(cres)),
+        "consolidated_two_in_flight_ms": round(cpipe_ms, 4), "consolidated_two_in_flight_GB_per_s": round(gib / cpipe_ms / 1e6, 1),
         "note": "consolidated = fz_generic_ngrams_consolidated: search + consolidate_overlapping_matches, first stage on the device"}
     cfgs["configs[3b] UTF-8 m=64 limits (5,2,2,5) (generic_search)"].update(api3b)
     # configs[1] through the public API (the headline workload): find_near_matches on a resident bytes sequence

@@ -266,6 +266,30 @@ __device__ __forceinline__ unsigned long long fz_bcast64(unsigned long long v) {
            (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
 }
 
+// _substitutions_only_ngrams_template.h:103-121 for the hits of a wave, four characters per step: the window's Hamming
+// distance to the WHOLE pattern (the n-gram's own positions agree — the caller has confirmed the n-gram — and add nothing),
+// text dwords brought to the pattern's alignment by v_alignbyte, nonzero bytes of the xor counted by one v_bcnt.  The loop is
+// wave-uniform (m / 4 steps, left when no lane is within the budget any more): fz_verify_subs's per-lane skip over the
+// n-gram and per-lane early return compile to ~90 scalar instructions per character and lane group on dense candidates
+// (1 GiB DNA, m = 20, 4 substitutions: 1.9e9 SALU instructions).  -> dist = the Hamming distance where it is <= k.
+__device__ __forceinline__ bool fz_verify_subs_wave(const FzDmaWindow &t, const uint8_t *pat_lds, uint32_t m, uint32_t k, uint32_t L,
+                                                    uint32_t s, uint64_t idx, bool valid, FzRec &rec) {
+    const uint32_t off = valid ? (uint32_t)(idx - s - t.wbase) : 0u;
+    const uint32_t a0 = off & ~3u, sh = off & 3u;
+    uint32_t prev = t.dword(a0), nd = 0;
+    for (uint32_t q = 0; q < m; q += 4u) {
+        const uint32_t next = t.dword(a0 + q + 4u);
+        uint32_t d = __builtin_amdgcn_alignbyte(next, prev, sh) ^ *reinterpret_cast<const uint32_t *>(pat_lds + q);
+        if (q + 4u > m) d &= (1u << (8u * (m - q))) - 1u;              // (uniform: the pattern's last, partial dword)
+        const uint32_t nz = (((d & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d) & 0x80808080u;   // bit 7 of every nonzero byte
+        nd += (uint32_t)__popc(nz);
+        prev = next;
+        if ((q & 4u) && !__ballot(valid && nd <= k)) break;
+    }
+    rec.l = s; rec.r = m - s - L; rec.dist = nd; rec.aux = 0;
+    return valid && nd <= k;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Wave-level verification of up to 64 candidates: each valid lane owns one (hit = block | idx), the segment it
 // is verified in and a slot vl of the window area.
@@ -288,7 +312,7 @@ __device__ __forceinline__ uint32_t fz_wave_verify(const uint8_t *__restrict__ b
                                                    uint64_t hit, const FzSeg &sg, bool valid,
                                                    FzRec *__restrict__ recs, unsigned long long *__restrict__ counters,
                                                    const uint8_t *pref_win = nullptr, const uint8_t *peq_tabs = nullptr) {
-    static_assert(BITS == 0 || PREF, "the bit-vector form verifies prefetched windows");
+    static_assert(BITS == 0 || PREF, "the bit-vector form verifies prefetched windows");     // (BITS = -1: Hamming count only)
     const uint32_t lane = fz_lane();
     const uint32_t g = fz_hit_block(hit);
     const uint64_t idx = fz_hit_index(hit);
@@ -342,7 +366,9 @@ __device__ __forceinline__ uint32_t fz_wave_verify(const uint8_t *__restrict__ b
             }
         }
         const uint32_t confirmed = (uint32_t)__popcll(__ballot(valid));
-        if constexpr (BITS != 0) {
+        if constexpr (BITS < 0) {                            // the substitutions-only form alone (fz_scan_kernel<..., 3>)
+            ok = fz_verify_subs_wave(t, pat_lds, a.m, a.k, a.L, s, idx, valid, rec);
+        } else if constexpr (BITS != 0) {
             // every lane takes part: the loop's control is wave-uniform (lanes without a candidate idle in it)
             const FzPeqLds<BITS> peq{(uint32_t)(uintptr_t)(FzLdsU8 *)peq_tabs};
             ok = fz_verify_lev_bits<BITS>(peq, [&](uint32_t o) -> uint32_t { return t.byte(o); }, wbase, sg.sa, sg.se, a.m, a.k,
@@ -650,7 +676,8 @@ __device__ __forceinline__ uint32_t fz_pooled_flush(const uint8_t *__restrict__ 
     return confirmed;
 }
 
-// Mid-scan flush of the fused bit-vector form (in-memory Levenshtein searches, fz_scan_kernel<..., WFG = 1 / 2>).  A pass
+// Mid-scan flush of the fused bit-vector forms (in-memory Levenshtein searches, fz_scan_kernel<..., WFG = 1 / 2>; NW = 0:
+// the register band / Hamming count under the same queue discipline, WFG = 3).  A pass
 // costs the wave ~m - L + 2k columns whatever its number of candidates, so passes are FULL: the queue is worked off 64
 // entries at a time, and what is left below 64 moves to the front of the queue — code and prefetched window pieces —
 // and waits for the next tiles' entries (only a queue that holds fewer than 64 in the first place is verified as it is:
@@ -726,13 +753,21 @@ template <int NWIN, int DH, bool FUSED, bool SEG, bool SA, int WFG = 0>
 // (the bit-vector forms: 6 waves per SIMD = 80 VGPRs with one-word columns, 5 = 96 with two-word ones — their queues and Peq
 //  tables leave LDS for at most that many workgroups per CU anyway, and the column loop keeps the next column's Peq word and
 //  character in flight)
-#define FZ_SCAN_WAVES(WFG) ((WFG) == 1 ? 6 : (WFG) == 2 ? 5 : 7)
-__global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_eu(FZ_SCAN_WAVES(WFG), FZ_SCAN_WAVES(WFG)))) void fz_scan_kernel(
+// (round 6, the equal-n-gram sets in the rare path: the file API's fused instances and the lane-per-cell forms, which sat at
+//  exactly 72 VGPRs, take 6 waves as well — the former are bound by the host's copies, the latter serve patterns beyond 128
+//  characters only)
+#define FZ_SCAN_WAVES(WFG, FUSED, SEG) ((WFG) == 2 ? 5 : ((WFG) != 0 || ((FUSED) && (SEG))) ? 6 : 7)
+__global__ __launch_bounds__(FZ_FILTER_THREADS)
+__attribute__((amdgpu_waves_per_eu(FZ_SCAN_WAVES(WFG, FUSED, SEG), FZ_SCAN_WAVES(WFG, FUSED, SEG)))) void fz_scan_kernel(
     const uint8_t *__restrict__ buf, const FzScanArgs a, uint64_t ntiles,
     uint64_t *__restrict__ hits, FzRec *__restrict__ recs, unsigned long long *__restrict__ counters) {
     constexpr bool WF = WFG == 16 || WFG == 32;       // lane-per-cell verification inside the scan, WFG lanes per candidate
     constexpr int BITS = (WFG == 1 || WFG == 2) ? WFG : 0;   // bit-vector verification inside the scan, one candidate per lane, WFG words
-    static_assert(WFG == 0 || BITS != 0 || WF, "0: register band / Hamming count; 1, 2: bit-vector words; 16, 32: lanes per candidate");
+    // WFG = 3: the Hamming count of WFG = 0 (substitutions-only searches) under the queue discipline of the bit-vector forms
+    // (full passes, block-range passes over dense tiles), for patterns that let expect dense candidates
+    constexpr bool ADAPT = BITS != 0 || WFG == 3;
+    constexpr int VF = WFG == 3 ? -1 : BITS;              // what fz_wave_verify runs: -1 Hamming count only, 0 by mode, 1 / 2 bit vectors
+    static_assert(WFG == 0 || ADAPT || WF, "0: register band / Hamming count; 3: Hamming count; 1, 2: bit-vector words; 16, 32: lanes per candidate");
     static_assert(WFG == 0 || (FUSED && !SEG), "the lane-per-cell and bit-vector forms are fused forms of the in-memory search");
     constexpr bool PREF = FUSED && !SEG && !WF;       // candidate windows are prefetched by LDS-DMA
     constexpr uint32_t peq_bytes = BITS ? FZ_PEQ_BYTES(BITS ? BITS : 1) : 0u;   // the two Peq tables behind the pattern
@@ -762,16 +797,12 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
     if (threadIdx.x < FZ_LUT_SLOTS) {
         uint32_t t = ((threadIdx.x + 1u) & (FZ_LUT_SLOTS - 1u)) << a.lut_shift;   // free slot: a value of the next slot
         uint32_t who = 0xffu;                                                     // ... and the block that lives in the slot
+        uint32_t set = 0;                                                         // ... or, with equal n-grams in the launch, all of them
         for (uint32_t g = a.nblk; g-- > 0;)
-            if (((a.H[g] >> a.lut_shift) & (FZ_LUT_SLOTS - 1u)) == threadIdx.x) { t = a.H[g]; who = g; }
+            if (((a.H[g] >> a.lut_shift) & (FZ_LUT_SLOTS - 1u)) == threadIdx.x) { t = a.H[g]; who = g; set |= 0x10000u << g; }
         lut[threadIdx.x] = t;
-        lut[FZ_LUT_SLOTS + threadIdx.x] = who;
+        lut[FZ_LUT_SLOTS + threadIdx.x] = (a.flags & FZ_FLAG_DUP_HASHES) ? (who | set) : who;
     }
-    // lane g of hvec = hash of block g (only launches whose blocks share hashes — equal n-grams — use it)
-    uint32_t hvec = 0;
-#pragma unroll
-    for (uint32_t g = 0; g < FZ_MAX_BLOCKS_PER_LAUNCH; ++g)
-        if (fz_lane() == g) hvec = a.H[g];
     const bool dup_hashes = (a.flags & FZ_FLAG_DUP_HASHES) != 0;
     // this workgroup's walk over the tiles: first_tile, first_tile + stride, .. below limit (scalar values); the flushes
     // decode queue entries with the copy in LDS (fz_code_local)
@@ -853,56 +884,50 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
             if constexpr (GRP == 8) acc = min(acc, min(min(am[4], am[5]), min(am[6], am[7])));
             const bool fire = __ballot(acc == 0) != 0;
             if (__builtin_expect(fire, 0)) {              // wave-uniform, rare: some lane, some offset
-                if (__builtin_expect(!dup_hashes, 1)) {
 #pragma unroll
-                    for (int i = 0; i < GRP; ++i) {
-                        const unsigned long long mi = __ballot(hv[i] == lv[i]);      // which offset (scalar branch)
-                        if (mi) {
-                            // which block: the window's hash equals the one in its slot, and the dword behind the hash
-                            // table says whose that is (one LDS read instead of a compare per block)
-                            uint32_t slot4;
-                            if constexpr (SA) asm("v_and_b32 %0, " FZ_LUT_ADDR_MASK_STR ", %1" : "=v"(slot4) : "v"(hv[i]));
-                            else asm("v_lshrrev_b32 %0, %1, %2\n\tv_and_b32 %0, " FZ_LUT_ADDR_MASK_STR ", %0" : "=v"(slot4) : "v"(slot_shift), "v"(hv[i]));
-                            const uint32_t g = *reinterpret_cast<FzLdsU32 *>(slot4 + FZ_LUT_BYTES);
-                            // the queue code is recomputed here: a (tid << 4 | titer << 18) kept in a VGPR across the tile
-                            // saves three ops per firing but is the register that spills (measured: 0.218 -> 0.221 ms)
-                            uint32_t pos = threadIdx.x;
-                            asm volatile("v_lshlrev_b32 %0, 4, %0" : "+v"(pos));
-                            if constexpr (BITS != 0) {
-                                // only the blocks of this pass over the tile (b0, bw below): g = 0xff (a free slot) never passes
-                                const bool take = hv[i] == lv[i] && g - b0 < bw;
-                                const unsigned long long mt = __ballot(take);
-                                const uint32_t slot = qn + fz_rank(mt);
-                                if (take && slot < qcap)
-                                    w.queue[slot] = fz_code(pos + (uint32_t)(r * FZ_ROW_BYTES + GRP * j + i), g, titer);
-                                qn += (uint32_t)__popcll(mt);
-                            } else {
-                                const uint32_t slot = qn + fz_rank(mi);
-                                if (hv[i] == lv[i] && slot < qcap)
-                                    w.queue[slot] = fz_code(pos + (uint32_t)(r * FZ_ROW_BYTES + GRP * j + i), g, titer);
-                                qn += (uint32_t)__popcll(mi);
-                            }
-                        }
-                    }
-                } else {
-                    // equal n-grams share a slot: compare with every block of the launch
-#pragma unroll 1
-                    for (int i = 0; i < GRP; ++i) {
-                        uint32_t hvi = hv[0], ofs = 0;
-#pragma unroll
-                        for (int q = 1; q < GRP; ++q) if (i == q) { hvi = hv[q]; ofs = (uint32_t)q; }
+                for (int i = 0; i < GRP; ++i) {
+                    const unsigned long long mi = __ballot(hv[i] == lv[i]);      // which offset (scalar branch)
+                    if (mi) {
+                        // which block: the window's hash equals the one in its slot, and the dword behind the hash
+                        // table says whose that is (one LDS read instead of a compare per block)
+                        uint32_t slot4;
+                        if constexpr (SA) asm("v_and_b32 %0, " FZ_LUT_ADDR_MASK_STR ", %1" : "=v"(slot4) : "v"(hv[i]));
+                        else asm("v_lshrrev_b32 %0, %1, %2\n\tv_and_b32 %0, " FZ_LUT_ADDR_MASK_STR ", %0" : "=v"(slot4) : "v"(slot_shift), "v"(hv[i]));
+                        const uint32_t g = *reinterpret_cast<FzLdsU32 *>(slot4 + FZ_LUT_BYTES);
+                        // the queue code is recomputed here: a (tid << 4 | titer << 18) kept in a VGPR across the tile
+                        // saves three ops per firing but is the register that spills (measured: 0.218 -> 0.221 ms)
                         uint32_t pos = threadIdx.x;
                         asm volatile("v_lshlrev_b32 %0, 4, %0" : "+v"(pos));
-                        pos += (uint32_t)(r * FZ_ROW_BYTES + GRP * j) + ofs;
-#pragma unroll 1
-                        for (uint32_t g = BITS ? b0 : 0u; g < (BITS ? min(a.nblk, b0 + bw) : a.nblk); ++g) {
-                            const uint32_t hg = (uint32_t)__builtin_amdgcn_readlane((int)hvec, (int)g);
-                            const unsigned long long mk = __ballot(hvi == hg);
-                            if (mk) {
+                        if (__builtin_expect(dup_hashes, 0)) {
+                            // equal n-grams (equal hashes) share a slot: the dword behind the hash table then carries, from
+                            // bit 16 up, the SET of the launch's blocks that live in the slot, and a firing lane queues one
+                            // entry per member (rounds 1 - 5 compared the window's hash with every block of the launch, offset
+                            // by offset: ~8 scalar instructions per block and offset of a fired group — a DNA pattern with a
+                            // repeated 4-character n-gram ran 4 x slower than one without)
+                            uint32_t set = hv[i] == lv[i] ? g >> 16 : 0u;
+                            pos += (uint32_t)(r * FZ_ROW_BYTES + GRP * j + i);
+                            while (__ballot(set != 0u)) {
+                                const uint32_t gb = (uint32_t)__ffs((int)set) - 1u;       // (an empty set: 0xffffffff, never taken)
+                                const bool take = set != 0u && (!ADAPT || gb - b0 < bw);
+                                const unsigned long long mk = __ballot(take);
                                 const uint32_t slot = qn + fz_rank(mk);
-                                if (hvi == hg && slot < qcap) w.queue[slot] = fz_code(pos, g, titer);
+                                if (take && slot < qcap) w.queue[slot] = fz_code(pos, gb, titer);
                                 qn += (uint32_t)__popcll(mk);
+                                set &= set - 1u;
                             }
+                        } else if constexpr (ADAPT) {
+                            // only the blocks of this pass over the tile (b0, bw below): g = 0xff (a free slot) never passes
+                            const bool take = hv[i] == lv[i] && g - b0 < bw;
+                            const unsigned long long mt = __ballot(take);
+                            const uint32_t slot = qn + fz_rank(mt);
+                            if (take && slot < qcap)
+                                w.queue[slot] = fz_code(pos + (uint32_t)(r * FZ_ROW_BYTES + GRP * j + i), g, titer);
+                            qn += (uint32_t)__popcll(mt);
+                        } else {
+                            const uint32_t slot = qn + fz_rank(mi);
+                            if (hv[i] == lv[i] && slot < qcap)
+                                w.queue[slot] = fz_code(pos + (uint32_t)(r * FZ_ROW_BYTES + GRP * j + i), g, titer);
+                            qn += (uint32_t)__popcll(mi);
                         }
                     }
                 }
@@ -913,10 +938,10 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
     for (;;) {
         if (slow) {
             // enumerate (row, offset, block) candidates of tile `tile`, 64 lanes at a time
-            const uint32_t nb = BITS ? min(bw, a.nblk - b0) : a.nblk;      // (bit-vector form: the blocks of this pass)
+            const uint32_t nb = ADAPT ? min(bw, a.nblk - b0) : a.nblk;      // (bit-vector form: the blocks of this pass)
             const uint32_t steps = FZ_FILTER_ROWS * 16u * nb;
             while (slow_pos < steps && qn + 64u <= qcap) {
-                const uint32_t blk = (BITS ? b0 : 0u) + slow_pos % nb;
+                const uint32_t blk = (ADAPT ? b0 : 0u) + slow_pos % nb;
                 const uint32_t ro = slow_pos / nb;
                 w.queue[qn + lane] = fz_code((ro >> 4) * FZ_ROW_BYTES + lane_off + (ro & 15u), blk, titer);
                 qn += 64u;
@@ -924,10 +949,10 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
             }
             if (slow_pos >= steps) {
                 slow = false;
-                if (BITS != 0 && b0 + bw < a.nblk) b0 += bw;
+                if (ADAPT && b0 + bw < a.nblk) b0 += bw;
                 else { b0 = 0; tile += stride; ++titer; }
             }
-        } else if (tile < limit && (BITS ? (qn == 0u || qn + ylast + (ylast >> 2) + 8u <= qcap) : qn <= qcap / 2)) {
+        } else if (tile < limit && (ADAPT ? (qn == 0u || qn + ylast + (ylast >> 2) + 8u <= qcap) : qn <= qcap / 2)) {
             uint4 va[2], vb[2];
             uint2 ha[2], hb[2];
             bool pre;                                 // va / ha hold rows 0-1 of the next tile
@@ -950,9 +975,9 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                 const uint32_t q_tile = qn;
                 test_row(va[0], ha[0], std::integral_constant<int, 0>{});
                 test_row(va[1], ha[1], std::integral_constant<int, 1>{});
-                const bool same_tile = BITS != 0 && b0 + bw < a.nblk;       // the next pass is over this tile again (its other blocks)
+                const bool same_tile = ADAPT && b0 + bw < a.nblk;       // the next pass is over this tile again (its other blocks)
                 const uint64_t next = same_tile ? tile : tile + stride;
-                if constexpr (BITS != 0) pre = next < limit && qn + 3u * (qn - q_tile) + 8u <= qcap;   // this pass's second half + the next pass
+                if constexpr (ADAPT) pre = next < limit && qn + 3u * (qn - q_tile) + 8u <= qcap;   // this pass's second half + the next pass
                 else pre = next < limit && qn <= qcap / 2;
                 {   // unconditional (a branch here would make the compiler wait for the prefetch at the join):
                     // without a next tile the loads re-read this one (L2 hits, results unused)
@@ -968,7 +993,7 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                 test_row(vb[1], hb[1], std::integral_constant<int, 3>{});
                 if (qn > qcap) {                      // this tile overflowed the queue: drop its
                     qn = q_tile;                      // partial entries and re-scan it by enumeration
-                    if constexpr (BITS != 0) {        // ... or, bit-vector form:
+                    if constexpr (ADAPT) {        // ... or, bit-vector form:
                         if (q_tile != 0u) {           // once more behind a flush of what the queue held,
                             ylast = qcap;
                             break;
@@ -984,13 +1009,13 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                     slow_pos = 0;
                     break;
                 }
-                if constexpr (BITS != 0) ylast = qn - q_tile;
+                if constexpr (ADAPT) ylast = qn - q_tile;
                 if (PREF && qn > qf) {
                     if (tile) fz_prefetch_tile(buf, a, w, qf, qn, tile * (uint64_t)FZ_TILE_BYTES);
                     else fz_prefetch_windows(buf, a, w, qf, qn);          // the first tile: windows clamped at the start
                     qf = qn;
                 }
-                if constexpr (BITS != 0) {
+                if constexpr (ADAPT) {
                     if (same_tile) {
                         b0 += bw;
                     } else {
@@ -1014,8 +1039,8 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
                                                     reinterpret_cast<volatile uint32_t *>(smem + 2u * FZ_LUT_BYTES), wave, qn, done, recs, counters);
         } else if (qn) {
             if (PREF && qn > qf) fz_prefetch_windows(buf, a, w, qf, qn);
-            if constexpr (BITS != 0) {
-                confirmed += fz_bits_flush<BITS ? BITS : 1>(buf, a, pat_lds, smem + FZ_TABLE_BYTES + mpad, w, qn, recs, counters);
+            if constexpr (ADAPT) {
+                confirmed += fz_bits_flush<VF>(buf, a, pat_lds, smem + FZ_TABLE_BYTES + mpad, w, qn, recs, counters);
                 qf = qn;                              // what stays queued has its window
                 continue;
             } else {
@@ -1028,7 +1053,7 @@ __global__ __launch_bounds__(FZ_FILTER_THREADS) __attribute__((amdgpu_waves_per_
     }
     if constexpr (PREF) {
         if (qn > qf) fz_prefetch_windows(buf, a, w, qf, qn);
-        confirmed += fz_pooled_flush<4, BITS>(buf, a, pat_lds, smem + FZ_TABLE_BYTES + mpad + peq_bytes, fz_wave_lds_pref_bytes(qcap, a.win_pieces),
+        confirmed += fz_pooled_flush<4, VF>(buf, a, pat_lds, smem + FZ_TABLE_BYTES + mpad + peq_bytes, fz_wave_lds_pref_bytes(qcap, a.win_pieces),
                                               reinterpret_cast<volatile uint32_t *>(smem + 2u * FZ_LUT_BYTES), wave, qn, recs, counters,
                                               smem + FZ_TABLE_BYTES + mpad);
     }

@@ -401,9 +401,6 @@ struct fz_ctx {
     // resets the back-off): inputs that always fail (dense repeats) pay a wasted launch now and then, not every time.
     bool gen_multi = !sw().gen_legacy;
     uint32_t gen_multi_skip = 0, gen_multi_backoff = 0;
-    // Levenshtein budgets 8 .. 15 (32 lanes per candidate): verification inside the scan kernel (1) or in a kernel of its
-    // own (0) — chosen by the candidate density the context's previous such search saw (enqueue_shard)
-    std::atomic<int> wf32_fused{0};
     // Single-shard searches in direct mode leave their records in the pinned staging buffer and only
     // publish a view of them (valid until the next search of this context): saves a 24 B x nr memcpy.
     const FzRec *view = nullptr;
@@ -638,10 +635,12 @@ ScanKernel scan_kernel_wf(int nwin, int dh) {
     }
 }
 
-// wf_gw: 0 = register band / Hamming count, 1 / 2 = bit-vector columns on one / two 64-bit words, 16 / 32 = lanes per candidate
+// wf_gw: 0 = register band / Hamming count, 1 / 2 = bit-vector columns on one / two 64-bit words, 3 = register band / Hamming
+// count under the bit-vector forms' queue discipline (dense candidates), 16 / 32 = lanes per candidate
 ScanKernel scan_kernel(int nwin, int dh, bool fused, bool seg, bool sa, int wf_gw = 0) {
 #ifdef FZ_LAB_ONLY      // lab builds (benchmarks/lab_build.sh): only the instances of the headline and exact-search workloads
     if (wf_gw == 1 && nwin == 2 && dh == 3 && fused && !seg) return sa ? fz_scan_kernel<2, 3, true, false, true, 1> : fz_scan_kernel<2, 3, true, false, false, 1>;
+    if (wf_gw == 3 && nwin == 2 && dh == 3 && fused && !seg) return sa ? fz_scan_kernel<2, 3, true, false, true, 3> : fz_scan_kernel<2, 3, true, false, false, 3>;
     if (wf_gw) return nullptr;
     if (nwin == 2 && dh == 3 && fused && !seg) return sa ? fz_scan_kernel<2, 3, true, false, true> : fz_scan_kernel<2, 3, true, false, false>;
     if (nwin == 2 && dh == 5 && !fused && !seg) return sa ? fz_scan_kernel<2, 5, false, false, true> : fz_scan_kernel<2, 5, false, false, false>;
@@ -649,6 +648,7 @@ ScanKernel scan_kernel(int nwin, int dh, bool fused, bool seg, bool sa, int wf_g
 #else
     if (wf_gw == 1) return seg ? nullptr : (sa ? scan_kernel_wf<true, 1>(nwin, dh) : scan_kernel_wf<false, 1>(nwin, dh));
     if (wf_gw == 2) return seg ? nullptr : (sa ? scan_kernel_wf<true, 2>(nwin, dh) : scan_kernel_wf<false, 2>(nwin, dh));
+    if (wf_gw == 3) return seg ? nullptr : (sa ? scan_kernel_wf<true, 3>(nwin, dh) : scan_kernel_wf<false, 3>(nwin, dh));
     if (wf_gw == 16) return seg ? nullptr : (sa ? scan_kernel_wf<true, 16>(nwin, dh) : scan_kernel_wf<false, 16>(nwin, dh));
     if (wf_gw == 32) return seg ? nullptr : (sa ? scan_kernel_wf<true, 32>(nwin, dh) : scan_kernel_wf<false, 32>(nwin, dh));
     if (seg) return fused ? scan_kernel_s<true, true>(nwin, dh, sa) : scan_kernel_s<false, true>(nwin, dh, sa);
@@ -999,20 +999,35 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
         if (fused_lds > kFusedLdsBudget) bits_nw = 0;
         else fa.fused = 1u;
     }
+    // Substitutions-only searches whose pattern lets expect dense candidates: the same Hamming count under the bit-vector forms' queue discipline — full 64-candidate passes, tiles denser than the queue
+    // taken in block-range passes — instead of round 1's (half-full queues; a tile that overflows is enumerated: DNA, m = 20,
+    // 4 substitutions: 14 ms per GiB; m = 12, 3: 45 ms).
+    bool adapt_plain = false;
+    if (!bits_nw && fa.fused && sh.geom.seg_stride == 0 && with_verify && !sw().no_bits && per_tile > 16.0 && q.mode == FZ_MODE_SUBS) {
+        const uint32_t fixed = mpad + FZ_TABLE_BYTES;
+        uint32_t qc = sw().bits_qcap > 0 ? (uint32_t)sw().bits_qcap : (uint32_t)std::min(512.0, 64.0 + 32.0 * std::ceil(2.0 * per_tile / 32.0));
+        while (qc > 64u && fixed + FZ_WAVES_PER_BLOCK * fz_wave_lds_pref_bytes(qc, fa.win_pieces) > target + 4096) qc -= 32u;
+        if (fixed + FZ_WAVES_PER_BLOCK * fz_wave_lds_pref_bytes(qc, fa.win_pieces) <= kFusedLdsBudget) {
+            adapt_plain = true;
+            fa.qcap = qc;
+            fused_lds = fixed + FZ_WAVES_PER_BLOCK * fz_wave_lds_pref_bytes(qc, fa.win_pieces);
+        }
+    }
     const bool no_wf_fuse = sw().no_wf_fuse;                                    // test / measurement knob: the stand-alone kernel
     const uint32_t wf_fused_lds = mpad + FZ_TABLE_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(fz_wf_fused_dwords(fa.win_dwords, (uint32_t)vp.gw), 0, 1, true);
     // (in-memory searches only: the segmented instances of this form spill registers — the file API keeps the kernel of its own)
     // 32 lanes per candidate (budgets 8 .. 15): the fused form is 7-14 % behind scan + stand-alone kernel where candidates
     // are rare (1 GiB of text, m = 64, k = 8 / 12: 0.546 / 0.654 against 0.509 / 0.597 ms) and 1.25 .. 7.7 x ahead where they
     // are not (DNA, m = 100, k = 10, 4.5e4 candidates: 0.551 against 0.687 ms; m = 54, k = 8, 2.4e6: 2.70 against 20.7 ms —
-    // the hit list outgrows its buffer and the search runs twice).  Which one a text is cannot be told from the pattern:
-    // the context remembers the candidate density of its last such search (collect_shard) and starts with the stand-alone
-    // kernel; FZ_WF32=0 / 1 pins the choice.
+    // the hit list outgrows its buffer and the search runs twice).  FZ_WF32=0 / 1 pins the choice.
     const int wf32_env = sw().wf32;
     const bool wf_candidate = !bits_nw && !fa.fused && sh.geom.seg_stride == 0 && with_verify && !force_big && !no_wf_fuse && vp.want_wf && !vp.big && vp.gw <= 32 &&
                               q.m <= FZ_MAX_M && wf_fused_lds <= target + 4096;
     d.wf32_candidate = wf_candidate && vp.gw == 32;
-    const bool wf_fused = wf_candidate && (vp.gw == 16 || (wf32_env >= 0 ? wf32_env != 0 : ctx->wf32_fused.load(std::memory_order_relaxed) != 0));
+    // (round 6: patterns up to 128 characters never get here — bit-vector columns; for the longer ones the choice follows the
+    //  expected density per_tile above, a function of the pattern — the measured crossover, 1.5e4 .. 4.5e4 candidates per GiB, is
+    //  ~0.1 per tile and wave — not, as in rounds 4 and 5, what the context's previous search saw)
+    const bool wf_fused = wf_candidate && (vp.gw == 16 || (wf32_env >= 0 ? wf32_env != 0 : per_tile > 0.1));
     if (wf_fused) { fa.fused = 1u; fused_lds = wf_fused_lds; fa.vlanes = 64; }
     // (the hit-emitting form keeps no pattern in LDS: fz_confirm reads it from the argument block / HBM)
     const uint32_t scan_lds = fa.fused ? fused_lds : FZ_TABLE_BYTES + FZ_WAVES_PER_BLOCK * fz_wave_lds_bytes(0, 0, 64, true);
@@ -1062,7 +1077,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
         for (uint32_t b = 1; b < nblk; ++b)
             for (uint32_t c = 0; c < b; ++c)
                 if (fa.H[b] == fa.H[c]) fa.flags |= FZ_FLAG_DUP_HASHES;
-        ScanKernel kern = scan_kernel(nwin, dh, fa.fused != 0, sh.geom.seg_stride != 0, fa.lut_shift == 2, bits_nw ? bits_nw : wf_fused ? vp.gw : 0);
+        ScanKernel kern = scan_kernel(nwin, dh, fa.fused != 0, sh.geom.seg_stride != 0, fa.lut_shift == 2, bits_nw ? bits_nw : adapt_plain ? 3 : wf_fused ? vp.gw : 0);
         if (!kern) return fail(FZ_EUNSUPPORTED, "this (lab) build carries no scan kernel for nwin=%d dh=%d", nwin, dh);
         const uint32_t extra_lds = (uint32_t)sw().extra_lds_kb * 1024u;
         hipEvent_t ev_start = (attach && ctx->timing && g0 == 0) ? d.ev[0] : nullptr;
@@ -1181,10 +1196,6 @@ int collect_shard(fz_ctx *ctx, const Shard &sh, bool with_verify, bool view_ok, 
     const uint64_t nr = cnt[1];
     const bool fused = with_verify && d.fused_used;
     if (fused) { nh = 0; for (int i = 0; i < 64; ++i) nh += cnt[8 + i]; }
-    // budgets 8 .. 15: more than ~24 candidates per MiB -> the context's next such search verifies inside the scan
-    // (the crossover lies between 1.5e4 and 4.5e4 candidates per GiB); a hit list that overflowed runs again that way
-    if (with_verify && d.wf32_candidate && sh.geom.buf_len)
-        ctx->wf32_fused.store(nh * 43691ull > sh.geom.buf_len ? 1 : 0, std::memory_order_relaxed);
     bool rerun = false;
     if (nh > d.hit_cap_used && !fused) {
         HIP_TRY(hipStreamSynchronize(d.stream));          // a second search in flight still uses the old buffers

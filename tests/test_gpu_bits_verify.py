@@ -181,3 +181,21 @@ def test_old_forms_stay_reachable_and_equal(engine, monkeypatch):
     _reload_switches()
     h.release()
     assert new == old and len(new) >= 30
+
+
+@pytest.mark.parametrize("m,k,mib", [(20, 4, 4), (12, 2, 4), (12, 3, 2), (9, 2, 1), (32, 7, 2)])
+def test_substitutions_only_with_dense_candidates(engine, m, k, mib):
+    """Substitutions-only n-gram searches of short DNA patterns (4- and 3-character n-grams: 50 .. 800 candidates per tile and
+    wave) run the Hamming count under the bit-vector forms' queue discipline (fz_scan_kernel<..., 3>): the oracle's stream,
+    duplicates across blocks and order included; the group-best form and has_near_match on top."""
+    seq = workloads.dna(mib << 20, 800 + m)
+    p = workloads.dna(m, 810 + m)
+    workloads.plant_edits(seq, p, 100, 820 + m, workloads.DNA, lambda i: i % (k + 1), kinds=(1,))
+    t = seq.tobytes()
+    h = engine.upload(seq)
+    got = engine.subs_ngrams(h, p.tobytes(), k)
+    want = oracle.subs_ngrams_raw(p.tobytes(), t, k)
+    assert len(want) >= 100
+    assert got == want
+    assert engine.subs_ngrams_any(h, p.tobytes(), k) is True
+    h.release()
