@@ -736,6 +736,9 @@ struct Search {
     bool collective = false;       // the context joined a communicator: every rank gets the merged stream of all ranks
     bool any = false;              // has_near_match_*: only whether a record exists
     bool fold = false;             // generic search: the device folds every hit's matches into (hull, best match) pairs
+    // has_near_match_* on a long single-shard sequence: the scan of THIS call covers the buffer bytes [part_lo, part_hi) only
+    // (multiples of the tile size; hits are owned by the tile their index lies in, windows reach wherever they must)
+    uint64_t part_lo = 0, part_hi = ~0ull;
 };
 
 static const uint32_t kFusedLdsBudget = (uint32_t)(sw().fused_lds_kb > 0 ? sw().fused_lds_kb : 64) * 1024u;   // dynamic LDS per scan workgroup when verification is fused
@@ -865,7 +868,11 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
 
     const uint32_t L = q.plan.L;
     const uint32_t G = (uint32_t)q.plan.s.size();
-    const uint64_t ntiles = (sh.geom.buf_len + FZ_TILE_BYTES - 1) / FZ_TILE_BYTES;
+    const uint64_t ntiles_all = (sh.geom.buf_len + FZ_TILE_BYTES - 1) / FZ_TILE_BYTES;
+    const uint64_t tile_lo = std::min<uint64_t>(ntiles_all, q.part_lo / FZ_TILE_BYTES);
+    const uint64_t tile_hi = q.part_hi == ~0ull ? ntiles_all : std::min<uint64_t>(ntiles_all, (q.part_hi + FZ_TILE_BYTES - 1) / FZ_TILE_BYTES);
+    const bool partial = tile_lo != 0 || tile_hi != ntiles_all;
+    const uint64_t ntiles = tile_hi > tile_lo ? tile_hi - tile_lo : 0;          // tiles this call scans
     // Grid: every workgroup strides over ~16 tiles (256 KiB).  Measured on MI355X at 1 GiB: 6 / 8 /
     // 12 / 16 / 20 / 32 / 64 workgroups per CU -> 0.302 / 0.302 / 0.276 / 0.267 / 0.265 / 0.280 /
     // 0.333 ms: several rounds of short workgroups overlap one workgroup's end-of-life verification
@@ -918,6 +925,10 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     // (kTaperSteps groups, down to kTaperMin of a full share) of their own tile range at the end of the buffer, the others
     // correspondingly more.
     plan_scan_regions(fa, ntiles, grid.x, (uint32_t)d.n_cus);
+    if (partial) {                                               // one region: the call's tiles, no taper
+        fa.nreg = 1;
+        fa.reg_wg0[0] = 0; fa.reg_nwg[0] = grid.x; fa.reg_tile0[0] = tile_lo; fa.reg_end[0] = tile_hi;
+    }
     if (q.mode == FZ_MODE_GENERIC && !with_verify) fa.gen_dedup = d.gen_dedup_arg;      // the scan fills the window table (run_generic)
     const bool force_big = sw().force_big_verify;
     const VerifyPlan vp = plan_verify(q);
@@ -2754,6 +2765,31 @@ int fz_search_end(fz_ctx *ctx, fz_match **out, uint64_t *n) {
 
 int fz_lev_ngrams_end(fz_ctx *ctx, fz_match **out, uint64_t *n) { return fz_search_end(ctx, out, n); }
 
+// has_near_match_* stops at the first match (substitutions_only.py:218-233, generic_search.py:240-253).  On a long
+// single-shard sequence the flag-only searches therefore scan the buffer in growing pieces — 64 MiB, then 4 x as much
+// each time — and stop behind the first piece that produced a match: a match in the first MiB of 4 GiB costs one 64 MiB
+// search (rounds 4 / 5: one launch whose not-yet-started workgroups skipped their tiles — a quarter of a full scan, bounded
+// by the skipped workgroups' finish tickets; the generic form: a full scan + the automaton launch).  Without a match the
+// pieces cost three more launches than one scan.  -> the byte ranges, or one whole-buffer range.
+static std::vector<std::pair<uint64_t, uint64_t>> any_pieces(fz_ctx *ctx, fz_seq *seq) {
+    std::vector<std::pair<uint64_t, uint64_t>> out;
+    const uint64_t first = 64ull << 20;
+    if (seq->shards.size() != 1 || comm_multi_process(ctx) || seq->shards[0].geom.seg_stride != 0 ||
+        seq->shards[0].geom.buf_len < 8 * first) {
+        out.emplace_back(0, ~0ull);
+        return out;
+    }
+    const uint64_t len = seq->shards[0].geom.buf_len;
+    uint64_t at = 0, size = first;
+    while (at < len) {
+        const uint64_t end = (len - at <= size + size / 2) ? len : at + size;      // (no sliver at the end)
+        out.emplace_back(at, end >= len ? ~0ull : end);
+        at = end;
+        size *= 4;
+    }
+    return out;
+}
+
 static int subs_ngrams_impl(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t m, uint32_t k, fz_match **out, uint64_t *n, int *found) {
     Search q;
     int rc = subs_plan(ctx, seq, p, m, k, q);
@@ -2764,14 +2800,21 @@ static int subs_ngrams_impl(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint32_t
     if (q.any) q.collective = false;                           // a flag, not a stream: exchanged below
     std::vector<FzRec> recs;
     std::vector<uint64_t> hits;
-    rc = run_search(ctx, seq, q, true, recs, hits);
-    if (rc) return rc;
     if (found) {
-        bool any = (ctx->view ? ctx->view_n : (uint64_t)recs.size()) > 0;
+        bool any = false;
+        for (const auto &piece : any_pieces(ctx, seq)) {
+            q.part_lo = piece.first; q.part_hi = piece.second;
+            rc = run_search(ctx, seq, q, true, recs, hits);
+            if (rc) return rc;
+            any = (ctx->view ? ctx->view_n : (uint64_t)recs.size()) > 0;
+            if (any) break;
+        }
         if (comm_multi_process(ctx)) { rc = comm_or(ctx, any); if (rc) return rc; }
         *found = any ? 1 : 0;
         return FZ_OK;
     }
+    rc = run_search(ctx, seq, q, true, recs, hits);
+    if (rc) return rc;
     return emit_matches(ctx, recs, L, out, n, seq->n, (uint32_t)q.plan.s.size());
 }
 
@@ -2854,15 +2897,22 @@ static int generic_ngrams_impl(fz_ctx *ctx, fz_seq *seq, const uint8_t *p, uint3
     q.fold = consolidated;
     std::vector<FzGenRec> recs_vec;
     Trace tr;
-    rc = run_generic(ctx, seq, q, recs_vec);
-    if (rc) return rc;
-    tr.mark("generic: kernels");
     if (found) {
-        bool any = ctx->any_found;
+        bool any = false;
+        for (const auto &piece : any_pieces(ctx, seq)) {       // (the scan of a piece lists its hits, the automaton runs on them)
+            q.part_lo = piece.first; q.part_hi = piece.second;
+            rc = run_generic(ctx, seq, q, recs_vec);
+            if (rc) return rc;
+            any = ctx->any_found;
+            if (any) break;
+        }
         if (comm_multi_process(ctx)) { rc = comm_or(ctx, any); if (rc) return rc; }
         *found = any ? 1 : 0;
         return FZ_OK;
     }
+    rc = run_generic(ctx, seq, q, recs_vec);
+    if (rc) return rc;
+    tr.mark("generic: kernels");
     rc = generic_exchange(ctx, recs_vec);
     if (rc) return rc;
     rc = emit_generic_result(ctx, seq, q, recs_vec, consolidated, out, n);

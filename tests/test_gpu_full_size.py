@@ -100,9 +100,10 @@ def test_beyond_4gib_indices(engine):
 
 
 def test_has_near_match_leaves_a_4gib_scan_early(engine):
-    """has_near_match_* (substitutions_only.py:218-233 returns at the first match): a match in the first MiB of a 4 GiB
-    sequence answers in a fraction of a full scan (a quarter: 0.21 against 0.84 ms) — workgroups that start after a record has
-    been counted skip their tiles (fz_scan_kernel: the FZ_FLAG_ANY check).
+    """has_near_match_* (substitutions_only.py:218-233, generic_search.py:240-253 return at the first match): on a long
+    sequence the flag-only searches scan in growing pieces (64 MiB, then 4 x as much each time) and stop behind the first
+    piece with a match — a match in the first MiB of a 4 GiB sequence answers in a few percent of a full scan, for the
+    substitutions form and (scan of the piece + automaton on its hits) for the generic one.
     Same flag, no match: the whole buffer is scanned and the answer is False."""
     import time
     n = 4 << 30
@@ -133,9 +134,28 @@ def test_has_near_match_leaves_a_4gib_scan_early(engine):
     t_gen, found_g = timed(lambda: engine.generic_ngrams_any(h2, p, 2, 1, 1, 2), 10)
     h2.release()
     assert found is True and found_g is True
-    # measured: 0.21 ms against 0.84 ms (25 %).  The remainder is the finish tickets of the ~21 800 workgroups that start
-    # after the first record and skip their tiles (fzhip.hip: enqueue_shard), not running workgroups finishing theirs.
-    assert t_hit < 0.33 * t_full, (t_hit, t_full)
-    # (the generic flag-only search does not leave early here: its scan only LISTS n-gram hits — records, which the check
-    #  looks at, appear in the automaton kernel behind it — so it costs a full scan + one automaton launch; found_g above)
-    assert t_gen < 1.5 * t_full, (t_gen, t_full)
+    # round 5: 0.21 against 0.84 ms (25 %: one launch whose late workgroups skipped their tiles, bounded by their finish
+    # tickets); the generic form paid a full scan + the automaton launch.  Round 6 (pieces): one 64 MiB search each.
+    assert t_hit < 0.08 * t_full, (t_hit, t_full)
+    assert t_gen < 0.5 * t_full, (t_gen, t_full)
+
+
+def test_has_near_match_pieces_find_matches_anywhere(engine):
+    """The flag-only searches' pieces (64 MiB, 256 MiB, the rest of a 640 MiB sequence): a match across a piece boundary —
+    its n-gram hits in one piece, its window reaching into the other —, a match in the last bytes, and no match."""
+    n = 640 << 20
+    base = workloads.dna(n, 910)
+    pattern = workloads.text65(24, 6)                   # letters a DNA sequence does not have
+    p = pattern.tobytes()
+    for where in ((64 << 20) - 11, (64 << 20) - 24, (320 << 20) - 7, n - len(pattern), None):
+        seq = base.copy()
+        if where is not None:
+            seq[where:where + len(pattern)] = pattern
+            seq[where + 5] = ord("A")                   # one substitution: blocks on both sides of it still hit
+        h = engine.upload(seq)
+        want = where is not None
+        assert engine.subs_ngrams_any(h, p, 2) is want, where
+        assert engine.generic_ngrams_any(h, p, 2, 1, 1, 2) is want, where
+        if where is not None:                           # the searches proper are untouched by the pieces
+            assert [r[0] for r in engine.subs_ngrams(h, p, 2)][:1] == [where]
+        h.release()
