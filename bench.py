@@ -305,7 +305,16 @@ def extra_blocks(engine, workloads, reps):
 
 
 FORM_NAMES = ["none", "fused register band", "fused lane-per-cell", "fused bit-vector (64-bit columns)",
-              "fused bit-vector (128-bit columns)", "stand-alone kernel"]
+              "fused bit-vector (128-bit columns)", "stand-alone kernel", "fused bit-vector (32-bit columns)"]
+
+
+def _csrc_digest():
+    """Which native sources this line was measured with (fuzzysearch_amd/build.py: source_digest)."""
+    try:
+        from fuzzysearch_amd import build as fzbuild
+        return fzbuild.source_digest()
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def regimes_block(engine, workloads, seq):
@@ -1073,6 +1082,7 @@ def main():
                                            "tail — not the kernel alone; frac / achieved use the synchronous figure",
                          "algorithmic_bytes_per_launch": shard_bytes},
             "settle": settle,
+            "csrc_digest": _csrc_digest(),
             "kernel_ms": {"filter": round(f_pipe, 4), "verify": round(float(np.mean(verify_ms)), 4),
                           "device_total": round(float(np.mean(device_ms)), 4)},
             "sync_ms_per_call": None if sync_ms is None else round(sync_ms, 4),

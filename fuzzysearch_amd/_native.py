@@ -43,7 +43,7 @@ class FzStats(ctypes.Structure):
 
 
 # FzStats.verify_form (include/fzhip.h: FZ_FORM_*)
-FORM_NONE, FORM_FUSED_BAND, FORM_FUSED_CELLS, FORM_FUSED_BITS1, FORM_FUSED_BITS2, FORM_KERNEL = range(6)
+FORM_NONE, FORM_FUSED_BAND, FORM_FUSED_CELLS, FORM_FUSED_BITS1, FORM_FUSED_BITS2, FORM_KERNEL, FORM_FUSED_BITS32 = range(7)
 
 
 class HipEngineError(RuntimeError):

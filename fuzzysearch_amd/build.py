@@ -25,6 +25,17 @@ def hipcc():
     raise RuntimeError("hipcc not found (need ROCm >= 7.0)")
 
 
+def source_digest():
+    """sha256 over the native sources the library is built from (csrc/*, include/fzhip.h): bench.py prints it
+    (`csrc_digest`), tests/test_bench_contract.py holds the committed bench line of the round against the tree's."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in sorted(DEPS + ["_fzmatch.c"]):
+        with open(os.path.join(CSRC, d), "rb") as f:
+            h.update(d.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True

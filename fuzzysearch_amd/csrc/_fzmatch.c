@@ -89,19 +89,31 @@ static int int_field(PyObject *v, const char *message, long long *out) {
     return (*out == -1 && PyErr_Occurred()) ? -1 : 0;
 }
 
+static int g_optimize = 0;                              /* sys.flags.optimize, read once at import (g_optimize is deprecated) */
+
 static PyObject *match_new(PyTypeObject *type, PyObject *args, PyObject *kwds) {
     static char *kwlist[] = {"start", "end", "dist", "matched", NULL};
     PyObject *s, *e, *d, *matched;
+    if (PyTuple_GET_SIZE(args) == 0 && (!kwds || PyDict_GET_SIZE(kwds) == 0)) {
+        /* Match.__new__(Match): what copyreg.__newobj__ calls when a pickle of the attrs class (or of this type's Python
+         * fallback, common.py) is loaded — the fields follow through __setstate__ */
+        MatchObject *m0 = match_alloc(type);
+        if (!m0) return NULL;
+        m0->start = m0->end = m0->dist = 0;
+        Py_INCREF(Py_None);
+        m0->matched = Py_None;
+        return (PyObject *)m0;
+    }
     if (!PyArg_ParseTupleAndKeywords(args, kwds, "OOOO:Match", kwlist, &s, &e, &d, &matched)) return NULL;
     long long vs, ve, vd;
     /* the reference's __attrs_post_init__ (common.py:21-32), in its order; the range checks only when __debug__ */
     if (int_field(s, "start must be a non-negative integer", &vs)) return NULL;
-    if (!Py_OptimizeFlag && vs < 0) { PyErr_SetString(PyExc_ValueError, "start must be a non-negative integer"); return NULL; }
+    if (!g_optimize && vs < 0) { PyErr_SetString(PyExc_ValueError, "start must be a non-negative integer"); return NULL; }
     if (int_field(e, "end must be an integer no smaller than start", &ve)) return NULL;
-    if (!Py_OptimizeFlag && ve < vs) { PyErr_SetString(PyExc_ValueError, "end must be an integer no smaller than start"); return NULL; }
+    if (!g_optimize && ve < vs) { PyErr_SetString(PyExc_ValueError, "end must be an integer no smaller than start"); return NULL; }
     if (int_field(d, "dist must be a non-negative integer", &vd)) return NULL;
-    if (!Py_OptimizeFlag && vd < 0) { PyErr_SetString(PyExc_ValueError, "dist must be a non-negative integer"); return NULL; }
-    if (!Py_OptimizeFlag && matched == Py_None) { PyErr_SetString(PyExc_ValueError, "matched must be supplied"); return NULL; }
+    if (!g_optimize && vd < 0) { PyErr_SetString(PyExc_ValueError, "dist must be a non-negative integer"); return NULL; }
+    if (!g_optimize && matched == Py_None) { PyErr_SetString(PyExc_ValueError, "matched must be supplied"); return NULL; }
     MatchObject *m = match_alloc(type);
     if (!m) return NULL;
     m->start = vs; m->end = ve; m->dist = vd;
@@ -175,6 +187,26 @@ static PyObject *match_get_matched(MatchObject *self, void *closure) {
     return m;
 }
 
+/* __setstate__: the state of an attrs slots class — a dict {field: value} (attrs >= 22.2) or a tuple in field order */
+static PyObject *match_setstate(MatchObject *self, PyObject *state) {
+    PyObject *v[4] = {NULL, NULL, NULL, NULL};
+    static const char *names[4] = {"start", "end", "dist", "matched"};
+    if (PyDict_Check(state)) {
+        for (int i = 0; i < 4; ++i) v[i] = PyDict_GetItemString(state, names[i]);
+    } else if (PyTuple_Check(state) && PyTuple_GET_SIZE(state) == 4) {
+        for (int i = 0; i < 4; ++i) v[i] = PyTuple_GET_ITEM(state, i);
+    }
+    if (!v[0] || !v[1] || !v[2] || !v[3]) { PyErr_SetString(PyExc_TypeError, "Match.__setstate__: a dict or 4-tuple of start, end, dist, matched"); return NULL; }
+    long long vs, ve, vd;
+    if (int_field(v[0], "start must be a non-negative integer", &vs) || int_field(v[1], "end must be an integer no smaller than start", &ve) ||
+        int_field(v[2], "dist must be a non-negative integer", &vd)) return NULL;
+    self->start = vs; self->end = ve; self->dist = vd;
+    Py_INCREF(v[3]);
+    Py_XSETREF(self->matched, v[3]);
+    if (Py_TYPE(self) == match_type && needs_tracking(v[3]) && !PyObject_GC_IsTracked((PyObject *)self)) PyObject_GC_Track((PyObject *)self);
+    Py_RETURN_NONE;
+}
+
 static PyObject *match_reduce(MatchObject *self, PyObject *ignored) {
     (void)ignored;
     return Py_BuildValue("(O(LLLO))", (PyObject *)Py_TYPE(self), self->start, self->end, self->dist,
@@ -196,6 +228,7 @@ static PyGetSetDef match_getset[] = {
 
 static PyMethodDef match_methods[] = {
     {"__reduce__", (PyCFunction)match_reduce, METH_NOARGS, "pickle / copy support: (Match, (start, end, dist, matched))"},
+    {"__setstate__", (PyCFunction)match_setstate, METH_O, "loads pickles made by the attrs class / the Python fallback (dict or tuple state)"},
     {NULL, NULL, 0, NULL}};
 
 static PyType_Slot match_slots[] = {
@@ -309,6 +342,12 @@ static struct PyModuleDef moduledef = {PyModuleDef_HEAD_INIT, "_fzmatch", "Match
 PyMODINIT_FUNC PyInit__fzmatch(void) {
     PyObject *mod = PyModule_Create(&moduledef);
     if (!mod) return NULL;
+    {
+        PyObject *flags = PySys_GetObject("flags");                 /* borrowed */
+        PyObject *opt = flags ? PyObject_GetAttrString(flags, "optimize") : NULL;
+        if (opt) { g_optimize = PyLong_AsLong(opt) > 0; Py_DECREF(opt); }
+        PyErr_Clear();
+    }
     PyObject *exc_mod = PyImport_ImportModule("attr.exceptions");
     if (exc_mod) {
         frozen_error = PyObject_GetAttrString(exc_mod, "FrozenInstanceError");

@@ -407,7 +407,8 @@ FZ_HD bool fz_verify_lev(Sc &sc, const Seq &t, uint64_t sa, uint64_t se, const u
 // outside it, every cell exact.  The piece's last row is the TOP bit of the vector, so the score D[m'][j] follows from the
 // sign bits of the horizontal differences; the reference's `D[0][j] = j` boundary (the window is matched from its first
 // character: prefix distance, not the search-anywhere form) is the 1 shifted into the horizontal +1 vector.
-// One candidate per LANE; a piece of up to 64 rows is one 64-bit word (NW = 1), up to 128 rows two (NW = 2).
+// One candidate per LANE; a piece of up to 64 rows is one 64-bit word (NW = 1), up to 128 rows two (NW = 2), up to 32 rows
+// half a word (NW = 4 names the 32-bit form: half the vector instructions per column for patterns up to 32 characters).
 //
 // Both pieces of a hit come out of TWO tables per search, not two per n-gram block: with the whole pattern laid down top-
 // aligned, position q at bit q + (64 NW - m) of the forward table Peq[c] and at bit 64 NW - 1 - q of the reversed one,
@@ -419,10 +420,12 @@ FZ_HD bool fz_verify_lev(Sc &sc, const Seq &t, uint64_t sa, uint64_t se, const u
 template <int NW> struct FzBitsWord;
 template <> struct FzBitsWord<1> { typedef uint64_t T; };
 template <> struct FzBitsWord<2> { typedef unsigned __int128 T; };
-#define FZ_BITS_MAX_M(NW) (64u * (NW))                   // longest pattern of the NW-word form
+template <> struct FzBitsWord<4> { typedef uint32_t T; };
+#define FZ_BITS_WIDTH(NW) ((NW) == 4 ? 32u : 64u * (uint32_t)(NW))   // bits of a column vector = longest pattern of the form
+#define FZ_BITS_MAX_M(NW) FZ_BITS_WIDTH(NW)
 
-template <int NW> FZ_HD uint32_t fz_bits_fwd_bit(uint32_t m, uint32_t q) { return q + (64u * NW - m); }
-template <int NW> FZ_HD uint32_t fz_bits_rev_bit(uint32_t, uint32_t q) { return 64u * NW - 1u - q; }
+template <int NW> FZ_HD uint32_t fz_bits_fwd_bit(uint32_t m, uint32_t q) { return q + (FZ_BITS_WIDTH(NW) - m); }
+template <int NW> FZ_HD uint32_t fz_bits_rev_bit(uint32_t, uint32_t q) { return FZ_BITS_WIDTH(NW) - 1u - q; }
 
 template <int NW>
 struct FzBitsCol {
@@ -438,7 +441,7 @@ template <class T> FZ_HD T fz_or_not(T a, T x) { return a | ~x; }
 template <int NW>
 FZ_HD int32_t fz_bits_column(FzBitsCol<NW> &c, typename FzBitsWord<NW>::T eq) {
     typedef typename FzBitsWord<NW>::T T;
-    constexpr int TOP = 64 * NW - 1;
+    constexpr int TOP = (int)FZ_BITS_WIDTH(NW) - 1;
     const T d0 = (((eq & c.vp) + c.vp) ^ c.vp) | eq | c.vn;     // rows whose diagonal difference is 0
     T hp = fz_or_not<T>(c.vn, d0 | c.vp);                       // horizontal +1
     T hn = c.vp & d0;                                           // horizontal -1
@@ -457,7 +460,7 @@ FZ_HD bool fz_expand_bits(PeqF peq, uint32_t sublen, WinF win, uint32_t winlen, 
                           uint32_t &dist, uint32_t &consumed) {
     typedef typename FzBitsWord<NW>::T T;
     if (sublen == 0) { dist = 0; consumed = 0; return true; }       // pyx:28-30
-    const T hm = ~(T)0 << (64u * NW - sublen);
+    const T hm = ~(T)0 << (FZ_BITS_WIDTH(NW) - sublen);
     FzBitsCol<NW> c;
     c.vp = hm; c.vn = 0;                                             // column 0: D[i][0] = i
     uint32_t score = sublen, best = sublen, arg = 0;                 // pyx:33-34
@@ -483,7 +486,7 @@ template <int NW, class PeqT, class TxtF>
 FZ_HD bool fz_verify_lev_bits(const PeqT &peq, TxtF txt, uint64_t wbase, uint64_t sa, uint64_t se, uint32_t m, uint32_t k,
                               uint32_t L, uint32_t s, uint64_t idx, bool valid, FzRec &rec) {
     typedef typename FzBitsWord<NW>::T T;
-    constexpr uint32_t NB = 64u * NW;
+    constexpr uint32_t NB = FZ_BITS_WIDTH(NW);
     FzBitsCol<NW> col;
     T hm = 0;
     uint32_t rem = 0, wl = 0, score = 0, key = 0, budget = k, dR = 0, r = 0;

@@ -210,16 +210,16 @@ struct FzDmaWindow {
 
 // The two whole-pattern Peq tables of the bit-vector verification in LDS (fz_device.h: fz_verify_lev_bits): [side][256]
 // words of NW x 8 bytes, forward table first.
-#define FZ_PEQ_BYTES(NW) (2u * 256u * 8u * (uint32_t)(NW))
+#define FZ_PEQ_BYTES(NW) (2u * 256u * (FZ_BITS_WIDTH(NW) / 8u))
 template <int NW>
 struct FzPeqLds {
     typedef typename FzBitsWord<NW>::T T;
     typedef __attribute__((address_space(3))) const T LdsT;
     uint32_t tabs;                                         // LDS byte address of the forward table
     // a table's handle = its LDS address: a word's address is one v_lshl_add_u32
-    __device__ __forceinline__ uint32_t table(uint32_t side) const { return tabs + side * (256u * 8u * (uint32_t)NW); }
+    __device__ __forceinline__ uint32_t table(uint32_t side) const { return tabs + side * (256u * (FZ_BITS_WIDTH(NW) / 8u)); }
     __device__ __forceinline__ T at(uint32_t tab, uint32_t ch) const {
-        return *(LdsT *)(uintptr_t)(tab + ch * (8u * (uint32_t)NW));
+        return *(LdsT *)(uintptr_t)(tab + ch * (FZ_BITS_WIDTH(NW) / 8u));
     }
 };
 
@@ -756,18 +756,19 @@ template <int NWIN, int DH, bool FUSED, bool SEG, bool SA, int WFG = 0>
 // (round 6, the equal-n-gram sets in the rare path: the file API's fused instances and the lane-per-cell forms, which sat at
 //  exactly 72 VGPRs, take 6 waves as well — the former are bound by the host's copies, the latter serve patterns beyond 128
 //  characters only)
-#define FZ_SCAN_WAVES(WFG, FUSED, SEG) ((WFG) == 2 ? 5 : ((WFG) != 0 || ((FUSED) && (SEG))) ? 6 : 7)
+#define FZ_SCAN_WAVES(WFG, FUSED, SEG) ((WFG) == 2 ? 5 : ((WFG) != 0 || ((FUSED) && (SEG))) ? 6 : 7)      // (WFG = 4: 6 as well)
 __global__ __launch_bounds__(FZ_FILTER_THREADS)
 __attribute__((amdgpu_waves_per_eu(FZ_SCAN_WAVES(WFG, FUSED, SEG), FZ_SCAN_WAVES(WFG, FUSED, SEG)))) void fz_scan_kernel(
     const uint8_t *__restrict__ buf, const FzScanArgs a, uint64_t ntiles,
     uint64_t *__restrict__ hits, FzRec *__restrict__ recs, unsigned long long *__restrict__ counters) {
     constexpr bool WF = WFG == 16 || WFG == 32;       // lane-per-cell verification inside the scan, WFG lanes per candidate
-    constexpr int BITS = (WFG == 1 || WFG == 2) ? WFG : 0;   // bit-vector verification inside the scan, one candidate per lane, WFG words
+    constexpr int BITS = (WFG == 1 || WFG == 2 || WFG == 4) ? WFG : 0;   // bit-vector verification inside the scan, one candidate per lane:
+                                                                         // one / two 64-bit words per column, 4 = one 32-bit word
     // WFG = 3: the Hamming count of WFG = 0 (substitutions-only searches) under the queue discipline of the bit-vector forms
     // (full passes, block-range passes over dense tiles), for patterns that let expect dense candidates
     constexpr bool ADAPT = BITS != 0 || WFG == 3;
     constexpr int VF = WFG == 3 ? -1 : BITS;              // what fz_wave_verify runs: -1 Hamming count only, 0 by mode, 1 / 2 bit vectors
-    static_assert(WFG == 0 || ADAPT || WF, "0: register band / Hamming count; 3: Hamming count; 1, 2: bit-vector words; 16, 32: lanes per candidate");
+    static_assert(WFG == 0 || ADAPT || WF, "0: register band / Hamming count; 3: Hamming count; 1, 2, 4: bit-vector columns; 16, 32: lanes per candidate");
     static_assert(WFG == 0 || (FUSED && !SEG), "the lane-per-cell and bit-vector forms are fused forms of the in-memory search");
     constexpr bool PREF = FUSED && !SEG && !WF;       // candidate windows are prefetched by LDS-DMA
     constexpr uint32_t peq_bytes = BITS ? FZ_PEQ_BYTES(BITS ? BITS : 1) : 0u;   // the two Peq tables behind the pattern
@@ -783,15 +784,16 @@ __attribute__((amdgpu_waves_per_eu(FZ_SCAN_WAVES(WFG, FUSED, SEG), FZ_SCAN_WAVES
         for (uint32_t i = threadIdx.x; i < a.m; i += FZ_FILTER_THREADS) pat_lds[i] = a.pat[i];
     if constexpr (BITS != 0) {
         // Peq tables (fz_device.h: fz_verify_lev_bits): zero, then one LDS atomic per pattern position and table
-        unsigned long long *peq = reinterpret_cast<unsigned long long *>(smem + FZ_TABLE_BYTES + mpad);
-        for (uint32_t i = threadIdx.x; i < peq_bytes / 8u; i += FZ_FILTER_THREADS) peq[i] = 0ull;
+        constexpr int NWc = BITS ? BITS : 1;
+        uint32_t *peq = reinterpret_cast<uint32_t *>(smem + FZ_TABLE_BYTES + mpad);
+        constexpr uint32_t wdw = FZ_BITS_WIDTH(NWc) / 32u;                   // dwords per table word
+        for (uint32_t i = threadIdx.x; i < peq_bytes / 4u; i += FZ_FILTER_THREADS) peq[i] = 0u;
         __syncthreads();
         if (threadIdx.x < a.m) {
-            constexpr int NWc = BITS ? BITS : 1;
             const uint32_t q = threadIdx.x, c = pat_lds[q];
             const uint32_t bf = fz_bits_fwd_bit<NWc>(a.m, q), br = fz_bits_rev_bit<NWc>(a.m, q);
-            atomicOr(&peq[c * NWc + (bf >> 6)], 1ull << (bf & 63u));
-            atomicOr(&peq[(256u + c) * NWc + (br >> 6)], 1ull << (br & 63u));
+            atomicOr(&peq[c * wdw + (bf >> 5)], 1u << (bf & 31u));
+            atomicOr(&peq[(256u + c) * wdw + (br >> 5)], 1u << (br & 31u));
         }
     }
     if (threadIdx.x < FZ_LUT_SLOTS) {

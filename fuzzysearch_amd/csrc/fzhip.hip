@@ -354,8 +354,9 @@ struct DevWorkers {
     }
     void post(size_t i, std::function<int()> fn) {
         W *w = ws[i];
-        // one job at a time per worker: the previous one has been waited for (the slot is overwritten below)
-        assert(w->done.load(std::memory_order_acquire) == w->posted.load(std::memory_order_relaxed));
+        // one job at a time per worker (the slot is overwritten below): callers wait for a job before they post the next; should
+        // one ever not, the post waits here instead of corrupting the slot (rounds 4-5: an assert, i.e. abort() of the host process)
+        while (w->done.load(std::memory_order_acquire) != w->posted.load(std::memory_order_relaxed)) std::this_thread::yield();
         w->job = std::move(fn);
         w->posted.fetch_add(1, std::memory_order_release);
         { std::lock_guard<std::mutex> g(w->mu); }
@@ -635,12 +636,13 @@ ScanKernel scan_kernel_wf(int nwin, int dh) {
     }
 }
 
-// wf_gw: 0 = register band / Hamming count, 1 / 2 = bit-vector columns on one / two 64-bit words, 3 = register band / Hamming
-// count under the bit-vector forms' queue discipline (dense candidates), 16 / 32 = lanes per candidate
+// wf_gw: 0 = register band / Hamming count, 1 / 2 = bit-vector columns on one / two 64-bit words, 4 = on one 32-bit word,
+// 3 = Hamming count under the bit-vector forms' queue discipline (dense candidates), 16 / 32 = lanes per candidate
 ScanKernel scan_kernel(int nwin, int dh, bool fused, bool seg, bool sa, int wf_gw = 0) {
 #ifdef FZ_LAB_ONLY      // lab builds (benchmarks/lab_build.sh): only the instances of the headline and exact-search workloads
     if (wf_gw == 1 && nwin == 2 && dh == 3 && fused && !seg) return sa ? fz_scan_kernel<2, 3, true, false, true, 1> : fz_scan_kernel<2, 3, true, false, false, 1>;
     if (wf_gw == 3 && nwin == 2 && dh == 3 && fused && !seg) return sa ? fz_scan_kernel<2, 3, true, false, true, 3> : fz_scan_kernel<2, 3, true, false, false, 3>;
+    if (wf_gw == 4 && nwin == 2 && dh == 3 && fused && !seg) return sa ? fz_scan_kernel<2, 3, true, false, true, 4> : fz_scan_kernel<2, 3, true, false, false, 4>;
     if (wf_gw) return nullptr;
     if (nwin == 2 && dh == 3 && fused && !seg) return sa ? fz_scan_kernel<2, 3, true, false, true> : fz_scan_kernel<2, 3, true, false, false>;
     if (nwin == 2 && dh == 5 && !fused && !seg) return sa ? fz_scan_kernel<2, 5, false, false, true> : fz_scan_kernel<2, 5, false, false, false>;
@@ -648,6 +650,7 @@ ScanKernel scan_kernel(int nwin, int dh, bool fused, bool seg, bool sa, int wf_g
 #else
     if (wf_gw == 1) return seg ? nullptr : (sa ? scan_kernel_wf<true, 1>(nwin, dh) : scan_kernel_wf<false, 1>(nwin, dh));
     if (wf_gw == 2) return seg ? nullptr : (sa ? scan_kernel_wf<true, 2>(nwin, dh) : scan_kernel_wf<false, 2>(nwin, dh));
+    if (wf_gw == 4) return seg ? nullptr : (sa ? scan_kernel_wf<true, 4>(nwin, dh) : scan_kernel_wf<false, 4>(nwin, dh));
     if (wf_gw == 3) return seg ? nullptr : (sa ? scan_kernel_wf<true, 3>(nwin, dh) : scan_kernel_wf<false, 3>(nwin, dh));
     if (wf_gw == 16) return seg ? nullptr : (sa ? scan_kernel_wf<true, 16>(nwin, dh) : scan_kernel_wf<false, 16>(nwin, dh));
     if (wf_gw == 32) return seg ? nullptr : (sa ? scan_kernel_wf<true, 32>(nwin, dh) : scan_kernel_wf<false, 32>(nwin, dh));
@@ -741,7 +744,8 @@ struct Search {
     uint64_t part_lo = 0, part_hi = ~0ull;
 };
 
-static const uint32_t kFusedLdsBudget = (uint32_t)(sw().fused_lds_kb > 0 ? sw().fused_lds_kb : 64) * 1024u;   // dynamic LDS per scan workgroup when verification is fused
+// dynamic LDS per scan workgroup when verification is fused (a function of the switches: fz_debug_reload_switches reaches it)
+#define kFusedLdsBudget ((uint32_t)(sw().fused_lds_kb > 0 ? sw().fused_lds_kb : 64) * 1024u)
 
 // Fields of FzScanArgs that every kernel of a search shares.
 void fill_common_args(FzScanArgs &fa, const Shard &sh, const Search &q) {
@@ -996,7 +1000,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     const bool bits_budget = q.k >= (uint32_t)sw().bits_min_k || per_tile > 16.0;
     if (q.mode == FZ_MODE_LEV && with_verify && !force_big && !sw().no_bits && sh.geom.seg_stride == 0 && bits_budget &&
         q.m <= FZ_BITS_MAX_M(2) && q.k <= FZ_MAX_K && fa.win_pieces * 16u + 16u <= FZ_PAD_BACK) {
-        bits_nw = q.m <= FZ_BITS_MAX_M(1) ? 1 : 2;
+        bits_nw = q.m <= FZ_BITS_MAX_M(4) ? 4 : q.m <= FZ_BITS_MAX_M(1) ? 1 : 2;      // 32-, 64-, 128-bit columns
         // (26 KB: six workgroups per CU.  Measured on 1 GiB of DNA, m = 54, k = 8, 2.4e6 candidates: 64 / 96 / 128 / 160 entries
         //  per wave = 26 / 37 / 47 / 58 KB -> 0.463 / 0.517 / 0.656 / 0.830 ms: fuller passes do not pay for the lost waves)
         const uint32_t budget = (uint32_t)(sw().bits_lds_kb > 0 ? sw().bits_lds_kb : 26) * 1024u;
@@ -1180,7 +1184,7 @@ int enqueue_shard(fz_ctx *ctx, const Shard &sh, const Search &q, bool with_verif
     }
     d.launches_used = launches;                  // (summed by search_enqueue: this may run on the device's worker thread)
     d.fused_used = fa.fused != 0;
-    d.form_used = !with_verify ? FZ_FORM_NONE : bits_nw == 1 ? FZ_FORM_FUSED_BITS1 : bits_nw == 2 ? FZ_FORM_FUSED_BITS2
+    d.form_used = !with_verify ? FZ_FORM_NONE : bits_nw == 4 ? FZ_FORM_FUSED_BITS32 : bits_nw == 1 ? FZ_FORM_FUSED_BITS1 : bits_nw == 2 ? FZ_FORM_FUSED_BITS2
                   : wf_fused ? FZ_FORM_FUSED_CELLS : fa.fused ? FZ_FORM_FUSED_BAND : FZ_FORM_KERNEL;
     d.hit_cap_used = d.hit_cap;
     d.rec_cap_used = d.rec_cap;
@@ -1696,7 +1700,12 @@ int run_generic(fz_ctx *ctx, fz_seq *seq, const Search &q, std::vector<FzGenRec>
             // r05_generic_kernels.txt): a hit's time is ~1 500 cycles per window character that has candidates, whatever the
             // number of waves or of slices per trip (the big tree of a true occurrence belongs to one start, and the per-character
             // cost is the dependent chain of one trip), so more waves per hit only cost residency; 2 otherwise (round 4)
-            const bool gh_bits = q.m <= 64u && q.k <= 32u && q.m >= 1u && !gh_no_bits;
+            // fz_gen_hit_kernel<W, true>'s implicit bounds, held HERE: one 64-bit equality word per window character (m <= 64),
+            // the equality words of a window in two register pairs (m + 2k <= 128), skip counts in 32 bits (k <= 32), counters
+            // below 2^31 (limits <= FZ_MAX_K = 255); anything else takes round 4's step
+            static_assert(FZ_MAX_K < (1u << 31), "fz_b_lt / fz_b_eq operands");
+            const bool gh_bits = q.m <= 64u && q.k <= 32u && q.m >= 1u && q.m + 2u * q.k <= 128u &&
+                                 std::max(std::max(q.max_subs, q.max_ins), std::max(q.max_dels, q.k)) <= FZ_MAX_K && !gh_no_bits;
             const uint32_t gh_waves = gh_waves_env == 4u || gh_waves_env == 2u || (gh_waves_env == 1u && gh_bits) ? gh_waves_env : gh_bits ? 1u : 2u;
             const uint32_t capw = gh_waves == 1u ? std::max<uint32_t>(64u, cand_cap) : std::max<uint32_t>(64u, cand_cap / 2u);   // slots per list of one wave
             const size_t lds_multi = (size_t)mpad + wpad + FZ_GH_CTL_BYTES + (size_t)gh_waves * 2u * capw * sizeof(FzGCand) +

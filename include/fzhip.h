@@ -86,6 +86,7 @@ typedef struct {
 #define FZ_FORM_FUSED_BITS1 3u   /* inside the scan: bit-vector columns on one 64-bit word, candidate per lane */
 #define FZ_FORM_FUSED_BITS2 4u   /* ... on two 64-bit words (patterns of 65 .. 128 characters)                 */
 #define FZ_FORM_KERNEL      5u   /* a verification kernel of its own behind a hit list                         */
+#define FZ_FORM_FUSED_BITS32 6u  /* inside the scan: bit-vector columns on one 32-bit word (patterns <= 32)     */
 
 int         fz_abi_version(void);
 const char *fz_last_error(void);

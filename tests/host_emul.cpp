@@ -641,9 +641,9 @@ template <int NW>
 static int expand_bits_nw(const uint8_t *sub, uint32_t sublen, const uint8_t *win, uint32_t winlen, uint32_t budget,
                           uint32_t *dist, uint32_t *consumed) {
     typedef typename FzBitsWord<NW>::T T;
-    if (sublen > 64u * NW) return -1;
+    if (sublen > FZ_BITS_WIDTH(NW)) return -1;
     std::vector<T> tab(256, (T)0);
-    for (uint32_t i = 0; i < sublen; ++i) tab[sub[i]] |= (T)1 << (64u * NW - sublen + i);
+    for (uint32_t i = 0; i < sublen; ++i) tab[sub[i]] |= (T)1 << (FZ_BITS_WIDTH(NW) - sublen + i);
     auto peq = [&](uint8_t c) -> T { return tab[c]; };
     auto w = [&](uint32_t j) -> uint8_t { return win[j]; };
     return fz_expand_bits<NW>(peq, sublen, w, winlen, budget, *dist, *consumed) ? 1 : 0;
@@ -670,7 +670,7 @@ template <int NW>
 static int64_t search_bits_nw(const uint8_t *p, uint32_t m, const uint8_t *t, uint64_t n, uint32_t k,
                               uint64_t buf_off, uint64_t buf_len, uint64_t own_lo, uint64_t own_hi, OutRec *out, int64_t cap) {
     const uint32_t L = m / (k + 1);
-    if (L == 0 || m > 64u * NW) return -1;
+    if (L == 0 || m > FZ_BITS_WIDTH(NW)) return -1;
     std::vector<uint8_t> shard(buf_len + 64, 0xEE);
     memcpy(shard.data(), t + buf_off, buf_len);
     const HostPeq<NW> peq(p, m);
@@ -711,11 +711,13 @@ extern "C" {
 int emul_expand_bits(int NW, const uint8_t *sub, uint32_t sublen, const uint8_t *win, uint32_t winlen, uint32_t budget,
                      uint32_t *dist, uint32_t *consumed) {
     return NW == 1 ? expand_bits_nw<1>(sub, sublen, win, winlen, budget, dist, consumed)
+         : NW == 4 ? expand_bits_nw<4>(sub, sublen, win, winlen, budget, dist, consumed)
                    : expand_bits_nw<2>(sub, sublen, win, winlen, budget, dist, consumed);
 }
 int64_t emul_search_bits(int NW, const uint8_t *p, uint32_t m, const uint8_t *t, uint64_t n, uint32_t k,
                          uint64_t buf_off, uint64_t buf_len, uint64_t own_lo, uint64_t own_hi, OutRec *out, int64_t cap) {
     return NW == 1 ? search_bits_nw<1>(p, m, t, n, k, buf_off, buf_len, own_lo, own_hi, out, cap)
+         : NW == 4 ? search_bits_nw<4>(p, m, t, n, k, buf_off, buf_len, own_lo, own_hi, out, cap)
                    : search_bits_nw<2>(p, m, t, n, k, buf_off, buf_len, own_lo, own_hi, out, cap);
 }
 }

@@ -52,6 +52,29 @@ def test_committed_bench_line_follows_the_contract(name):
         assert "1024 MiB" in c["sample"] and "whole" in c["sample"]
 
 
+def test_round6_line_was_measured_with_the_tree_s_native_sources():
+    """profiles/r06_bench_n1.json is the unedited stdout of `python bench.py` on an MI355X with THIS tree's kernels: its
+    `csrc_digest` equals the digest of fuzzysearch_amd/csrc + include/fzhip.h as they are now (the committed
+    "final" line of round 5 predated the round's last product change).  And it carries the round's additions."""
+    from fuzzysearch_amd import build as fzbuild
+    with open(os.path.join(ROOT, "profiles", "r06_bench_n1.json")) as f:
+        text = f.read().strip()
+    assert "\n" not in text
+    d = json.loads(text)
+    assert d["csrc_digest"] == fzbuild.source_digest(), "profiles/r06_bench_n1.json predates a change of the native sources: re-run bench.py"
+    r = d["roofline"]
+    assert r["avg_kernel_ms"] == r["avg_kernel_ms_sync"] and r["avg_kernel_ms_pipelined"] >= r["avg_kernel_ms_sync"] * 0.98
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "200 synchronous launches" in r["avg_kernel_ms_source"]
+    assert r["traffic"] is None or 0.9 < r["traffic"] * 1e9 / r["algorithmic_bytes_per_launch"] < 1.5
+    assert d["settle"]["searches"] >= 64 and d["settle"]["ms"] <= 1600
+    rows = {(x["m"], x["k"]): x for x in d["regimes"]["rows"]}
+    assert set(rows) == {(20, 1), (20, 2), (20, 3), (20, 4), (54, 8), (100, 20)}
+    assert rows[(54, 8)]["verify_form"].startswith("fused bit-vector") and rows[(54, 8)]["ms_per_call"] < 0.6
+    assert rows[(20, 4)]["ms_per_call"] < 2.0 and rows[(100, 20)]["ms_per_call"] < 80.0
+    assert all(abs(x["first_call_ms"] - x["ms_per_call"]) < max(0.25, 0.15 * x["ms_per_call"]) for x in rows.values()), "the form must not depend on earlier calls"
+    assert "consolidated_two_in_flight_ms" in [k2 for v in d["configs"].values() for k2 in v]
+
+
 def test_two_device_states_line():
     """`FZ_DEVICES=0,0 python bench.py --gpus 2` (the torch-free N > 1 form on one GPU): n_gpus follows --gpus."""
     with open(os.path.join(ROOT, "profiles", "r03_bench_two_device_states.json")) as f:

@@ -122,11 +122,11 @@ def test_bit_vector_expand_equals_full_dp(emul):
     up to 128, small alphabets (ties along the bottom row are the rule there), windows shorter and longer than the piece,
     empty pieces and windows, budgets from 0 to beyond the piece."""
     rnd = random.Random(61)
-    done = {1: 0, 2: 0}
-    for it in range(125000):
-        nw = 1 if it < 100000 else 2
+    done = {1: 0, 2: 0, 4: 0}
+    for it in range(150000):
+        nw = 1 if it < 100000 else 2 if it < 125000 else 4          # 4 names the 32-bit form
         alpha = bytes(rnd.sample(range(1, 256), rnd.choice([1, 2, 2, 3, 4, 4, 20])))
-        top = 64 * nw
+        top = 32 if nw == 4 else 64 * nw
         ln = rnd.choice([0, 1, 2, top - 1, top, rnd.randint(0, top), rnd.randint(0, 24), rnd.randint(0, 24)])
         sub = bytes(rnd.choice(alpha) for _ in range(ln))
         b = rnd.choice([0, 1, 2, 3, 5, 8, 13, 21, ln, ln + 1])
@@ -141,7 +141,7 @@ def test_bit_vector_expand_equals_full_dp(emul):
         assert r in (0, 1)
         assert ((d.value, c.value) if r else (None, None)) == oracle.expand(sub, win, b), (nw, sub, win, b)
         done[nw] += 1
-    assert done[1] >= 100000 and done[2] >= 25000
+    assert done[1] >= 100000 and done[2] >= 25000 and done[4] >= 25000
 
 
 def _search_bits(L, nw, p, t, k, buf_off=0, buf_len=None, own_lo=0, own_hi=None):
@@ -161,14 +161,15 @@ def test_bit_vector_per_hit_verification_equals_oracle(emul):
     shard geometry with a poisoned halo."""
     rnd = random.Random(62)
     done = 0
-    while done < 6000:
-        nw = 1 if done < 4500 else 2
+    while done < 7500:
+        nw = 1 if done < 4500 else 2 if done < 6000 else 4
+        top = 32 if nw == 4 else 64 * nw
         sigma = rnd.choice([2, 3, 4, 4, 4, 20])
         alpha = bytes(rnd.sample(range(1, 256), sigma))
         k = rnd.choice([1, 2, 3, 4, 5, 6, 8, 8, 12, 21])
         lo_m = max(k + 1, 2)
-        m = rnd.choice([lo_m, 64 * nw, 64 * nw - 1, rnd.randint(lo_m, max(lo_m, 64 * nw)), rnd.randint(lo_m, max(lo_m, 30))])
-        if m > 64 * nw or m // (k + 1) == 0:
+        m = rnd.choice([lo_m, top, top - 1, rnd.randint(lo_m, max(lo_m, top)), rnd.randint(lo_m, max(lo_m, 30))])
+        if m > top or m // (k + 1) == 0:
             continue
         p = bytes(rnd.choice(alpha) for _ in range(m))
         n = rnd.choice([0, rnd.randint(0, m), rnd.randint(m, 3 * m + 40), rnd.randint(m, 400)])

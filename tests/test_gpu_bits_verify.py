@@ -17,7 +17,11 @@ from tests import workloads
 
 pytestmark = pytest.mark.gpu
 
-BITS = (_native.FORM_FUSED_BITS1, _native.FORM_FUSED_BITS2)
+BITS = (_native.FORM_FUSED_BITS1, _native.FORM_FUSED_BITS2, _native.FORM_FUSED_BITS32)
+
+
+def _form_of(m):
+    return BITS[2] if m <= 32 else BITS[0] if m <= 64 else BITS[1]
 
 
 def _reload_switches():
@@ -86,7 +90,7 @@ def test_random_and_planted_small_cases_every_budget(engine, all_budgets):
         h.release()
         assert got == want, (p, t, k)
         if len(t):
-            assert st["verify_form"] == (BITS[0] if len(p) <= 64 else BITS[1]), (len(p), k, st)
+            assert st["verify_form"] == _form_of(len(p)), (len(p), k, st)
             forms.add(st["verify_form"])
         done += 1
     assert forms == set(BITS)
@@ -108,7 +112,7 @@ def test_default_routing_budgets_5_to_31(engine):
         got = engine.lev_ngrams(h2, p, k)
         st = engine.stats()
         h2.release()
-        assert st["verify_form"] == (BITS[0] if m <= 64 else BITS[1]), (m, k, st)
+        assert st["verify_form"] == _form_of(m), (m, k, st)
         assert got == oracle.lev_ngrams_raw(p, bytes(tt), k), (m, k)
         assert len(got) >= 1
     h.release()
@@ -153,7 +157,7 @@ def test_queue_sizes_and_degenerate_density(engine, all_budgets, monkeypatch):
         _reload_switches()
         h = engine.upload(seq)
         assert engine.lev_ngrams(h, p.tobytes(), 5) == want1
-        assert engine.stats()["verify_form"] == BITS[0]
+        assert engine.stats()["verify_form"] == BITS[2]
         h.release()
         h = engine.upload(bytes(runs))
         for k in (2, 4):

@@ -549,7 +549,7 @@ def test_no_kernel_spills_to_scratch():
         if len(parts) >= 3:
             rows[parts[0]] = dict(kv.split("=") for kv in parts[1:])
     scan = {k: v for k, v in rows.items() if "fz_scan_kernel" in k}
-    assert len(scan) == 90                 # round 6: + 3 x 10 instances: the fused bit-vector forms (one / two words per column) and the plain form under their queue discipline
+    assert len(scan) == 100                # round 6: + 4 x 10 instances: bit-vector columns (32-, 64-, 128-bit) and the Hamming count under their queue discipline
     assert len(rows) >= 60 and any("fz_gen_hit_kernel" in k for k in rows) and any("fz_verify_kernel" in k for k in rows)
     for name, r in rows.items():
         # round 4: EVERY kernel (fz_verify_kernel had 232 B of scratch and 57 spilled VGPRs); round 5: the tiled Levenshtein
