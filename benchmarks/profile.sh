@@ -8,8 +8,8 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # kernel trace over the whole default bench (headline + 4 GiB target + the other configs); counters over the headline only
-BENCH="python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras"   # (two searches in flight, as the default bench)
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $OUT/stats.log 2>&1
+BENCH="python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras --no-live-traffic"   # (two searches in flight, as the default bench)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-live-traffic > $OUT/stats.log 2>&1
 echo "stats rc=$?"
 i=0
 for CNT in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" \

@@ -102,7 +102,8 @@ def test_default_routing_budgets_5_to_31(engine):
     rnd = random.Random(602)
     t = workloads.dna(1 << 20, 5).tobytes()
     h = engine.upload(t)
-    for m, k in [(54, 8), (30, 5), (64, 5), (64, 12), (100, 20), (128, 31), (65, 6), (40, 9)]:
+    # (9, 2) and (8, 1): budgets below 3 whose pattern lets expect dense candidates (3- / 4-character n-grams over 4 letters)
+    for m, k in [(54, 8), (30, 5), (64, 5), (64, 12), (100, 20), (128, 31), (65, 6), (40, 9), (9, 2), (8, 1), (20, 3)]:
         p = workloads.dna(m, 100 + m + k).tobytes()
         tt = bytearray(t)
         at = rnd.randrange(1000, len(t) - 1000)

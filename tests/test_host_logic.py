@@ -834,3 +834,23 @@ def test_symbol_remapping_of_integer_items_never_wraps():
         sub = [rnd.choice(pool) for _ in range(rnd.randint(1, 5))]
         seq = [rnd.choice(pool) for _ in range(rnd.randint(0, 12))]
         check(sub, seq)
+
+
+def test_match_loads_pickles_of_the_attrs_form():
+    """A pickle made where the C extension is absent (the attrs-style fallback class: copyreg.__newobj__(Match) + a dict or tuple
+    state through __setstate__) loads where it is present, and the other way round: results stay portable."""
+    import pickle
+
+    def attrs_style(state):
+        # protocol 2, as an attrs slots instance of Match pickles: GLOBAL Match, EMPTY_TUPLE, NEWOBJ, <state>, BUILD, STOP
+        return b'\x80\x02cfuzzysearch_amd.common\nMatch\n)\x81' + pickle.dumps(state, 2)[2:-1] + b'b.'
+
+    want = Match(3, 9, 1, 'PATERN')
+    for state in ({'start': 3, 'end': 9, 'dist': 1, 'matched': 'PATERN'}, (3, 9, 1, 'PATERN')):
+        got = pickle.loads(attrs_style(state))
+        assert type(got) is Match and got == want and got.matched == 'PATERN' and repr(got) == repr(want)
+    assert pickle.loads(pickle.dumps(want)) == want
+    blank = Match.__new__(Match)                     # what __newobj__ makes before the state arrives
+    assert (blank.start, blank.end, blank.dist, blank.matched) == (0, 0, 0, None)
+    with pytest.raises(TypeError):
+        blank.__setstate__([1, 2])
