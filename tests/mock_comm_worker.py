@@ -256,9 +256,16 @@ def main(argv):
     st = (ctypes.c_uint64 * 4)()
     ctypes.CDLL(os.environ["FZ_RCCL_LIB"]).fzmock_rccl_stats(st)
     assert st[0] >= 20 and st[3] == world, list(st)      # the collectives really went through the stand-in, with `world` ranks
+    lib = ctypes.CDLL(os.environ["FZ_RCCL_LIB"])
+    lib.fzmock_rccl_async_allgathers.restype = ctypes.c_uint64
+    n_async = lib.fzmock_rccl_async_allgathers()
+    if mode == "rank" and world > 1 and not os.environ.get("FZMOCK_SHM_BLOCKING"):
+        # one process per rank: the all-gathers were ASYNCHRONOUS (ordered by the caller's stream only, as RCCL's are): a missing
+        # dependency between the search stream and the communicator's stream could not hide behind a stream synchronise
+        assert n_async >= 20, (n_async, list(st))
     eng.comm_destroy()
     eng.close()
-    print("OK %d %d allgathers=%d" % (checks[0], checks[1], st[0]), flush=True)
+    print("OK %d %d allgathers=%d async=%d" % (checks[0], checks[1], st[0], n_async), flush=True)
 
 
 if __name__ == "__main__":

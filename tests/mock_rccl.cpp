@@ -13,10 +13,16 @@
 //     all readers of its send buffer — i.e. the work is asynchronous, ordered only by the streams, exactly as with RCCL.
 //     The receive buffer is poisoned (0xEE) on the stream first, so stale bytes of an earlier gather cannot pass.
 //   * ncclCommInitRank(comm, n, id, rank): ranks in DIFFERENT processes (one process per "GPU", the launcher form).
-//     The 128-byte id names a POSIX shared-memory control block; a collective is blocking (a legal execution of the
-//     asynchronous contract): synchronise the stream, copy the send buffer into this rank's shared file, barrier,
-//     read every rank's file into the receive buffer, barrier.  Every wait has a deadline (FZ_MOCK_RCCL_TIMEOUT_S,
-//     default 120 s): a rank that never arrives yields ncclSystemError, not a hung GPU box.
+//     The 128-byte id names a POSIX shared-memory control block; every rank owns a shared data file that all ranks map
+//     and page-lock (hipHostRegister) at init.  An ALL-GATHER is asynchronous, ordered only by the caller's stream,
+//     as RCCL's is (round 6; rounds 4-5 synchronised the stream first, which would have hidden a missing dependency
+//     between the search stream and the communicator's stream in exactly this form): on the caller's stream a host
+//     function waits until every rank has read this rank's previous contribution, an asynchronous D2H copy moves the
+//     send buffer into the rank's data file, a host function publishes it and waits for the other ranks' publications,
+//     asynchronous H2D copies fill the (poisoned) receive buffer, a host function reports "read".  The caller's thread
+//     never waits.  The (8-byte) all-reduce stays blocking: stream synchronise, copy, barrier, reduce.  Every wait
+//     has a deadline (FZ_MOCK_RCCL_TIMEOUT_S, default 120 s): a rank that never arrives marks the communicator failed
+//     (the next call returns ncclRemoteError), not a hung GPU box.  FZMOCK_SHM_BLOCKING=1: rounds 4-5's blocking form.
 //   * misuse that would hang or corrupt with the real library is an ERROR here: a collective with fewer calls than
 //     ranks, differing byte counts between ranks, a rank used twice in one group.
 //
@@ -101,6 +107,8 @@ struct Ctl {
     std::atomic<uint32_t> failed;
     std::atomic<uint64_t> size[kMaxRanks];       // bytes rank r published for the collective in progress
     std::atomic<uint64_t> cap[kMaxRanks];        // size of rank r's data file
+    // asynchronous all-gathers: rank r has published / has finished reading its pub[r]-th / rd[r]-th one
+    std::atomic<uint64_t> pub[kMaxRanks], pub_bytes[kMaxRanks], rd[kMaxRanks];
 };
 
 struct Mapping {
@@ -123,6 +131,9 @@ struct ncclComm {
     Mapping mine;
     std::vector<Mapping> theirs;
     uint32_t barrier_gen = 0;
+    bool async_ok = false;                       // every rank's data file is mapped and page-locked: asynchronous all-gathers
+    uint64_t async_seq = 0;                      // asynchronous all-gathers this rank has issued
+    uint64_t async_cap = 0;
 };
 
 namespace {
@@ -147,6 +158,7 @@ thread_local int g_depth = 0;
 thread_local std::vector<Op> g_ops;
 
 std::atomic<uint64_t> g_stats[4];                // all-gathers, all-gather bytes (one rank's contribution), all-reduces, largest world
+std::atomic<uint64_t> g_async_allgathers{0};     // cross-process all-gathers that took the asynchronous (stream-ordered) form
 
 size_t dt_bytes(ncclDataType_t dt) {
     switch (dt) {
@@ -260,6 +272,8 @@ ncclResult_t local_allreduce(Clique *q, const std::vector<const Op *> &ops) {   
     return ncclSuccess;
 }
 
+bool spin_until(ncclComm *c, const std::atomic<uint64_t> *arr, uint64_t want, const char *what);
+
 // ---- one process per rank: shared memory, blocking ------------------------------------------------------------
 ncclResult_t shm_barrier(ncclComm *c) {
     Ctl *ctl = c->ctl;
@@ -303,6 +317,11 @@ ncclResult_t map_file(const std::string &name, uint64_t need, Mapping &m, bool w
 ncclResult_t shm_publish(ncclComm *c, const void *send_dev, size_t bytes, hipStream_t stream) {
     HIPQ(hipSetDevice(c->device));
     HIPQ(hipStreamSynchronize(stream));
+    // (the data file is shared with the asynchronous all-gathers: every rank must have read this rank's last one)
+    if (c->async_ok && !spin_until(c, c->ctl->rd, c->async_seq, "finish reading"))
+        return bad(ncclRemoteError, "mock: the communicator failed (a rank never finished an asynchronous all-gather)");
+    if (c->async_ok && bytes > c->async_cap)
+        return bad(ncclInvalidArgument, "mock: %zu bytes per rank exceed the shared data files (FZ_MOCK_SHM_CAP_MIB)", bytes);
     if (c->mine.bytes < bytes) {
         const uint64_t want = (bytes + (bytes >> 2) + 65535) / 65536 * 65536;
         if (c->mine.p) { munmap(c->mine.p, c->mine.bytes); c->mine.p = nullptr; c->mine.bytes = 0; }
@@ -363,6 +382,71 @@ ncclResult_t shm_allreduce(const Op &op) {
     return shm_barrier(c);
 }
 
+// ---- one process per rank: the asynchronous all-gather -----------------------------------------------------------
+struct AsyncStep { ncclComm *c; uint64_t seq; uint64_t bytes; int what; };   // what: 0 wait-for-readers, 1 publish-and-wait, 2 read-done
+
+bool spin_until(ncclComm *c, const std::atomic<uint64_t> *arr, uint64_t want, const char *what) {
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeout_s());
+    for (int j = 0; j < c->world; ++j) {
+        unsigned spins = 0;
+        while (arr[j].load(std::memory_order_acquire) < want) {
+            if (c->ctl->failed.load(std::memory_order_acquire)) return false;
+            if (++spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(20));
+            if ((spins & 1023) == 0 && std::chrono::steady_clock::now() > deadline) {
+                c->ctl->failed.store(1, std::memory_order_release);
+                fprintf(stderr, "[mock_rccl] rank %d waited %.0f s for rank %d to %s all-gather %llu\n", c->rank, timeout_s(), j, what,
+                        (unsigned long long)want);
+                return false;
+            }
+        }
+    }
+    return true;
+}
+
+void async_step(void *arg) {                     // runs on the HIP runtime's callback thread, in stream order; no HIP calls here
+    AsyncStep *st = static_cast<AsyncStep *>(arg);
+    ncclComm *c = st->c;
+    Ctl *ctl = c->ctl;
+    if (st->what == 0) {
+        (void)spin_until(c, ctl->rd, st->seq - 1, "finish reading");
+    } else if (st->what == 1) {
+        ctl->pub_bytes[c->rank].store(st->bytes, std::memory_order_release);
+        ctl->pub[c->rank].store(st->seq, std::memory_order_release);
+        if (spin_until(c, ctl->pub, st->seq, "publish"))
+            for (int j = 0; j < c->world; ++j)
+                if (ctl->pub_bytes[j].load(std::memory_order_acquire) != st->bytes) {
+                    ctl->failed.store(1, std::memory_order_release);
+                    fprintf(stderr, "[mock_rccl] all-gather %llu with %llu bytes on rank %d and %llu on rank %d (RCCL would corrupt or hang)\n",
+                            (unsigned long long)st->seq, (unsigned long long)st->bytes, c->rank,
+                            (unsigned long long)ctl->pub_bytes[j].load(), j);
+                }
+    } else {
+        ctl->rd[c->rank].store(st->seq, std::memory_order_release);
+    }
+    delete st;
+}
+
+ncclResult_t shm_allgather_async(const Op &op) {
+    ncclComm *c = op.comm;
+    const size_t bytes = op.count * dt_bytes(op.dt);
+    if (c->ctl->failed.load(std::memory_order_acquire)) return bad(ncclRemoteError, "mock: the communicator failed earlier (a rank never arrived, or ranks disagreed on a size)");
+    g_stats[0]++; g_stats[1] += bytes;
+    g_async_allgathers++;
+    const uint64_t seq = ++c->async_seq;
+    HIPQ(hipSetDevice(c->device));
+    uint8_t *recv = static_cast<uint8_t *>(op.recv);
+    HIPQ(hipLaunchHostFunc(op.stream, async_step, new AsyncStep{c, seq, bytes, 0}));
+    if (bytes) HIPQ(hipMemcpyAsync(c->mine.p, op.send, bytes, hipMemcpyDeviceToHost, op.stream));
+    HIPQ(hipLaunchHostFunc(op.stream, async_step, new AsyncStep{c, seq, bytes, 1}));
+    if (bytes) {
+        HIPQ(hipMemsetAsync(recv, 0xEE, bytes * (size_t)c->world, op.stream));
+        for (int j = 0; j < c->world; ++j)
+            HIPQ(hipMemcpyAsync(recv + (size_t)j * bytes, shm_block(c, j), bytes, hipMemcpyHostToDevice, op.stream));
+    }
+    HIPQ(hipLaunchHostFunc(op.stream, async_step, new AsyncStep{c, seq, bytes, 2}));
+    return ncclSuccess;
+}
+
 // ---- the group machinery ---------------------------------------------------------------------------------------
 ncclResult_t run_ops(std::vector<Op> &ops) {
     // multi-process communicators: every op blocks on its own, in call order (all ranks make the same calls in the same order)
@@ -397,7 +481,10 @@ ncclResult_t run_ops(std::vector<Op> &ops) {
     }
     for (const Op &op : ops) {
         if (!op.comm->ctl) continue;
-        ncclResult_t rc = op.kind == 0 ? shm_allgather(op) : shm_allreduce(op);
+        if (op.kind == 0 && op.comm->async_ok && op.count * dt_bytes(op.dt) > op.comm->async_cap)
+            return bad(ncclInvalidArgument, "mock: %zu bytes per rank exceed the shared data files (FZ_MOCK_SHM_CAP_MIB)", op.count * dt_bytes(op.dt));
+        const bool async = op.kind == 0 && op.comm->async_ok;
+        ncclResult_t rc = async ? shm_allgather_async(op) : op.kind == 0 ? shm_allgather(op) : shm_allreduce(op);
         if (rc != ncclSuccess) return rc;
     }
     return ncclSuccess;
@@ -424,6 +511,7 @@ extern "C" {
 int fzmock_rccl = 1;
 
 void fzmock_rccl_stats(uint64_t out[4]) { for (int i = 0; i < 4; ++i) out[i] = g_stats[i].load(); }
+uint64_t fzmock_rccl_async_allgathers(void) { return g_async_allgathers.load(); }
 
 ncclResult_t ncclGetUniqueId(ncclUniqueId *id) {
     if (!id) return bad(ncclInvalidArgument, "mock: null id");
@@ -477,13 +565,47 @@ ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int
     if (c->data_fd < 0) return bad(ncclSystemError, "mock: shm_open(data): %s", strerror(errno));
     c->ctl->joined.fetch_add(1);
     *comm = c;
-    return shm_barrier(c);                                      // RCCL's init is collective as well
+    // the data files of the asynchronous all-gather: a fixed capacity (FZ_MOCK_SHM_CAP_MIB, 32), created before the init
+    // barrier, mapped and page-locked by every rank behind it (a failure anywhere leaves the blocking form)
+    const bool want_async = !getenv("FZMOCK_SHM_BLOCKING");
+    const uint64_t cap = (uint64_t)std::max(1L, env_long("FZ_MOCK_SHM_CAP_MIB", 32)) << 20;
+    bool mine_ok = false;
+    if (want_async && ftruncate(c->data_fd, (off_t)cap) == 0) {
+        void *mp = mmap(nullptr, cap, PROT_READ | PROT_WRITE, MAP_SHARED, c->data_fd, 0);
+        if (mp != MAP_FAILED) { c->mine.p = mp; c->mine.bytes = cap; c->ctl->cap[rank].store(cap, std::memory_order_release); mine_ok = true; }
+    }
+    ncclResult_t rc = shm_barrier(c);                           // RCCL's init is collective as well
+    if (rc != ncclSuccess) return rc;
+    bool ok = want_async && mine_ok;
+    for (int j = 0; j < nranks && ok; ++j) {
+        if (j == rank) continue;
+        ok = c->ctl->cap[j].load(std::memory_order_acquire) == cap && map_file(data_name(c->name, j), cap, c->theirs[j], true) == ncclSuccess;
+    }
+    for (int j = 0; j < nranks && ok; ++j) {
+        void *q = j == rank ? c->mine.p : c->theirs[j].p;
+        if (hipHostRegister(q, cap, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); ok = false; }
+    }
+    if (!ok) c->ctl->failed.load();                             // (nothing to do: the blocking form serves)
+    // every rank must take the same form: the slowest common denominator, agreed through one more barrier
+    if (!ok) c->ctl->size[rank].store(~0ull, std::memory_order_release); else c->ctl->size[rank].store(1, std::memory_order_release);
+    rc = shm_barrier(c);
+    if (rc != ncclSuccess) return rc;
+    for (int j = 0; j < nranks; ++j) ok = ok && c->ctl->size[j].load(std::memory_order_acquire) == 1;
+    rc = shm_barrier(c);                                        // (sizes are reused by the blocking collectives: read them first)
+    if (rc != ncclSuccess) return rc;
+    c->async_ok = ok;
+    c->async_cap = cap;
+    return ncclSuccess;
 }
 
 ncclResult_t ncclCommDestroy(ncclComm_t c) {
     if (!c) return ncclSuccess;
     if (c->ev_ready) { (void)hipEventDestroy(c->ev_ready); (void)hipEventDestroy(c->ev_done); }
     if (c->ctl) {
+        if (c->async_ok) {
+            if (c->mine.p) (void)hipHostUnregister(c->mine.p);
+            for (Mapping &m : c->theirs) if (m.p) (void)hipHostUnregister(m.p);
+        }
         if (c->mine.p) munmap(c->mine.p, c->mine.bytes);
         for (Mapping &m : c->theirs) if (m.p) munmap(m.p, m.bytes);
         if (c->data_fd >= 0) close(c->data_fd);
