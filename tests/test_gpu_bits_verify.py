@@ -204,3 +204,26 @@ def test_substitutions_only_with_dense_candidates(engine, m, k, mib):
     assert got == want
     assert engine.subs_ngrams_any(h, p.tobytes(), k) is True
     h.release()
+
+
+def test_sharded_sequence_two_device_states(all_budgets):
+    """The bit-vector form on a sharded sequence (two device states on one GPU: contiguous shards, (m + k)-byte halos, hits owned
+    by index, global clamps): the merged stream is the oracle's, for hits on both sides of the shard boundary."""
+    eng = _native.Engine([0, 0])
+    try:
+        rnd = random.Random(77)
+        for m, k in [(54, 8), (20, 3), (100, 20)]:
+            seq = workloads.dna(6 << 20, 900 + m)
+            p = workloads.dna(m, 910 + m)
+            workloads.plant_edits(seq, p, 60, 920 + m, workloads.DNA, lambda i: i % (k + 1))
+            mid = len(seq) // 2
+            for delta in (-m - k, -m // 2, -3, 0, 5):                  # occurrences across and next to the shard boundary
+                v = _edited(rnd, p.tobytes(), b"ACGT", rnd.randint(0, k))
+                seq[mid + delta:mid + delta + len(v)] = np.frombuffer(v, dtype=np.uint8)
+            h = eng.upload(seq)
+            got = eng.lev_ngrams(h, p.tobytes(), k)
+            assert eng.stats()["verify_form"] in BITS
+            h.release()
+            assert got == oracle.lev_ngrams_raw(p.tobytes(), seq.tobytes(), k), (m, k)
+    finally:
+        eng.close()

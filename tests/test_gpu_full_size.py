@@ -65,10 +65,12 @@ def test_config3_utf8_1gib_wide_band_and_generic(engine):
     assert len(exp_b) > 100000
 
 
-def test_beyond_4gib_indices(engine):
+@pytest.mark.parametrize("k", [2, 3])
+def test_beyond_4gib_indices(engine, k):
     """64-bit index paths: 4.5 GiB = nine copies of one 512 MiB block, variants planted beyond 2^32 and
     across 2^32.  Size-independent property: the matches inside copy i are those of copy 0 shifted by
-    i * 512 MiB (the oracle only has to run on one block and on the planted tail)."""
+    i * 512 MiB (the oracle only has to run on one block and on the planted tail).  k = 2: the register band (the
+    headline instance); k = 3: the fused bit-vector form (round 6)."""
     block = 512 << 20
     copies = 9
     n = block * copies
@@ -81,18 +83,18 @@ def test_beyond_4gib_indices(engine):
     planted = workloads.plant_variants(seq[tail0:], pattern, 256, 17)
     seq[(1 << 32) - 10:(1 << 32) + 10] = pattern         # a match straddling 2^32 (= start of copy 8)
     h = engine.upload(seq)
-    got = _rows(engine.lev_ngrams(h, p, 2, as_array=True))
+    got = _rows(engine.lev_ngrams(h, p, k, as_array=True))
     h.release()
     keys = [(g, s) for (s, e, d, g) in got]
     assert keys == sorted(keys)                          # block-major, ascending: reference order
     margin = 64
-    exp0 = [r for r in oracle.lev_ngrams_raw(p, base.tobytes(), 2) if margin <= r[0] and r[1] <= block - margin]
+    exp0 = [r for r in oracle.lev_ngrams_raw(p, base.tobytes(), k) if margin <= r[0] and r[1] <= block - margin]
     assert len(exp0) > 0
     for i in range(8):                                   # copies 0..7 are untouched away from their seams
         lo, hi = i * block, (i + 1) * block
         inside = sorted((s - lo, e - lo, d, g) for (s, e, d, g) in got if lo + margin <= s and e <= hi - margin)
         assert inside == sorted(exp0), i
-    exp_tail = oracle.lev_ngrams_raw(p, seq[tail0:].tobytes(), 2)
+    exp_tail = oracle.lev_ngrams_raw(p, seq[tail0:].tobytes(), k)
     got_tail = [(s - tail0, e - tail0, d, g) for (s, e, d, g) in got if s >= tail0 + margin]
     assert got_tail == [r for r in exp_tail if r[0] >= margin]
     assert len(planted) >= 200 and len(got_tail) >= len(planted)
