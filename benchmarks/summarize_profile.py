@@ -7,7 +7,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 base = os.path.join(root, "gpurun_out", "prof_" + tag)
 alg = int(sys.argv[2]) if len(sys.argv) > 2 else 2 ** 30
 # the headline instance: hash windows (NWIN = 2, DH = 3), fused, in-memory, low-bits slot
-HEAD_KERNEL = "fz_scan_kernel<2, 3, true, false, true"
+HEAD_KERNEL = "fz_scan_kernel<2, 3, true, false, true, 0>"
 TILES_PER_WG = 12
 # threads of the headline launch: round 1-2 (and inputs of 10+ rounds): one workgroup per 12 tiles; round 3: a whole
 # number of rounds of the 6 x 256 resident workgroups, ~9.5 tiles each (fzhip.hip: enqueue_shard)
@@ -37,7 +37,7 @@ with open(os.path.join(root, "profiles", tag + "_kernel_stats.csv"), "w", newlin
     for name, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
         vs = sorted(v)
         wr.writerow([name, len(v), sum(v), round(sum(v) / len(v), 1), round(100.0 * sum(v) / total, 2), vs[0], vs[-1], vs[len(vs) // 2]])
-avg_ns, kname, calls = sum(head) / len(head), "void " + HEAD_KERNEL + ">", len(head)
+avg_ns, kname, calls = sum(head) / len(head), "void " + HEAD_KERNEL, len(head)
 out = {}
 for d in sorted(glob.glob(os.path.join(base, "pmc*"))):
     if not os.path.isdir(d):

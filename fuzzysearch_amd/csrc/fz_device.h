@@ -453,6 +453,30 @@ FZ_HD int32_t fz_bits_column(FzBitsCol<NW> &c, typename FzBitsWord<NW>::T eq) {
     return delta;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// The one-word column on the GPU, written on its 32-bit halves (only the addition is a 64-bit operation): gfx950 has a
+// three-input bit operation (v_bitop3_b32) and a funnel shift (v_alignbit_b32), which the compiler only forms from 32-bit
+// operands — 22 vector instructions per column instead of 29.  Same function, bit for bit (the host model runs the generic one;
+// tests/test_gpu_bits_verify.py holds this one against the oracle).
+template <>
+FZ_HD int32_t fz_bits_column<1>(FzBitsCol<1> &c, uint64_t eq) {
+    const uint32_t vpl = (uint32_t)c.vp, vph = (uint32_t)(c.vp >> 32), vnl = (uint32_t)c.vn, vnh = (uint32_t)(c.vn >> 32);
+    const uint32_t eql = (uint32_t)eq, eqh = (uint32_t)(eq >> 32);
+    const uint64_t sum = (eq & c.vp) + c.vp;
+    const uint32_t d0l = (((uint32_t)sum ^ vpl) | eql) | vnl, d0h = (((uint32_t)(sum >> 32) ^ vph) | eqh) | vnh;
+    const uint32_t hpl = vnl | ~(d0l | vpl), hph = vnh | ~(d0h | vph);
+    const uint32_t hnl = vpl & d0l, hnh = vph & d0h;
+    const int32_t delta = (int32_t)(hph >> 31) - (int32_t)(hnh >> 31);
+    const uint32_t hpsl = (hpl << 1) | 1u, hpsh = (hph << 1) | (hpl >> 31);       // D[0][j] - D[0][j-1] = +1
+    const uint32_t hnsl = hnl << 1, hnsh = (hnh << 1) | (hnl >> 31);
+    const uint32_t nvpl = hnsl | ~(d0l | hpsl), nvph = hnsh | ~(d0h | hpsh);
+    const uint32_t nvnl = hpsl & d0l, nvnh = hpsh & d0h;
+    c.vp = ((uint64_t)nvph << 32) | nvpl;
+    c.vn = ((uint64_t)nvnh << 32) | nvnl;
+    return delta;
+}
+#endif
+
 // One expansion on its own (tests, and the statement of what the two-phase loop below computes per side):
 // peq(c) = the piece's rows that hold character c, bit i = row i + 1 at bit 64 NW - sublen + i.
 template <int NW, class PeqF, class WinF>
@@ -513,54 +537,68 @@ FZ_HD bool fz_verify_lev_bits(const PeqT &peq, TxtF txt, uint64_t wbase, uint64_
     uint32_t tab = peq.table(0);
     uint32_t chn = 0;                                                // character of the column after the next one
     T eqn = 0;                                                       // Peq word of the next column
+    // (the reads of an expansion's first two characters are made whether it has columns or not: txt tolerates them)
     auto prime = [&]() {
-        if (rem != 0u) {
-            eqn = peq.at(tab, txt(pos));
-            chn = txt(pos + dir);
-            pos += 2u * dir;
-        }
+        eqn = peq.at(tab, txt(pos));
+        chn = txt(pos + dir);
+        pos += 2u * dir;
     };
-    prime();
+    if (valid) prime();
     bool ok = false;
+    uint32_t res_l = 0, res_dist = 0;
+    // what the left expansion will be, as far as it does not depend on the right one's outcome
+    const T hm_left = s ? ~(T)0 << (NB - s) : (T)0;
+    const uint32_t pos_left = (uint32_t)(idx - wbase) - 1u;
+    const uint64_t room_left = idx - sa;                             // sequence bytes to the left of the hit
     // Loop control on wave masks (the host model is a wave of one lane): `live` = lanes that still have an expansion to
-    // finish.  A column costs ~40 vector instructions; what is added per column for control is one compare and scalar work.
+    // finish.  A column costs ~36 vector instructions; what is added per column for control is one compare and scalar work.
     unsigned long long live = FZ_WAVE_BALLOT(phase < 2u);
     while (live) {
         if (FZ_WAVE_BALLOT(rem == 0u) & live) {                     // some lane's expansion has seen its last column
             if (rem == 0u && phase < 2u) {
+                // ONE divergent region with selects inside it, and one WAVE-UNIFORM branch around the left expansion's start
+                // (nested divergent branches cost this block more in exec-mask bookkeeping than its arithmetic; most of a
+                // wave's ~40 turn events per pass only end lanes — a failed right side, a finished left one — and skip it)
                 const uint32_t best = key >> 8, arg = wl - (key & 255u);
-                if (best > budget) {
-                    phase = 2;
-                } else if (phase == 0) {
+                const bool pass = best <= budget;
+                const bool to_left = pass && phase == 0u, finish = pass && phase == 1u;
+                res_l = finish ? arg : res_l;
+                res_dist = finish ? dR + best : res_dist;
+                ok = ok || finish;
+                phase = to_left ? 1u : 2u;
+                if (FZ_WAVE_ANY(to_left)) {
                     // left: reversed p[:s] vs reversed t[max(sa, idx-s-(k-dR)) : idx], budget k - dR
-                    dR = best; r = arg;
-                    budget = k - dR;
+                    dR = to_left ? best : dR;
+                    r = to_left ? arg : r;
+                    budget = to_left ? k - best : budget;
                     const uint64_t want = (uint64_t)s + budget;
-                    const uint64_t lbeg = (idx - sa > want) ? idx - want : sa;
-                    start(s, (uint32_t)(idx - lbeg));
-                    pos = (uint32_t)(idx - wbase) - 1u; dir = ~0u;
+                    const uint32_t lcols = (uint32_t)(room_left > want ? want : room_left);
+                    hm = hm_left;
+                    col.vp = hm_left; col.vn = 0;
+                    score = s;
+                    wl = (to_left && s) ? lcols : 0u;                // (an empty piece expands to (0, 0))
+                    rem = wl;
+                    key = (s << 8) | wl;
+                    pos = pos_left; dir = ~0u;
                     tab = peq.table(1);
-                    phase = 1;
                     prime();
-                } else {
-                    rec.l = arg; rec.r = r; rec.dist = dR + best; rec.aux = 0;
-                    ok = true;
-                    phase = 2;
                 }
             }
             live = FZ_WAVE_BALLOT(phase < 2u);
         }
-        if (rem != 0u) {                                             // (rem != 0 only in phases 0 and 1)
+        const uint32_t act = rem != 0u ? 1u : 0u;                    // (rem != 0 only in phases 0 and 1)
+        if (act) {
             const T eq = eqn & hm;
             eqn = peq.at(tab, chn);
             chn = txt(pos);
             pos += dir;
             score += (uint32_t)fz_bits_column<NW>(col, eq);
-            --rem;
-            const uint32_t cand = (score << 8) | rem;
+            const uint32_t cand = (score << 8) | (rem - 1u);
             if (cand < key) key = cand;
         }
+        rem -= act;
     }
+    rec.l = res_l; rec.r = r; rec.dist = res_dist; rec.aux = 0;
     return ok;
 }
 
