@@ -433,7 +433,6 @@ struct FzBitsCol {
 };
 
 // a | ~x
-FZ_HD uint32_t fz_or_not32(uint32_t a, uint32_t x) { return a | ~x; }
 template <class T> FZ_HD T fz_or_not(T a, T x) { return a | ~x; }
 
 // Column j-1 -> column j.  `eq`: the piece's rows whose character equals the column's (masked to the piece).
@@ -454,27 +453,38 @@ FZ_HD int32_t fz_bits_column(FzBitsCol<NW> &c, typename FzBitsWord<NW>::T eq) {
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// The one-word column on the GPU, written on its 32-bit halves (only the addition is a 64-bit operation): gfx950 has a
-// three-input bit operation (v_bitop3_b32) and a funnel shift (v_alignbit_b32), which the compiler only forms from 32-bit
-// operands — 22 vector instructions per column instead of 29.  Same function, bit for bit (the host model runs the generic one;
-// tests/test_gpu_bits_verify.py holds this one against the oracle).
-template <>
-FZ_HD int32_t fz_bits_column<1>(FzBitsCol<1> &c, uint64_t eq) {
-    const uint32_t vpl = (uint32_t)c.vp, vph = (uint32_t)(c.vp >> 32), vnl = (uint32_t)c.vn, vnh = (uint32_t)(c.vn >> 32);
-    const uint32_t eql = (uint32_t)eq, eqh = (uint32_t)(eq >> 32);
-    const uint64_t sum = (eq & c.vp) + c.vp;
-    const uint32_t d0l = (((uint32_t)sum ^ vpl) | eql) | vnl, d0h = (((uint32_t)(sum >> 32) ^ vph) | eqh) | vnh;
-    const uint32_t hpl = vnl | ~(d0l | vpl), hph = vnh | ~(d0h | vph);
-    const uint32_t hnl = vpl & d0l, hnh = vph & d0h;
-    const int32_t delta = (int32_t)(hph >> 31) - (int32_t)(hnh >> 31);
-    const uint32_t hpsl = (hpl << 1) | 1u, hpsh = (hph << 1) | (hpl >> 31);       // D[0][j] - D[0][j-1] = +1
-    const uint32_t hnsl = hnl << 1, hnsh = (hnh << 1) | (hnl >> 31);
-    const uint32_t nvpl = hnsl | ~(d0l | hpsl), nvph = hnsh | ~(d0h | hpsh);
-    const uint32_t nvnl = hpsl & d0l, nvnh = hpsh & d0h;
-    c.vp = ((uint64_t)nvph << 32) | nvpl;
-    c.vn = ((uint64_t)nvnh << 32) | nvnl;
+// The one- and two-word columns on the GPU, written on their 32-bit words (only the addition is a wide operation): gfx950
+// has a three-input bit operation (v_bitop3_b32) and a funnel shift (v_alignbit_b32), which the compiler only forms from
+// 32-bit operands — 36 vector instructions per one-word column instead of 41, 58 instead of 70 per two-word one.  Same
+// function, bit for bit (the host model runs the generic one; tests/test_gpu_bits_verify.py holds these against the oracle).
+template <int NW>
+__device__ __forceinline__ int32_t fz_bits_column_words(FzBitsCol<NW> &c, typename FzBitsWord<NW>::T eq) {
+    typedef typename FzBitsWord<NW>::T T;
+    constexpr int NH = 2 * NW;                                   // 32-bit words of a vector
+    const T sum = (eq & c.vp) + c.vp;
+    uint32_t d0[NH], hp[NH], hn[NH];
+#pragma unroll
+    for (int w = 0; w < NH; ++w) {
+        const uint32_t vpw = (uint32_t)(c.vp >> (32 * w)), vnw = (uint32_t)(c.vn >> (32 * w)), eqw = (uint32_t)(eq >> (32 * w));
+        d0[w] = (((uint32_t)(sum >> (32 * w)) ^ vpw) | eqw) | vnw;
+        hp[w] = vnw | ~(d0[w] | vpw);
+        hn[w] = vpw & d0[w];
+    }
+    const int32_t delta = (int32_t)(hp[NH - 1] >> 31) - (int32_t)(hn[NH - 1] >> 31);
+    T nvp = 0, nvn = 0;
+#pragma unroll
+    for (int w = 0; w < NH; ++w) {
+        const uint32_t hps = (hp[w] << 1) | (w ? hp[w ? w - 1 : 0] >> 31 : 1u);      // D[0][j] - D[0][j-1] = +1 enters word 0
+        const uint32_t hns = (hn[w] << 1) | (w ? hn[w ? w - 1 : 0] >> 31 : 0u);
+        nvp |= (T)(hns | ~(d0[w] | hps)) << (32 * w);
+        nvn |= (T)(hps & d0[w]) << (32 * w);
+    }
+    c.vp = nvp;
+    c.vn = nvn;
     return delta;
 }
+template <> FZ_HD int32_t fz_bits_column<1>(FzBitsCol<1> &c, uint64_t eq) { return fz_bits_column_words<1>(c, eq); }
+template <> FZ_HD int32_t fz_bits_column<2>(FzBitsCol<2> &c, unsigned __int128 eq) { return fz_bits_column_words<2>(c, eq); }
 #endif
 
 // One expansion on its own (tests, and the statement of what the two-phase loop below computes per side):

@@ -642,6 +642,7 @@ ScanKernel scan_kernel(int nwin, int dh, bool fused, bool seg, bool sa, int wf_g
 #ifdef FZ_LAB_ONLY      // lab builds (benchmarks/lab_build.sh): only the instances of the headline and exact-search workloads
     if (wf_gw == 1 && nwin == 2 && dh == 3 && fused && !seg) return sa ? fz_scan_kernel<2, 3, true, false, true, 1> : fz_scan_kernel<2, 3, true, false, false, 1>;
     if (wf_gw == 3 && nwin == 2 && dh == 3 && fused && !seg) return sa ? fz_scan_kernel<2, 3, true, false, true, 3> : fz_scan_kernel<2, 3, true, false, false, 3>;
+    if (wf_gw == 2 && nwin == 2 && dh == 3 && fused && !seg) return sa ? fz_scan_kernel<2, 3, true, false, true, 2> : fz_scan_kernel<2, 3, true, false, false, 2>;
     if (wf_gw == 4 && nwin == 2 && dh == 3 && fused && !seg) return sa ? fz_scan_kernel<2, 3, true, false, true, 4> : fz_scan_kernel<2, 3, true, false, false, 4>;
     if (wf_gw) return nullptr;
     if (nwin == 2 && dh == 3 && fused && !seg) return sa ? fz_scan_kernel<2, 3, true, false, true> : fz_scan_kernel<2, 3, true, false, false>;
