@@ -193,8 +193,9 @@ def load_library():
         L.fz_merge_ranks.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, u32, u32, ctypes.c_void_p]
         L.fz_stats.restype = ci
         L.fz_stats.argtypes = [vp, ctypes.POINTER(FzStats)]
-        L.fz_mem_info.restype = ci
-        L.fz_mem_info.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+        if hasattr(L, "fz_mem_info"):                       # (absent from builds of earlier rounds named by FUZZYSEARCH_HIP_LIB for an A/B)
+            L.fz_mem_info.restype = ci
+            L.fz_mem_info.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
         L.fz_set_timing.restype = ci
         L.fz_set_timing.argtypes = [vp, ci]
         L.fz_set_streams.restype = ci
