@@ -1077,6 +1077,8 @@ def main():
                          "avg_kernel_ms_source": ("mean hipEvent span of %d synchronous launches after the timed region" % len(sync_spans))
                                                  if sync_spans else "mean hipEvent span of the timed region's launches",
                          "avg_kernel_ms_sync": round(f_ms, 4) if sync_spans else None,
+                         "median_kernel_ms_sync": round(float(np.median(sync_spans)), 4) if sync_spans else None,
+                         "min_max_kernel_ms_sync": [round(float(np.min(sync_spans)), 4), round(float(np.max(sync_spans)), 4)] if sync_spans else None,
                          "avg_kernel_ms_pipelined": round(f_pipe, 4),
                          "pipelined_note": "spans of the timed region's launches, two searches in flight: each overlaps its predecessor's "
                                            "tail — not the kernel alone; frac / achieved use the synchronous figure",
