@@ -31,7 +31,7 @@ import time
 import numpy as np
 
 __all__ = ['shard_bounds', 'merge_rank_streams', 'init_engine_from_env', 'local_device', 'share_blob',
-           'exchange_halos_native']
+           'exchange_halos_native', 'halos_from_edges', 'FileRendezvous']
 
 _rdzv_seq = [0]
 
@@ -94,6 +94,84 @@ def share_blob(make_blob, world, rank, timeout=300.0, directory=None):
     return blob
 
 
+class FileRendezvous(object):
+    """All-gather and barrier of small blobs between the ranks of ONE node through files (/dev/shm), for the moments a job
+    has no working collective library: `bench.py` under a launcher falls back to it when RCCL cannot set the communicator up,
+    fails in the middle of a run or never completes (every rank searches its shard, the streams are merged once through
+    here and the line says so).  Milliseconds per exchange — a way to agree and to hand results over, not a data path.
+    Every rank must make the same sequence of calls; every wait has a deadline (TimeoutError)."""
+
+    def __init__(self, world, rank, tag="fb", timeout=300.0, directory=None):
+        self.world, self.rank, self.timeout = int(world), int(rank), float(timeout)
+        directory = directory or os.environ.get("FZ_RENDEZVOUS_DIR") or ("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
+        self.dir = os.path.join(directory, "fz_%s_%s" % (tag, _job_key()))
+        os.makedirs(self.dir, exist_ok=True)
+        self.step = 0
+        self._mine = []
+
+    def _name(self, step, rank):
+        return os.path.join(self.dir, "%d_%d" % (step, rank))
+
+    def allgather(self, blob):
+        """-> [rank 0's blob, rank 1's, ...] on every rank."""
+        step = self.step
+        self.step += 1
+        mine = self._name(step, self.rank)
+        tmp = mine + ".tmp"
+        with open(tmp, "wb") as f:
+            f.write(bytes(blob))
+        os.replace(tmp, mine)
+        self._mine.append(mine)
+        deadline = time.monotonic() + self.timeout
+        out = []
+        for r in range(self.world):
+            name = self._name(step, r)
+            while True:
+                try:
+                    with open(name, "rb") as f:
+                        out.append(f.read())
+                    break
+                except FileNotFoundError:
+                    if time.monotonic() > deadline:
+                        raise TimeoutError("file rendezvous %s: rank %d never arrived at step %d" % (self.dir, r, step))
+                    time.sleep(0.0005)
+        # whoever is past step n has seen every rank's file of step n, which a rank writes after it has read all of step n - 1:
+        # this rank's file of step n - 1 has been read by everybody
+        while len(self._mine) > 1:
+            try:
+                os.remove(self._mine.pop(0))
+            except OSError:
+                pass
+        return out
+
+    def barrier(self):
+        self.allgather(b"")
+
+    def close(self):
+        """Collective, once, last: every rank leaves a `done` mark behind its last read; rank 0 waits for all of them and
+        removes the directory (a rank cannot know when ITS last file has been read by everybody — rank 0 can)."""
+        done = os.path.join(self.dir, "done_%d" % self.rank)
+        with open(done, "wb"):
+            pass
+        self._mine = []
+        if self.rank != 0:
+            return
+        deadline = time.monotonic() + self.timeout
+        while not all(os.path.exists(os.path.join(self.dir, "done_%d" % r)) for r in range(self.world)):
+            if time.monotonic() > deadline:
+                return
+            time.sleep(0.001)
+        for name in os.listdir(self.dir):
+            try:
+                os.remove(os.path.join(self.dir, name))
+            except OSError:
+                pass
+        try:
+            os.rmdir(self.dir)
+        except OSError:
+            pass
+
+
 def local_device(local_rank):
     """The HIP device of this rank: LOCAL_RANK, unless the launcher already narrowed the visible devices per rank
     (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES: then fewer devices are visible than there are local ranks)."""
@@ -128,11 +206,11 @@ def exchange_halos_native(engine, shard, halo):
     blob[16:16 + len(head)] = head
     blob[16 + halo:16 + halo + len(tail)] = tail
     parts = [np.frombuffer(b, dtype=np.uint8) for b in engine.comm_allgather(blob.tobytes())]
-    return _halos_from_edges([(p[16:16 + int(p[:8].view(np.uint64)[0])], p[16 + halo:16 + halo + int(p[8:16].view(np.uint64)[0])])
+    return halos_from_edges([(p[16:16 + int(p[:8].view(np.uint64)[0])], p[16 + halo:16 + halo + int(p[8:16].view(np.uint64)[0])])
                               for p in parts], rank, halo)
 
 
-def _halos_from_edges(edges, rank, halo):
+def halos_from_edges(edges, rank, halo):
     """edges[r] = (first, last) `halo` bytes of rank r's shard (all of it when it is shorter) -> (left, right) of
     `rank`: a shard shorter than the halo contributes all of itself, so keep walking."""
     world = len(edges)
@@ -168,3 +246,6 @@ def merge_rank_streams(streams):
     if len(allm) == 0:
         return allm
     return allm[np.argsort(allm[:, 3], kind='stable')]
+
+
+_halos_from_edges = halos_from_edges

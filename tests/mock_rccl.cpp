@@ -28,10 +28,12 @@
 //
 //   * fault injection (tests/test_gpu_mock_rccl.py: what bench.py --gpus N must survive on its first real node):
 //       FZMOCK_FAIL_INIT=1            ncclCommInitAll / ncclCommInitRank return ncclSystemError
-//       FZMOCK_FAIL_ALLGATHER=n       the n-th all-gather of the process (1-based) returns ncclSystemError
+//       FZMOCK_HANG_INIT_S=s          ncclCommInitRank blocks for s seconds first (a peer that never joins: the caller's watchdog)
+//       FZMOCK_FAIL_ALLGATHER=n       the n-th all-gather of the process (1-based) returns ncclSystemError (one process per rank: on
+//                                     every rank, or with FZMOCK_FAIL_RANK=r on rank r alone — its peers then wait for it in vain)
 //       FZMOCK_LATE_RANK=r:ms         rank r's send buffer becomes "ready" ms milliseconds late in every in-process all-gather
 //                                     (a host function sleeping on its stream): slower, never wrong
-//       FZMOCK_STALL_ALLGATHER=n:ms   the n-th in-process all-gather stalls rank 0's stream for ms milliseconds — a rank that
+//       FZMOCK_STALL_ALLGATHER=n:ms   the n-th all-gather (either form) stalls rank 0's stream for ms milliseconds — a rank that
 //                                     (for the caller's deadline) never arrives
 // Not emulated: RCCL's transports (xGMI rings, IPC handles, channels) — those stay unverified until an 8-GPU node
 // runs bench.py.  The product never loads this file; tests/ and nothing else names it.
@@ -430,10 +432,19 @@ ncclResult_t shm_allgather_async(const Op &op) {
     ncclComm *c = op.comm;
     const size_t bytes = op.count * dt_bytes(op.dt);
     if (c->ctl->failed.load(std::memory_order_acquire)) return bad(ncclRemoteError, "mock: the communicator failed earlier (a rank never arrived, or ranks disagreed on a size)");
-    g_stats[0]++; g_stats[1] += bytes;
+    const uint64_t call_no = ++g_stats[0];
+    g_stats[1] += bytes;
+    // fault injection, launcher form: the n-th all-gather of every process — or of rank FZMOCK_FAIL_RANK alone, whose peers then
+    // wait for a rank that never comes — returns an error; rank 0's stream stalls in front of its n-th all-gather
+    const long fail_rank = env_long("FZMOCK_FAIL_RANK", -1);
+    if ((long)call_no == env_long("FZMOCK_FAIL_ALLGATHER", -1) && (fail_rank < 0 || fail_rank == c->rank))
+        return bad(ncclSystemError, "mock: injected failure of all-gather %llu on rank %d", (unsigned long long)call_no, c->rank);
+    long stall_no, stall_ms;
+    env_pair("FZMOCK_STALL_ALLGATHER", stall_no, stall_ms);
     g_async_allgathers++;
     const uint64_t seq = ++c->async_seq;
     HIPQ(hipSetDevice(c->device));
+    if (c->rank == 0 && (long)call_no == stall_no && stall_ms > 0) HIPQ(hipLaunchHostFunc(op.stream, sleep_on_stream, (void *)(intptr_t)stall_ms));
     uint8_t *recv = static_cast<uint8_t *>(op.recv);
     HIPQ(hipLaunchHostFunc(op.stream, async_step, new AsyncStep{c, seq, bytes, 0}));
     if (bytes) HIPQ(hipMemcpyAsync(c->mine.p, op.send, bytes, hipMemcpyDeviceToHost, op.stream));
@@ -539,6 +550,7 @@ ncclResult_t ncclCommInitAll(ncclComm_t *comms, int ndev, const int *devlist) {
 ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int rank) {
     if (!comm || nranks < 1 || nranks > kMaxRanks || rank < 0 || rank >= nranks) return bad(ncclInvalidArgument, "mock: ncclCommInitRank(%d, %d)", nranks, rank);
     if (env_long("FZMOCK_FAIL_INIT", 0)) return bad(ncclSystemError, "mock: injected failure of ncclCommInitRank");
+    if (const long hang_s = env_long("FZMOCK_HANG_INIT_S", 0)) std::this_thread::sleep_for(std::chrono::seconds(hang_s));   // a peer that never joins
     int dev = 0;
     HIPQ(hipGetDevice(&dev));
     ncclComm *c = new ncclComm;

@@ -92,6 +92,51 @@ def test_torch_free_rendezvous_hands_rank0_bytes_to_every_rank():
         assert os.listdir(d) == []                      # rank 0 cleaned up
 
 
+def _file_rdzv_child(args):
+    rank, world, directory = args
+    import time
+    from fuzzysearch_amd import distributed as fzd
+    os.environ["FZ_RENDEZVOUS_KEY"] = "filerdzv_test"          # (the pool's children have different parents' views: pin the job key)
+    rv = fzd.FileRendezvous(world, rank, timeout=60, directory=directory)
+    time.sleep(0.01 * ((rank * 7) % 3))                         # ranks arrive in different orders
+    a = rv.allgather(b"rank%d" % rank)
+    rv.barrier()
+    b = rv.allgather(bytes([rank]) * (1000 * (rank + 1)))       # blobs of different sizes
+    for i in range(20):                                         # many quick rounds: a round's files never leak into the next
+        c = rv.allgather(b"%d:%d" % (i, rank))
+        assert c == [b"%d:%d" % (i, r) for r in range(world)], (i, c)
+    left_behind = len([n for n in os.listdir(rv.dir) if n.endswith("_%d" % rank)])
+    rv.close()
+    return a, [len(x) for x in b], left_behind
+
+
+def test_file_rendezvous_allgather_and_barrier():
+    """FileRendezvous: what bench.py's launcher form falls back to when the collective library fails (every rank gets every
+    rank's blob, in rank order; files of finished rounds are removed; close() leaves nothing behind)."""
+    import multiprocessing as mp
+    world = 4
+    with tempfile.TemporaryDirectory() as d:
+        with mp.get_context("fork").Pool(world) as pool:
+            res = pool.map(_file_rdzv_child, [(r, world, d) for r in range(world)], chunksize=1)
+        for a, sizes, left in res:
+            assert a == [b"rank%d" % r for r in range(world)]
+            assert sizes == [1000 * (r + 1) for r in range(world)]
+            assert left <= 1                                    # only the last round's own file is still there before close()
+        assert os.listdir(d) == []
+
+
+def test_file_rendezvous_has_a_deadline():
+    from fuzzysearch_amd import distributed as fzd
+    with tempfile.TemporaryDirectory() as d:
+        os.environ["FZ_RENDEZVOUS_KEY"] = "filerdzv_deadline"
+        try:
+            rv = fzd.FileRendezvous(2, 0, timeout=0.2, directory=d)
+            with pytest.raises(TimeoutError, match="rank 1 never arrived"):
+                rv.allgather(b"x")
+        finally:
+            del os.environ["FZ_RENDEZVOUS_KEY"]
+
+
 def test_halos_from_edges_walks_over_short_shards():
     import numpy as np
     from fuzzysearch_amd import distributed as fzd

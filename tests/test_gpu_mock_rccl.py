@@ -97,36 +97,82 @@ def test_bench_collective_line_with_eight_ranks_on_one_gpu():
     assert d["value_no_collective"] > 0 and d["value_no_collective"] != d["value"]
 
 
-def test_launcher_form_of_bench_with_three_ranks_on_one_gpu():
-    """The launch contract's form — one process per rank, RANK / WORLD_SIZE / LOCAL_RANK in the environment — with three
-    ranks on device 0 (LOCAL_RANK beyond the visible devices wraps: distributed.local_device)."""
-    world = 3
-    env = mock_rccl.env({"FZ_RENDEZVOUS_KEY": "mockbench_%s" % uuid.uuid4().hex, "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
-                         "MASTER_PORT": "29571"})
+def _bench_launcher(world, extra_env=None, timeout=300):
+    """bench.py in the launch contract's form — one process per rank, RANK / WORLD_SIZE / LOCAL_RANK in the environment —
+    with `world` ranks on device 0 (LOCAL_RANK beyond the visible devices wraps: distributed.local_device).
+    -> (rank 0's line, [stderr of every rank])."""
+    env = mock_rccl.env(dict({"FZ_RENDEZVOUS_KEY": "mockbench_%s" % uuid.uuid4().hex, "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
+                              "MASTER_PORT": "29571"}, **(extra_env or {})))
     procs = []
+    shm_before = set(os.listdir("/dev/shm")) if os.path.isdir("/dev/shm") else set()
     for r in range(world):
         e = dict(env)
         e["RANK"] = e["LOCAL_RANK"] = str(r)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--mib", "128", "--steps", "12",
-                                       "--warmup", "3", "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
-                                      env=e, cwd=ROOT))
+                                       "--warmup", "3", "--settle-ms", "300", "--no-cpu-baseline"], stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True, env=e, cwd=ROOT))
     outs = []
     try:
         for p in procs:
-            out, err = p.communicate(timeout=900)
+            out, err = p.communicate(timeout=timeout)
             outs.append((out, err, p.returncode))
     finally:
         for p in procs:
             if p.poll() is None:
                 p.kill()
+        if os.path.isdir("/dev/shm"):                            # a communicator the stand-in gave up on leaves its shm files behind
+            for name in set(os.listdir("/dev/shm")) - shm_before:
+                if name.startswith("fzmock_"):
+                    try:
+                        os.remove(os.path.join("/dev/shm", name))
+                    except OSError:
+                        pass
     for r, (out, err, rc) in enumerate(outs):
         assert rc == 0, "rank %d: %s" % (r, err[-3000:])
     lines = [ln for ln in outs[0][0].splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, outs[0][0][-2000:]
     assert not [ln for o in outs[1:] for ln in o[0].splitlines() if ln.strip().startswith("{")]      # rank 0 prints the line
-    d = json.loads(lines[0])
+    return json.loads(lines[0]), [o[1] for o in outs]
+
+
+def test_launcher_form_of_bench_with_three_ranks_on_one_gpu():
+    world = 3
+    d, _errs = _bench_launcher(world)
     assert d["n_gpus"] == world and d["rccl_ranks"] == world and d["allgather_ms"] > 0
-    assert d["stream_in_reference_order"] is True
+    assert d["stream_in_reference_order"] is True and d["boundary_plants_found"] == 3 + 2
+    assert d["collective_error"] is None and d["exchange_in_timed_region"] is True
+
+
+@pytest.mark.parametrize("fault,env", [
+    ("the communicator cannot be set up", {"FZMOCK_FAIL_INIT": "1"}),
+    ("an all-gather fails on every rank in the middle of the run", {"FZMOCK_FAIL_ALLGATHER": "30"}),
+    ("an all-gather fails on ONE rank: its peers wait for it until their deadline", {"FZMOCK_FAIL_ALLGATHER": "30", "FZMOCK_FAIL_RANK": "1",
+                                                                                   "FZ_COMM_TIMEOUT_MS": "400", "FZ_MOCK_RCCL_TIMEOUT_S": "3"}),
+    ("rank 0 never arrives at an all-gather (deadline)", {"FZMOCK_STALL_ALLGATHER": "30:3000", "FZ_COMM_TIMEOUT_MS": "400",
+                                                         "FZ_MOCK_RCCL_TIMEOUT_S": "5"}),
+    ("ncclCommInitRank never returns (bench.py's watchdog; the process leaves through os._exit)", {"FZMOCK_HANG_INIT_S": "60",
+                                                                                                 "FZ_COMM_INIT_TIMEOUT_S": "2"}),
+])
+def test_launcher_form_prints_its_line_when_the_collective_fails(fault, env):
+    """The form the driver's N > 1 runs take (torch.distributed.run: one process per GPU).  Whatever the collective library
+    does, the ranks agree through files to give the collective form up, search their shards without it, hand the streams
+    of the last step to rank 0 through files, and rank 0 prints the line: `collective_error`, `rccl_ranks` 0, the aggregate
+    `value`, all boundary plants found in the merged stream, reference order; every rank exits 0."""
+    world = 3
+    d, errs = _bench_launcher(world, env)
+    assert d["n_gpus"] == world and d["rccl_ranks"] == 0 and d["collective_error"], (fault, d)
+    assert d["value"] > 0 and d["exchange_in_timed_region"] is False
+    assert d["boundary_plants_found"] == 3 + 2 and d["stream_in_reference_order"] is True     # (world 3: one odd, one even boundary)
+    assert d["raw_matches"] > 0 and len(d["per_rank_ms_per_step"]) == world
+    assert "per-rank form" in errs[0]
+    if "HANG_INIT" in "".join(env):
+        assert "joining the RCCL communicator did not return within 2 s" in d["collective_error"]
+    elif "FAIL_INIT" in "".join(env):
+        assert "injected failure of ncclCommInitRank" in d["collective_error"]
+    elif "STALL" in "".join(env) or "FAIL_RANK" in "".join(env):
+        assert "did not complete within 400 ms" in d["collective_error"]
+    else:
+        assert "injected failure of all-gather" in d["collective_error"]
 
 
 def test_collective_search_of_eight_ranks_beyond_4gib():
