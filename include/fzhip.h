@@ -294,7 +294,11 @@ int  fz_stream_finish(fz_stream *st, fz_match **out, uint32_t **seg, uint64_t *n
 void fz_stream_close(fz_stream *st);
 
 /* Test hook: the library reads its FZ_* environment switches (none is needed to use it) once,
- * on first use; this reads them again.  For tests that flip a switch inside one process; nothing may be in flight. */
+ * on first use; this reads them again.  For tests that flip a switch inside one process; nothing may be in flight.
+ * What a reload reaches: every switch that is consulted per search (routing, queue sizes, grids, the fused forms' LDS
+ * budget, FZ_COMM_TIMEOUT_MS).  What it does NOT reach: the collective library (FZ_NO_RCCL / FZ_RCCL_LIB: loaded once per
+ * process) and what a context took over when it was created (fz_create: timing, streams, the generic search's kernel
+ * choice, the worker threads' spin time) — create a new context, or a new process, for those. */
 void fz_debug_reload_switches(void);
 
 /* Test hook (no device needed): how the scan would split the n-gram blocks of pattern p (block
