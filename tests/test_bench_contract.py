@@ -75,6 +75,26 @@ def test_round6_line_was_measured_with_the_tree_s_native_sources():
     assert "consolidated_two_in_flight_ms" in [k2 for v in d["configs"].values() for k2 in v]
 
 
+def test_launcher_fallback_line_follows_the_contract():
+    """The line bench.py prints under a launcher when the collective library fails (main_launcher_fallback; the committed
+    sample: three ranks on one GPU through the stand-in, one rank's all-gather failing): the contract's keys, the failure said."""
+    with open(os.path.join(ROOT, "profiles", "r06_bench_launcher_fallback.json")) as f:
+        lines = [ln for ln in f.read().splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 3 and d["rccl_ranks"] == 0 and d["collective_error"] and d["exchange_in_timed_region"] is False
+    assert d["unit"] == "GB/s" and d["scaling"] == "weak" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    total = d["config"]["bytes_per_gpu"] * d["n_gpus"]
+    assert abs(d["value"] - total / (d["ms_per_step"] * 1e-3) / 1e9) / d["value"] < 0.01
+    assert d["ms_per_step"] == max(d["per_rank_ms_per_step"])              # the MAX over the ranks
+    assert d["boundary_plants_found"] == 5 and d["stream_in_reference_order"] is True
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+
+
 def test_two_device_states_line():
     """`FZ_DEVICES=0,0 python bench.py --gpus 2` (the torch-free N > 1 form on one GPU): n_gpus follows --gpus."""
     with open(os.path.join(ROOT, "profiles", "r03_bench_two_device_states.json")) as f:
